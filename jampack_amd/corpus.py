@@ -1,0 +1,215 @@
+"""Deterministic synthetic corpora standing in for enwik6/8/9 and Silesia (none are available offline).
+
+Everything is driven by a counter-based splitmix64 generator written in numpy, so a (kind, nbytes, seed)
+triple gives the same bytes on every machine.  ``JAMPACK_CORPUS_DIR`` may point at real files
+(enwik8, enwik9, silesia.tar); ``load_or_make`` prefers them when present.
+
+Workloads:
+  C1 enwik6-like : text, 1 000 000 B, seed 6
+  C2/C3 enwik8-like : text, 100 000 000 B, seed 8   -> blocks 67 108 864 + 32 891 136
+  C4 enwik9-like : text, 1 000 000 000 B, seed 9
+  C5 silesia-like: mixed, 211 938 580 B, seed 5
+"""
+from __future__ import annotations
+
+import functools
+import os
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(seed: int, start: int, count: int) -> np.ndarray:
+    """count 64-bit outputs of splitmix64 seeded with `seed`, outputs start .. start+count-1."""
+    with np.errstate(over="ignore"):
+        i = np.arange(start + 1, start + count + 1, dtype=np.uint64)
+        z = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _uniform(seed: int, start: int, count: int) -> np.ndarray:
+    return (splitmix64(seed, start, count) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+_LETTERS = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", dtype=np.uint8)
+
+
+def _vocab(seed: int, nwords: int = 50000):
+    lens = (2 + (splitmix64(seed ^ 0x5EED, 0, nwords) % np.uint64(10))).astype(np.int64)
+    starts = np.concatenate(([0], np.cumsum(lens)))[:-1]
+    total = int(lens.sum())
+    p = np.arange(1, 27, dtype=np.float64) ** -0.8
+    cdf = np.cumsum(p / p.sum())
+    u = _uniform(seed ^ 0xABCD, 0, total)
+    letters = _LETTERS[np.minimum(np.searchsorted(cdf, u), 25)]
+    return letters, starts, lens
+
+
+@functools.lru_cache(maxsize=4)
+def _phrases(seed: int, nphr: int = 200000):
+    """phrase book: each phrase is 1..8 Zipf-chosen vocabulary words; gives text multi-word repeats like real prose."""
+    letters, vstart, vlen = _vocab(seed)
+    nw = len(vlen)
+    pz = np.arange(1, nw + 1, dtype=np.float64) ** -1.05
+    zcdf = np.cumsum(pz / pz.sum())
+    pwords = (1 + (splitmix64(seed ^ 0x9A5E, 0, nphr) % np.uint64(8))).astype(np.int64)
+    tw = int(pwords.sum())
+    ids = np.minimum(np.searchsorted(zcdf, _uniform(seed ^ 0x1D5, 0, tw)), nw - 1)
+    wl = vlen[ids] + 1                       # word + separator
+    ends = np.cumsum(wl)
+    begs = ends - wl
+    tot = int(ends[-1])
+    pos = np.arange(tot, dtype=np.int64) - np.repeat(begs, wl)
+    is_sep = pos == np.repeat(vlen[ids], wl)
+    src = np.where(is_sep, 0, np.repeat(vstart[ids], wl) + pos)
+    pbytes = np.where(is_sep, np.uint8(32), letters[src]).astype(np.uint8)
+    # phrase extents in pbytes; every 8th phrase ends its last separator with a newline
+    wend = np.cumsum(pwords)
+    pend = ends[wend - 1]
+    pbeg = np.concatenate(([0], pend[:-1]))
+    nl = pend[7::8] - 1
+    pbytes[nl] = 10
+    return pbytes, pbeg, pend - pbeg
+
+
+def text(nbytes: int, seed: int) -> np.ndarray:
+    """Zipf-phrase text: 50 000-word vocabulary, 200 000-phrase book, phrase choice Zipf s=0.8."""
+    if nbytes <= 0:
+        return np.zeros(0, dtype=np.uint8)
+    pbytes, pbeg, plen = _phrases(seed)
+    nphr = len(plen)
+    pz = np.arange(1, nphr + 1, dtype=np.float64) ** -0.8
+    zcdf = np.cumsum(pz / pz.sum())
+    out = np.empty(nbytes, dtype=np.uint8)
+    filled = 0
+    widx = 0
+    batch = 1 << 19
+    while filled < nbytes:
+        u = _uniform(seed, widx, batch)
+        ids = np.minimum(np.searchsorted(zcdf, u), nphr - 1)
+        ln = plen[ids]
+        ends = np.cumsum(ln)
+        tot = int(ends[-1])
+        src = np.arange(tot, dtype=np.int64) - np.repeat(ends - ln, ln) + np.repeat(pbeg[ids], ln)
+        take = min(tot, nbytes - filled)
+        out[filled:filled + take] = pbytes[src[:take]]
+        filled += take
+        widx += batch
+    return out
+
+
+def random_bytes(nbytes: int, seed: int) -> np.ndarray:
+    n8 = (nbytes + 7) // 8
+    return splitmix64(seed, 0, n8).view(np.uint8)[:nbytes].copy()
+
+
+def alphabet(nbytes: int, seed: int, symbols: bytes) -> np.ndarray:
+    tab = np.frombuffer(symbols, dtype=np.uint8)
+    r = random_bytes(nbytes, seed)
+    return tab[r % len(tab)]
+
+
+def geometric(nbytes: int, seed: int) -> np.ndarray:
+    """bytes with P(v) ~ 2^-(v/8): exercises every exponent class of the entropy stage."""
+    u = _uniform(seed, 0, nbytes)
+    v = np.floor(-np.log2(np.maximum(u, 1e-300)) * 8.0)
+    return np.minimum(v, 255).astype(np.uint8)
+
+
+def samples16(nbytes: int, seed: int) -> np.ndarray:
+    n = (nbytes + 1) // 2
+    steps = (splitmix64(seed, 0, n) % np.uint64(65)).astype(np.int64) - 32
+    wav = (np.cumsum(steps) & 0xFFFF).astype(np.uint16)
+    return wav.view(np.uint8)[:nbytes].copy()
+
+
+def runs(nbytes: int, seed: int) -> np.ndarray:
+    """long runs of 0x00 / 0xFF with occasional other bytes."""
+    out = np.empty(nbytes, dtype=np.uint8)
+    nr = max(1, nbytes // 512)
+    rl = 1 + (splitmix64(seed, 0, nr) % np.uint64(2048)).astype(np.int64)
+    val = splitmix64(seed ^ 0x77, 0, nr)
+    vals = np.where(val % np.uint64(16) == 0, (val >> np.uint64(8)) % np.uint64(256),
+                    np.where(val % np.uint64(2) == 0, 0, 255)).astype(np.uint8)
+    seq = np.repeat(vals, rl)
+    while len(seq) < nbytes:
+        seq = np.concatenate((seq, seq))
+    out[:] = seq[:nbytes]
+    return out
+
+
+def repeated(nbytes: int, seed: int, period: int = 1 << 20) -> np.ndarray:
+    """one text segment of `period` bytes repeated: LCP stress for suffix sorting."""
+    period = max(1, min(period, nbytes))
+    seg = text(period, seed)
+    reps = (nbytes + period - 1) // period
+    return np.tile(seg, reps)[:nbytes].copy()
+
+
+def silesia_like(nbytes: int, seed: int) -> np.ndarray:
+    parts = [("text", 0.40), ("samples16", 0.15), ("random", 0.15), ("dna", 0.10), ("runs", 0.10), ("repeat", 0.10)]
+    out = []
+    left = nbytes
+    for k, (kind, frac) in enumerate(parts):
+        n = left if k == len(parts) - 1 else int(nbytes * frac)
+        out.append(make(kind, n, seed + 17 * k))
+        left -= n
+    return np.concatenate(out)
+
+
+def make(kind: str, nbytes: int, seed: int) -> np.ndarray:
+    if nbytes <= 0:
+        return np.zeros(0, dtype=np.uint8)
+    if kind == "text":
+        return text(nbytes, seed)
+    if kind == "random":
+        return random_bytes(nbytes, seed)
+    if kind == "dna":
+        return alphabet(nbytes, seed, b"ACGT")
+    if kind == "two":
+        return alphabet(nbytes, seed, b"ab")
+    if kind == "zero":
+        return np.zeros(nbytes, dtype=np.uint8)
+    if kind == "geometric":
+        return geometric(nbytes, seed)
+    if kind == "samples16":
+        return samples16(nbytes, seed)
+    if kind == "runs":
+        return runs(nbytes, seed)
+    if kind == "repeat":
+        return repeated(nbytes, seed)
+    if kind == "repeat4k":
+        return repeated(nbytes, seed, 4096)
+    if kind == "silesia":
+        return silesia_like(nbytes, seed)
+    raise ValueError(f"unknown corpus kind {kind!r}")
+
+
+KINDS = ("text", "random", "dna", "two", "zero", "geometric", "samples16", "runs", "repeat", "repeat4k", "silesia")
+
+WORKLOADS = {
+    "enwik6": ("text", 1_000_000, 6, "enwik6"),
+    "enwik8": ("text", 100_000_000, 8, "enwik8"),
+    "enwik9": ("text", 1_000_000_000, 9, "enwik9"),
+    "silesia": ("silesia", 211_938_580, 5, "silesia.tar"),
+}
+
+
+def load_or_make(name: str, limit: int | None = None, seed_offset: int = 0):
+    """returns (bytes ndarray, source) where source is 'file:<path>' or 'synthetic'."""
+    kind, nbytes, seed, fname = WORKLOADS[name]
+    if limit is not None:
+        nbytes = min(nbytes, limit)
+    d = os.environ.get("JAMPACK_CORPUS_DIR")
+    if d and seed_offset == 0:
+        p = os.path.join(d, fname)
+        if os.path.isfile(p):
+            return np.fromfile(p, dtype=np.uint8, count=nbytes), f"file:{p}"
+    return make(kind, nbytes, seed + seed_offset), "synthetic"
+
+
+def split_blocks(data: np.ndarray, block_size: int):
+    return [data[i:i + block_size] for i in range(0, len(data), block_size)]
