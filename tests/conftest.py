@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle.pyoracle import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def ref():
+    from oracle.pyoracle import Ref
+    if not Ref.available():
+        pytest.skip("oracle/_ref/libjamref.so not built (reference tree absent)")
+    return Ref()

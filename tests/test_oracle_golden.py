@@ -1,0 +1,65 @@
+"""The C restatement (oracle/jam_oracle.c) against the committed golden vectors, which were generated from
+the real reference (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from golden_util import case_input, cases, manifest, sha, small
+
+PREFILL = 0xAB
+
+
+@pytest.mark.parametrize("case", cases(), ids=lambda c: c["name"])
+def test_forward_and_encode_match_golden(oracle, case):
+    t = case_input(case)
+    bwt = oracle.bwt_forward(t, prefill=PREFILL)
+    assert len(bwt) == case["bwt_len"]
+    assert sha(bwt) == case["bwt_sha256"]
+    ans = oracle.ans_encode(bwt)
+    assert len(ans) == case["ans_len"]
+    assert sha(ans) == case["ans_sha256"]
+    if case["raw"]:
+        assert np.array_equal(bwt, small()[case["name"] + ".bwt"])
+        assert np.array_equal(ans, small()[case["name"] + ".ans"])
+
+
+@pytest.mark.parametrize("case", cases(), ids=lambda c: c["name"])
+def test_decode_roundtrip_from_golden(oracle, case):
+    t = case_input(case)
+    if case["raw"]:
+        ans = small()[case["name"] + ".ans"]
+    else:
+        ans = oracle.ans_encode(oracle.bwt_forward(t, prefill=PREFILL))
+    bwt = oracle.ans_decode(ans, case["bwt_len"])
+    assert sha(bwt) == case["bwt_sha256"]
+    back = oracle.bwt_inverse(bwt)
+    assert np.array_equal(back, t)
+
+
+@pytest.mark.parametrize("case", cases(), ids=lambda c: c["name"])
+def test_stage_vectors(oracle, case):
+    t = case_input(case)
+    bwt = oracle.bwt_forward(t, prefill=PREFILL)
+    ranks, freq = oracle.rank_encode(bwt[: 1 << 20])
+    assert sha(ranks) == case["rank0_sha256"]
+    assert sha(freq.astype("<i4")) == case["freq0_sha256"]
+    rle = oracle.rle_encode(ranks)
+    assert len(rle) == case["rle0_len"]
+    assert sha(rle.astype("<u2")) == case["rle0_sha256"]
+    assert np.array_equal(oracle.rle_decode(rle, len(ranks)), ranks)
+    assert np.array_equal(oracle.rank_decode(ranks, freq), bwt[: 1 << 20])
+
+
+def test_leb128_golden(oracle):
+    for v, hx in manifest()["leb128"].items():
+        enc = oracle.leb_encode(int(v))
+        assert enc.hex() == hx
+        assert oracle.leb_decode(enc) == (int(v), len(enc))
+
+
+def test_short_block_leaves_trailer_untouched(oracle):
+    # bwt.cpp:35 -- nlen == 0: tail copied raw, the 480 trailer bytes are never written
+    t = np.arange(100, dtype=np.uint8)
+    out = oracle.bwt_forward(t, prefill=0x5C)
+    assert len(out) == 580
+    assert np.array_equal(out[:100], t)
+    assert np.all(out[100:] == 0x5C)
