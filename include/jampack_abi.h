@@ -1,0 +1,118 @@
+/*
+ * jampack_abi.h -- C ABI of libjampack_amd.so: the MI355X (gfx950) implementation of Jampack's block hot path.
+ *
+ * Every entry point replaces one interface of the reference (loxxous/Jampack, cited file:line).  Plain
+ * pointers and sizes only.  Return value: 0 (JPK_OK) or a negative jpk_status; the library never calls
+ * exit() (the reference's Error(), format.cpp:6-10, does -- the C++ shim in jampack_amd/csrc/shim maps a
+ * non-zero status back to Error() to stay drop-in).
+ *
+ * Two families:
+ *   host-buffer entry points  jpk_*      -- what the reference's call sites would bind (buffers owned by the
+ *                                           caller exactly like `Buffer{block,size}`, format.hpp:36-40); data is
+ *                                           staged over PCIe on a per-thread context (re-entrant: jampack.cpp:215,
+ *                                           313 call these from OpenMP threads, one Jampack instance each).
+ *   device-buffer entry points jpk_dev_*  -- same operations on HBM-resident buffers with an explicit context and
+ *                                           stream (used by the fused block pipeline, bench.py and the tests).
+ *
+ * There is no CPU fallback: without a usable gfx950 device every call returns JPK_E_NODEVICE.
+ */
+#ifndef JAMPACK_ABI_H
+#define JAMPACK_ABI_H
+
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define JPK_API __attribute__((visibility("default")))
+#else
+#define JPK_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JPK_BWT_UNITS 120                 /* format.hpp:26  BWT_UNITS */
+#define JPK_TRAILER_BYTES (JPK_BWT_UNITS * 4)
+#define JPK_ANS_CHUNK (1 << 20)           /* ans.hpp:21     StackSize */
+
+typedef enum jpk_status {
+    JPK_OK = 0,
+    JPK_E_ARG = -1,        /* null pointer / negative size */
+    JPK_E_CAPACITY = -2,   /* output buffer too small (the reference would overflow) */
+    JPK_E_CORRUPT = -3,    /* malformed stream (reference: Error("...") at ans.cpp:92, 298; rle.cpp:72; rank.cpp:107) */
+    JPK_E_DEVICE = -4,     /* HIP runtime error */
+    JPK_E_ALLOC = -5,      /* device/host allocation failed */
+    JPK_E_NODEVICE = -6    /* no gfx950 device visible */
+} jpk_status;
+
+typedef struct jpk_ctx jpk_ctx;
+
+/* per-call statistics of the last operation on a context (for bench.py / DESIGN.md accounting) */
+typedef struct jpk_stats {
+    int32_t sa_rounds;            /* prefix-doubling rounds of the last forward BWT */
+    int32_t reserved0;
+    int64_t sa_sorted_elems;      /* sum over rounds of active suffixes that went through a sort */
+    int64_t inv_splitters;        /* walkers used by the last inverse BWT */
+    int64_t inv_overflow_slots;   /* sub-lists that exceeded one scratch slot */
+    int64_t workspace_bytes;      /* HBM arena currently held by the context */
+    int64_t ans_chunks;           /* 1 MiB chunks in the last entropy call */
+    int64_t ans_rle_symbols;      /* RLE0 symbols in the last entropy call */
+} jpk_stats;
+
+/* ---- contexts ------------------------------------------------------------------------------------------ */
+/* stream: a hipStream_t to launch on (NULL = the context creates its own non-blocking stream).
+ * Replaces the reference's per-call cudaMalloc/cudaMemcpy/cudaFree staging (bwt.cpp:189-239). */
+JPK_API int jpk_ctx_create(jpk_ctx **out, int device, void *hip_stream);
+JPK_API void jpk_ctx_destroy(jpk_ctx *ctx);
+JPK_API int jpk_ctx_stats(jpk_ctx *ctx, jpk_stats *out);
+/* pre-size the HBM arena for blocks up to max_block_bytes (otherwise it grows on demand) */
+JPK_API int jpk_ctx_reserve(jpk_ctx *ctx, int64_t max_block_bytes);
+JPK_API int jpk_device_count(void);
+JPK_API const char *jpk_strerror(int status);
+JPK_API const char *jpk_version(void);
+
+/* ---- host-buffer entry points (drop-in boundary) ------------------------------------------------------- */
+/* BlockSort::Bwt::ForwardBwt(Buffer,Buffer)            bwt.hpp:15, bwt.cpp:22-65.   *out_len = in_len + 480. */
+JPK_API int jpk_bwt_forward(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len);
+/* BlockSort::Bwt::InverseBwt(Buffer,Buffer,Options)    bwt.hpp:16, bwt.cpp:72-282.  threads/use_gpu mirror
+ * Options.Threads / Options.Gpu (format.hpp:46-54); they do not change the bytes and are accepted for ABI fidelity. */
+JPK_API int jpk_bwt_inverse(const uint8_t *in, int32_t in_len_with_trailer, uint8_t *out, int32_t out_cap, int32_t *out_len,
+                    int32_t threads, int32_t use_gpu);
+/* Ans::Encode(Buffer,Buffer,Options)                   ans.hpp:32, ans.cpp:113-234. The reference clobbers its
+ * input (rank.cpp:88); this implementation leaves it intact but the contract still allows clobbering. */
+JPK_API int jpk_ans_encode(uint8_t *in_clobbered, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len);
+/* Ans::Decode(Buffer,Buffer,Options)                   ans.hpp:33, ans.cpp:236-270 */
+JPK_API int jpk_ans_decode(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len, int32_t threads);
+/* Postcoder::Encode / Decode                           rank.hpp:12-13, rank.cpp:45-151 (in place) */
+JPK_API int jpk_rank_encode(uint8_t *t, int32_t *freq256, int32_t len);
+JPK_API int jpk_rank_decode(uint8_t *ranks, const int32_t *freq256, int32_t len);
+/* fused Jampack::Comp()/Decomp() tail: ForwardBwt -> Ans::Encode / Ans::Decode -> InverseBwt with the BWT
+ * image kept in HBM between the two stages (jampack.cpp:40-41, 49-50). */
+JPK_API int jpk_block_compress(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len);
+JPK_API int jpk_block_decompress(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len);
+
+/* ---- device-buffer entry points (all pointers except ctx/out_len are HBM addresses on ctx's device) ---- */
+JPK_API int jpk_dev_bwt_forward(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
+JPK_API int jpk_dev_bwt_inverse(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len_with_trailer, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
+JPK_API int jpk_dev_ans_encode(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
+JPK_API int jpk_dev_ans_decode(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
+JPK_API int jpk_dev_rank_encode(jpk_ctx *ctx, uint8_t *d_t, int32_t *d_freq256, int32_t len);
+JPK_API int jpk_dev_rank_decode(jpk_ctx *ctx, uint8_t *d_ranks, const int32_t *d_freq256, int32_t len);
+JPK_API int jpk_dev_block_compress(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
+JPK_API int jpk_dev_block_decompress(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
+
+/* ---- kernel-level probes used by tests/ (device buffers) ------------------------------------------------ */
+/* suffix array of d_t[0..n) into d_sa (int32[n]) -- the divsufsort() replacement, divsufsort.cpp:1721 */
+JPK_API int jpk_dev_suffix_array(jpk_ctx *ctx, const uint8_t *d_t, int32_t n, int32_t *d_sa);
+/* stable LSD radix sort of (u64 key, u32 value) pairs on bits [bit_lo, bit_hi) */
+JPK_API int jpk_dev_sort_pairs_u64(jpk_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int32_t n, int32_t bit_lo, int32_t bit_hi);
+/* exclusive prefix sum of uint32[n] in place; returns the total in *total */
+JPK_API int jpk_dev_exclusive_scan_u32(jpk_ctx *ctx, uint32_t *d_data, int32_t n, uint32_t *total);
+/* entropy sub-stages of one chunk: rank array -> RLE0 symbols; symbols -> packed (low | freq<<16) pairs */
+JPK_API int jpk_dev_rle_encode(jpk_ctx *ctx, const uint8_t *d_ranks, int32_t len, uint16_t *d_rle, int32_t *rlen);
+JPK_API int jpk_dev_model_pairs(jpk_ctx *ctx, const uint16_t *d_rle, int32_t rlen, uint32_t *d_pairs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JAMPACK_ABI_H */

@@ -1,0 +1,8 @@
+"""jampack_amd -- MI355X (gfx950) implementation of Jampack's block hot path behind the reference's own
+bwt.hpp / ans.hpp / rank.hpp interface.  The compute path is libjampack_amd.so (hand-written HIP kernels);
+importing this package loads it and fails loudly if it has not been built."""
+from . import corpus  # noqa: F401
+from ._lib import ABI_SYMBOLS, CHUNK, LIB_PATH, TRAILER, JampackError, lib  # noqa: F401
+from .api import Ans, Bwt, Context, Postcoder, ans_capacity, block_compress, block_decompress  # noqa: F401
+
+lib()  # no lazy fallback: the HIP extension must be present

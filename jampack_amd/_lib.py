@@ -1,0 +1,86 @@
+"""ctypes loader for libjampack_amd.so (HIP kernels + C ABI, include/jampack_abi.h).
+
+There is no CPU fallback: if the shared library is missing the import fails loudly, and if no gfx950 device is
+visible every call raises JampackError(JPK_E_NODEVICE).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libjampack_amd.so")
+
+TRAILER = 480
+CHUNK = 1 << 20
+
+JPK_OK, JPK_E_ARG, JPK_E_CAPACITY, JPK_E_CORRUPT, JPK_E_DEVICE, JPK_E_ALLOC, JPK_E_NODEVICE = 0, -1, -2, -3, -4, -5, -6
+
+
+class JampackError(RuntimeError):
+    def __init__(self, status: int, what: str = ""):
+        self.status = status
+        msg = lib().jpk_strerror(status).decode() if _lib is not None else str(status)
+        super().__init__(f"{what}: {msg} ({status})" if what else f"{msg} ({status})")
+
+
+class Stats(C.Structure):
+    _fields_ = [("sa_rounds", C.c_int32), ("reserved0", C.c_int32), ("sa_sorted_elems", C.c_int64),
+                ("inv_splitters", C.c_int64), ("inv_overflow_slots", C.c_int64), ("workspace_bytes", C.c_int64),
+                ("ans_chunks", C.c_int64), ("ans_rle_symbols", C.c_int64)]
+
+
+_lib = None
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_vp = C.c_void_p
+
+_SIGS = {
+    "jpk_ctx_create": (C.c_int, [C.POINTER(_vp), C.c_int, _vp]),
+    "jpk_ctx_destroy": (None, [_vp]),
+    "jpk_ctx_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "jpk_ctx_reserve": (C.c_int, [_vp, C.c_int64]),
+    "jpk_device_count": (C.c_int, []),
+    "jpk_strerror": (C.c_char_p, [C.c_int]),
+    "jpk_version": (C.c_char_p, []),
+    "jpk_bwt_forward": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_bwt_inverse": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p, C.c_int32, C.c_int32]),
+    "jpk_ans_encode": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_ans_decode": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p, C.c_int32]),
+    "jpk_rank_encode": (C.c_int, [_vp, _vp, C.c_int32]),
+    "jpk_rank_decode": (C.c_int, [_vp, _vp, C.c_int32]),
+    "jpk_block_compress": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_block_decompress": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_dev_bwt_forward": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_dev_bwt_inverse": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_dev_ans_encode": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_dev_ans_decode": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_dev_rank_encode": (C.c_int, [_vp, _vp, _vp, C.c_int32]),
+    "jpk_dev_rank_decode": (C.c_int, [_vp, _vp, _vp, C.c_int32]),
+    "jpk_dev_block_compress": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_dev_block_decompress": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_dev_suffix_array": (C.c_int, [_vp, _vp, C.c_int32, _vp]),
+    "jpk_dev_sort_pairs_u64": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32]),
+    "jpk_dev_exclusive_scan_u32": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(C.c_uint32)]),
+    "jpk_dev_rle_encode": (C.c_int, [_vp, _vp, C.c_int32, _vp, _i32p]),
+    "jpk_dev_model_pairs": (C.c_int, [_vp, _vp, C.c_int32, _vp]),
+}
+
+ABI_SYMBOLS = tuple(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+                "or make -C jampack_amd/csrc). jampack_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)          # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib

@@ -1,0 +1,192 @@
+"""Python mirror of the reference's operator interface for the block hot path, on top of the C ABI.
+
+Reference interface mirrored (same names and argument meaning; errors raise JampackError instead of exit(-1)):
+  BlockSort::Bwt::ForwardBwt / InverseBwt   bwt.hpp:13-18
+  Ans::Encode / Ans::Decode                 ans.hpp:32-33
+  Postcoder::Encode / Decode                rank.hpp:12-13
+Host-buffer calls take/return numpy uint8 arrays; `Context` exposes the device-buffer entry points for data that
+already lives in HBM (torch CUDA tensors or raw device pointers).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._lib import CHUNK, TRAILER, JampackError, Stats, lib
+
+
+def _np_u8(a) -> np.ndarray:
+    return np.ascontiguousarray(np.frombuffer(a, dtype=np.uint8) if isinstance(a, (bytes, bytearray, memoryview)) else a, dtype=np.uint8)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data if a.size else None
+
+
+def _chk(rc: int, what: str):
+    if rc != 0:
+        raise JampackError(rc, what)
+
+
+def ans_capacity(n: int) -> int:
+    """generous output bound for Ans::Encode of n bytes (the reference gives 1.05 x BlockSize, jampack.cpp:74)"""
+    return int(n * 1.25) + 4096 + 1400 * (n // CHUNK + 1)
+
+
+class Bwt:
+    """BlockSort::Bwt (bwt.hpp:13-18)."""
+
+    def ForwardBwt(self, block, out: np.ndarray | None = None) -> np.ndarray:
+        t = _np_u8(block)
+        if out is None:
+            out = np.zeros(len(t) + TRAILER, dtype=np.uint8)
+        n = C.c_int32(0)
+        _chk(lib().jpk_bwt_forward(_ptr(t), len(t), out.ctypes.data, len(out), C.byref(n)), "ForwardBwt")
+        return out[: n.value]
+
+    def InverseBwt(self, bwt, threads: int = 1, gpu: bool = True) -> np.ndarray:
+        b = _np_u8(bwt)
+        out = np.zeros(max(len(b), 1), dtype=np.uint8)
+        n = C.c_int32(0)
+        _chk(lib().jpk_bwt_inverse(_ptr(b), len(b), out.ctypes.data, len(out), C.byref(n), threads, int(gpu)), "InverseBwt")
+        return out[: n.value]
+
+
+class Ans:
+    """Ans (ans.hpp:15-45)."""
+
+    def Encode(self, data, cap: int | None = None) -> np.ndarray:
+        x = np.array(_np_u8(data), copy=True)       # the ABI may clobber its input like the reference (rank.cpp:88)
+        cap = ans_capacity(len(x)) if cap is None else cap
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        n = C.c_int32(0)
+        _chk(lib().jpk_ans_encode(_ptr(x), len(x), out.ctypes.data, cap, C.byref(n)), "Ans::Encode")
+        return out[: n.value]
+
+    def Decode(self, data, cap: int, threads: int = 1) -> np.ndarray:
+        c = _np_u8(data)
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        n = C.c_int32(0)
+        _chk(lib().jpk_ans_decode(_ptr(c), len(c), out.ctypes.data, cap, C.byref(n), threads), "Ans::Decode")
+        return out[: n.value]
+
+
+class Postcoder:
+    """Postcoder (rank.hpp:9-16)."""
+
+    def Encode(self, t):
+        r = np.array(_np_u8(t), copy=True)
+        f = np.zeros(256, dtype=np.int32)
+        _chk(lib().jpk_rank_encode(_ptr(r), f.ctypes.data, len(r)), "Postcoder::Encode")
+        return r, f
+
+    def Decode(self, ranks, freq) -> np.ndarray:
+        r = np.array(_np_u8(ranks), copy=True)
+        f = np.ascontiguousarray(freq, dtype=np.int32)
+        _chk(lib().jpk_rank_decode(_ptr(r), f.ctypes.data, len(r)), "Postcoder::Decode")
+        return r
+
+
+def block_compress(block, cap: int | None = None) -> np.ndarray:
+    """ForwardBwt + Ans::Encode (jampack.cpp:40-41) with the BWT image kept in HBM."""
+    t = _np_u8(block)
+    cap = ans_capacity(len(t) + TRAILER) if cap is None else cap
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = C.c_int32(0)
+    _chk(lib().jpk_block_compress(_ptr(t), len(t), out.ctypes.data, cap, C.byref(n)), "block_compress")
+    return out[: n.value]
+
+
+def block_decompress(comp, cap: int) -> np.ndarray:
+    """Ans::Decode + InverseBwt (jampack.cpp:49-50)."""
+    c = _np_u8(comp)
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = C.c_int32(0)
+    _chk(lib().jpk_block_decompress(_ptr(c), len(c), out.ctypes.data, cap, C.byref(n)), "block_decompress")
+    return out[: n.value]
+
+
+def _dptr(x):
+    """device pointer of a torch CUDA tensor or a raw int"""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    return x.data_ptr() if x.numel() else None
+
+
+class Context:
+    """jpk_ctx: one HBM arena + stream per context.  `stream` is a raw hipStream_t (e.g.
+    torch.cuda.current_stream().cuda_stream) or None for a private stream."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = C.c_void_p()
+        _chk(lib().jpk_ctx_create(C.byref(self._h), device, stream), "jpk_ctx_create")
+
+    def close(self):
+        if self._h:
+            lib().jpk_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reserve(self, max_block_bytes: int):
+        _chk(lib().jpk_ctx_reserve(self._h, max_block_bytes), "jpk_ctx_reserve")
+
+    def stats(self) -> Stats:
+        s = Stats()
+        _chk(lib().jpk_ctx_stats(self._h, C.byref(s)), "jpk_ctx_stats")
+        return s
+
+    def _io(self, fn, what, d_in, in_len, d_out, out_cap) -> int:
+        n = C.c_int32(0)
+        _chk(fn(self._h, _dptr(d_in), in_len, _dptr(d_out), out_cap, C.byref(n)), what)
+        return n.value
+
+    def bwt_forward(self, d_in, in_len, d_out, out_cap) -> int:
+        return self._io(lib().jpk_dev_bwt_forward, "jpk_dev_bwt_forward", d_in, in_len, d_out, out_cap)
+
+    def bwt_inverse(self, d_in, in_len, d_out, out_cap) -> int:
+        return self._io(lib().jpk_dev_bwt_inverse, "jpk_dev_bwt_inverse", d_in, in_len, d_out, out_cap)
+
+    def ans_encode(self, d_in, in_len, d_out, out_cap) -> int:
+        return self._io(lib().jpk_dev_ans_encode, "jpk_dev_ans_encode", d_in, in_len, d_out, out_cap)
+
+    def ans_decode(self, d_in, in_len, d_out, out_cap) -> int:
+        return self._io(lib().jpk_dev_ans_decode, "jpk_dev_ans_decode", d_in, in_len, d_out, out_cap)
+
+    def block_compress(self, d_in, in_len, d_out, out_cap) -> int:
+        return self._io(lib().jpk_dev_block_compress, "jpk_dev_block_compress", d_in, in_len, d_out, out_cap)
+
+    def block_decompress(self, d_in, in_len, d_out, out_cap) -> int:
+        return self._io(lib().jpk_dev_block_decompress, "jpk_dev_block_decompress", d_in, in_len, d_out, out_cap)
+
+    def rank_encode(self, d_t, d_freq, n):
+        _chk(lib().jpk_dev_rank_encode(self._h, _dptr(d_t), _dptr(d_freq), n), "jpk_dev_rank_encode")
+
+    def rank_decode(self, d_r, d_freq, n):
+        _chk(lib().jpk_dev_rank_decode(self._h, _dptr(d_r), _dptr(d_freq), n), "jpk_dev_rank_decode")
+
+    def suffix_array(self, d_t, n, d_sa):
+        _chk(lib().jpk_dev_suffix_array(self._h, _dptr(d_t), n, _dptr(d_sa)), "jpk_dev_suffix_array")
+
+    def sort_pairs_u64(self, d_keys, d_vals, n, bit_lo=0, bit_hi=64):
+        _chk(lib().jpk_dev_sort_pairs_u64(self._h, _dptr(d_keys), _dptr(d_vals), n, bit_lo, bit_hi), "jpk_dev_sort_pairs_u64")
+
+    def exclusive_scan_u32(self, d_data, n) -> int:
+        t = C.c_uint32(0)
+        _chk(lib().jpk_dev_exclusive_scan_u32(self._h, _dptr(d_data), n, C.byref(t)), "jpk_dev_exclusive_scan_u32")
+        return t.value
+
+    def rle_encode(self, d_ranks, n, d_rle) -> int:
+        r = C.c_int32(0)
+        _chk(lib().jpk_dev_rle_encode(self._h, _dptr(d_ranks), n, _dptr(d_rle), C.byref(r)), "jpk_dev_rle_encode")
+        return r.value
+
+    def model_pairs(self, d_rle, rlen, d_pairs):
+        _chk(lib().jpk_dev_model_pairs(self._h, _dptr(d_rle), rlen, _dptr(d_pairs)), "jpk_dev_model_pairs")

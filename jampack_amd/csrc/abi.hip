@@ -1,0 +1,394 @@
+// abi.hip -- C ABI of libjampack_amd.so (include/jampack_abi.h): contexts, HBM arena, PCIe staging for the
+// host-buffer (drop-in) entry points, and the fused block pipeline.  No CPU fallback: without a gfx950 device
+// every entry point returns JPK_E_NODEVICE.
+#include <mutex>
+
+#include "common.hpp"
+
+// ---- arena / staging ---------------------------------------------------------------------------------------
+int jpk_arena_ensure(jpk_ctx *ctx, size_t bytes)
+{
+    bytes = jpk_align(bytes + 4096, 1 << 20);
+    if (bytes <= ctx->arena_cap) return JPK_OK;
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->arena) { JPK_HIP(hipFree(ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; }
+    // grow geometrically so that a sequence of slightly larger blocks does not re-allocate every time
+    size_t want = bytes + bytes / 8;
+    hipError_t e = hipMalloc((void **)&ctx->arena, want);
+    if (e != hipSuccess) {
+        want = bytes;
+        e = hipMalloc((void **)&ctx->arena, want);
+        if (e != hipSuccess) { ctx->arena = nullptr; return JPK_E_ALLOC; }
+    }
+    ctx->arena_cap = want;
+    ctx->stats.workspace_bytes = (int64_t)want;
+    return JPK_OK;
+}
+
+static int buf_ensure(jpk_ctx *ctx, uint8_t **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return JPK_OK;
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    if (*p) { JPK_HIP(hipFree(*p)); *p = nullptr; *cap = 0; }
+    bytes = jpk_align(bytes + bytes / 16 + 4096, 1 << 16);
+    if (hipMalloc((void **)p, bytes) != hipSuccess) { *p = nullptr; return JPK_E_ALLOC; }
+    *cap = bytes;
+    return JPK_OK;
+}
+
+int jpk_stage_ensure(jpk_ctx *ctx, size_t in_bytes, size_t out_bytes)
+{
+    JPK_TRY(buf_ensure(ctx, &ctx->stage_in, &ctx->stage_in_cap, in_bytes));
+    JPK_TRY(buf_ensure(ctx, &ctx->stage_out, &ctx->stage_out_cap, out_bytes));
+    return JPK_OK;
+}
+
+int jpk_read_mail(jpk_ctx *ctx, uint32_t *dst, int words)
+{
+    JPK_HIP(hipMemcpyAsync(ctx->h_mail, ctx->d_mail, (size_t)words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(dst, ctx->h_mail, (size_t)words * 4);
+    return JPK_OK;
+}
+
+// ---- contexts ----------------------------------------------------------------------------------------------
+extern "C" int jpk_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int jpk_ctx_create(jpk_ctx **out, int device, void *hip_stream)
+{
+    if (!out) return JPK_E_ARG;
+    *out = nullptr;
+    int n = jpk_device_count();
+    if (n <= 0 || device < 0 || device >= n) return JPK_E_NODEVICE;
+    JPK_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    JPK_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("JPK_ALLOW_ANY_ARCH")) return JPK_E_NODEVICE;
+    jpk_ctx *c = new (std::nothrow) jpk_ctx();
+    if (!c) return JPK_E_ALLOC;
+    memset(&c->stats, 0, sizeof c->stats);
+    c->device = device;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return JPK_E_DEVICE; }
+        c->own_stream = true;
+    }
+    if (hipHostMalloc((void **)&c->h_mail, 256 * 4, hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&c->d_mail, 256 * 4) != hipSuccess) {
+        jpk_ctx_destroy(c);
+        return JPK_E_ALLOC;
+    }
+    *out = c;
+    return JPK_OK;
+}
+
+extern "C" void jpk_ctx_destroy(jpk_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->stage_in) (void)hipFree(c->stage_in);
+    if (c->stage_out) (void)hipFree(c->stage_out);
+    if (c->stage_res) (void)hipFree(c->stage_res);
+    if (c->d_mail) (void)hipFree(c->d_mail);
+    if (c->h_mail) (void)hipHostFree(c->h_mail);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int jpk_ctx_stats(jpk_ctx *ctx, jpk_stats *out)
+{
+    if (!ctx || !out) return JPK_E_ARG;
+    *out = ctx->stats;
+    return JPK_OK;
+}
+
+extern "C" int jpk_ctx_reserve(jpk_ctx *ctx, int64_t max_block_bytes)
+{
+    if (!ctx || max_block_bytes < 0) return JPK_E_ARG;
+    JPK_HIP(hipSetDevice(ctx->device));
+    return jpk_arena_ensure(ctx, (size_t)max_block_bytes * 56 + (64u << 20));
+}
+
+extern "C" const char *jpk_strerror(int s)
+{
+    switch (s) {
+    case JPK_OK: return "ok";
+    case JPK_E_ARG: return "invalid argument";
+    case JPK_E_CAPACITY: return "output buffer too small";
+    case JPK_E_CORRUPT: return "corrupt or misaligned stream";
+    case JPK_E_DEVICE: return "HIP runtime error";
+    case JPK_E_ALLOC: return "allocation failed";
+    case JPK_E_NODEVICE: return "no gfx950 device";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char *jpk_version(void) { return "jampack_amd 0.1 (gfx950)"; }
+
+// ---- device-buffer entry points ----------------------------------------------------------------------------
+#define JPK_ENTER(ctx)                         \
+    if (!(ctx)) return JPK_E_ARG;              \
+    JPK_HIP(hipSetDevice((ctx)->device))
+
+extern "C" int jpk_dev_bwt_forward(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
+{
+    JPK_ENTER(ctx);
+    if (!d_out || !out_len || in_len < 0 || (in_len > 0 && !d_in)) return JPK_E_ARG;
+    if ((int64_t)in_len + JPK_TRAILER_BYTES > (int64_t)out_cap) return JPK_E_CAPACITY;
+    JPK_TRY(jpk_fwd_bwt_device(ctx, d_in, in_len, d_out));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    *out_len = in_len + JPK_TRAILER_BYTES;
+    return JPK_OK;
+}
+
+extern "C" int jpk_dev_bwt_inverse(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
+{
+    JPK_ENTER(ctx);
+    if (!d_in || !d_out || !out_len || in_len < 0) return JPK_E_ARG;
+    if (in_len < JPK_TRAILER_BYTES) return JPK_E_CORRUPT;
+    if (in_len - JPK_TRAILER_BYTES > out_cap) return JPK_E_CAPACITY;
+    JPK_TRY(jpk_inv_bwt_device(ctx, d_in, in_len, d_out));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    *out_len = in_len - JPK_TRAILER_BYTES;
+    return JPK_OK;
+}
+
+extern "C" int jpk_dev_ans_encode(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
+{
+    JPK_ENTER(ctx);
+    if (!d_out || !out_len || in_len < 0 || out_cap < 0 || (in_len > 0 && !d_in)) return JPK_E_ARG;
+    return jpk_ans_encode_device(ctx, d_in, in_len, d_out, out_cap, out_len);
+}
+
+extern "C" int jpk_dev_ans_decode(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
+{
+    JPK_ENTER(ctx);
+    if (!d_out || !out_len || in_len < 0 || out_cap < 0 || (in_len > 0 && !d_in)) return JPK_E_ARG;
+    return jpk_ans_decode_device(ctx, d_in, in_len, d_out, out_cap, out_len);
+}
+
+extern "C" int jpk_dev_rank_encode(jpk_ctx *ctx, uint8_t *d_t, int32_t *d_freq256, int32_t len)
+{
+    JPK_ENTER(ctx);
+    if (!d_freq256 || len < 0 || (len > 0 && !d_t)) return JPK_E_ARG;
+    JPK_TRY(jpk_rank_encode_device(ctx, d_t, d_freq256, len));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    return JPK_OK;
+}
+
+extern "C" int jpk_dev_rank_decode(jpk_ctx *ctx, uint8_t *d_ranks, const int32_t *d_freq256, int32_t len)
+{
+    JPK_ENTER(ctx);
+    if (!d_freq256 || len < 0 || (len > 0 && !d_ranks)) return JPK_E_ARG;
+    return jpk_rank_decode_device(ctx, d_ranks, d_freq256, len);
+}
+
+// fused tail of Jampack::Comp(): the BWT image stays in HBM (ctx->stage_out) between the stages
+extern "C" int jpk_dev_block_compress(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
+{
+    JPK_ENTER(ctx);
+    if (!d_out || !out_len || in_len < 0 || out_cap < 0 || (in_len > 0 && !d_in)) return JPK_E_ARG;
+    if ((int64_t)in_len + JPK_TRAILER_BYTES > 0x7fffffffLL) return JPK_E_ARG;
+    const size_t mid = (size_t)in_len + JPK_TRAILER_BYTES;
+    JPK_TRY(buf_ensure(ctx, &ctx->stage_out, &ctx->stage_out_cap, mid));
+    if (in_len < JPK_BWT_UNITS) JPK_HIP(hipMemsetAsync(ctx->stage_out, 0, mid, ctx->stream));   // untouched trailer: defined bytes
+    JPK_TRY(jpk_fwd_bwt_device(ctx, d_in, in_len, ctx->stage_out));
+    return jpk_ans_encode_device(ctx, ctx->stage_out, (int32_t)mid, d_out, out_cap, out_len);
+}
+
+extern "C" int jpk_dev_block_decompress(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
+{
+    JPK_ENTER(ctx);
+    if (!d_out || !out_len || in_len < 0 || out_cap < 0 || (in_len > 0 && !d_in)) return JPK_E_ARG;
+    const size_t mid_cap = (size_t)out_cap + JPK_TRAILER_BYTES;
+    JPK_TRY(buf_ensure(ctx, &ctx->stage_out, &ctx->stage_out_cap, mid_cap));
+    int32_t mid = 0;
+    JPK_TRY(jpk_ans_decode_device(ctx, d_in, in_len, ctx->stage_out, (int32_t)(mid_cap > 0x7fffffff ? 0x7fffffff : mid_cap), &mid));
+    if (mid < JPK_TRAILER_BYTES) return JPK_E_CORRUPT;
+    JPK_TRY(jpk_inv_bwt_device(ctx, ctx->stage_out, mid, d_out));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    *out_len = mid - JPK_TRAILER_BYTES;
+    return JPK_OK;
+}
+
+// ---- probes ------------------------------------------------------------------------------------------------
+extern "C" int jpk_dev_suffix_array(jpk_ctx *ctx, const uint8_t *d_t, int32_t n, int32_t *d_sa)
+{
+    JPK_ENTER(ctx);
+    if (n < 0 || (n > 0 && (!d_t || !d_sa))) return JPK_E_ARG;
+    JPK_TRY(jpk_suffix_array_device(ctx, d_t, n, d_sa));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    return JPK_OK;
+}
+
+extern "C" int jpk_dev_sort_pairs_u64(jpk_ctx *ctx, uint64_t *d_keys, uint32_t *d_vals, int32_t n, int32_t bit_lo, int32_t bit_hi)
+{
+    JPK_ENTER(ctx);
+    if (n < 0 || bit_lo < 0 || bit_hi > 64 || bit_lo > bit_hi || (n > 0 && (!d_keys || !d_vals))) return JPK_E_ARG;
+    if (n == 0) return JPK_OK;
+    Arena plan(ctx, true);
+    plan.get<uint64_t>(n); plan.get<uint32_t>(n); plan.get<uint32_t>(jpk_radix_scratch_words(n));
+    JPK_TRY(jpk_arena_ensure(ctx, plan.need));
+    Arena real(ctx, false);
+    uint64_t *ka = real.get<uint64_t>(n);
+    uint32_t *va = real.get<uint32_t>(n);
+    uint32_t *sc = real.get<uint32_t>(jpk_radix_scratch_words(n));
+    int shifts[8], ns = 0;
+    for (int s = bit_lo; s < bit_hi; s += 8) shifts[ns++] = s;
+    JPK_TRY(jpk_radix_sort_pairs_u64(ctx, d_keys, d_vals, ka, va, (size_t)n, shifts, ns, sc));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    return JPK_OK;
+}
+
+extern "C" int jpk_dev_exclusive_scan_u32(jpk_ctx *ctx, uint32_t *d_data, int32_t n, uint32_t *total)
+{
+    JPK_ENTER(ctx);
+    if (n < 0 || (n > 0 && !d_data)) return JPK_E_ARG;
+    Arena plan(ctx, true);
+    plan.get<uint32_t>(jpk_scan_scratch_words(n));
+    JPK_TRY(jpk_arena_ensure(ctx, plan.need));
+    Arena real(ctx, false);
+    uint32_t *sc = real.get<uint32_t>(jpk_scan_scratch_words(n));
+    JPK_TRY(jpk_exclusive_sum_u32(ctx, d_data, d_data, (size_t)n, sc, ctx->d_mail));
+    uint32_t t = 0;
+    JPK_TRY(jpk_read_mail(ctx, &t, 1));
+    if (total) *total = t;
+    return JPK_OK;
+}
+
+extern "C" int jpk_dev_rle_encode(jpk_ctx *ctx, const uint8_t *d_ranks, int32_t len, uint16_t *d_rle, int32_t *rlen)
+{
+    JPK_ENTER(ctx);
+    if (len < 0 || !rlen || (len > 0 && (!d_ranks || !d_rle))) return JPK_E_ARG;
+    return jpk_rle_encode_device(ctx, d_ranks, len, d_rle, rlen);
+}
+
+extern "C" int jpk_dev_model_pairs(jpk_ctx *ctx, const uint16_t *d_rle, int32_t rlen, uint32_t *d_pairs)
+{
+    JPK_ENTER(ctx);
+    if (rlen < 0 || (rlen > 0 && (!d_rle || !d_pairs))) return JPK_E_ARG;
+    return jpk_model_pairs_device(ctx, d_rle, rlen, d_pairs);
+}
+
+// ---- host-buffer (drop-in) entry points --------------------------------------------------------------------
+// One lazily created context per calling thread: re-entrant from the OpenMP block loop of jampack.cpp:215/313.
+namespace {
+struct TlsCtx {
+    jpk_ctx *ctx = nullptr;
+    int rc = JPK_OK;
+    ~TlsCtx() { if (ctx) jpk_ctx_destroy(ctx); }
+};
+thread_local TlsCtx tls;
+
+int tls_ctx(jpk_ctx **out)
+{
+    if (!tls.ctx) {
+        int dev = 0;
+        if (const char *e = getenv("JPK_DEVICE")) dev = atoi(e);
+        tls.rc = jpk_ctx_create(&tls.ctx, dev, nullptr);
+    }
+    *out = tls.ctx;
+    return tls.ctx ? JPK_OK : tls.rc;
+}
+
+typedef int (*dev_fn)(jpk_ctx *, const uint8_t *, int32_t, uint8_t *, int32_t, int32_t *);
+
+// H2D -> device entry -> D2H.  prefill_out: copy the caller's out bytes to the device first (used where the
+// reference leaves part of the output untouched).
+int staged(dev_fn fn, const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len, bool prefill_out)
+{
+    if (!out || !out_len || in_len < 0 || out_cap < 0 || (in_len > 0 && !in)) return JPK_E_ARG;
+    jpk_ctx *ctx;
+    JPK_TRY(tls_ctx(&ctx));
+    JPK_HIP(hipSetDevice(ctx->device));
+    JPK_TRY(buf_ensure(ctx, &ctx->stage_in, &ctx->stage_in_cap, (size_t)in_len + 64));
+    // the fused entry points use stage_out as their intermediate, so the host-visible result gets its own buffer
+    JPK_TRY(buf_ensure(ctx, &ctx->stage_res, &ctx->stage_res_cap, (size_t)out_cap + 64));
+    uint8_t *d_res = ctx->stage_res;
+    if (in_len) JPK_HIP(hipMemcpyAsync(ctx->stage_in, in, (size_t)in_len, hipMemcpyHostToDevice, ctx->stream));
+    if (prefill_out && out_cap) JPK_HIP(hipMemcpyAsync(d_res, out, (size_t)out_cap, hipMemcpyHostToDevice, ctx->stream));
+    int32_t n = 0;
+    JPK_TRY(fn(ctx, ctx->stage_in, in_len, d_res, out_cap, &n));
+    if (n > 0) JPK_HIP(hipMemcpyAsync(out, d_res, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    *out_len = n;
+    return JPK_OK;
+}
+}  // namespace
+
+extern "C" int jpk_bwt_forward(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len)
+{
+    if (in_len >= 0 && (int64_t)in_len + JPK_TRAILER_BYTES > (int64_t)out_cap) return JPK_E_CAPACITY;
+    // a block shorter than 120 bytes leaves the trailer untouched (bwt.cpp:35): round-trip the caller's bytes
+    const bool keep = in_len >= 0 && in_len < JPK_BWT_UNITS;
+    return staged(jpk_dev_bwt_forward, in, in_len, out, keep ? in_len + JPK_TRAILER_BYTES : out_cap, out_len, keep);
+}
+
+extern "C" int jpk_bwt_inverse(const uint8_t *in, int32_t in_len_with_trailer, uint8_t *out, int32_t out_cap, int32_t *out_len,
+                               int32_t threads, int32_t use_gpu)
+{
+    (void)threads; (void)use_gpu;      // Options.Threads / Options.Gpu do not change the bytes (bwt.cpp:92-132)
+    return staged(jpk_dev_bwt_inverse, in, in_len_with_trailer, out, out_cap, out_len, false);
+}
+
+extern "C" int jpk_ans_encode(uint8_t *in_clobbered, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len)
+{
+    return staged(jpk_dev_ans_encode, in_clobbered, in_len, out, out_cap, out_len, false);
+}
+
+extern "C" int jpk_ans_decode(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len, int32_t threads)
+{
+    (void)threads;
+    return staged(jpk_dev_ans_decode, in, in_len, out, out_cap, out_len, false);
+}
+
+extern "C" int jpk_block_compress(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len)
+{
+    return staged(jpk_dev_block_compress, in, in_len, out, out_cap, out_len, false);
+}
+
+extern "C" int jpk_block_decompress(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len)
+{
+    return staged(jpk_dev_block_decompress, in, in_len, out, out_cap, out_len, false);
+}
+
+extern "C" int jpk_rank_encode(uint8_t *t, int32_t *freq256, int32_t len)
+{
+    if (!freq256 || len < 0 || (len > 0 && !t)) return JPK_E_ARG;
+    jpk_ctx *ctx;
+    JPK_TRY(tls_ctx(&ctx));
+    JPK_HIP(hipSetDevice(ctx->device));
+    JPK_TRY(buf_ensure(ctx, &ctx->stage_in, &ctx->stage_in_cap, (size_t)len + 2048));
+    uint8_t *d_t = ctx->stage_in + 1024;
+    int32_t *d_f = (int32_t *)ctx->stage_in;
+    if (len) JPK_HIP(hipMemcpyAsync(d_t, t, (size_t)len, hipMemcpyHostToDevice, ctx->stream));
+    JPK_TRY(jpk_rank_encode_device(ctx, d_t, d_f, len));
+    if (len) JPK_HIP(hipMemcpyAsync(t, d_t, (size_t)len, hipMemcpyDeviceToHost, ctx->stream));
+    JPK_HIP(hipMemcpyAsync(freq256, d_f, 1024, hipMemcpyDeviceToHost, ctx->stream));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    return JPK_OK;
+}
+
+extern "C" int jpk_rank_decode(uint8_t *ranks, const int32_t *freq256, int32_t len)
+{
+    if (!freq256 || len < 0 || (len > 0 && !ranks)) return JPK_E_ARG;
+    jpk_ctx *ctx;
+    JPK_TRY(tls_ctx(&ctx));
+    JPK_HIP(hipSetDevice(ctx->device));
+    JPK_TRY(buf_ensure(ctx, &ctx->stage_in, &ctx->stage_in_cap, (size_t)len + 2048));
+    uint8_t *d_t = ctx->stage_in + 1024;
+    int32_t *d_f = (int32_t *)ctx->stage_in;
+    if (len) JPK_HIP(hipMemcpyAsync(d_t, ranks, (size_t)len, hipMemcpyHostToDevice, ctx->stream));
+    JPK_HIP(hipMemcpyAsync(d_f, freq256, 1024, hipMemcpyHostToDevice, ctx->stream));
+    JPK_TRY(jpk_rank_decode_device(ctx, d_t, d_f, len));
+    if (len) JPK_HIP(hipMemcpyAsync(ranks, d_t, (size_t)len, hipMemcpyDeviceToHost, ctx->stream));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    return JPK_OK;
+}

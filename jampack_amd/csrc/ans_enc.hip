@@ -1,0 +1,834 @@
+// ans_enc.hip -- Ans::Encode (ans.cpp:113-234) on gfx950: per 1 MiB chunk
+//   sorted-rank coding (rank.cpp:45-90) -> RLE0 (rle.cpp:22-47) -> exponent/mantissa models (model.cpp) ->
+//   4-way interleaved byte rANS (rans_byte.hpp:62-110) -> LEB128 header (ans.cpp:272-285).
+//
+// Parallel restructuring (bytes identical to the reference):
+//   rank coding   MTF rank of byte i = #symbols whose last occurrence is later than the previous occurrence of
+//                 T[i]; last-occurrence tables are carried across 4 KiB tiles by a per-symbol max-scan, so every
+//                 tile is an independent wave-sequential pass (lanes hold the 256 time stamps, v_cmp -> popcount);
+//                 the bucket scatter uses per-tile per-symbol prefix counts.
+//   RLE0          run heads found per tile, run lengths through a per-chunk "zeros that follow the tile" table,
+//                 output offsets by scans.
+//   models        QuasiModel tables only change at fixed per-class symbol counts -> built in parallel from
+//                 per-interval histograms; the AdaptiveModel CDF entries are independent scalar recurrences.
+//   rANS          pair j lives in state lane j mod 4 -> four independent sequential chains per chunk that record
+//                 (bytes, count) per step; byte positions are a prefix sum; payload scattered afterwards.
+#include "ans_common.hpp"
+#include "common.hpp"
+
+using namespace jpk;
+
+namespace {
+
+constexpr int TB = 256;
+
+struct EncDims {
+    uint32_t len;         // total bytes
+    uint32_t chunk;       // chunk size (ANS_CHUNK, or len for the stand-alone Postcoder entry)
+    uint32_t nch;         // chunks
+    uint32_t tpc;         // tiles per chunk
+};
+__device__ __forceinline__ uint32_t chunk_len(const EncDims &d, uint32_t c)
+{
+    uint64_t beg = (uint64_t)c * d.chunk;
+    uint64_t left = d.len - beg;
+    return left < d.chunk ? (uint32_t)left : d.chunk;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rank coding
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TB) void k_enc_hist(const uint8_t *__restrict__ in, EncDims d, uint32_t *__restrict__ tilecnt,
+                                                int32_t *__restrict__ lastpos)
+{
+    const uint32_t c = blockIdx.y, t = blockIdx.x;
+    const uint32_t clen = chunk_len(d, c), ts = t * ATILE;
+    if (ts >= clen) return;
+    __shared__ uint32_t h[256];
+    __shared__ int32_t lp[256];
+    h[threadIdx.x] = 0;
+    lp[threadIdx.x] = -1;
+    __syncthreads();
+    const uint8_t *src = in + (size_t)c * d.chunk;
+#pragma unroll 4
+    for (int it = 0; it < ATILE / TB; it++) {
+        uint32_t i = ts + it * TB + threadIdx.x;
+        if (i < clen) {
+            uint32_t s = src[i];
+            atomicAdd(&h[s], 1u);
+            atomicMax(&lp[s], (int32_t)i);
+        }
+    }
+    __syncthreads();
+    size_t o = ((size_t)c * d.tpc + t) * 256 + threadIdx.x;
+    tilecnt[o] = h[threadIdx.x];
+    lastpos[o] = lp[threadIdx.x];
+}
+
+// per chunk: Freq[], per-tile prefix counts, carried last-occurrence table, bucket starts in the order of
+// GenerateSortedMap (rank.cpp:15-39: descending frequency, ties -> smaller symbol first)
+__global__ __launch_bounds__(256) void k_enc_prep(EncDims d, uint32_t *__restrict__ tilecnt, int32_t *__restrict__ lastpos,
+                                                 int32_t *__restrict__ freq, uint32_t *__restrict__ bstart)
+{
+    const uint32_t c = blockIdx.x, s = threadIdx.x;
+    const uint32_t clen = chunk_len(d, c);
+    const uint32_t nt = (clen + ATILE - 1) / ATILE;
+    uint32_t f = 0;
+    int32_t p = -1;
+    for (uint32_t t = 0; t < nt; t++) {
+        size_t o = ((size_t)c * d.tpc + t) * 256 + s;
+        uint32_t n = tilecnt[o];
+        tilecnt[o] = f;
+        f += n;
+        int32_t l = lastpos[o];
+        lastpos[o] = p;
+        p = l > p ? l : p;
+    }
+    __shared__ uint32_t sf[256];
+    sf[s] = f;
+    freq[(size_t)c * 256 + s] = (int32_t)f;
+    __syncthreads();
+    uint32_t b = 0;
+    for (uint32_t k = 0; k < 256; k++) {
+        uint32_t fk = sf[k];
+        if (fk > f || (fk == f && k < s)) b += fk;
+    }
+    bstart[(size_t)c * 256 + s] = b;
+}
+
+// v_writelane has no clang builtin on this toolchain: compare-and-select on the lane id instead
+#define JPK_WL(val, lane, old) (((uint32_t)l == (uint32_t)(lane)) ? (val) : (old))
+#define JPK_SEL4(q, a0, a1, a2, a3) ((q) == 0 ? (a0) : (q) == 1 ? (a1) : (q) == 2 ? (a2) : (a3))
+
+// one wave per tile: wave-sequential MTF by time stamps + bucket scatter (rank.cpp:69-87)
+__global__ __launch_bounds__(TB) void k_enc_mtf(const uint8_t *__restrict__ in, EncDims d, const uint32_t *__restrict__ tilebase,
+                                               const int32_t *__restrict__ prevlast, const uint32_t *__restrict__ bstart,
+                                               uint8_t *__restrict__ ranks)
+{
+    const uint32_t c = blockIdx.y;
+    const uint32_t t = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+    const uint32_t clen = chunk_len(d, c), ts = t * ATILE;
+    if (ts >= clen) return;
+    const int l = lane_id();
+    const size_t o = ((size_t)c * d.tpc + t) * 256;
+    int32_t last0 = prevlast[o + l], last1 = prevlast[o + 64 + l], last2 = prevlast[o + 128 + l], last3 = prevlast[o + 192 + l];
+    const uint32_t *bs = bstart + (size_t)c * 256;
+    uint32_t pos0 = bs[l] + tilebase[o + l], pos1 = bs[64 + l] + tilebase[o + 64 + l], pos2 = bs[128 + l] + tilebase[o + 128 + l],
+             pos3 = bs[192 + l] + tilebase[o + 192 + l];
+    const uint8_t *src = in + (size_t)c * d.chunk;
+    uint8_t *dst = ranks + (size_t)c * d.chunk;
+    uint32_t prevc = 256;
+    const uint32_t te = (ts + ATILE < clen) ? ts + ATILE : clen;
+    for (uint32_t i0 = ts; i0 < te; i0 += 64) {
+        const uint32_t nvalid = (te - i0 < 64u) ? te - i0 : 64u;
+        uint32_t b = ((uint32_t)l < nvalid) ? src[i0 + l] : 0u;
+        uint32_t mydest = 0, myrank = 0;
+        for (uint32_t k = 0; k < nvalid; k++) {
+            const uint32_t cc = __builtin_amdgcn_readlane(b, k);
+            const uint32_t q = cc >> 6, ln = cc & 63u;
+            uint32_t rank = 0;
+            if (cc != prevc) {
+                const int32_t lr = JPK_SEL4(q, last0, last1, last2, last3);
+                const int32_t own = __builtin_amdgcn_readlane(lr, ln);
+                rank = (uint32_t)__popcll(__ballot(last0 > own)) + (uint32_t)__popcll(__ballot(last1 > own)) +
+                       (uint32_t)__popcll(__ballot(last2 > own)) + (uint32_t)__popcll(__ballot(last3 > own));
+                const int32_t nv = (int32_t)(i0 + k);
+                if (q == 0) last0 = JPK_WL(nv, ln, last0);
+                else if (q == 1) last1 = JPK_WL(nv, ln, last1);
+                else if (q == 2) last2 = JPK_WL(nv, ln, last2);
+                else last3 = JPK_WL(nv, ln, last3);
+                prevc = cc;
+            }
+            const uint32_t pr = JPK_SEL4(q, pos0, pos1, pos2, pos3);
+            const uint32_t dpos = __builtin_amdgcn_readlane(pr, ln);
+            if (q == 0) pos0 = JPK_WL(dpos + 1, ln, pos0);
+            else if (q == 1) pos1 = JPK_WL(dpos + 1, ln, pos1);
+            else if (q == 2) pos2 = JPK_WL(dpos + 1, ln, pos2);
+            else pos3 = JPK_WL(dpos + 1, ln, pos3);
+            mydest = JPK_WL(dpos, k, mydest);
+            myrank = JPK_WL(rank, k, myrank);
+        }
+        if ((uint32_t)l < nvalid) dst[mydest] = (uint8_t)myrank;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RLE0 (rle.cpp:22-47)
+// ---------------------------------------------------------------------------------------------------------------
+// leading zeros of every tile of the rank array
+__global__ __launch_bounds__(TB) void k_rle_lz(const uint8_t *__restrict__ ranks, EncDims d, uint32_t *__restrict__ lz)
+{
+    const uint32_t c = blockIdx.y, t = blockIdx.x;
+    const uint32_t clen = chunk_len(d, c), ts = t * ATILE;
+    if (ts >= clen) return;
+    const uint32_t tl = (clen - ts < (uint32_t)ATILE) ? clen - ts : (uint32_t)ATILE;
+    const uint8_t *src = ranks + (size_t)c * d.chunk + ts;
+    uint32_t first = 0xFFFFFFFFu;
+    for (int k = ATILE / TB - 1; k >= 0; k--) {
+        uint32_t p = k * TB + threadIdx.x;
+        if (p < tl && src[p] != 0) first = p;
+    }
+    __shared__ uint32_t sm[TB / 64 + 1];
+    uint32_t tot;
+    block_incl_scan<OpMin>(first, sm, &tot);
+    if (threadIdx.x == 0) lz[(size_t)c * d.tpc + t] = tot < tl ? tot : tl;
+}
+
+// ext[t] = zeros that follow the end of tile t without interruption (within the chunk)
+__global__ void k_rle_ext(EncDims d, const uint32_t *__restrict__ lz, uint32_t *__restrict__ ext)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nch) return;
+    const uint32_t clen = chunk_len(d, c);
+    const uint32_t nt = (clen + ATILE - 1) / ATILE;
+    uint32_t e = 0;
+    for (int t = (int)nt - 1; t >= 0; t--) {
+        ext[(size_t)c * d.tpc + t] = e;
+        uint32_t tl = (clen - t * ATILE < (uint32_t)ATILE) ? clen - t * ATILE : (uint32_t)ATILE;
+        uint32_t z = lz[(size_t)c * d.tpc + t];
+        e = (z == tl) ? z + e : z;
+    }
+}
+
+// EMIT=false: symbols per tile -> tcount ; EMIT=true: write symbols at toff[tile]
+template <bool EMIT>
+__global__ __launch_bounds__(TB) void k_rle_tiles(const uint8_t *__restrict__ ranks, EncDims d, const uint32_t *__restrict__ ext,
+                                                 uint32_t *__restrict__ tcount, const uint32_t *__restrict__ toff, uint16_t *__restrict__ rle,
+                                                 size_t rle_stride)
+{
+    const uint32_t c = blockIdx.y, t = blockIdx.x;
+    const uint32_t clen = chunk_len(d, c), ts = t * ATILE;
+    if (ts >= clen) return;
+    const uint32_t tl = (clen - ts < (uint32_t)ATILE) ? clen - ts : (uint32_t)ATILE;
+    const uint8_t *src = ranks + (size_t)c * d.chunk + ts;
+    const uint32_t p0 = threadIdx.x * 16;
+    uint8_t v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = (p0 + k < tl) ? src[p0 + k] : (uint8_t)1;
+    uint32_t first = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 15; k >= 0; k--)
+        if (p0 + k < tl && v[k] != 0) first = p0 + k;
+    // exclusive suffix-min over threads of `first`
+    __shared__ uint32_t fz[TB];
+    __shared__ uint32_t res[TB];
+    __shared__ uint32_t sm[TB / 64 + 1];
+    fz[threadIdx.x] = first;
+    __syncthreads();
+    uint32_t rv = fz[TB - 1 - threadIdx.x];
+    uint32_t inc = block_incl_scan<OpMin>(rv, sm, nullptr);
+    res[threadIdx.x] = inc;
+    __syncthreads();
+    uint32_t after = (threadIdx.x == TB - 1) ? 0xFFFFFFFFu : res[TB - 2 - threadIdx.x];
+    if (after == 0xFFFFFFFFu) after = tl + ext[(size_t)c * d.tpc + t];
+    // next non-zero position for every zero of my segment
+    uint32_t nxt[16];
+    uint32_t nn = after;
+#pragma unroll
+    for (int k = 15; k >= 0; k--) {
+        nxt[k] = nn;
+        if (p0 + k < tl && v[k] != 0) nn = p0 + k;
+    }
+    uint32_t prev;
+    if (p0 == 0) prev = (ts == 0) ? 1u : src[-1];
+    else prev = (p0 - 1 < tl) ? src[p0 - 1] : 1u;
+    uint32_t cnt = 0;
+    uint32_t pv = prev;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (p0 + k < tl) {
+            if (v[k] != 0) cnt += 1;
+            else if (pv != 0) {
+                uint32_t L = nxt[k] - (p0 + k) + 1;
+                cnt += 31 - __clz((int)L);
+            }
+            pv = v[k];
+        }
+    }
+    uint32_t tot;
+    uint32_t incl = block_incl_scan<OpSum>(cnt, sm, &tot);
+    if (!EMIT) {
+        if (threadIdx.x == 0) tcount[(size_t)c * d.tpc + t] = tot;
+        return;
+    }
+    uint16_t *out = rle + (size_t)c * rle_stride + toff[(size_t)c * d.tpc + t] + (incl - cnt);
+    pv = prev;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (p0 + k < tl) {
+            if (v[k] != 0) *out++ = (uint16_t)(v[k] + 1);
+            else if (pv != 0) {
+                uint32_t L = nxt[k] - (p0 + k) + 1;
+                for (int b = 30 - __clz((int)L); b >= 0; b--) *out++ = (uint16_t)((L >> b) & 1u);
+            }
+            pv = v[k];
+        }
+    }
+}
+
+// serial prefix over the tiles of each chunk (<= 256 tiles in the ANS path)
+__global__ void k_tile_prefix(EncDims d, const uint32_t *__restrict__ tcount, uint32_t *__restrict__ toff, uint32_t *__restrict__ total,
+                              uint32_t unit_from_len /*1: tiles from chunk_len, 0: tiles from total_in*/, const uint32_t *__restrict__ count_in)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.nch) return;
+    const uint32_t n = unit_from_len ? chunk_len(d, c) : count_in[c];
+    const uint32_t nt = (n + ATILE - 1) / ATILE;
+    uint32_t s = 0;
+    for (uint32_t t = 0; t < nt; t++) {
+        uint32_t v = tcount[(size_t)c * d.tpc + t];
+        toff[(size_t)c * d.tpc + t] = s;
+        s += v;
+    }
+    total[c] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// models (ans.cpp:152-187)
+// ---------------------------------------------------------------------------------------------------------------
+// class histogram per tile of RLE symbols
+__global__ __launch_bounds__(TB) void k_cls_count(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
+                                                 uint32_t *__restrict__ clscnt)
+{
+    const uint32_t c = blockIdx.y, t = blockIdx.x;
+    const uint32_t n = rlen[c], ts = t * ATILE;
+    if (ts >= n) return;
+    __shared__ uint32_t h[8];
+    if (threadIdx.x < 8) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint16_t *src = rle + (size_t)c * rle_stride;
+    uint32_t loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int it = 0; it < ATILE / TB; it++) {
+        uint32_t i = ts + it * TB + threadIdx.x;
+        if (i < n) {
+            int e = sym_class(src[i]);
+#pragma unroll
+            for (int k = 0; k < 8; k++) loc[k] += (e == k);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint32_t s = wave_sum(loc[k]);
+        if (lane_id() == 0 && s) atomicAdd(&h[k], s);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) clscnt[((size_t)c * d.tpc + t) * 8 + threadIdx.x] = h[threadIdx.x];
+}
+
+__global__ void k_cls_prefix(EncDims d, const uint32_t *__restrict__ rlen, uint32_t *__restrict__ clscnt, uint32_t *__restrict__ clstotal)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = g >> 3, k = g & 7u;
+    if (c >= d.nch) return;
+    const uint32_t nt = (rlen[c] + ATILE - 1) / ATILE;
+    uint32_t s = 0;
+    for (uint32_t t = 0; t < nt; t++) {
+        size_t o = ((size_t)c * d.tpc + t) * 8 + k;
+        uint32_t v = clscnt[o];
+        clscnt[o] = s;
+        s += v;
+    }
+    clstotal[(size_t)c * 8 + k] = s;
+}
+
+// ordinal of every symbol inside its class (stable) + per-interval mantissa histograms of the quasi classes
+__global__ __launch_bounds__(TB) void k_cls_ord(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
+                                               const uint32_t *__restrict__ clsbase, uint32_t *__restrict__ ord, uint32_t *__restrict__ qhist)
+{
+    const uint32_t c = blockIdx.y, t = blockIdx.x;
+    const uint32_t n = rlen[c], ts = t * ATILE;
+    if (ts >= n) return;
+    constexpr int W = TB / 64, IT = ATILE / TB;
+    __shared__ uint32_t cnt[W][8];
+    if (threadIdx.x < W * 8) (&cnt[0][0])[threadIdx.x] = 0;
+    __syncthreads();
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const uint16_t *src = rle + (size_t)c * rle_stride;
+    const uint64_t lt = lanemask_lt();
+    uint32_t sy[IT], rk[IT];
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        uint32_t i = ts + w * (64 * IT) + it * 64 + l;
+        bool valid = i < n;
+        uint32_t s = valid ? src[i] : 0;
+        sy[it] = s;
+        uint32_t e = (uint32_t)sym_class(s);
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            bool bit = (e >> b) & 1u;
+            uint64_t bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        uint32_t below = (uint32_t)__popcll(m & lt);
+        uint32_t cc = valid ? cnt[w][e] : 0;
+        rk[it] = cc + below;
+        if (valid && below == 0) cnt[w][e] = cc + (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        uint32_t s = clsbase[((size_t)c * d.tpc + t) * 8 + threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < W; k++) { uint32_t v = cnt[k][threadIdx.x]; cnt[k][threadIdx.x] = s; s += v; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; it++) {
+        uint32_t i = ts + w * (64 * IT) + it * 64 + l;
+        if (i < n) {
+            uint32_t s = sy[it];
+            int e = sym_class(s);
+            uint32_t k = cnt[w][e] + rk[it];
+            ord[(size_t)c * rle_stride + i] = k;
+            if (e >= 2) {
+                int q = qinterval(k);
+                atomicAdd(&qhist[(((size_t)c * 6 + (e - 2)) * NQ + q) * QSTRIDE + (s - (uint32_t)class_base(e))], 1u);
+            }
+        }
+    }
+}
+
+// one wave per (interval, class, chunk): CDF of interval r from the histogram of interval r-1 (model.cpp:160-204)
+__global__ __launch_bounds__(64) void k_quasi_build(EncDims d, const uint32_t *__restrict__ clstotal, const uint32_t *__restrict__ qhist,
+                                                   uint32_t *__restrict__ qcdf)
+{
+    const int r = blockIdx.x, e = blockIdx.y + 2;
+    const uint32_t c = blockIdx.z;
+    const int A = class_alpha(e), l = lane_id();
+    uint32_t *cdf = qcdf + (((size_t)c * 6 + (e - 2)) * NQ + r) * QSTRIDE;
+    if (r == 0) {
+        for (int i = l; i <= A; i += 64) cdf[i] = uniform_cdf(A, i);
+        return;
+    }
+    if (clstotal[(size_t)c * 8 + e] < qbound(r)) return;   // this table is never reached
+    const uint32_t *h = qhist + (((size_t)c * 6 + (e - 2)) * NQ + (r - 1)) * QSTRIDE;
+    uint32_t F[3];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int i = l + 64 * k;
+        F[k] = (i < A) ? 16u * h[i] : 0u;
+        tot += F[k];
+    }
+    tot = wave_sum(tot);
+    int lg = 0;
+    while ((tot >> lg) + (uint32_t)A > 65536u) lg++;
+    uint32_t t2 = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int i = l + 64 * k;
+        F[k] = (i < A) ? (F[k] >> lg) + 1u : 0u;
+        t2 += F[k];
+    }
+    t2 = wave_sum(t2);
+    uint32_t t3 = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        F[k] = (65536u * F[k]) / t2;      // unsigned 32-bit, as model.cpp:183
+        t3 += F[k];
+    }
+    t3 = wave_sum(t3);
+    if (l == 0) F[0] += 65536u - t3;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int i = l + 64 * k;
+        uint32_t inc = wave_incl_sum(F[k]);
+        if (i < A) cdf[i] = carry + inc - F[k];
+        carry += __shfl(inc, 63, 64);
+    }
+    if (l == 0) cdf[A] = 65536u;
+}
+
+// AdaptiveModel recurrences: lane = (chunk, entry).  entries 0..6 = exponent model cdf[1..7] (alphabet 8),
+// 7 / 8 = mantissa models of classes 0 / 1 (alphabet 2, cdf[1]).  Sequential in time (v1).
+__global__ __launch_bounds__(64) void k_adaptive(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
+                                                uint16_t *__restrict__ explo, uint16_t *__restrict__ exphi, uint32_t *__restrict__ mantad)
+{
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t c = g >> 4, rec = g & 15u;
+    if (c >= d.nch || rec >= 9) return;
+    const uint32_t n = rlen[c];
+    const uint16_t *src = rle + (size_t)c * rle_stride;
+    uint16_t *lo = explo + (size_t)c * rle_stride;
+    uint16_t *hi = exphi + (size_t)c * rle_stride;
+    uint32_t *ma = mantad + (size_t)c * rle_stride;
+    if (rec < 7) {
+        const int i = (int)rec + 1;
+        int32_t x = (int32_t)uniform_cdf(8, i);
+        for (uint32_t t = 0; t < n; t++) {
+            const int e = sym_class(src[t]);
+            if (e == i) lo[t] = (uint16_t)x;
+            if (e + 1 == i) hi[t] = (uint16_t)(x - 1);
+            x = adapt_step(x, i, e, 8);
+        }
+    } else {
+        const int cls = (int)rec - 7;
+        int32_t x = 32768;
+        for (uint32_t t = 0; t < n; t++) {
+            const uint32_t s = src[t];
+            if (sym_class(s) == cls) {
+                const int m = (int)s - class_base(cls);
+                const uint32_t l0 = m ? (uint32_t)x : 0u, fr = m ? 65536u - (uint32_t)x : (uint32_t)x;
+                ma[t] = l0 | (fr << 16);
+                x = adapt_step(x, 1, m, 2);
+            }
+        }
+    }
+}
+
+// (low | freq << 16) pairs in coding order: pairs[2t] exponent, pairs[2t+1] mantissa
+__global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
+                                             const uint16_t *__restrict__ explo, const uint16_t *__restrict__ exphi, const uint32_t *__restrict__ mantad,
+                                             const uint32_t *__restrict__ ord, const uint32_t *__restrict__ qcdf, uint32_t *__restrict__ pairs)
+{
+    const uint32_t c = blockIdx.y;
+    const uint32_t t = blockIdx.x * TB + threadIdx.x;
+    if (t >= rlen[c]) return;
+    const size_t o = (size_t)c * rle_stride + t;
+    const uint32_t s = rle[o];
+    const int e = sym_class(s);
+    const uint32_t m = s - (uint32_t)class_base(e);
+    const uint32_t l0 = (e == 0) ? 0u : explo[o];
+    const uint32_t h0 = (e == 7) ? 65536u : (uint32_t)exphi[o] + 1u;
+    uint32_t *out = pairs + (size_t)c * 2 * rle_stride + 2 * (size_t)t;
+    out[0] = l0 | ((h0 - l0) << 16);
+    if (e < 2) out[1] = mantad[o];
+    else {
+        const int q = qinterval(ord[o]);
+        const uint32_t *cdf = qcdf + (((size_t)c * 6 + (e - 2)) * NQ + q) * QSTRIDE;
+        const uint32_t l1 = cdf[m], h1 = cdf[m + 1];
+        out[1] = l1 | ((h1 - l1) << 16);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rANS (ans.cpp:189-208)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_rans_lanes(const uint32_t *__restrict__ pairs, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
+                                                  uint16_t *__restrict__ ebytes, uint8_t *__restrict__ ecnt, uint32_t *__restrict__ fstate)
+{
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t c = g >> 2, L = g & 3u;
+    if (c >= d.nch) return;
+    const uint32_t np = 2 * rlen[c];
+    const uint32_t *pr = pairs + (size_t)c * 2 * rle_stride;
+    uint16_t *eb = ebytes + (size_t)c * 2 * rle_stride;
+    uint8_t *ec = ecnt + (size_t)c * 2 * rle_stride;
+    uint32_t x = RANS_L;
+    if (L < np) {
+        int64_t j = (int64_t)((np - 1 - L) / 4) * 4 + L;
+        for (; j >= 0; j -= 4) {
+            const uint32_t p = pr[j];
+            const uint32_t lo = p & 0xffffu, fr = p >> 16;
+            const uint32_t xmax = fr << 15;          // ((RANS_L >> 16) << 8) * freq
+            uint32_t bytes = 0, cnt = 0;
+            if (x >= xmax) {
+                bytes = x & 0xffu; x >>= 8; cnt = 1;
+                if (x >= xmax) { bytes |= (x & 0xffu) << 8; x >>= 8; cnt = 2; }
+            }
+            x = ((x / fr) << 16) + (x % fr) + lo;
+            eb[j] = (uint16_t)bytes;
+            ec[j] = (uint8_t)cnt;
+        }
+    }
+    fstate[(size_t)c * 4 + L] = x;
+}
+
+// per chunk: exclusive prefix sum of the emit counts (forward pair order) -> byte positions; csize = 16 + total
+__global__ __launch_bounds__(1024) void k_emit_scan(const uint8_t *__restrict__ ecnt, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
+                                                   uint32_t *__restrict__ epos, uint32_t *__restrict__ csize)
+{
+    const uint32_t c = blockIdx.x;
+    const uint32_t np = 2 * rlen[c];
+    const uint8_t *ec = ecnt + (size_t)c * 2 * rle_stride;
+    uint32_t *ep = epos + (size_t)c * 2 * rle_stride;
+    __shared__ uint32_t sm[1024 / 64 + 1];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < np; b0 += 1024 * 8) {
+        const uint32_t p0 = b0 + threadIdx.x * 8;
+        uint32_t v[8];
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { v[k] = (p0 + k < np) ? ec[p0 + k] : 0u; s += v[k]; }
+        uint32_t tot;
+        uint32_t inc = block_incl_scan<OpSum>(s, sm, &tot);
+        uint32_t run = carry_s + inc - s;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (p0 + k < np) ep[p0 + k] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) csize[c] = 16u + carry_s;
+}
+
+constexpr int HDR_MAX = 259 * 5 + 1;   // 1296
+
+// header bytes per chunk (ans.cpp:272-285) and the output offset of every chunk
+__global__ __launch_bounds__(1024) void k_headers(EncDims d, const int32_t *__restrict__ freq, const uint32_t *__restrict__ csize,
+                                                 const uint32_t *__restrict__ rlen, uint8_t *__restrict__ hdr, uint32_t *__restrict__ hsize,
+                                                 uint64_t *__restrict__ outoff, uint32_t *__restrict__ mail)
+{
+    for (uint32_t c = threadIdx.x; c < d.nch; c += blockDim.x) {
+        uint8_t *h = hdr + (size_t)c * HDR_MAX;
+        int p = 0;
+        for (int s = 0; s < 256; s++) p += leb_encode((uint32_t)freq[(size_t)c * 256 + s], h + p);
+        p += leb_encode(chunk_len(d, c), h + p);
+        p += leb_encode(csize[c], h + p);
+        p += leb_encode(rlen[c], h + p);
+        hsize[c] = (uint32_t)p;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t o = 0;
+        for (uint32_t c = 0; c < d.nch; c++) { outoff[c] = o; o += (uint64_t)hsize[c] + csize[c]; }
+        outoff[d.nch] = o;
+        mail[0] = (uint32_t)o;
+        mail[1] = (uint32_t)(o >> 32);
+        uint64_t rs = 0;
+        for (uint32_t c = 0; c < d.nch; c++) rs += rlen[c];
+        mail[2] = (uint32_t)rs;
+        mail[3] = (uint32_t)(rs >> 32);
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_put_headers(EncDims d, const uint8_t *__restrict__ hdr, const uint32_t *__restrict__ hsize,
+                                                   const uint64_t *__restrict__ outoff, const uint32_t *__restrict__ fstate, uint8_t *__restrict__ out)
+{
+    const uint32_t c = blockIdx.x;
+    uint8_t *o = out + outoff[c];
+    const uint32_t hs = hsize[c];
+    for (uint32_t i = threadIdx.x; i < hs; i += TB) o[i] = hdr[(size_t)c * HDR_MAX + i];
+    if (threadIdx.x < 16) {
+        // flush order R[3],R[2],R[1],R[0] downwards => forward stream R0 R1 R2 R3, little endian (ans.cpp:203-206)
+        uint32_t st = fstate[(size_t)c * 4 + (threadIdx.x >> 2)];
+        o[hs + threadIdx.x] = (uint8_t)(st >> (8 * (threadIdx.x & 3)));
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_put_payload(size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen, const uint16_t *__restrict__ ebytes,
+                                                   const uint8_t *__restrict__ ecnt, const uint32_t *__restrict__ epos, const uint32_t *__restrict__ hsize,
+                                                   const uint64_t *__restrict__ outoff, uint8_t *__restrict__ out)
+{
+    const uint32_t c = blockIdx.y;
+    const uint32_t j = blockIdx.x * TB + threadIdx.x;
+    if (j >= 2 * rlen[c]) return;
+    const size_t o = (size_t)c * 2 * rle_stride + j;
+    const uint32_t cnt = ecnt[o];
+    if (!cnt) return;
+    uint8_t *dst = out + outoff[c] + hsize[c] + 16 + epos[o];
+    const uint32_t b = ebytes[o];
+    if (cnt == 1) dst[0] = (uint8_t)b;
+    else { dst[0] = (uint8_t)(b >> 8); dst[1] = (uint8_t)b; }   // the later (higher) byte of a step sits first in the stream
+}
+
+struct EncBufs {
+    uint32_t *tilecnt; int32_t *lastpos; int32_t *freq; uint32_t *bstart; uint8_t *ranks;
+    uint32_t *lz, *ext, *tcount, *toff, *rlen;
+    uint16_t *rle;
+    uint32_t *clscnt, *clstotal, *ord, *qhist, *qcdf;
+    uint16_t *explo, *exphi; uint32_t *mantad, *pairs;
+    uint16_t *ebytes; uint8_t *ecnt; uint32_t *epos, *fstate, *csize;
+    uint8_t *hdr; uint32_t *hsize; uint64_t *outoff;
+};
+
+enum { LAY_RANK = 1, LAY_RLE = 2, LAY_MODEL = 4, LAY_RANS = 8 };
+
+void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what)
+{
+    const size_t tiles = (size_t)d.nch * d.tpc;
+    const size_t stride = d.chunk;                 // rle symbols per chunk <= chunk bytes
+    memset(&b, 0, sizeof b);
+    if (what & LAY_RANK) {
+        b.tilecnt = a.get<uint32_t>(tiles * 256);
+        b.lastpos = a.get<int32_t>(tiles * 256);
+        b.freq = a.get<int32_t>((size_t)d.nch * 256);
+        b.bstart = a.get<uint32_t>((size_t)d.nch * 256);
+        b.ranks = a.get<uint8_t>((size_t)d.nch * stride + 64);
+    }
+    if (what & LAY_RLE) {
+        b.lz = a.get<uint32_t>(tiles);
+        b.ext = a.get<uint32_t>(tiles);
+        b.tcount = a.get<uint32_t>(tiles);
+        b.toff = a.get<uint32_t>(tiles);
+        b.rlen = a.get<uint32_t>(d.nch + 1);
+        b.rle = a.get<uint16_t>((size_t)d.nch * stride + 64);
+    }
+    if (what & LAY_MODEL) {
+        b.clscnt = a.get<uint32_t>(tiles * 8);
+        b.clstotal = a.get<uint32_t>((size_t)d.nch * 8);
+        b.ord = a.get<uint32_t>((size_t)d.nch * stride);
+        b.qhist = a.get<uint32_t>((size_t)d.nch * 6 * NQ * QSTRIDE);
+        b.qcdf = a.get<uint32_t>((size_t)d.nch * 6 * NQ * QSTRIDE);
+        b.explo = a.get<uint16_t>((size_t)d.nch * stride);
+        b.exphi = a.get<uint16_t>((size_t)d.nch * stride);
+        b.mantad = a.get<uint32_t>((size_t)d.nch * stride);
+        b.pairs = a.get<uint32_t>((size_t)d.nch * stride * 2);
+    }
+    if (what & LAY_RANS) {
+        b.ebytes = a.get<uint16_t>((size_t)d.nch * stride * 2);
+        b.ecnt = a.get<uint8_t>((size_t)d.nch * stride * 2);
+        b.epos = a.get<uint32_t>((size_t)d.nch * stride * 2);
+        b.fstate = a.get<uint32_t>((size_t)d.nch * 4);
+        b.csize = a.get<uint32_t>(d.nch);
+        b.hdr = a.get<uint8_t>((size_t)d.nch * HDR_MAX);
+        b.hsize = a.get<uint32_t>(d.nch);
+        b.outoff = a.get<uint64_t>(d.nch + 1);
+    }
+}
+
+EncDims make_dims(uint32_t len, uint32_t chunk)
+{
+    EncDims d;
+    d.len = len;
+    d.chunk = chunk;
+    d.nch = (len + chunk - 1) / chunk;
+    d.tpc = (chunk + ATILE - 1) / ATILE;
+    return d;
+}
+
+int run_rank(jpk_ctx *ctx, const uint8_t *d_in, const EncDims &d, EncBufs &b)
+{
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_enc_hist, dim3(d.tpc, d.nch), dim3(TB), 0, st, d_in, d, b.tilecnt, b.lastpos);
+    hipLaunchKernelGGL(k_enc_prep, dim3(d.nch), dim3(256), 0, st, d, b.tilecnt, b.lastpos, b.freq, b.bstart);
+    hipLaunchKernelGGL(k_enc_mtf, dim3((d.tpc + 3) / 4, d.nch), dim3(TB), 0, st, d_in, d, b.tilecnt, b.lastpos, b.bstart, b.ranks);
+    JPK_HIP(hipGetLastError());
+    return JPK_OK;
+}
+
+int run_rle(jpk_ctx *ctx, const uint8_t *d_ranks, const EncDims &d, EncBufs &b)
+{
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_rle_lz, dim3(d.tpc, d.nch), dim3(TB), 0, st, d_ranks, d, b.lz);
+    hipLaunchKernelGGL(k_rle_ext, dim3(jpk_grid(d.nch, 64)), dim3(64), 0, st, d, b.lz, b.ext);
+    hipLaunchKernelGGL((k_rle_tiles<false>), dim3(d.tpc, d.nch), dim3(TB), 0, st, d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
+    hipLaunchKernelGGL(k_tile_prefix, dim3(jpk_grid(d.nch, 64)), dim3(64), 0, st, d, b.tcount, b.toff, b.rlen, 1u, (const uint32_t *)nullptr);
+    hipLaunchKernelGGL((k_rle_tiles<true>), dim3(d.tpc, d.nch), dim3(TB), 0, st, d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
+    JPK_HIP(hipGetLastError());
+    return JPK_OK;
+}
+
+int run_model(jpk_ctx *ctx, const uint16_t *d_rle, const uint32_t *d_rlen, const EncDims &d, EncBufs &b)
+{
+    hipStream_t st = ctx->stream;
+    const size_t stride = d.chunk;
+    JPK_HIP(hipMemsetAsync(b.qhist, 0, (size_t)d.nch * 6 * NQ * QSTRIDE * 4, st));
+    hipLaunchKernelGGL(k_cls_count, dim3(d.tpc, d.nch), dim3(TB), 0, st, d_rle, stride, d, d_rlen, b.clscnt);
+    hipLaunchKernelGGL(k_cls_prefix, dim3(jpk_grid((size_t)d.nch * 8, 64)), dim3(64), 0, st, d, d_rlen, b.clscnt, b.clstotal);
+    hipLaunchKernelGGL(k_cls_ord, dim3(d.tpc, d.nch), dim3(TB), 0, st, d_rle, stride, d, d_rlen, b.clscnt, b.ord, b.qhist);
+    hipLaunchKernelGGL(k_quasi_build, dim3(NQ, 6, d.nch), dim3(64), 0, st, d, b.clstotal, b.qhist, b.qcdf);
+    hipLaunchKernelGGL(k_adaptive, dim3(jpk_grid((size_t)d.nch * 16, 64)), dim3(64), 0, st, d_rle, stride, d, d_rlen, b.explo, b.exphi, b.mantad);
+    hipLaunchKernelGGL(k_pairs, dim3(jpk_grid(stride, TB), d.nch), dim3(TB), 0, st, d_rle, stride, d, d_rlen, b.explo, b.exphi, b.mantad, b.ord,
+                       b.qcdf, b.pairs);
+    JPK_HIP(hipGetLastError());
+    return JPK_OK;
+}
+
+}  // namespace
+
+int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
+{
+    *out_len = 0;
+    ctx->stats.ans_chunks = 0;
+    ctx->stats.ans_rle_symbols = 0;
+    if (len == 0) return JPK_OK;
+    hipStream_t st = ctx->stream;
+    const EncDims d = make_dims((uint32_t)len, ANS_CHUNK);
+    EncBufs b;
+    Arena plan(ctx, true);
+    enc_layout(plan, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
+    JPK_TRY(jpk_arena_ensure(ctx, plan.need));
+    Arena real(ctx, false);
+    enc_layout(real, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
+
+    JPK_TRY(run_rank(ctx, d_in, d, b));
+    JPK_TRY(run_rle(ctx, b.ranks, d, b));
+    JPK_TRY(run_model(ctx, b.rle, b.rlen, d, b));
+    const size_t stride = d.chunk;
+    hipLaunchKernelGGL(k_rans_lanes, dim3(jpk_grid((size_t)d.nch * 4, 64)), dim3(64), 0, st, b.pairs, stride, d, b.rlen, b.ebytes, b.ecnt, b.fstate);
+    hipLaunchKernelGGL(k_emit_scan, dim3(d.nch), dim3(1024), 0, st, b.ecnt, stride, d, b.rlen, b.epos, b.csize);
+    hipLaunchKernelGGL(k_headers, dim3(1), dim3(1024), 0, st, d, b.freq, b.csize, b.rlen, b.hdr, b.hsize, b.outoff, ctx->d_mail);
+    JPK_HIP(hipGetLastError());
+    uint32_t mail[4];
+    JPK_TRY(jpk_read_mail(ctx, mail, 4));
+    const uint64_t total = ((uint64_t)mail[1] << 32) | mail[0];
+    ctx->stats.ans_chunks = d.nch;
+    ctx->stats.ans_rle_symbols = (int64_t)(((uint64_t)mail[3] << 32) | mail[2]);
+    if (total > (uint64_t)out_cap) return JPK_E_CAPACITY;
+    hipLaunchKernelGGL(k_put_headers, dim3(d.nch), dim3(TB), 0, st, d, b.hdr, b.hsize, b.outoff, b.fstate, d_out);
+    hipLaunchKernelGGL(k_put_payload, dim3(jpk_grid(2 * stride, TB), d.nch), dim3(TB), 0, st, stride, d, b.rlen, b.ebytes, b.ecnt, b.epos, b.hsize,
+                       b.outoff, d_out);
+    JPK_HIP(hipGetLastError());
+    JPK_HIP(hipStreamSynchronize(st));
+    *out_len = (int32_t)total;
+    return JPK_OK;
+}
+
+// Postcoder::Encode (rank.cpp:45-90) for one buffer of any length, in place
+int jpk_rank_encode_device(jpk_ctx *ctx, uint8_t *d_t, int32_t *d_freq, int32_t len)
+{
+    if (len == 0) {
+        JPK_HIP(hipMemsetAsync(d_freq, 0, 256 * 4, ctx->stream));
+        return JPK_OK;
+    }
+    const EncDims d = make_dims((uint32_t)len, (uint32_t)len);
+    EncBufs b;
+    Arena plan(ctx, true);
+    enc_layout(plan, d, b, LAY_RANK);
+    JPK_TRY(jpk_arena_ensure(ctx, plan.need));
+    Arena real(ctx, false);
+    enc_layout(real, d, b, LAY_RANK);
+    JPK_TRY(run_rank(ctx, d_t, d, b));
+    JPK_HIP(hipMemcpyAsync(d_t, b.ranks, (size_t)len, hipMemcpyDeviceToDevice, ctx->stream));
+    JPK_HIP(hipMemcpyAsync(d_freq, b.freq, 256 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return JPK_OK;
+}
+
+// RLE::encode (rle.cpp:22-47) of one chunk
+int jpk_rle_encode_device(jpk_ctx *ctx, const uint8_t *d_ranks, int32_t len, uint16_t *d_rle, int32_t *rlen)
+{
+    *rlen = 0;
+    if (len == 0) return JPK_OK;
+    const EncDims d = make_dims((uint32_t)len, (uint32_t)len);
+    EncBufs b;
+    Arena plan(ctx, true);
+    enc_layout(plan, d, b, LAY_RLE);
+    JPK_TRY(jpk_arena_ensure(ctx, plan.need));
+    Arena real(ctx, false);
+    enc_layout(real, d, b, LAY_RLE);
+    JPK_TRY(run_rle(ctx, d_ranks, d, b));
+    JPK_HIP(hipMemcpyAsync(ctx->d_mail, b.rlen, 4, hipMemcpyDeviceToDevice, ctx->stream));
+    uint32_t n = 0;
+    JPK_TRY(jpk_read_mail(ctx, &n, 1));
+    JPK_HIP(hipMemcpyAsync(d_rle, b.rle, (size_t)n * 2, hipMemcpyDeviceToDevice, ctx->stream));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    *rlen = (int32_t)n;
+    return JPK_OK;
+}
+
+// model pass of one chunk: rle symbols -> packed pairs
+int jpk_model_pairs_device(jpk_ctx *ctx, const uint16_t *d_rle, int32_t rlen, uint32_t *d_pairs)
+{
+    if (rlen == 0) return JPK_OK;
+    const EncDims d = make_dims((uint32_t)rlen, (uint32_t)rlen);
+    EncBufs b;
+    Arena plan(ctx, true);
+    enc_layout(plan, d, b, LAY_RLE | LAY_MODEL);
+    JPK_TRY(jpk_arena_ensure(ctx, plan.need));
+    Arena real(ctx, false);
+    enc_layout(real, d, b, LAY_RLE | LAY_MODEL);
+    uint32_t n = (uint32_t)rlen;
+    JPK_HIP(hipMemcpyAsync(b.rlen, &n, 4, hipMemcpyHostToDevice, ctx->stream));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    JPK_TRY(run_model(ctx, d_rle, b.rlen, d, b));
+    JPK_HIP(hipMemcpyAsync(d_pairs, b.pairs, (size_t)rlen * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    return JPK_OK;
+}

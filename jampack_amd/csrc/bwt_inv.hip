@@ -1,0 +1,318 @@
+// bwt_inv.hip -- inverse BWT on gfx950, replacing BlockSort::Bwt::InverseBwt (bwt.cpp:72-282) and its
+// CUDAInverse<<<40,3>>> kernel (bwt.cpp:8-19), which walks only 120 chains.
+//
+// The reference builds Map[] by a stable counting sort of the BWT image and then follows
+//     p = Map[p-1];  T[i] = Bwt[p - (p >= idx)]            (idx = trailer[0])
+// from p = idx.  Two facts make this massively parallel without changing a byte of T:
+//   * T[i] is the symbol whose bucket [cum[c], cum[c+1]) contains j = p_old - 1, so the walk needs ONE random
+//     4-byte gather per output byte (nxt[j] = Map[j] - 1) and no gather from the BWT image at all;
+//   * the chain j -> nxt[j] is a single linked list over all n positions, so it can be list-ranked: ~n/64
+//     pseudo-random splitters each walk to the next splitter writing their bytes to a private scratch slot,
+//     the slots are ranked by pointer jumping, and a copy pass places every slot at its text offset.
+// Kernels: tile histograms (LDS 256 bins) -> scan -> stable scatter (wave match-any) -> walk -> rank -> copy.
+#include "common.hpp"
+#include "prims.hpp"
+
+using namespace jpk;
+
+namespace {
+
+constexpr int TB = 256;
+constexpr int WAVES = TB / 64;
+constexpr int ITEMS = 32;                  // bytes per thread in the Map-build tiles
+constexpr int TILE = TB * ITEMS;           // 8192 bytes
+constexpr int STRIDE = 64;                 // one splitter per 64 positions of j-space
+constexpr int CAP = 256;                   // scratch bytes per slot (4x the mean sub-list length)
+constexpr uint32_t NIL = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t splitter_of(uint32_t k) { return k * STRIDE + (mix32(k) & (STRIDE - 1)); }
+__device__ __forceinline__ bool is_splitter(uint32_t j) { return (j & (STRIDE - 1)) == (mix32(j / STRIDE) & (STRIDE - 1)); }
+
+// ---- Map build ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TB) void k_hist(const uint8_t *__restrict__ B, uint32_t n, uint32_t *__restrict__ tilehist, uint32_t ntiles)
+{
+    __shared__ uint32_t h[WAVES][256];
+    for (int i = threadIdx.x; i < WAVES * 256; i += TB) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const size_t base = (size_t)blockIdx.x * TILE + (size_t)w * (64 * ITEMS) + l;
+#pragma unroll 8
+    for (int it = 0; it < ITEMS; it++) {
+        size_t i = base + (size_t)it * 64;
+        if (i < n) atomicAdd(&h[w][B[i]], 1u);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < 256; d += TB)
+        tilehist[(size_t)d * ntiles + blockIdx.x] = h[0][d] + h[1][d] + h[2][d] + h[3][d];
+}
+
+// cum[c] = first F-position of symbol c (= scanned table entry of tile 0), cum[256] = n
+__global__ void k_cum(const uint32_t *__restrict__ tileoff, uint32_t ntiles, uint32_t n, uint32_t *__restrict__ cum)
+{
+    uint32_t c = threadIdx.x;
+    if (c < 256) cum[c] = tileoff[(size_t)c * ntiles];
+    if (c == 0) cum[256] = n;
+}
+
+// nxt[F-position] = (i < I ? i : i + 1) - 1     (bwt.cpp:171-174, minus one so that -1 terminates the chain)
+__global__ __launch_bounds__(TB) void k_build_nxt(const uint8_t *__restrict__ B, uint32_t n, uint32_t I, const uint32_t *__restrict__ tileoff,
+                                                 uint32_t ntiles, int32_t *__restrict__ nxt)
+{
+    __shared__ uint32_t cnt[WAVES][256];
+    __shared__ uint32_t gbase[256];
+    for (int i = threadIdx.x; i < WAVES * 256; i += TB) (&cnt[0][0])[i] = 0;
+    for (int d = threadIdx.x; d < 256; d += TB) gbase[d] = tileoff[(size_t)d * ntiles + blockIdx.x];
+    __syncthreads();
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const size_t base = (size_t)blockIdx.x * TILE + (size_t)w * (64 * ITEMS) + l;
+    const uint64_t lt = lanemask_lt();
+    uint8_t sym[ITEMS];
+    uint16_t rnk[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        size_t i = base + (size_t)it * 64;
+        bool valid = i < n;
+        uint32_t d = valid ? B[i] : 0;
+        sym[it] = (uint8_t)d;
+        uint64_t m = match_any8(d, valid);
+        uint32_t below = (uint32_t)__popcll(m & lt);
+        uint32_t c = valid ? cnt[w][d] : 0;
+        rnk[it] = (uint16_t)(c + below);
+        if (valid && below == 0) cnt[w][d] = c + (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < 256; d += TB) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < WAVES; k++) { uint32_t t = cnt[k][d]; cnt[k][d] = s; s += t; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        size_t i = base + (size_t)it * 64;
+        if (i < n) {
+            uint32_t d = sym[it];
+            size_t dst = (size_t)gbase[d] + cnt[w][d] + rnk[it];
+            uint32_t ii = (uint32_t)i;
+            nxt[dst] = (ii < I) ? (int32_t)ii - 1 : (int32_t)ii;
+        }
+    }
+}
+
+// ---- walk ----------------------------------------------------------------------------------------------
+// One lane per splitter (+ one for the chain head j0 = I-1).  Lane k walks from its splitter to the next
+// one, turning every visited j into its symbol via cum[] (LDS, with a 4096-entry coarse LUT) and writing
+// the symbols 16 bytes at a time to scratch[slot*CAP ...].  A sub-list longer than CAP continues in a
+// freshly allocated overflow slot, so every slot holds <= CAP bytes.
+constexpr int LUT = 4096;
+
+__global__ __launch_bounds__(TB) void k_walk(const int32_t *__restrict__ nxt, const uint32_t *__restrict__ cum_g, uint32_t n, uint32_t I,
+                                            uint32_t nsplit, uint32_t lut_shift, uint8_t *__restrict__ scratch,
+                                            uint32_t *__restrict__ slot_len, uint32_t *__restrict__ slot_next, uint32_t *__restrict__ ovf_counter,
+                                            uint32_t max_slots)
+{
+    __shared__ uint32_t cum[257];
+    __shared__ uint8_t lut[LUT];
+    for (int i = threadIdx.x; i < 257; i += TB) cum[i] = cum_g[i];
+    __syncthreads();
+    for (int q = threadIdx.x; q < LUT; q += TB) {
+        uint64_t pos = (uint64_t)q << lut_shift;
+        int lo = 0, hi = 256;                 // largest c with cum[c] <= pos
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if ((uint64_t)cum[mid] <= pos) lo = mid; else hi = mid;
+        }
+        lut[q] = (uint8_t)lo;
+    }
+    __syncthreads();
+
+    const uint32_t k = blockIdx.x * TB + threadIdx.x;
+    if (k > nsplit) return;
+    const uint32_t j0 = I - 1;
+    uint32_t j;
+    if (k == nsplit) j = j0;
+    else {
+        j = splitter_of(k);
+        if (j >= n || j == j0) {              // splitter outside the block, or the head (walked by lane nsplit)
+            slot_len[k] = 0;
+            slot_next[k] = NIL;
+            return;
+        }
+    }
+    uint32_t slot = k, len = 0, steps = 0;
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    uint8_t *dst = scratch + (size_t)slot * CAP;
+    for (;;) {
+        uint32_t c = lut[j >> lut_shift];
+        while (cum[c + 1] <= j) c++;
+        const uint32_t sh = (len & 3u) * 8u, wi = (len >> 2) & 3u;
+        const uint32_t cv = c << sh;
+        if (wi == 0) w0 |= cv; else if (wi == 1) w1 |= cv; else if (wi == 2) w2 |= cv; else w3 |= cv;
+        len++;
+        if ((len & 15u) == 0) {
+            *reinterpret_cast<uint4 *>(dst + len - 16) = make_uint4(w0, w1, w2, w3);
+            w0 = w1 = w2 = w3 = 0;
+        }
+        const int32_t nx = nxt[j];
+        uint32_t link = NIL;
+        bool stop = false;
+        if (nx < 0 || ++steps > n) stop = true;      // steps > n: only on a corrupt (non-injective) map
+        else if (is_splitter((uint32_t)nx)) { stop = true; link = (uint32_t)nx / STRIDE; }
+        if (stop) {
+            if (len & 15u) *reinterpret_cast<uint4 *>(dst + (len & ~15u)) = make_uint4(w0, w1, w2, w3);
+            slot_len[slot] = len;
+            slot_next[slot] = link;
+            return;
+        }
+        if (len == CAP) {                       // overflow: chain a new slot
+            uint32_t ns = nsplit + 1 + atomicAdd(ovf_counter, 1u);
+            if (ns >= max_slots) { slot_len[slot] = len; slot_next[slot] = NIL; return; }   // corrupt input guard
+            slot_len[slot] = len;
+            slot_next[slot] = ns;
+            slot = ns; len = 0;
+            dst = scratch + (size_t)slot * CAP;
+        }
+        j = (uint32_t)nx;
+    }
+}
+
+// ---- list ranking of the slots (Wyllie pointer jumping, ping-pong buffers) ----------------------------
+// dist[s] = bytes from the start of slot s to the end of the text.
+__global__ __launch_bounds__(TB) void k_rank_init(const uint32_t *__restrict__ slot_len, const uint32_t *__restrict__ slot_next, uint32_t nslots,
+                                                 uint32_t *__restrict__ dist, uint32_t *__restrict__ link)
+{
+    uint32_t s = blockIdx.x * TB + threadIdx.x;
+    if (s >= nslots) return;
+    dist[s] = slot_len[s];
+    link[s] = slot_next[s];
+}
+__global__ __launch_bounds__(TB) void k_rank_jump(const uint32_t *__restrict__ dist_in, const uint32_t *__restrict__ link_in, uint32_t nslots,
+                                                 uint32_t *__restrict__ dist_out, uint32_t *__restrict__ link_out)
+{
+    uint32_t s = blockIdx.x * TB + threadIdx.x;
+    if (s >= nslots) return;
+    uint32_t d = dist_in[s], l = link_in[s];
+    if (l != NIL) { d += dist_in[l]; l = link_in[l]; }
+    dist_out[s] = d;
+    link_out[s] = l;
+}
+
+// one wave per 4 slots (16 lanes each): T[n - dist[s] ...] = scratch[s*CAP ... + len)
+__global__ __launch_bounds__(TB) void k_copy_out(const uint8_t *__restrict__ scratch, const uint32_t *__restrict__ slot_len,
+                                                const uint32_t *__restrict__ dist, uint32_t nslots, uint32_t n, uint8_t *__restrict__ T)
+{
+    const uint32_t gid = blockIdx.x * TB + threadIdx.x;
+    const uint32_t s = gid >> 4, sub = gid & 15u;
+    if (s >= nslots) return;
+    const uint32_t len = slot_len[s];
+    if (len == 0) return;
+    const uint32_t d = dist[s];
+    if (d > n || d < len) return;              // corrupt chain; reported by the host-side check of the head slot
+    const uint8_t *src = scratch + (size_t)s * CAP;
+    uint8_t *dst = T + (n - d);
+    for (uint32_t b = sub; b < len; b += 16) dst[b] = src[b];
+}
+
+__global__ void k_inv_tail(const uint8_t *__restrict__ B, uint32_t n, uint32_t len, uint8_t *__restrict__ T)
+{
+    uint32_t t = threadIdx.x;
+    if (t < len - n) T[n + t] = B[n + t];
+}
+
+__global__ void k_head_check(const uint32_t *__restrict__ dist, uint32_t head_slot, uint32_t *__restrict__ mail)
+{
+    mail[1] = dist[head_slot];
+}
+
+struct InvBufs {
+    uint32_t *tilehist, *scan_scratch, *cum, *slot_len, *slot_next, *distA, *distB, *linkA, *linkB;
+    int32_t *nxt;
+    uint8_t *scratch;
+};
+
+void inv_layout(Arena &a, size_t n, InvBufs &b, size_t &ntiles, size_t &nsplit, size_t &max_slots)
+{
+    ntiles = (n + TILE - 1) / TILE;
+    nsplit = (n + STRIDE - 1) / STRIDE;
+    max_slots = nsplit + 1 + n / CAP + 2;
+    b.tilehist = a.get<uint32_t>(256 * ntiles);
+    b.scan_scratch = a.get<uint32_t>(jpk_scan_scratch_words(256 * ntiles));
+    b.cum = a.get<uint32_t>(260);
+    b.nxt = a.get<int32_t>(n);
+    b.slot_len = a.get<uint32_t>(max_slots);
+    b.slot_next = a.get<uint32_t>(max_slots);
+    b.distA = a.get<uint32_t>(max_slots);
+    b.distB = a.get<uint32_t>(max_slots);
+    b.linkA = a.get<uint32_t>(max_slots);
+    b.linkB = a.get<uint32_t>(max_slots);
+    b.scratch = a.get<uint8_t>(max_slots * CAP);
+}
+
+}  // namespace
+
+int jpk_inv_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trailer, uint8_t *d_out)
+{
+    hipStream_t st = ctx->stream;
+    const int32_t len = len_with_trailer - JPK_TRAILER_BYTES;
+    if (len < 0) return JPK_E_CORRUPT;
+    const int32_t rem = len % JPK_BWT_UNITS;
+    const uint32_t n = (uint32_t)(len - rem);
+    if (n == 0) {
+        if (rem > 0) JPK_HIP(hipMemcpyAsync(d_out, d_in, (size_t)rem, hipMemcpyDeviceToDevice, st));
+        return JPK_OK;
+    }
+    // trailer[0] = ISA[0] + 1 (bwt.cpp:57-61 / :134)
+    uint32_t I = 0;
+    JPK_HIP(hipMemcpyAsync(ctx->h_mail, d_in + len, 4, hipMemcpyDeviceToHost, st));
+    JPK_HIP(hipStreamSynchronize(st));
+    I = ctx->h_mail[0];
+    if (I < 1 || I > n) return JPK_E_CORRUPT;
+
+    InvBufs b;
+    size_t ntiles, nsplit, max_slots;
+    Arena plan(ctx, true);
+    inv_layout(plan, n, b, ntiles, nsplit, max_slots);
+    JPK_TRY(jpk_arena_ensure(ctx, plan.need));
+    Arena real(ctx, false);
+    inv_layout(real, n, b, ntiles, nsplit, max_slots);
+
+    hipLaunchKernelGGL(k_hist, dim3((unsigned)ntiles), dim3(TB), 0, st, d_in, n, b.tilehist, (uint32_t)ntiles);
+    JPK_TRY(jpk_exclusive_sum_u32(ctx, b.tilehist, b.tilehist, 256 * ntiles, b.scan_scratch, nullptr));
+    hipLaunchKernelGGL(k_cum, dim3(1), dim3(256), 0, st, b.tilehist, (uint32_t)ntiles, n, b.cum);
+    hipLaunchKernelGGL(k_build_nxt, dim3((unsigned)ntiles), dim3(TB), 0, st, d_in, n, I, b.tilehist, (uint32_t)ntiles, b.nxt);
+
+    JPK_HIP(hipMemsetAsync(ctx->d_mail, 0, 16, st));
+    int lut_shift = 0;
+    while (((uint64_t)(n - 1) >> lut_shift) >= LUT) lut_shift++;
+    hipLaunchKernelGGL(k_walk, dim3(jpk_grid(nsplit + 1, TB)), dim3(TB), 0, st, b.nxt, b.cum, n, I, (uint32_t)nsplit, (uint32_t)lut_shift,
+                       b.scratch, b.slot_len, b.slot_next, ctx->d_mail, (uint32_t)max_slots);
+    uint32_t novf = 0;
+    JPK_TRY(jpk_read_mail(ctx, &novf, 1));
+    size_t nslots = nsplit + 1 + novf;
+    if (nslots > max_slots) return JPK_E_CORRUPT;
+    ctx->stats.inv_splitters = (int64_t)nsplit + 1;
+    ctx->stats.inv_overflow_slots = novf;
+
+    const unsigned g_s = jpk_grid(nslots, TB);
+    hipLaunchKernelGGL(k_rank_init, dim3(g_s), dim3(TB), 0, st, b.slot_len, b.slot_next, (uint32_t)nslots, b.distA, b.linkA);
+    uint32_t *di = b.distA, *li = b.linkA, *dout = b.distB, *lo = b.linkB;
+    int rounds = jpk_bits_for((uint32_t)nslots) + 1;
+    for (int r = 0; r < rounds; r++) {
+        hipLaunchKernelGGL(k_rank_jump, dim3(g_s), dim3(TB), 0, st, di, li, (uint32_t)nslots, dout, lo);
+        uint32_t *t = di; di = dout; dout = t;
+        t = li; li = lo; lo = t;
+    }
+    hipLaunchKernelGGL(k_head_check, dim3(1), dim3(1), 0, st, di, (uint32_t)nsplit, ctx->d_mail);
+    hipLaunchKernelGGL(k_copy_out, dim3(jpk_grid(nslots * 16, TB)), dim3(TB), 0, st, b.scratch, b.slot_len, di, (uint32_t)nslots, n, d_out);
+    if (rem > 0) hipLaunchKernelGGL(k_inv_tail, dim3(1), dim3(128), 0, st, d_in, n, (uint32_t)len, d_out);
+    JPK_HIP(hipGetLastError());
+    uint32_t chk[2] = {0, 0};
+    JPK_TRY(jpk_read_mail(ctx, chk, 2));
+    if (chk[1] != n) return JPK_E_CORRUPT;      // the chain from trailer[0] must cover the whole block
+    return JPK_OK;
+}

@@ -1,0 +1,97 @@
+// common.hpp -- context, HBM arena and launch helpers shared by all translation units of libjampack_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/jampack_abi.h"
+
+#define JPK_HIP(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            if (getenv("JPK_VERBOSE"))                                                                  \
+                fprintf(stderr, "[jampack_amd] HIP error %s at %s:%d: %s\n", hipGetErrorName(_e),       \
+                        __FILE__, __LINE__, #expr);                                                     \
+            return (_e == hipErrorOutOfMemory) ? JPK_E_ALLOC : JPK_E_DEVICE;                            \
+        }                                                                                               \
+    } while (0)
+
+#define JPK_TRY(expr)                 \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != JPK_OK) return _rc; \
+    } while (0)
+
+// HBM arena: one allocation per context, bump-allocated per call, grown (free + malloc) when a bigger
+// block arrives.  Replaces the reference's five cudaMalloc/cudaFree per block (bwt.cpp:195-239).
+struct jpk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint8_t *arena = nullptr;
+    size_t arena_cap = 0;
+    size_t arena_off = 0;
+    // small pinned host mailbox for device->host scalars
+    uint32_t *h_mail = nullptr;   // 256 words pinned
+    uint32_t *d_mail = nullptr;   // 256 words device
+    // persistent staging buffers for the host-buffer entry points
+    uint8_t *stage_in = nullptr, *stage_out = nullptr, *stage_res = nullptr;
+    size_t stage_in_cap = 0, stage_out_cap = 0, stage_res_cap = 0;
+    jpk_stats stats;
+};
+
+static inline size_t jpk_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct Arena {
+    jpk_ctx *c;
+    size_t need = 0;      // planning pass accumulates here
+    bool planning;
+    Arena(jpk_ctx *ctx, bool plan) : c(ctx), planning(plan) { if (!plan) c->arena_off = 0; }
+    template <typename T> T *get(size_t count)
+    {
+        size_t bytes = jpk_align(count * sizeof(T) + 64);
+        if (planning) { need += bytes; return nullptr; }
+        T *p = (T *)(c->arena + c->arena_off);
+        c->arena_off += bytes;
+        return p;
+    }
+};
+
+int jpk_arena_ensure(jpk_ctx *ctx, size_t bytes);
+int jpk_stage_ensure(jpk_ctx *ctx, size_t in_bytes, size_t out_bytes);
+// copy `words` u32 from device mailbox offset to host (synchronises the stream)
+int jpk_read_mail(jpk_ctx *ctx, uint32_t *dst, int words);
+
+static inline unsigned jpk_grid(size_t work, unsigned per_block) { return (unsigned)((work + per_block - 1) / per_block); }
+
+static inline int jpk_bits_for(uint32_t maxval)
+{
+    int b = 0;
+    while (b < 32 && (maxval >> b)) b++;
+    return b;
+}
+
+// ---- primitives implemented in scan.hip / radix.hip -------------------------------------------------
+// scratch requirements are sized by the *_scratch_words helpers; all buffers come from the arena.
+size_t jpk_scan_scratch_words(size_t n);
+int jpk_exclusive_sum_u32(jpk_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch, uint32_t *d_total /*nullable*/);
+int jpk_inclusive_max_u32(jpk_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint32_t *scratch);
+
+size_t jpk_radix_scratch_words(size_t n);
+// LSD radix sort on bit ranges; result is left in keys/vals (alt buffers used for ping-pong)
+int jpk_radix_sort_pairs_u64(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_alt, uint32_t *vals_alt, size_t n,
+                             const int *shifts, int nshifts, uint32_t *scratch);
+
+// ---- stage drivers (device buffers) -----------------------------------------------------------------
+int jpk_fwd_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out);
+int jpk_suffix_array_device(jpk_ctx *ctx, const uint8_t *d_t, int32_t n, int32_t *d_sa);
+int jpk_inv_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trailer, uint8_t *d_out);
+int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
+int jpk_ans_decode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
+int jpk_rank_encode_device(jpk_ctx *ctx, uint8_t *d_t, int32_t *d_freq, int32_t len);
+int jpk_rank_decode_device(jpk_ctx *ctx, uint8_t *d_r, const int32_t *d_freq, int32_t len);
+int jpk_rle_encode_device(jpk_ctx *ctx, const uint8_t *d_ranks, int32_t len, uint16_t *d_rle, int32_t *rlen);
+int jpk_model_pairs_device(jpk_ctx *ctx, const uint16_t *d_rle, int32_t rlen, uint32_t *d_pairs);

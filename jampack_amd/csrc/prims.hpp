@@ -1,0 +1,98 @@
+// prims.hpp -- wave64 / workgroup primitives for gfx950 (CDNA4).  Wavefront width is hard-coded to 64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jpk {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// inclusive wave scans -----------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, WAVE);
+        if (l >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, WAVE);
+        if (l >= d) v = v > o ? v : o;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_min(uint32_t v)
+{
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, WAVE);
+        if (l >= d) v = v < o ? v : o;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
+    return v;
+}
+
+struct OpSum { static __device__ __forceinline__ uint32_t id() { return 0u; }
+               static __device__ __forceinline__ uint32_t f(uint32_t a, uint32_t b) { return a + b; }
+               static __device__ __forceinline__ uint32_t wscan(uint32_t v) { return wave_incl_sum(v); } };
+struct OpMax { static __device__ __forceinline__ uint32_t id() { return 0u; }
+               static __device__ __forceinline__ uint32_t f(uint32_t a, uint32_t b) { return a > b ? a : b; }
+               static __device__ __forceinline__ uint32_t wscan(uint32_t v) { return wave_incl_max(v); } };
+struct OpMin { static __device__ __forceinline__ uint32_t id() { return 0xFFFFFFFFu; }
+               static __device__ __forceinline__ uint32_t f(uint32_t a, uint32_t b) { return a < b ? a : b; }
+               static __device__ __forceinline__ uint32_t wscan(uint32_t v) { return wave_incl_min(v); } };
+
+// Workgroup inclusive scan of one value per thread.  `sm` holds >= blockDim/64 + 1 words.  Returns the
+// inclusive result; *block_total receives the reduction over the whole workgroup (all threads).
+template <class Op>
+__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t *sm, uint32_t *block_total)
+{
+    const int l = lane_id(), w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    uint32_t inc = Op::wscan(v);
+    __syncthreads();                       // protect sm from a previous use
+    if (l == WAVE - 1) sm[w] = inc;
+    __syncthreads();
+    if (w == 0) {
+        uint32_t t = (l < nw) ? sm[l] : Op::id();
+        uint32_t ti = Op::wscan(t);
+        if (l < nw) sm[l] = ti;            // inclusive wave totals
+    }
+    __syncthreads();
+    uint32_t prefix = (w > 0) ? sm[w - 1] : Op::id();
+    if (block_total) *block_total = sm[nw - 1];
+    return Op::f(prefix, inc);
+}
+
+// lanes of this wave whose 8-bit digit equals mine (valid lanes only)
+__device__ __forceinline__ uint64_t match_any8(uint32_t d, bool valid)
+{
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    return m;
+}
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+}  // namespace jpk

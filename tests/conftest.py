@@ -8,6 +8,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _ensure_built():
+    """the .so files are git-ignored build products: build them when a fresh checkout runs the tests"""
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "jampack_amd", "libjampack_amd.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "jampack_amd", "csrc"), "-j8"], stdout=subprocess.DEVNULL)
+    if not os.path.exists(os.path.join(ROOT, "oracle", "libjamoracle.so")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle", "ref"], stdout=subprocess.DEVNULL)
+
+
+_ensure_built()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running")

@@ -1,0 +1,118 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the committed golden vectors.  -m gpu
+
+Bit-exact is the bar for every byte: BWT image + trailer, entropy stream, decoded block.
+"""
+import numpy as np
+import pytest
+
+from golden_util import case_input, cases, sha, small
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ["text", "random", "dna", "two", "zero", "geometric", "samples16", "runs", "repeat4k", "silesia"]
+SIZES = [0, 1, 119, 120, 121, 240, 1207, 4097, 70_000, 300_000]
+
+
+def _first_diff(a, b):
+    n = min(len(a), len(b))
+    d = np.nonzero(a[:n] != b[:n])[0]
+    return f"len {len(a)} vs {len(b)}, first diff at {d[:4].tolist()} of {d.size}"
+
+
+@pytest.fixture(scope="module")
+def jam():
+    import jampack_amd
+    return jampack_amd
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_forward_bwt_equals_oracle(jam, oracle, kind):
+    for n in SIZES:
+        t = jam.corpus.make(kind, n, 21)
+        out = np.full(n + 480, 0x11, dtype=np.uint8)
+        got = jam.Bwt().ForwardBwt(t, out=out)
+        exp = oracle.bwt_forward(t, prefill=0x11)
+        assert np.array_equal(got, exp), f"{kind} n={n}: {_first_diff(got, exp)}"
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_inverse_bwt_equals_input(jam, oracle, kind):
+    for n in SIZES:
+        t = jam.corpus.make(kind, n, 22)
+        b = oracle.bwt_forward(t)
+        got = jam.Bwt().InverseBwt(b, threads=8, gpu=True)
+        assert np.array_equal(got, t), f"{kind} n={n}: {_first_diff(got, t)}"
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_rank_coding_equals_oracle(jam, oracle, kind):
+    for n in [0, 1, 2, 100, 4096, 4097, 70_000, 1 << 20]:
+        t = jam.corpus.make(kind, n, 23)
+        r, f = jam.Postcoder().Encode(t)
+        er, ef = oracle.rank_encode(t)
+        assert np.array_equal(f, ef), f"{kind} n={n}: freq differs"
+        assert np.array_equal(r, er), f"{kind} n={n}: {_first_diff(r, er)}"
+        back = jam.Postcoder().Decode(er, ef)
+        assert np.array_equal(back, t), f"{kind} n={n} decode: {_first_diff(back, t)}"
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_ans_encode_equals_oracle(jam, oracle, kind):
+    for n in [0, 1, 100, 4097, 70_000, 1 << 20, (1 << 20) + 480, 2_500_000]:
+        x = oracle.bwt_forward(jam.corpus.make(kind, n, 24)) if n else np.zeros(0, dtype=np.uint8)
+        got = jam.Ans().Encode(x)
+        exp = oracle.ans_encode(x)
+        assert np.array_equal(got, exp), f"{kind} n={n}: {_first_diff(got, exp)}"
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_ans_decode_equals_oracle(jam, oracle, kind):
+    for n in [0, 1, 100, 4097, 70_000, (1 << 20) + 480, 2_500_000]:
+        x = oracle.bwt_forward(jam.corpus.make(kind, n, 25)) if n else np.zeros(0, dtype=np.uint8)
+        enc = oracle.ans_encode(x)
+        got = jam.Ans().Decode(enc, len(x), threads=4)
+        assert np.array_equal(got, x), f"{kind} n={n}: {_first_diff(got, x)}"
+
+
+@pytest.mark.parametrize("kind", ["text", "geometric", "silesia", "zero"])
+def test_block_pipeline_equals_oracle(jam, oracle, kind):
+    for n in [0, 50, 5000, 1_300_000]:
+        t = jam.corpus.make(kind, n, 26)
+        comp = jam.block_compress(t)
+        if n >= 120:      # below 120 bytes the reference codes an uninitialised trailer (bwt.cpp:35)
+            assert np.array_equal(comp, oracle.compress_block(t)), f"{kind} n={n}"
+        back = jam.block_decompress(comp, n)
+        assert np.array_equal(back, t), f"{kind} n={n}: {_first_diff(back, t)}"
+
+
+@pytest.mark.parametrize("case", cases(), ids=lambda c: c["name"])
+def test_golden_vectors(jam, case):
+    t = case_input(case)
+    out = np.full(len(t) + 480, 0xAB, dtype=np.uint8)
+    bwt = jam.Bwt().ForwardBwt(t, out=out)
+    assert sha(bwt) == case["bwt_sha256"], "ForwardBwt differs from the reference"
+    ans = jam.Ans().Encode(bwt)
+    assert len(ans) == case["ans_len"] and sha(ans) == case["ans_sha256"], "Ans::Encode differs from the reference"
+    if case["raw"]:
+        assert np.array_equal(ans, small()[case["name"] + ".ans"])
+    dec = jam.Ans().Decode(ans, len(bwt))
+    assert sha(dec) == case["bwt_sha256"], "Ans::Decode differs"
+    back = jam.Bwt().InverseBwt(dec)
+    assert np.array_equal(back, t), "InverseBwt differs"
+    r, f = jam.Postcoder().Encode(bwt[: 1 << 20])
+    assert sha(r) == case["rank0_sha256"] and sha(f.astype("<i4")) == case["freq0_sha256"]
+
+
+def test_error_codes(jam):
+    from jampack_amd import JampackError
+    with pytest.raises(JampackError) as e:
+        jam.Ans().Encode(np.zeros(100000, dtype=np.uint8) + np.arange(100000, dtype=np.uint8), cap=64)
+    assert e.value.status == -2            # JPK_E_CAPACITY instead of the reference's buffer overflow
+    with pytest.raises(JampackError) as e:
+        jam.Ans().Decode(np.full(300, 0x80, dtype=np.uint8), 1000)
+    assert e.value.status == -3
+    bad = np.zeros(1200 + 480, dtype=np.uint8)
+    bad[1200:1204] = np.frombuffer(np.int32(5000).tobytes(), dtype=np.uint8)     # primary index out of range
+    with pytest.raises(JampackError) as e:
+        jam.Bwt().InverseBwt(bad)
+    assert e.value.status == -3
