@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- block hot path throughput on MI355X (see DESIGN.md section "Measurement").
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the compress hot path (forward BWT -> rANS encode, Jampack::Comp() tail, jampack.cpp:40-41)
+over one batch = the enwik8-like workload (100 000 000 B, BASELINE.json configs[1]) cut into 64 MiB blocks
+(67 108 864 + 32 891 136 B), inputs already resident in HBM.  For N > 1 every rank compresses its own batch
+(blocks are independent, jampack.cpp:215: weak scaling) and the compressed blocks are gathered on rank 0 with RCCL.
+value = uncompressed bytes of all ranks / max-over-ranks time, in MB/s (1e6 B/s).
+
+Extra keys on the same JSON line: `decompress` (rANS decode -> inverse BWT over the same batch), per-stage
+timings, `roofline` for the dominant kernel (HIP-event timed inside the library on the launch stream) and
+`cpu_baseline` (the real reference, oracle/_ref, on this box's host cores; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="enwik8", choices=["enwik6", "enwik8", "enwik9", "silesia"])
+    ap.add_argument("--block-mib", type=int, default=64)
+    ap.add_argument("--limit-bytes", type=int, default=0, help="truncate the workload (debug only; marks the line invalid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mib", type=int, default=24)
+    return ap.parse_args()
+
+
+def cpu_baseline(block: np.ndarray, sample_mib: int):
+    """the reference itself (oracle/_ref/libjamref.so) on the host cores, bounded sample of the same block"""
+    from oracle.pyoracle import Oracle, Ref
+    cores = os.cpu_count() or 1
+    n = min(len(block), sample_mib << 20)
+    n -= n % 120
+    sample = np.ascontiguousarray(block[:n])
+    kind = "reference" if Ref.available() else "port"
+    impl = Ref() if kind == "reference" else Oracle()
+    t0 = time.perf_counter()
+    bwt = impl.bwt_forward(sample)
+    t1 = time.perf_counter()
+    enc = impl.ans_encode(bwt)
+    t2 = time.perf_counter()
+    if kind == "reference":
+        dec = impl.ans_decode(enc, len(bwt), threads=cores)
+        t3 = time.perf_counter()
+        back = impl.bwt_inverse(dec, threads=cores)
+    else:
+        dec = impl.ans_decode(enc, len(bwt))
+        t3 = time.perf_counter()
+        back = impl.bwt_inverse(dec)
+    t4 = time.perf_counter()
+    assert np.array_equal(back, sample)
+    mb = n / 1e6
+    return {
+        "value": round(mb / (t2 - t0), 3), "unit": "MB/s", "cores": cores if kind == "reference" else 1, "kind": kind,
+        "sample": f"first {n} B of block 0 as one block: ForwardBwt (divsufsort, OpenMP {cores} threads) + Ans::Encode (single-threaded by design)",
+        "forward_bwt_MBps": round(mb / (t1 - t0), 3), "ans_encode_MBps": round(mb / (t2 - t1), 3),
+        "decompress_MBps": round(mb / (t4 - t2), 3), "ans_decode_MBps": round(mb / (t3 - t2), 3), "inverse_bwt_MBps": round(mb / (t4 - t3), 3),
+    }, enc
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import jampack_amd as jam
+    from jampack_amd import corpus
+
+    # ---- workload: every rank gets its own batch of the same shape (weak scaling over independent blocks) ----
+    data, source = corpus.load_or_make(args.workload, limit=args.limit_bytes or None, seed_offset=1000 * rank)
+    blocks = corpus.split_blocks(data, args.block_mib << 20)
+    batch_bytes = int(sum(len(b) for b in blocks))
+    d_in = [torch.from_numpy(np.ascontiguousarray(b)).to(dev) for b in blocks]
+    caps = [jam.ans_capacity(len(b) + jam.TRAILER) for b in blocks]
+    d_out = [torch.empty(c, dtype=torch.uint8, device=dev) for c in caps]
+    stream = torch.cuda.current_stream()
+    ctx = jam.Context(local_rank, stream.cuda_stream)
+    ctx.reserve(max(len(b) for b in blocks))
+
+    sizes = [0] * len(blocks)
+    max_comp = max(caps)
+    gather_buf = torch.empty((world, max_comp), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+    pad_buf = torch.empty(max_comp, dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def compress_step():
+        for i, b in enumerate(blocks):
+            sizes[i] = ctx.block_compress(d_in[i], len(b), d_out[i], caps[i])
+        if world > 1:
+            # the only exchange of the path: compressed blocks -> rank 0 (sizes first, then payload), RCCL over xGMI
+            sz = torch.tensor(sizes, dtype=torch.int64, device=dev)
+            allsz = [torch.empty_like(sz) for _ in range(world)] if rank == 0 else None
+            dist.gather(sz, allsz, dst=0)
+            for i in range(len(blocks)):
+                pad_buf[: sizes[i]].copy_(d_out[i][: sizes[i]])
+                dist.gather(pad_buf, list(gather_buf.unbind(0)) if rank == 0 else None, dst=0)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        compress_step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        compress_step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * batch_bytes / 1e6 / (dt / args.steps)
+
+    # ---- un-timed extras on rank 0: stage breakdown, decompress leg, parity flags, roofline ----
+    extra = {}
+    if rank == 0:
+        st = ctx.stats()
+        ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731  (same stream as the library's launches)
+        stage_ms = {"forward_bwt": 0.0, "ans_encode": 0.0, "ans_decode": 0.0, "inverse_bwt": 0.0}
+        comp_sizes = []
+        ok = True
+        for i, b in enumerate(blocks):
+            n = len(b)
+            d_bwt = torch.empty(n + jam.TRAILER, dtype=torch.uint8, device=dev)
+            d_enc = torch.empty(caps[i], dtype=torch.uint8, device=dev)
+            d_dec = torch.empty(n + jam.TRAILER, dtype=torch.uint8, device=dev)
+            d_back = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+            e = [ev() for _ in range(5)]
+            e[0].record(stream)
+            ctx.bwt_forward(d_in[i], n, d_bwt, n + jam.TRAILER)
+            e[1].record(stream)
+            clen = ctx.ans_encode(d_bwt, n + jam.TRAILER, d_enc, caps[i])
+            e[2].record(stream)
+            dl = ctx.ans_decode(d_enc, clen, d_dec, n + jam.TRAILER)
+            e[3].record(stream)
+            bl = ctx.bwt_inverse(d_dec, dl, d_back, n)
+            e[4].record(stream)
+            torch.cuda.synchronize()
+            for k, name in enumerate(stage_ms):
+                stage_ms[name] += e[k].elapsed_time(e[k + 1])
+            comp_sizes.append(clen)
+            ok = ok and bl == n and bool(torch.equal(d_back[:n], d_in[i])) and clen == sizes[i] and bool(torch.equal(d_enc[:clen], d_out[i][:clen]))
+            del d_bwt, d_enc, d_dec, d_back
+        mb = batch_bytes / 1e6
+        extra["stages_ms"] = {k: round(v, 3) for k, v in stage_ms.items()}
+        extra["stages_MBps"] = {k: round(mb / (v / 1e3), 1) for k, v in stage_ms.items() if v > 0}
+        extra["decompress"] = {"value": round(mb / ((stage_ms["ans_decode"] + stage_ms["inverse_bwt"]) / 1e3), 1), "unit": "MB/s",
+                               "inverse_bwt_MBps": round(mb / (stage_ms["inverse_bwt"] / 1e3), 1)}
+        extra["round_trip_ok"] = ok
+        extra["compressed_bytes"] = int(sum(comp_sizes))
+        extra["sa_rounds_last_block"] = int(st.sa_rounds)
+        extra["workspace_bytes"] = int(ctx.stats().workspace_bytes)
+        # algorithmic HBM traffic of the stages: fwd BWT 10 B/B, ANS 4+c B/B, inverse BWT 12 B/B
+        c = sum(comp_sizes) / batch_bytes
+        alg = {"forward_bwt": 10.0, "ans_encode": 4.0 + c, "ans_decode": 4.0 + c, "inverse_bwt": 12.0}
+        extra["stages_alg_GBps"] = {k: round(alg[k] * batch_bytes / 1e9 / (stage_ms[k] / 1e3), 2) for k in alg if stage_ms[k] > 0}
+        prof = ctx.profile() if hasattr(ctx, "profile") else None
+        if prof:
+            extra["roofline"] = prof
+        else:
+            # stage-level figure until the per-kernel HIP-event counters are wired (dominant stage = forward BWT)
+            a = alg["forward_bwt"] * batch_bytes / 1e9 / (stage_ms["forward_bwt"] / 1e3)
+            extra["roofline"] = {"bound": "hbm", "achieved": round(a, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(a / 8000.0, 5),
+                                 "traffic": None, "kernel": "forward_bwt stage (all kernels)", "note": "10 B per block byte / stage time"}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cb, ref_enc = cpu_baseline(blocks[0], args.cpu_sample_mib)
+                n = min(len(blocks[0]), args.cpu_sample_mib << 20)
+                n -= n % 120
+                # bit-exact vs the CPU reference on the same sample block
+                d_s = d_in[0][:n].contiguous()
+                d_o = torch.empty(jam.ans_capacity(n + jam.TRAILER), dtype=torch.uint8, device=dev)
+                m = ctx.block_compress(d_s, n, d_o, d_o.numel())
+                cb["bit_exact_vs_cpu"] = bool(m == len(ref_enc) and np.array_equal(d_o[:m].cpu().numpy(), ref_enc))
+                extra["cpu_baseline"] = cb
+            except Exception as ex:  # the baseline must never take the GPU line down
+                extra["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 0, "kind": "error", "sample": repr(ex)}
+
+    if rank == 0:
+        line = {
+            "metric": "MB/s compress (forward BWT + rANS encode) on 64 MiB blocks; bit-exact vs CPU ref",
+            "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int32", "data": "synthetic" if source == "synthetic" else source,
+            "config": {"workload": f"{args.workload}-like {batch_bytes} B per GPU as {args.block_mib} MiB blocks ({len(blocks)} blocks), forward BWT + rANS encode, inputs resident in HBM"
+                       + ("" if not args.limit_bytes else " [TRUNCATED: not a valid headline]"),
+                       "block_bytes": [len(b) for b in blocks], "parallelism": f"blocks sharded over {world} GPU(s), RCCL gather of compressed blocks" if world > 1 else "1 GPU"},
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
