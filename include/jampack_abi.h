@@ -67,6 +67,12 @@ JPK_API void jpk_ctx_destroy(jpk_ctx *ctx);
 JPK_API int jpk_ctx_stats(jpk_ctx *ctx, jpk_stats *out);
 /* pre-size the HBM arena for blocks up to max_block_bytes (otherwise it grows on demand) */
 JPK_API int jpk_ctx_reserve(jpk_ctx *ctx, int64_t max_block_bytes);
+/* per-kernel timing with HIP events recorded on the context's stream: enable = 1 on, 2 on + reset, 0 off + reset.
+ * id < jpk_ctx_profile_count(); units = elements the timed launches processed (see DESIGN.md for bytes per unit). */
+JPK_API int jpk_ctx_profile(jpk_ctx *ctx, int enable);
+JPK_API int jpk_ctx_profile_count(void);
+JPK_API const char *jpk_ctx_profile_name(int id);
+JPK_API int jpk_ctx_profile_get(jpk_ctx *ctx, int id, double *ms, int64_t *launches, int64_t *units);
 JPK_API int jpk_device_count(void);
 JPK_API const char *jpk_strerror(int status);
 JPK_API const char *jpk_version(void);

@@ -48,6 +48,68 @@ int jpk_read_mail(jpk_ctx *ctx, uint32_t *dst, int words)
     JPK_HIP(hipMemcpyAsync(ctx->h_mail, ctx->d_mail, (size_t)words * 4, hipMemcpyDeviceToHost, ctx->stream));
     JPK_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(dst, ctx->h_mail, (size_t)words * 4);
+    if (ctx->prof_on) jpk_prof_resolve(ctx);
+    return JPK_OK;
+}
+
+// ---- per-kernel HIP-event profiler (events are recorded on the launch stream) ------------------------------
+static hipEvent_t prof_event(jpk_ctx *ctx)
+{
+    hipEvent_t e = nullptr;
+    if (!ctx->prof_pool.empty()) { e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }
+    else (void)hipEventCreate(&e);
+    return e;
+}
+void jpk_prof_begin(jpk_ctx *ctx, int id, uint64_t units)
+{
+    JpkProfPending p;
+    p.a = prof_event(ctx); p.b = prof_event(ctx); p.id = id; p.units = units;
+    (void)hipEventRecord(p.a, ctx->stream);
+    ctx->prof_pending.push_back(p);
+}
+void jpk_prof_end(jpk_ctx *ctx) { (void)hipEventRecord(ctx->prof_pending.back().b, ctx->stream); }
+void jpk_prof_resolve(jpk_ctx *ctx)
+{
+    for (auto &p : ctx->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ctx->prof_ms[p.id] += ms;
+            ctx->prof_launches[p.id] += 1;
+            ctx->prof_units[p.id] += p.units;
+        }
+        ctx->prof_pool.push_back(p.a);
+        ctx->prof_pool.push_back(p.b);
+    }
+    ctx->prof_pending.clear();
+}
+static const char *const PROF_NAMES[PROF_COUNT] = {
+    "k_rs_hist", "k_rs_scatter", "k_scan_*", "k_init_keys/k_make_keys", "sa rerank kernels", "k_bwt_gather",
+    "k_hist", "k_build_nxt", "k_walk", "k_rank_jump", "k_copy_out",
+    "k_enc_hist/k_enc_prep", "k_enc_mtf", "k_rle_*", "k_cls_*/k_quasi_build", "k_adaptive", "k_pairs", "k_rans_lanes", "k_emit_scan/k_put_*",
+    "k_dec_headers", "k_dec_rans", "k_dec_rle", "k_dec_rank"};
+
+extern "C" int jpk_ctx_profile(jpk_ctx *ctx, int enable)
+{
+    if (!ctx) return JPK_E_ARG;
+    JPK_HIP(hipSetDevice(ctx->device));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    jpk_prof_resolve(ctx);
+    ctx->prof_on = enable != 0;
+    if (enable == 2 || enable == 0) {   // 2 = enable and reset counters
+        for (int i = 0; i < PROF_COUNT; i++) { ctx->prof_ms[i] = 0; ctx->prof_launches[i] = 0; ctx->prof_units[i] = 0; }
+    }
+    return JPK_OK;
+}
+extern "C" int jpk_ctx_profile_count(void) { return PROF_COUNT; }
+extern "C" const char *jpk_ctx_profile_name(int id) { return (id >= 0 && id < PROF_COUNT) ? PROF_NAMES[id] : ""; }
+extern "C" int jpk_ctx_profile_get(jpk_ctx *ctx, int id, double *ms, int64_t *launches, int64_t *units)
+{
+    if (!ctx || id < 0 || id >= PROF_COUNT) return JPK_E_ARG;
+    (void)hipStreamSynchronize(ctx->stream);
+    jpk_prof_resolve(ctx);
+    if (ms) *ms = ctx->prof_ms[id];
+    if (launches) *launches = (int64_t)ctx->prof_launches[id];
+    if (units) *units = (int64_t)ctx->prof_units[id];
     return JPK_OK;
 }
 
@@ -98,6 +160,8 @@ extern "C" void jpk_ctx_destroy(jpk_ctx *c)
     if (c->stage_res) (void)hipFree(c->stage_res);
     if (c->d_mail) (void)hipFree(c->d_mail);
     if (c->h_mail) (void)hipHostFree(c->h_mail);
+    for (auto &p : c->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

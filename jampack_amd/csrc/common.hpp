@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/jampack_abi.h"
 
 #define JPK_HIP(expr)                                                                                   \
@@ -27,6 +29,15 @@
 
 // HBM arena: one allocation per context, bump-allocated per call, grown (free + malloc) when a bigger
 // block arrives.  Replaces the reference's five cudaMalloc/cudaFree per block (bwt.cpp:195-239).
+// per-kernel HIP-event timing (bench.py roofline): ids index jpk_prof_name()
+enum JpkProfId {
+    PROF_RS_HIST = 0, PROF_RS_SCATTER, PROF_SCAN, PROF_SA_KEYS, PROF_SA_RERANK, PROF_BWT_GATHER,
+    PROF_INV_HIST, PROF_INV_BUILD, PROF_INV_WALK, PROF_INV_RANK, PROF_INV_COPY,
+    PROF_ENC_HIST, PROF_ENC_MTF, PROF_ENC_RLE, PROF_ENC_CLASS, PROF_ENC_ADAPTIVE, PROF_ENC_PAIRS, PROF_ENC_RANS, PROF_ENC_EMIT,
+    PROF_DEC_HEADERS, PROF_DEC_RANS, PROF_DEC_RLE, PROF_DEC_RANK, PROF_COUNT
+};
+struct JpkProfPending { hipEvent_t a, b; int id; uint64_t units; };
+
 struct jpk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -41,7 +52,26 @@ struct jpk_ctx {
     uint8_t *stage_in = nullptr, *stage_out = nullptr, *stage_res = nullptr;
     size_t stage_in_cap = 0, stage_out_cap = 0, stage_res_cap = 0;
     jpk_stats stats;
+    // profiler
+    bool prof_on = false;
+    std::vector<JpkProfPending> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[PROF_COUNT] = {0};
+    uint64_t prof_launches[PROF_COUNT] = {0};
+    uint64_t prof_units[PROF_COUNT] = {0};
 };
+
+void jpk_prof_begin(jpk_ctx *ctx, int id, uint64_t units);
+void jpk_prof_end(jpk_ctx *ctx);
+void jpk_prof_resolve(jpk_ctx *ctx);   // call after a stream synchronisation
+
+// JPK_LAUNCH(ctx, prof id, units processed, kernel, grid, block, args...)
+#define JPK_LAUNCH(ctx, id, units, kernel, grid, block, ...)                                   \
+    do {                                                                                       \
+        if ((ctx)->prof_on) jpk_prof_begin((ctx), (id), (uint64_t)(units));                    \
+        hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);               \
+        if ((ctx)->prof_on) jpk_prof_end((ctx));                                               \
+    } while (0)
 
 static inline size_t jpk_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
