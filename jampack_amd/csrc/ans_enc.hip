@@ -333,7 +333,8 @@ __global__ void k_cls_prefix(EncDims d, const uint32_t *__restrict__ rlen, uint3
 
 // ordinal of every symbol inside its class (stable) + per-interval mantissa histograms of the quasi classes
 __global__ __launch_bounds__(TB) void k_cls_ord(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
-                                               const uint32_t *__restrict__ clsbase, uint32_t *__restrict__ ord, uint32_t *__restrict__ qhist)
+                                               const uint32_t *__restrict__ clsbase, uint32_t *__restrict__ ord, uint32_t *__restrict__ qhist,
+                                               uint8_t *__restrict__ cls8)
 {
     const uint32_t c = blockIdx.y, t = blockIdx.x;
     const uint32_t n = rlen[c], ts = t * ATILE;
@@ -380,6 +381,7 @@ __global__ __launch_bounds__(TB) void k_cls_ord(const uint16_t *__restrict__ rle
             int e = sym_class(s);
             uint32_t k = cnt[w][e] + rk[it];
             ord[(size_t)c * rle_stride + i] = k;
+            cls8[(size_t)c * rle_stride + i] = (uint8_t)(e | ((s & 1u) << 3));      // class | mantissa bit of classes 0/1
             if (e >= 2) {
                 int q = qinterval(k);
                 atomicAdd(&qhist[(((size_t)c * 6 + (e - 2)) * NQ + q) * QSTRIDE + (s - (uint32_t)class_base(e))], 1u);
@@ -440,47 +442,199 @@ __global__ __launch_bounds__(64) void k_quasi_build(EncDims d, const uint32_t *_
     if (l == 0) cdf[A] = 65536u;
 }
 
-// AdaptiveModel recurrences: lane = (chunk, entry).  entries 0..6 = exponent model cdf[1..7] (alphabet 8),
-// 7 / 8 = mantissa models of classes 0 / 1 (alphabet 2, cdf[1]).  Sequential in time (v1).
-__global__ __launch_bounds__(64) void k_adaptive(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
-                                                uint16_t *__restrict__ explo, uint16_t *__restrict__ exphi, uint32_t *__restrict__ mantad)
+// ---- AdaptiveModel recurrences, parallel in time ---------------------------------------------------------------
+// Nine independent scalar recurrences per chunk: exponent model cdf[1..7] (alphabet 8) and cdf[1] of the two
+// alphabet-2 mantissa models.  One step is x += (mix - x) >> 5 with mix in {i, i + 65536 - A} (model.cpp:60-77):
+// a monotone map that shrinks any interval of states by >= floor(width/32) per update, so after >= ~500 updates
+// the set of reachable states is an interval of width <= 31 whatever the history was.  Per 4096-symbol segment:
+//   A  warm up the two extreme states over the preceding >= 1280 updates -> [lo, hi].  lo == hi: the start state
+//      is exact; run the segment, write the outputs, record the end state.  Otherwise run all 32 candidate
+//      start states lo..lo+31 through the segment and record their end states (a transfer table).
+//   B  one lane per (chunk, recurrence) walks the segments in order composing exact states through the tables.
+//   C  the unresolved segments are run again from their now exact start state, writing the outputs.
+// Every output is produced from an exact state: the result is bit-identical to the sequential reference.
+constexpr uint32_t AD_WARM = 1280;      // multiple of 16
+
+struct AdRec {                          // one recurrence
+    bool exp;                           // exponent model entry (true) or alphabet-2 mantissa model (false)
+    int i;                              // cdf index (exp) / 1
+    int cls;                            // class of the mantissa model
+    int A;
+    __device__ __forceinline__ AdRec(uint32_t rec) : exp(rec < 7), i(rec < 7 ? (int)rec + 1 : 1), cls((int)rec - 7), A(rec < 7 ? 8 : 2) {}
+    __device__ __forceinline__ int32_t init() const { return (int32_t)uniform_cdf(A, i); }
+    __device__ __forceinline__ int32_t smin() const { return i; }
+    __device__ __forceinline__ int32_t smax() const { return i + 65536 - A; }
+    // does symbol byte c8 update this recurrence, and with which coded symbol
+    __device__ __forceinline__ bool hits(uint32_t c8) const { return exp || (int)(c8 & 7u) == cls; }
+    __device__ __forceinline__ int sym(uint32_t c8) const { return exp ? (int)(c8 & 7u) : (int)((c8 >> 3) & 1u); }
+};
+
+// f(t, c8) for every symbol byte of [t0, t1); 16-byte loads where aligned, next load issued before the current
+// group is consumed
+template <class F>
+__device__ __forceinline__ void for_each_cls(const uint8_t *__restrict__ p, uint32_t t0, uint32_t t1, F f)
 {
-    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
-    const uint32_t c = g >> 4, rec = g & 15u;
-    if (c >= d.nch || rec >= 9) return;
-    const uint32_t n = rlen[c];
-    const uint16_t *src = rle + (size_t)c * rle_stride;
-    uint16_t *lo = explo + (size_t)c * rle_stride;
-    uint16_t *hi = exphi + (size_t)c * rle_stride;
-    uint32_t *ma = mantad + (size_t)c * rle_stride;
-    if (rec < 7) {
-        const int i = (int)rec + 1;
-        int32_t x = (int32_t)uniform_cdf(8, i);
-        for (uint32_t t = 0; t < n; t++) {
-            const int e = sym_class(src[t]);
+    uint32_t t = t0;
+    while (t < t1 && (t & 15u)) { f(t, (uint32_t)p[t]); t++; }
+    if (t + 16 <= t1) {
+        uint4 v = *reinterpret_cast<const uint4 *>(p + t);
+        for (; t + 16 <= t1; t += 16) {
+            uint4 nv = v;
+            if (t + 32 <= t1) nv = *reinterpret_cast<const uint4 *>(p + t + 16);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++) f(t + k, (w[k >> 2] >> (8 * (k & 3))) & 0xffu);
+            v = nv;
+        }
+    }
+    while (t < t1) { f(t, (uint32_t)p[t]); t++; }
+}
+
+// run one exact trajectory over [t0,t1) writing the model outputs (ans.cpp:159-176)
+__device__ __forceinline__ int32_t ad_run_write(const AdRec &r, const uint8_t *__restrict__ c8p, uint32_t t0, uint32_t t1, int32_t x,
+                                                uint16_t *__restrict__ lo, uint16_t *__restrict__ hi, uint32_t *__restrict__ ma)
+{
+    if (r.exp) {
+        const int i = r.i;
+        for_each_cls(c8p, t0, t1, [&](uint32_t t, uint32_t c8) {
+            const int e = (int)(c8 & 7u);
             if (e == i) lo[t] = (uint16_t)x;
             if (e + 1 == i) hi[t] = (uint16_t)(x - 1);
             x = adapt_step(x, i, e, 8);
-        }
+        });
     } else {
-        const int cls = (int)rec - 7;
-        int32_t x = 32768;
-        for (uint32_t t = 0; t < n; t++) {
-            const uint32_t s = src[t];
-            if (sym_class(s) == cls) {
-                const int m = (int)s - class_base(cls);
+        const int cls = r.cls;
+        for_each_cls(c8p, t0, t1, [&](uint32_t t, uint32_t c8) {
+            if ((int)(c8 & 7u) == cls) {
+                const int m = (int)((c8 >> 3) & 1u);
                 const uint32_t l0 = m ? (uint32_t)x : 0u, fr = m ? 65536u - (uint32_t)x : (uint32_t)x;
                 ma[t] = l0 | (fr << 16);
                 x = adapt_step(x, 1, m, 2);
             }
+        });
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(64) void k_adapt_a(const uint8_t *__restrict__ cls8, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
+                                               const uint32_t *__restrict__ clsbase, uint16_t *__restrict__ explo, uint16_t *__restrict__ exphi,
+                                               uint32_t *__restrict__ mantad, uint32_t *__restrict__ seg_flag, int32_t *__restrict__ seg_lo,
+                                               int32_t *__restrict__ seg_end, uint16_t *__restrict__ seg_tab)
+{
+    const uint32_t c = blockIdx.z, rec = blockIdx.y;
+    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t n = rlen[c];
+    const uint32_t nt = (n + ATILE - 1) / ATILE;
+    if (k >= nt) return;
+    const AdRec r(rec);
+    const uint8_t *c8p = cls8 + (size_t)c * rle_stride;
+    const uint32_t t0 = k * ATILE, t1 = (t0 + ATILE < n) ? t0 + ATILE : n;
+    int32_t lo, hi;
+    uint32_t ws;
+    if (r.exp) {
+        if (k == 0) { lo = hi = r.init(); ws = 0; }
+        else { ws = t0 - AD_WARM; lo = r.smin(); hi = r.smax(); }
+    } else {
+        // walk back over whole tiles until >= AD_WARM updates of this class lie between the warm start and t0
+        const uint32_t *cb = clsbase + (size_t)c * d.tpc * 8 + r.cls;
+        const uint32_t here = cb[(size_t)k * 8];
+        uint32_t w = k;
+        while (w > 0 && here - cb[(size_t)w * 8] < AD_WARM) w--;
+        ws = w * ATILE;
+        if (w == 0) lo = hi = r.init();
+        else { lo = r.smin(); hi = r.smax(); }
+    }
+    if (ws < t0) {
+        const int i = r.i, A = r.A;
+        for_each_cls(c8p, ws, t0, [&](uint32_t, uint32_t c8) {
+            if (r.hits(c8)) { const int sy = r.sym(c8); lo = adapt_step(lo, i, sy, A); hi = adapt_step(hi, i, sy, A); }
+        });
+    }
+    const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
+    if (lo == hi) {
+        seg_flag[so] = 1u;
+        seg_end[so] = ad_run_write(r, c8p, t0, t1, lo, explo + (size_t)c * rle_stride, exphi + (size_t)c * rle_stride, mantad + (size_t)c * rle_stride);
+        return;
+    }
+    // transfer table of the 32 candidate start states lo .. lo+31 (hi - lo <= 31 after the warm-up)
+    seg_flag[so] = 0u;
+    seg_lo[so] = lo;
+    int32_t x[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) x[q] = (lo + q < hi) ? lo + q : hi;
+    {
+        const int i = r.i, A = r.A;
+        for_each_cls(c8p, t0, t1, [&](uint32_t, uint32_t c8) {
+            if (r.hits(c8)) {
+                const int sy = r.sym(c8);
+#pragma unroll
+                for (int q = 0; q < 32; q++) x[q] = adapt_step(x[q], i, sy, A);
+            }
+        });
+    }
+#pragma unroll
+    for (int q = 0; q < 32; q++) seg_tab[so * 32 + q] = (uint16_t)(x[q] - 1);     // states are in [1, 65535+1)
+}
+
+__global__ __launch_bounds__(64) void k_adapt_b(EncDims d, const uint32_t *__restrict__ rlen, const uint32_t *__restrict__ seg_flag,
+                                               const int32_t *__restrict__ seg_lo, const int32_t *__restrict__ seg_end,
+                                               const uint16_t *__restrict__ seg_tab, int32_t *__restrict__ seg_start)
+{
+    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t c = g >> 4, rec = g & 15u;
+    if (c >= d.nch || rec >= 9) return;
+    const AdRec r(rec);
+    const uint32_t nt = (rlen[c] + ATILE - 1) / ATILE;
+    int32_t x = r.init();
+    for (uint32_t k = 0; k < nt; k++) {
+        const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
+        if (seg_flag[so]) x = seg_end[so];
+        else {
+            seg_start[so] = x;
+            int q = x - seg_lo[so];
+            q = q < 0 ? 0 : (q > 31 ? 31 : q);
+            x = (int32_t)seg_tab[so * 32 + q] + 1;
         }
     }
 }
 
-// (low | freq << 16) pairs in coding order: pairs[2t] exponent, pairs[2t+1] mantissa
+__global__ __launch_bounds__(64) void k_adapt_c(const uint8_t *__restrict__ cls8, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
+                                               const uint32_t *__restrict__ seg_flag, const int32_t *__restrict__ seg_start,
+                                               uint16_t *__restrict__ explo, uint16_t *__restrict__ exphi, uint32_t *__restrict__ mantad)
+{
+    const uint32_t c = blockIdx.z, rec = blockIdx.y;
+    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t n = rlen[c];
+    const uint32_t nt = (n + ATILE - 1) / ATILE;
+    if (k >= nt) return;
+    const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
+    if (seg_flag[so]) return;
+    const AdRec r(rec);
+    const uint32_t t0 = k * ATILE, t1 = (t0 + ATILE < n) ? t0 + ATILE : n;
+    ad_run_write(r, cls8 + (size_t)c * rle_stride, t0, t1, seg_start[so], explo + (size_t)c * rle_stride, exphi + (size_t)c * rle_stride,
+                 mantad + (size_t)c * rle_stride);
+}
+
+// rANS records in coding order.  Pair j = 2t (exponent) / 2t+1 (mantissa) belongs to state lane j & 3; the
+// records are stored lane-major (rec[lane][j >> 2]) so that every lane streams its own array.  A record is
+// {low | freq << 16, Alverson reciprocal of freq}: x / freq == mulhi(x, rcp) >> (ceil(log2 freq) - 1) for x < 2^31.
+// records per state lane, even so that two-record (16-byte) loads stay aligned
+__host__ __device__ __forceinline__ size_t rans_lane_stride(size_t rle_stride) { return (rle_stride / 2 + 2) & ~(size_t)1; }
+
+__device__ __forceinline__ uint2 rans_record(uint32_t lo, uint32_t fr)
+{
+    uint32_t rcp = 0;
+    if (fr >= 2) {
+        const int sh = 32 - __clz((int)(fr - 1));
+        rcp = (uint32_t)((((uint64_t)1 << (sh + 31)) + fr - 1) / fr);
+    }
+    return make_uint2(lo | (fr << 16), rcp);
+}
+
 __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
                                              const uint16_t *__restrict__ explo, const uint16_t *__restrict__ exphi, const uint32_t *__restrict__ mantad,
-                                             const uint32_t *__restrict__ ord, const uint32_t *__restrict__ qcdf, uint32_t *__restrict__ pairs)
+                                             const uint32_t *__restrict__ ord, const uint32_t *__restrict__ qcdf, uint2 *__restrict__ recs,
+                                             uint32_t *__restrict__ pairs_plain)
 {
     const uint32_t c = blockIdx.y;
     const uint32_t t = blockIdx.x * TB + threadIdx.x;
@@ -491,45 +645,74 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
     const uint32_t m = s - (uint32_t)class_base(e);
     const uint32_t l0 = (e == 0) ? 0u : explo[o];
     const uint32_t h0 = (e == 7) ? 65536u : (uint32_t)exphi[o] + 1u;
-    uint32_t *out = pairs + (size_t)c * 2 * rle_stride + 2 * (size_t)t;
-    out[0] = l0 | ((h0 - l0) << 16);
-    if (e < 2) out[1] = mantad[o];
+    uint32_t l1, f1;
+    if (e < 2) { const uint32_t p = mantad[o]; l1 = p & 0xffffu; f1 = p >> 16; }
     else {
         const int q = qinterval(ord[o]);
         const uint32_t *cdf = qcdf + (((size_t)c * 6 + (e - 2)) * NQ + q) * QSTRIDE;
-        const uint32_t l1 = cdf[m], h1 = cdf[m + 1];
-        out[1] = l1 | ((h1 - l1) << 16);
+        l1 = cdf[m];
+        f1 = cdf[m + 1] - l1;
+    }
+    // lane-major: pairs 2t, 2t+1 -> lanes (2t)&3, (2t+1)&3 at index t >> 1
+    const size_t lane_stride = rans_lane_stride(rle_stride);
+    uint2 *rc = recs + (size_t)c * 4 * lane_stride;
+    const uint32_t j0 = 2 * t;
+    rc[(size_t)(j0 & 3u) * lane_stride + (j0 >> 2)] = rans_record(l0, h0 - l0);
+    rc[(size_t)((j0 + 1) & 3u) * lane_stride + (j0 >> 2)] = rans_record(l1, f1);
+    if (pairs_plain) {
+        uint32_t *out = pairs_plain + (size_t)c * 2 * rle_stride + 2 * (size_t)t;
+        out[0] = l0 | ((h0 - l0) << 16);
+        out[1] = l1 | (f1 << 16);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// rANS (ans.cpp:189-208)
+// rANS (ans.cpp:189-208): four independent sequential chains per chunk (state lane = pair index & 3), last pair
+// first.  Each step records the 0..2 renormalisation bytes it emits; their stream positions are a prefix sum.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_rans_lanes(const uint32_t *__restrict__ pairs, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
+__device__ __forceinline__ uint32_t rans_step(uint32_t x, uint2 r, uint16_t *eb, uint8_t *ec)
+{
+    const uint32_t lo = r.x & 0xffffu, fr = r.x >> 16;
+    const uint32_t xmax = fr << 15;          // ((RANS_L >> 16) << 8) * freq
+    uint32_t bytes = 0, cnt = 0;
+    if (x >= xmax) {
+        bytes = x & 0xffu; x >>= 8; cnt = 1;
+        if (x >= xmax) { bytes |= (x & 0xffu) << 8; x >>= 8; cnt = 2; }
+    }
+    uint32_t q;
+    if (fr >= 2) q = __umulhi(x, r.y) >> (31 - __clz((int)(fr - 1)));    // ceil(log2 fr) - 1 = 32 - clz(fr-1) - 1
+    else q = x;
+    x = x + lo + q * (65536u - fr);           // == ((x / fr) << 16) + x % fr + lo
+    *eb = (uint16_t)bytes;
+    *ec = (uint8_t)cnt;
+    return x;
+}
+
+__global__ __launch_bounds__(64) void k_rans_lanes(const uint2 *__restrict__ recs, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
                                                   uint16_t *__restrict__ ebytes, uint8_t *__restrict__ ecnt, uint32_t *__restrict__ fstate)
 {
     const uint32_t g = blockIdx.x * 64 + threadIdx.x;
     const uint32_t c = g >> 2, L = g & 3u;
     if (c >= d.nch) return;
     const uint32_t np = 2 * rlen[c];
-    const uint32_t *pr = pairs + (size_t)c * 2 * rle_stride;
+    const size_t lane_stride = rans_lane_stride(rle_stride);
+    const uint2 *rc = recs + ((size_t)c * 4 + L) * lane_stride;
     uint16_t *eb = ebytes + (size_t)c * 2 * rle_stride;
     uint8_t *ec = ecnt + (size_t)c * 2 * rle_stride;
     uint32_t x = RANS_L;
     if (L < np) {
-        int64_t j = (int64_t)((np - 1 - L) / 4) * 4 + L;
-        for (; j >= 0; j -= 4) {
-            const uint32_t p = pr[j];
-            const uint32_t lo = p & 0xffffu, fr = p >> 16;
-            const uint32_t xmax = fr << 15;          // ((RANS_L >> 16) << 8) * freq
-            uint32_t bytes = 0, cnt = 0;
-            if (x >= xmax) {
-                bytes = x & 0xffu; x >>= 8; cnt = 1;
-                if (x >= xmax) { bytes |= (x & 0xffu) << 8; x >>= 8; cnt = 2; }
+        int64_t k = (int64_t)((np - 1 - L) / 4);          // index of this lane's last record
+        // 16-byte loads of two records, next pair of records requested before the current one is consumed
+        if ((k & 1) == 0) { x = rans_step(x, rc[k], eb + 4 * k + L, ec + 4 * k + L); k--; }
+        if (k >= 1) {
+            uint4 v = *reinterpret_cast<const uint4 *>(rc + k - 1);
+            for (; k >= 1; k -= 2) {
+                uint4 nv = v;
+                if (k >= 3) nv = *reinterpret_cast<const uint4 *>(rc + k - 3);
+                x = rans_step(x, make_uint2(v.z, v.w), eb + 4 * k + L, ec + 4 * k + L);
+                x = rans_step(x, make_uint2(v.x, v.y), eb + 4 * (k - 1) + L, ec + 4 * (k - 1) + L);
+                v = nv;
             }
-            x = ((x / fr) << 16) + (x % fr) + lo;
-            eb[j] = (uint16_t)bytes;
-            ec[j] = (uint8_t)cnt;
         }
     }
     fstate[(size_t)c * 4 + L] = x;
@@ -633,12 +816,14 @@ struct EncBufs {
     uint32_t *lz, *ext, *tcount, *toff, *rlen;
     uint16_t *rle;
     uint32_t *clscnt, *clstotal, *ord, *qhist, *qcdf;
-    uint16_t *explo, *exphi; uint32_t *mantad, *pairs;
+    uint8_t *cls8;
+    uint32_t *seg_flag; int32_t *seg_lo, *seg_end, *seg_start; uint16_t *seg_tab;
+    uint16_t *explo, *exphi; uint32_t *mantad, *pairs; uint2 *recs;
     uint16_t *ebytes; uint8_t *ecnt; uint32_t *epos, *fstate, *csize;
     uint8_t *hdr; uint32_t *hsize; uint64_t *outoff;
 };
 
-enum { LAY_RANK = 1, LAY_RLE = 2, LAY_MODEL = 4, LAY_RANS = 8 };
+enum { LAY_RANK = 1, LAY_RLE = 2, LAY_MODEL = 4, LAY_RANS = 8, LAY_PLAIN = 16 };
 
 void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what)
 {
@@ -669,7 +854,15 @@ void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what)
         b.explo = a.get<uint16_t>((size_t)d.nch * stride);
         b.exphi = a.get<uint16_t>((size_t)d.nch * stride);
         b.mantad = a.get<uint32_t>((size_t)d.nch * stride);
-        b.pairs = a.get<uint32_t>((size_t)d.nch * stride * 2);
+        b.cls8 = a.get<uint8_t>((size_t)d.nch * stride + 64);
+        const size_t segs = (size_t)d.nch * 9 * d.tpc;
+        b.seg_flag = a.get<uint32_t>(segs);
+        b.seg_lo = a.get<int32_t>(segs);
+        b.seg_end = a.get<int32_t>(segs);
+        b.seg_start = a.get<int32_t>(segs);
+        b.seg_tab = a.get<uint16_t>(segs * 32);
+        b.recs = a.get<uint2>((size_t)d.nch * 4 * rans_lane_stride(stride));
+        b.pairs = (what & LAY_PLAIN) ? a.get<uint32_t>((size_t)d.nch * stride * 2) : nullptr;
     }
     if (what & LAY_RANS) {
         b.ebytes = a.get<uint16_t>((size_t)d.nch * stride * 2);
@@ -722,11 +915,15 @@ int run_model(jpk_ctx *ctx, const uint16_t *d_rle, const uint32_t *d_rlen, const
     JPK_HIP(hipMemsetAsync(b.qhist, 0, (size_t)d.nch * 6 * NQ * QSTRIDE * 4, st));
     hipLaunchKernelGGL(k_cls_count, dim3(d.tpc, d.nch), dim3(TB), 0, st, d_rle, stride, d, d_rlen, b.clscnt);
     hipLaunchKernelGGL(k_cls_prefix, dim3(jpk_grid((size_t)d.nch * 8, 64)), dim3(64), 0, st, d, d_rlen, b.clscnt, b.clstotal);
-    hipLaunchKernelGGL(k_cls_ord, dim3(d.tpc, d.nch), dim3(TB), 0, st, d_rle, stride, d, d_rlen, b.clscnt, b.ord, b.qhist);
+    hipLaunchKernelGGL(k_cls_ord, dim3(d.tpc, d.nch), dim3(TB), 0, st, d_rle, stride, d, d_rlen, b.clscnt, b.ord, b.qhist, b.cls8);
     hipLaunchKernelGGL(k_quasi_build, dim3(NQ, 6, d.nch), dim3(64), 0, st, d, b.clstotal, b.qhist, b.qcdf);
-    hipLaunchKernelGGL(k_adaptive, dim3(jpk_grid((size_t)d.nch * 16, 64)), dim3(64), 0, st, d_rle, stride, d, d_rlen, b.explo, b.exphi, b.mantad);
+    hipLaunchKernelGGL(k_adapt_a, dim3((d.tpc + 63) / 64, 9, d.nch), dim3(64), 0, st, b.cls8, stride, d, d_rlen, b.clscnt, b.explo, b.exphi, b.mantad,
+                       b.seg_flag, b.seg_lo, b.seg_end, b.seg_tab);
+    hipLaunchKernelGGL(k_adapt_b, dim3(jpk_grid((size_t)d.nch * 16, 64)), dim3(64), 0, st, d, d_rlen, b.seg_flag, b.seg_lo, b.seg_end, b.seg_tab, b.seg_start);
+    hipLaunchKernelGGL(k_adapt_c, dim3((d.tpc + 63) / 64, 9, d.nch), dim3(64), 0, st, b.cls8, stride, d, d_rlen, b.seg_flag, b.seg_start, b.explo, b.exphi,
+                       b.mantad);
     hipLaunchKernelGGL(k_pairs, dim3(jpk_grid(stride, TB), d.nch), dim3(TB), 0, st, d_rle, stride, d, d_rlen, b.explo, b.exphi, b.mantad, b.ord,
-                       b.qcdf, b.pairs);
+                       b.qcdf, b.recs, b.pairs);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
 }
@@ -752,7 +949,7 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     JPK_TRY(run_rle(ctx, b.ranks, d, b));
     JPK_TRY(run_model(ctx, b.rle, b.rlen, d, b));
     const size_t stride = d.chunk;
-    hipLaunchKernelGGL(k_rans_lanes, dim3(jpk_grid((size_t)d.nch * 4, 64)), dim3(64), 0, st, b.pairs, stride, d, b.rlen, b.ebytes, b.ecnt, b.fstate);
+    hipLaunchKernelGGL(k_rans_lanes, dim3(jpk_grid((size_t)d.nch * 4, 64)), dim3(64), 0, st, b.recs, stride, d, b.rlen, b.ebytes, b.ecnt, b.fstate);
     hipLaunchKernelGGL(k_emit_scan, dim3(d.nch), dim3(1024), 0, st, b.ecnt, stride, d, b.rlen, b.epos, b.csize);
     hipLaunchKernelGGL(k_headers, dim3(1), dim3(1024), 0, st, d, b.freq, b.csize, b.rlen, b.hdr, b.hsize, b.outoff, ctx->d_mail);
     JPK_HIP(hipGetLastError());
@@ -820,10 +1017,10 @@ int jpk_model_pairs_device(jpk_ctx *ctx, const uint16_t *d_rle, int32_t rlen, ui
     const EncDims d = make_dims((uint32_t)rlen, (uint32_t)rlen);
     EncBufs b;
     Arena plan(ctx, true);
-    enc_layout(plan, d, b, LAY_RLE | LAY_MODEL);
+    enc_layout(plan, d, b, LAY_RLE | LAY_MODEL | LAY_PLAIN);
     JPK_TRY(jpk_arena_ensure(ctx, plan.need));
     Arena real(ctx, false);
-    enc_layout(real, d, b, LAY_RLE | LAY_MODEL);
+    enc_layout(real, d, b, LAY_RLE | LAY_MODEL | LAY_PLAIN);
     uint32_t n = (uint32_t)rlen;
     JPK_HIP(hipMemcpyAsync(b.rlen, &n, 4, hipMemcpyHostToDevice, ctx->stream));
     JPK_HIP(hipStreamSynchronize(ctx->stream));
