@@ -618,8 +618,8 @@ __global__ __launch_bounds__(64) void k_adapt_c(const uint8_t *__restrict__ cls8
 // rANS records in coding order.  Pair j = 2t (exponent) / 2t+1 (mantissa) belongs to state lane j & 3; the
 // records are stored lane-major (rec[lane][j >> 2]) so that every lane streams its own array.  A record is
 // {low | freq << 16, Alverson reciprocal of freq}: x / freq == mulhi(x, rcp) >> (ceil(log2 freq) - 1) for x < 2^31.
-// records per state lane, even so that two-record (16-byte) loads stay aligned
-__host__ __device__ __forceinline__ size_t rans_lane_stride(size_t rle_stride) { return (rle_stride / 2 + 2) & ~(size_t)1; }
+// records per state lane, a multiple of 8 so that batched 16-byte loads/stores stay aligned
+__host__ __device__ __forceinline__ size_t rans_lane_stride(size_t rle_stride) { return (rle_stride / 2 + 8) & ~(size_t)7; }
 
 __device__ __forceinline__ uint2 rans_record(uint32_t lo, uint32_t fr)
 {
@@ -670,72 +670,84 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
 // rANS (ans.cpp:189-208): four independent sequential chains per chunk (state lane = pair index & 3), last pair
 // first.  Each step records the 0..2 renormalisation bytes it emits; their stream positions are a prefix sum.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t rans_step(uint32_t x, uint2 r, uint16_t *eb, uint8_t *ec)
+// one encoder step; returns the new state, *em = emitted bytes | count << 16
+__device__ __forceinline__ uint32_t rans_step(uint32_t x, uint32_t lf, uint32_t rcp, uint32_t *em)
 {
-    const uint32_t lo = r.x & 0xffffu, fr = r.x >> 16;
+    const uint32_t lo = lf & 0xffffu, fr = lf >> 16;
     const uint32_t xmax = fr << 15;          // ((RANS_L >> 16) << 8) * freq
-    uint32_t bytes = 0, cnt = 0;
+    uint32_t e = 0;
     if (x >= xmax) {
-        bytes = x & 0xffu; x >>= 8; cnt = 1;
-        if (x >= xmax) { bytes |= (x & 0xffu) << 8; x >>= 8; cnt = 2; }
+        e = (x & 0xffu) | (1u << 16); x >>= 8;
+        if (x >= xmax) { e = (e & 0xffu) | ((x & 0xffu) << 8) | (2u << 16); x >>= 8; }
     }
     uint32_t q;
-    if (fr >= 2) q = __umulhi(x, r.y) >> (31 - __clz((int)(fr - 1)));    // ceil(log2 fr) - 1 = 32 - clz(fr-1) - 1
+    if (fr >= 2) q = __umulhi(x, rcp) >> (31 - __clz((int)(fr - 1)));    // ceil(log2 fr) - 1
     else q = x;
-    x = x + lo + q * (65536u - fr);           // == ((x / fr) << 16) + x % fr + lo
-    *eb = (uint16_t)bytes;
-    *ec = (uint8_t)cnt;
-    return x;
+    *em = e;
+    return x + lo + q * (65536u - fr);        // == ((x / fr) << 16) + x % fr + lo
 }
 
+// lanes = (chunk, state lane).  Records are consumed last-to-first in batches of 8 (four 16-byte loads, the next
+// batch requested before the current one is consumed); the 8 emit words of a batch leave as two 16-byte stores.
 __global__ __launch_bounds__(64) void k_rans_lanes(const uint2 *__restrict__ recs, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
-                                                  uint16_t *__restrict__ ebytes, uint8_t *__restrict__ ecnt, uint32_t *__restrict__ fstate)
+                                                  uint32_t *__restrict__ emit, uint32_t *__restrict__ fstate)
 {
     const uint32_t g = blockIdx.x * 64 + threadIdx.x;
     const uint32_t c = g >> 2, L = g & 3u;
     if (c >= d.nch) return;
     const uint32_t np = 2 * rlen[c];
     const size_t lane_stride = rans_lane_stride(rle_stride);
-    const uint2 *rc = recs + ((size_t)c * 4 + L) * lane_stride;
-    uint16_t *eb = ebytes + (size_t)c * 2 * rle_stride;
-    uint8_t *ec = ecnt + (size_t)c * 2 * rle_stride;
+    const uint4 *rc = reinterpret_cast<const uint4 *>(recs + ((size_t)c * 4 + L) * lane_stride);
+    uint4 *em = reinterpret_cast<uint4 *>(emit + ((size_t)c * 4 + L) * lane_stride);
     uint32_t x = RANS_L;
     if (L < np) {
-        int64_t k = (int64_t)((np - 1 - L) / 4);          // index of this lane's last record
-        // 16-byte loads of two records, next pair of records requested before the current one is consumed
-        if ((k & 1) == 0) { x = rans_step(x, rc[k], eb + 4 * k + L, ec + 4 * k + L); k--; }
-        if (k >= 1) {
-            uint4 v = *reinterpret_cast<const uint4 *>(rc + k - 1);
-            for (; k >= 1; k -= 2) {
-                uint4 nv = v;
-                if (k >= 3) nv = *reinterpret_cast<const uint4 *>(rc + k - 3);
-                x = rans_step(x, make_uint2(v.z, v.w), eb + 4 * k + L, ec + 4 * k + L);
-                x = rans_step(x, make_uint2(v.x, v.y), eb + 4 * (k - 1) + L, ec + 4 * (k - 1) + L);
-                v = nv;
-            }
+        const int64_t kmax = (int64_t)((np - 1 - L) / 4);     // this lane's last record
+        int64_t kb = kmax & ~(int64_t)7;
+        uint4 v0 = rc[kb / 2], v1 = rc[kb / 2 + 1], v2 = rc[kb / 2 + 2], v3 = rc[kb / 2 + 3];
+        for (; kb >= 0; kb -= 8) {
+            uint4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
+            if (kb >= 8) { n0 = rc[kb / 2 - 4]; n1 = rc[kb / 2 - 3]; n2 = rc[kb / 2 - 2]; n3 = rc[kb / 2 - 1]; }
+            uint32_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (kb + 7 <= kmax) x = rans_step(x, v3.z, v3.w, &e[7]);
+            if (kb + 6 <= kmax) x = rans_step(x, v3.x, v3.y, &e[6]);
+            if (kb + 5 <= kmax) x = rans_step(x, v2.z, v2.w, &e[5]);
+            if (kb + 4 <= kmax) x = rans_step(x, v2.x, v2.y, &e[4]);
+            if (kb + 3 <= kmax) x = rans_step(x, v1.z, v1.w, &e[3]);
+            if (kb + 2 <= kmax) x = rans_step(x, v1.x, v1.y, &e[2]);
+            if (kb + 1 <= kmax) x = rans_step(x, v0.z, v0.w, &e[1]);
+            x = rans_step(x, v0.x, v0.y, &e[0]);
+            em[kb / 4] = make_uint4(e[0], e[1], e[2], e[3]);
+            em[kb / 4 + 1] = make_uint4(e[4], e[5], e[6], e[7]);
+            v0 = n0; v1 = n1; v2 = n2; v3 = n3;
         }
     }
     fstate[(size_t)c * 4 + L] = x;
 }
 
-// per chunk: exclusive prefix sum of the emit counts (forward pair order) -> byte positions; csize = 16 + total
-__global__ __launch_bounds__(1024) void k_emit_scan(const uint8_t *__restrict__ ecnt, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
+// per chunk: exclusive prefix sum of the emit counts (forward pair order) -> byte positions; csize = 16 + total.
+// emit words are lane-major: pair j sits at emit[j & 3][j >> 2].
+__global__ __launch_bounds__(1024) void k_emit_scan(const uint32_t *__restrict__ emit, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
                                                    uint32_t *__restrict__ epos, uint32_t *__restrict__ csize)
 {
     const uint32_t c = blockIdx.x;
     const uint32_t np = 2 * rlen[c];
-    const uint8_t *ec = ecnt + (size_t)c * 2 * rle_stride;
+    const size_t lane_stride = rans_lane_stride(rle_stride);
+    const uint32_t *em = emit + (size_t)c * 4 * lane_stride;
     uint32_t *ep = epos + (size_t)c * 2 * rle_stride;
     __shared__ uint32_t sm[1024 / 64 + 1];
     __shared__ uint32_t carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
     for (uint32_t b0 = 0; b0 < np; b0 += 1024 * 8) {
-        const uint32_t p0 = b0 + threadIdx.x * 8;
+        const uint32_t p0 = b0 + threadIdx.x * 8;       // multiple of 8: pairs p0..p0+7 = records p0/4, p0/4+1 of each lane
         uint32_t v[8];
         uint32_t s = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { v[k] = (p0 + k < np) ? ec[p0 + k] : 0u; s += v[k]; }
+        for (int k = 0; k < 8; k++) {
+            const uint32_t j = p0 + k;
+            v[k] = (j < np) ? (em[(size_t)(j & 3u) * lane_stride + (j >> 2)] >> 16) : 0u;
+            s += v[k];
+        }
         uint32_t tot;
         uint32_t inc = block_incl_scan<OpSum>(s, sm, &tot);
         uint32_t run = carry_s + inc - s;
@@ -795,20 +807,19 @@ __global__ __launch_bounds__(TB) void k_put_headers(EncDims d, const uint8_t *__
     }
 }
 
-__global__ __launch_bounds__(TB) void k_put_payload(size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen, const uint16_t *__restrict__ ebytes,
-                                                   const uint8_t *__restrict__ ecnt, const uint32_t *__restrict__ epos, const uint32_t *__restrict__ hsize,
+__global__ __launch_bounds__(TB) void k_put_payload(size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen, const uint32_t *__restrict__ emit,
+                                                   const uint32_t *__restrict__ epos, const uint32_t *__restrict__ hsize,
                                                    const uint64_t *__restrict__ outoff, uint8_t *__restrict__ out)
 {
     const uint32_t c = blockIdx.y;
     const uint32_t j = blockIdx.x * TB + threadIdx.x;
     if (j >= 2 * rlen[c]) return;
-    const size_t o = (size_t)c * 2 * rle_stride + j;
-    const uint32_t cnt = ecnt[o];
+    const uint32_t e = emit[(size_t)c * 4 * rans_lane_stride(rle_stride) + (size_t)(j & 3u) * rans_lane_stride(rle_stride) + (j >> 2)];
+    const uint32_t cnt = e >> 16;
     if (!cnt) return;
-    uint8_t *dst = out + outoff[c] + hsize[c] + 16 + epos[o];
-    const uint32_t b = ebytes[o];
-    if (cnt == 1) dst[0] = (uint8_t)b;
-    else { dst[0] = (uint8_t)(b >> 8); dst[1] = (uint8_t)b; }   // the later (higher) byte of a step sits first in the stream
+    uint8_t *dst = out + outoff[c] + hsize[c] + 16 + epos[(size_t)c * 2 * rle_stride + j];
+    if (cnt == 1) dst[0] = (uint8_t)e;
+    else { dst[0] = (uint8_t)(e >> 8); dst[1] = (uint8_t)e; }   // the later (lower-address) byte of a step comes first in the stream
 }
 
 struct EncBufs {
@@ -819,7 +830,7 @@ struct EncBufs {
     uint8_t *cls8;
     uint32_t *seg_flag; int32_t *seg_lo, *seg_end, *seg_start; uint16_t *seg_tab;
     uint16_t *explo, *exphi; uint32_t *mantad, *pairs; uint2 *recs;
-    uint16_t *ebytes; uint8_t *ecnt; uint32_t *epos, *fstate, *csize;
+    uint32_t *emit, *epos, *fstate, *csize;
     uint8_t *hdr; uint32_t *hsize; uint64_t *outoff;
 };
 
@@ -865,8 +876,7 @@ void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what)
         b.pairs = (what & LAY_PLAIN) ? a.get<uint32_t>((size_t)d.nch * stride * 2) : nullptr;
     }
     if (what & LAY_RANS) {
-        b.ebytes = a.get<uint16_t>((size_t)d.nch * stride * 2);
-        b.ecnt = a.get<uint8_t>((size_t)d.nch * stride * 2);
+        b.emit = a.get<uint32_t>((size_t)d.nch * 4 * rans_lane_stride(stride));
         b.epos = a.get<uint32_t>((size_t)d.nch * stride * 2);
         b.fstate = a.get<uint32_t>((size_t)d.nch * 4);
         b.csize = a.get<uint32_t>(d.nch);
@@ -949,8 +959,8 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     JPK_TRY(run_rle(ctx, b.ranks, d, b));
     JPK_TRY(run_model(ctx, b.rle, b.rlen, d, b));
     const size_t stride = d.chunk;
-    hipLaunchKernelGGL(k_rans_lanes, dim3(jpk_grid((size_t)d.nch * 4, 64)), dim3(64), 0, st, b.recs, stride, d, b.rlen, b.ebytes, b.ecnt, b.fstate);
-    hipLaunchKernelGGL(k_emit_scan, dim3(d.nch), dim3(1024), 0, st, b.ecnt, stride, d, b.rlen, b.epos, b.csize);
+    hipLaunchKernelGGL(k_rans_lanes, dim3(jpk_grid((size_t)d.nch * 4, 64)), dim3(64), 0, st, b.recs, stride, d, b.rlen, b.emit, b.fstate);
+    hipLaunchKernelGGL(k_emit_scan, dim3(d.nch), dim3(1024), 0, st, b.emit, stride, d, b.rlen, b.epos, b.csize);
     hipLaunchKernelGGL(k_headers, dim3(1), dim3(1024), 0, st, d, b.freq, b.csize, b.rlen, b.hdr, b.hsize, b.outoff, ctx->d_mail);
     JPK_HIP(hipGetLastError());
     uint32_t mail[4];
@@ -960,7 +970,7 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     ctx->stats.ans_rle_symbols = (int64_t)(((uint64_t)mail[3] << 32) | mail[2]);
     if (total > (uint64_t)out_cap) return JPK_E_CAPACITY;
     hipLaunchKernelGGL(k_put_headers, dim3(d.nch), dim3(TB), 0, st, d, b.hdr, b.hsize, b.outoff, b.fstate, d_out);
-    hipLaunchKernelGGL(k_put_payload, dim3(jpk_grid(2 * stride, TB), d.nch), dim3(TB), 0, st, stride, d, b.rlen, b.ebytes, b.ecnt, b.epos, b.hsize,
+    hipLaunchKernelGGL(k_put_payload, dim3(jpk_grid(2 * stride, TB), d.nch), dim3(TB), 0, st, stride, d, b.rlen, b.emit, b.epos, b.hsize,
                        b.outoff, d_out);
     JPK_HIP(hipGetLastError());
     JPK_HIP(hipStreamSynchronize(st));
