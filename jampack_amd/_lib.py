@@ -41,6 +41,10 @@ _SIGS = {
     "jpk_ctx_destroy": (None, [_vp]),
     "jpk_ctx_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "jpk_ctx_reserve": (C.c_int, [_vp, C.c_int64]),
+    "jpk_ctx_profile": (C.c_int, [_vp, C.c_int]),
+    "jpk_ctx_profile_count": (C.c_int, []),
+    "jpk_ctx_profile_name": (C.c_char_p, [C.c_int]),
+    "jpk_ctx_profile_get": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "jpk_device_count": (C.c_int, []),
     "jpk_strerror": (C.c_char_p, [C.c_int]),
     "jpk_version": (C.c_char_p, []),

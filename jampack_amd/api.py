@@ -143,6 +143,20 @@ class Context:
         _chk(lib().jpk_ctx_stats(self._h, C.byref(s)), "jpk_ctx_stats")
         return s
 
+    def profile_enable(self, mode: int = 2):
+        """per-kernel HIP-event timing on the context's stream: 1 = on, 2 = on + reset, 0 = off + reset"""
+        _chk(lib().jpk_ctx_profile(self._h, mode), "jpk_ctx_profile")
+
+    def profile_table(self):
+        """[{name, ms, launches, units}] for every timed kernel class with at least one launch"""
+        out = []
+        for i in range(lib().jpk_ctx_profile_count()):
+            ms, ln, un = C.c_double(0), C.c_int64(0), C.c_int64(0)
+            _chk(lib().jpk_ctx_profile_get(self._h, i, C.byref(ms), C.byref(ln), C.byref(un)), "jpk_ctx_profile_get")
+            if ln.value:
+                out.append({"id": i, "name": lib().jpk_ctx_profile_name(i).decode(), "ms": ms.value, "launches": ln.value, "units": un.value})
+        return out
+
     def _io(self, fn, what, d_in, in_len, d_out, out_cap) -> int:
         n = C.c_int32(0)
         _chk(fn(self._h, _dptr(d_in), in_len, _dptr(d_out), out_cap, C.byref(n)), what)

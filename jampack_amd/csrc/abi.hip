@@ -83,7 +83,7 @@ void jpk_prof_resolve(jpk_ctx *ctx)
     ctx->prof_pending.clear();
 }
 static const char *const PROF_NAMES[PROF_COUNT] = {
-    "k_rs_hist", "k_rs_scatter", "k_scan_*", "k_init_keys/k_make_keys", "sa rerank kernels", "k_bwt_gather",
+    "k_rs_hist", "k_rs_scatter", "k_scan_*", "k_init_keys/k_make_keys/k_win_heads", "k_seg_round", "sa rerank kernels", "k_bwt_gather",
     "k_hist", "k_build_nxt", "k_walk", "k_rank_jump", "k_copy_out",
     "k_enc_hist/k_enc_prep", "k_enc_mtf", "k_rle_*", "k_cls_*/k_quasi_build", "k_adaptive", "k_pairs", "k_rans_lanes", "k_emit_scan/k_put_*",
     "k_dec_headers", "k_dec_rans", "k_dec_rle", "k_dec_rank"};

@@ -353,7 +353,7 @@ int jpk_ans_decode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
         freq = real.get<int32_t>((size_t)max_chunks * 256);
         head_bytes = ctx->arena_off;
     }
-    hipLaunchKernelGGL(k_dec_headers, dim3(1), dim3(64), 0, st, d_in, (uint32_t)len, (uint64_t)out_cap, max_chunks, info, freq, ctx->d_mail);
+    JPK_LAUNCH(ctx, PROF_DEC_HEADERS, 0, k_dec_headers, dim3(1), dim3(64), d_in, (uint32_t)len, (uint64_t)out_cap, max_chunks, info, freq, ctx->d_mail);
     JPK_HIP(hipGetLastError());
     uint32_t mail[6];
     JPK_TRY(jpk_read_mail(ctx, mail, 6));
@@ -372,16 +372,16 @@ int jpk_ans_decode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
         Arena real(ctx, false);
         info = real.get<ChunkInfo>(max_chunks);
         freq = real.get<int32_t>((size_t)max_chunks * 256);
-        hipLaunchKernelGGL(k_dec_headers, dim3(1), dim3(64), 0, st, d_in, (uint32_t)len, (uint64_t)out_cap, max_chunks, info, freq, ctx->d_mail);
+        JPK_LAUNCH(ctx, PROF_DEC_HEADERS, 0, k_dec_headers, dim3(1), dim3(64), d_in, (uint32_t)len, (uint64_t)out_cap, max_chunks, info, freq, ctx->d_mail);
     }
     uint16_t *rle = (uint16_t *)(ctx->arena + head_bytes);
     uint8_t *tmp = ctx->arena + head_bytes + jpk_align(total_rle * 2 + 64);
     uint32_t *status = ctx->d_mail + 8;
     JPK_HIP(hipMemsetAsync(status, 0, 4, st));
     JPK_HIP(hipMemsetAsync(d_out, 0, total_out, st));
-    hipLaunchKernelGGL(k_dec_rans, dim3(nch), dim3(64), 0, st, d_in, info, rle, status);
-    hipLaunchKernelGGL(k_dec_rle, dim3(nch), dim3(1024), 0, st, rle, info, d_out, status);
-    hipLaunchKernelGGL(k_dec_rank, dim3(nch), dim3(64), 0, st, d_out, info, freq, tmp, status);
+    JPK_LAUNCH(ctx, PROF_DEC_RANS, 0, k_dec_rans, dim3(nch), dim3(64), d_in, info, rle, status);
+    JPK_LAUNCH(ctx, PROF_DEC_RLE, 0, k_dec_rle, dim3(nch), dim3(1024), rle, info, d_out, status);
+    JPK_LAUNCH(ctx, PROF_DEC_RANK, 0, k_dec_rank, dim3(nch), dim3(64), d_out, info, freq, tmp, status);
     JPK_HIP(hipGetLastError());
     JPK_HIP(hipMemcpyAsync(d_out, tmp, total_out, hipMemcpyDeviceToDevice, st));
     JPK_HIP(hipMemcpyAsync(ctx->d_mail, status, 4, hipMemcpyDeviceToDevice, st));
@@ -420,7 +420,7 @@ int jpk_rank_decode_device(jpk_ctx *ctx, uint8_t *d_r, const int32_t *d_freq, in
     JPK_HIP(hipMemcpyAsync(info, &ci, sizeof ci, hipMemcpyHostToDevice, st));
     JPK_HIP(hipStreamSynchronize(st));
     uint32_t *status = ctx->d_mail + 8;
-    hipLaunchKernelGGL(k_dec_rank, dim3(1), dim3(64), 0, st, d_r, info, hf, tmp, status);
+    JPK_LAUNCH(ctx, PROF_DEC_RANK, 0, k_dec_rank, dim3(1), dim3(64), d_r, info, hf, tmp, status);
     JPK_HIP(hipGetLastError());
     JPK_HIP(hipMemcpyAsync(d_r, tmp, (size_t)len, hipMemcpyDeviceToDevice, st));
     JPK_HIP(hipStreamSynchronize(st));

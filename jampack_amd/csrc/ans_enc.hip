@@ -899,9 +899,9 @@ EncDims make_dims(uint32_t len, uint32_t chunk)
 int run_rank(jpk_ctx *ctx, const uint8_t *d_in, const EncDims &d, EncBufs &b)
 {
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(k_enc_hist, dim3(d.tpc, d.nch), dim3(TB), 0, st, d_in, d, b.tilecnt, b.lastpos);
-    hipLaunchKernelGGL(k_enc_prep, dim3(d.nch), dim3(256), 0, st, d, b.tilecnt, b.lastpos, b.freq, b.bstart);
-    hipLaunchKernelGGL(k_enc_mtf, dim3((d.tpc + 3) / 4, d.nch), dim3(TB), 0, st, d_in, d, b.tilecnt, b.lastpos, b.bstart, b.ranks);
+    JPK_LAUNCH(ctx, PROF_ENC_HIST, 0, k_enc_hist, dim3(d.tpc, d.nch), dim3(TB), d_in, d, b.tilecnt, b.lastpos);
+    JPK_LAUNCH(ctx, PROF_ENC_HIST, 0, k_enc_prep, dim3(d.nch), dim3(256), d, b.tilecnt, b.lastpos, b.freq, b.bstart);
+    JPK_LAUNCH(ctx, PROF_ENC_MTF, 0, k_enc_mtf, dim3((d.tpc + 3) / 4, d.nch), dim3(TB), d_in, d, b.tilecnt, b.lastpos, b.bstart, b.ranks);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
 }
@@ -909,11 +909,11 @@ int run_rank(jpk_ctx *ctx, const uint8_t *d_in, const EncDims &d, EncBufs &b)
 int run_rle(jpk_ctx *ctx, const uint8_t *d_ranks, const EncDims &d, EncBufs &b)
 {
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(k_rle_lz, dim3(d.tpc, d.nch), dim3(TB), 0, st, d_ranks, d, b.lz);
-    hipLaunchKernelGGL(k_rle_ext, dim3(jpk_grid(d.nch, 64)), dim3(64), 0, st, d, b.lz, b.ext);
-    hipLaunchKernelGGL((k_rle_tiles<false>), dim3(d.tpc, d.nch), dim3(TB), 0, st, d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
-    hipLaunchKernelGGL(k_tile_prefix, dim3(jpk_grid(d.nch, 64)), dim3(64), 0, st, d, b.tcount, b.toff, b.rlen, 1u, (const uint32_t *)nullptr);
-    hipLaunchKernelGGL((k_rle_tiles<true>), dim3(d.tpc, d.nch), dim3(TB), 0, st, d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, 0, k_rle_lz, dim3(d.tpc, d.nch), dim3(TB), d_ranks, d, b.lz);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, 0, k_rle_ext, dim3(jpk_grid(d.nch, 64)), dim3(64), d, b.lz, b.ext);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, 0, (k_rle_tiles<false>), dim3(d.tpc, d.nch), dim3(TB), d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, 0, k_tile_prefix, dim3(jpk_grid(d.nch, 64)), dim3(64), d, b.tcount, b.toff, b.rlen, 1u, (const uint32_t *)nullptr);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, 0, (k_rle_tiles<true>), dim3(d.tpc, d.nch), dim3(TB), d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
 }
@@ -923,16 +923,16 @@ int run_model(jpk_ctx *ctx, const uint16_t *d_rle, const uint32_t *d_rlen, const
     hipStream_t st = ctx->stream;
     const size_t stride = d.chunk;
     JPK_HIP(hipMemsetAsync(b.qhist, 0, (size_t)d.nch * 6 * NQ * QSTRIDE * 4, st));
-    hipLaunchKernelGGL(k_cls_count, dim3(d.tpc, d.nch), dim3(TB), 0, st, d_rle, stride, d, d_rlen, b.clscnt);
-    hipLaunchKernelGGL(k_cls_prefix, dim3(jpk_grid((size_t)d.nch * 8, 64)), dim3(64), 0, st, d, d_rlen, b.clscnt, b.clstotal);
-    hipLaunchKernelGGL(k_cls_ord, dim3(d.tpc, d.nch), dim3(TB), 0, st, d_rle, stride, d, d_rlen, b.clscnt, b.ord, b.qhist, b.cls8);
-    hipLaunchKernelGGL(k_quasi_build, dim3(NQ, 6, d.nch), dim3(64), 0, st, d, b.clstotal, b.qhist, b.qcdf);
-    hipLaunchKernelGGL(k_adapt_a, dim3((d.tpc + 63) / 64, 9, d.nch), dim3(64), 0, st, b.cls8, stride, d, d_rlen, b.clscnt, b.explo, b.exphi, b.mantad,
+    JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_count, dim3(d.tpc, d.nch), dim3(TB), d_rle, stride, d, d_rlen, b.clscnt);
+    JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_prefix, dim3(jpk_grid((size_t)d.nch * 8, 64)), dim3(64), d, d_rlen, b.clscnt, b.clstotal);
+    JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_ord, dim3(d.tpc, d.nch), dim3(TB), d_rle, stride, d, d_rlen, b.clscnt, b.ord, b.qhist, b.cls8);
+    JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_quasi_build, dim3(NQ, 6, d.nch), dim3(64), d, b.clstotal, b.qhist, b.qcdf);
+    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_a, dim3((d.tpc + 63) / 64, 9, d.nch), dim3(64), b.cls8, stride, d, d_rlen, b.clscnt, b.explo, b.exphi, b.mantad,
                        b.seg_flag, b.seg_lo, b.seg_end, b.seg_tab);
-    hipLaunchKernelGGL(k_adapt_b, dim3(jpk_grid((size_t)d.nch * 16, 64)), dim3(64), 0, st, d, d_rlen, b.seg_flag, b.seg_lo, b.seg_end, b.seg_tab, b.seg_start);
-    hipLaunchKernelGGL(k_adapt_c, dim3((d.tpc + 63) / 64, 9, d.nch), dim3(64), 0, st, b.cls8, stride, d, d_rlen, b.seg_flag, b.seg_start, b.explo, b.exphi,
+    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_b, dim3(jpk_grid((size_t)d.nch * 16, 64)), dim3(64), d, d_rlen, b.seg_flag, b.seg_lo, b.seg_end, b.seg_tab, b.seg_start);
+    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_c, dim3((d.tpc + 63) / 64, 9, d.nch), dim3(64), b.cls8, stride, d, d_rlen, b.seg_flag, b.seg_start, b.explo, b.exphi,
                        b.mantad);
-    hipLaunchKernelGGL(k_pairs, dim3(jpk_grid(stride, TB), d.nch), dim3(TB), 0, st, d_rle, stride, d, d_rlen, b.explo, b.exphi, b.mantad, b.ord,
+    JPK_LAUNCH(ctx, PROF_ENC_PAIRS, 0, k_pairs, dim3(jpk_grid(stride, TB), d.nch), dim3(TB), d_rle, stride, d, d_rlen, b.explo, b.exphi, b.mantad, b.ord,
                        b.qcdf, b.recs, b.pairs);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
@@ -959,9 +959,9 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     JPK_TRY(run_rle(ctx, b.ranks, d, b));
     JPK_TRY(run_model(ctx, b.rle, b.rlen, d, b));
     const size_t stride = d.chunk;
-    hipLaunchKernelGGL(k_rans_lanes, dim3(jpk_grid((size_t)d.nch * 4, 64)), dim3(64), 0, st, b.recs, stride, d, b.rlen, b.emit, b.fstate);
-    hipLaunchKernelGGL(k_emit_scan, dim3(d.nch), dim3(1024), 0, st, b.emit, stride, d, b.rlen, b.epos, b.csize);
-    hipLaunchKernelGGL(k_headers, dim3(1), dim3(1024), 0, st, d, b.freq, b.csize, b.rlen, b.hdr, b.hsize, b.outoff, ctx->d_mail);
+    JPK_LAUNCH(ctx, PROF_ENC_RANS, 0, k_rans_lanes, dim3(jpk_grid((size_t)d.nch * 4, 64)), dim3(64), b.recs, stride, d, b.rlen, b.emit, b.fstate);
+    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_emit_scan, dim3(d.nch), dim3(1024), b.emit, stride, d, b.rlen, b.epos, b.csize);
+    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_headers, dim3(1), dim3(1024), d, b.freq, b.csize, b.rlen, b.hdr, b.hsize, b.outoff, ctx->d_mail);
     JPK_HIP(hipGetLastError());
     uint32_t mail[4];
     JPK_TRY(jpk_read_mail(ctx, mail, 4));
@@ -969,8 +969,8 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     ctx->stats.ans_chunks = d.nch;
     ctx->stats.ans_rle_symbols = (int64_t)(((uint64_t)mail[3] << 32) | mail[2]);
     if (total > (uint64_t)out_cap) return JPK_E_CAPACITY;
-    hipLaunchKernelGGL(k_put_headers, dim3(d.nch), dim3(TB), 0, st, d, b.hdr, b.hsize, b.outoff, b.fstate, d_out);
-    hipLaunchKernelGGL(k_put_payload, dim3(jpk_grid(2 * stride, TB), d.nch), dim3(TB), 0, st, stride, d, b.rlen, b.emit, b.epos, b.hsize,
+    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_headers, dim3(d.nch), dim3(TB), d, b.hdr, b.hsize, b.outoff, b.fstate, d_out);
+    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_payload, dim3(jpk_grid(2 * stride, TB), d.nch), dim3(TB), stride, d, b.rlen, b.emit, b.epos, b.hsize,
                        b.outoff, d_out);
     JPK_HIP(hipGetLastError());
     JPK_HIP(hipStreamSynchronize(st));

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(TB) void k_win_heads(const uint32_t *__restrict__ a
 
 // the sort / re-rank of all groups of <= SEG_TILE elements, one window per workgroup
 __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, uint32_t m, uint32_t n,
-                                                 uint32_t h, int key_passes, const uint32_t *__restrict__ prevhead /* exclusive max-scan of lasthead */,
+                                                 uint32_t h, int key_passes, const uint32_t *__restrict__ winscan /* inclusive max-scan of lasthead */,
                                                  const uint32_t *__restrict__ ISA_cur, uint32_t *__restrict__ ISA_nxt, uint32_t *__restrict__ SA,
                                                  uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint32_t *__restrict__ lflag)
 {
@@ -181,7 +181,8 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
     if (tid == 0) { s_fo = 0xFFFFFFFFu; s_oe = 0; }
     __syncthreads();
     // ---- classify: size of the group of each position; owned = starts in my window and size <= SEG_TILE ----
-    const uint32_t spill_start = (base > 0 && prevhead[blockIdx.x] > 0) ? prevhead[blockIdx.x] - 1 : 0u;   // global index
+    const uint32_t ph = (blockIdx.x > 0) ? winscan[blockIdx.x - 1] : 0u;          // 1 + last head before my window
+    const uint32_t spill_start = ph > 0 ? ph - 1 : 0u;                              // global index
     uint32_t my_fo = 0xFFFFFFFFu, my_oe = 0;
 #pragma unroll
     for (int k = 0; k < SEG_ITEMS; k++) {
@@ -501,8 +502,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b, uint32_t **i
         // window bookkeeping: start of the group that spills into each window
         JPK_LAUNCH(ctx, PROF_SA_KEYS, m, k_win_heads, dim3(nwin), dim3(TB), b.a_grp, m, b.win);
         JPK_TRY(jpk_inclusive_max_u32(ctx, b.win, b.win, nwin, b.scratch));
-        // k_seg_round wants the exclusive scan: prevhead[w] = win[w-1]; pass win - 1 with a guarded first window
-        JPK_LAUNCH(ctx, PROF_SA_SEG, m, k_seg_round, dim3(nwin), dim3(TB), b.a_sa, b.a_grp, m, n, (uint32_t)h, key_passes, b.win - 1, isa_cur, isa_nxt,
+        JPK_LAUNCH(ctx, PROF_SA_SEG, m, k_seg_round, dim3(nwin), dim3(TB), b.a_sa, b.a_grp, m, n, (uint32_t)h, key_passes, b.win, isa_cur, isa_nxt,
                    b.SA, b.b_sa, b.b_grp, b.t1);                                       // t1 = lflag
         JPK_TRY(jpk_exclusive_sum_u32(ctx, b.t1, b.t2, m, b.scratch, ctx->d_mail));   // t2 = position in the large list
         uint32_t lc = 0;

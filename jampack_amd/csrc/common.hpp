@@ -31,7 +31,7 @@
 // block arrives.  Replaces the reference's five cudaMalloc/cudaFree per block (bwt.cpp:195-239).
 // per-kernel HIP-event timing (bench.py roofline): ids index jpk_prof_name()
 enum JpkProfId {
-    PROF_RS_HIST = 0, PROF_RS_SCATTER, PROF_SCAN, PROF_SA_KEYS, PROF_SA_RERANK, PROF_BWT_GATHER,
+    PROF_RS_HIST = 0, PROF_RS_SCATTER, PROF_SCAN, PROF_SA_KEYS, PROF_SA_SEG, PROF_SA_RERANK, PROF_BWT_GATHER,
     PROF_INV_HIST, PROF_INV_BUILD, PROF_INV_WALK, PROF_INV_RANK, PROF_INV_COPY,
     PROF_ENC_HIST, PROF_ENC_MTF, PROF_ENC_RLE, PROF_ENC_CLASS, PROF_ENC_ADAPTIVE, PROF_ENC_PAIRS, PROF_ENC_RANS, PROF_ENC_EMIT,
     PROF_DEC_HEADERS, PROF_DEC_RANS, PROF_DEC_RLE, PROF_DEC_RANK, PROF_COUNT

@@ -110,9 +110,9 @@ int jpk_radix_sort_pairs_u64(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint6
     uint64_t *ki = keys, *ko = keys_alt;
     uint32_t *vi = vals, *vo = vals_alt;
     for (int p = 0; p < nshifts; p++) {
-        hipLaunchKernelGGL(k_rs_hist, dim3(ntiles), dim3(RS_THREADS), 0, ctx->stream, ki, n, shifts[p], hist, ntiles);
+        JPK_LAUNCH(ctx, PROF_RS_HIST, n, k_rs_hist, dim3(ntiles), dim3(RS_THREADS), ki, n, shifts[p], hist, ntiles);
         JPK_TRY(jpk_exclusive_sum_u32(ctx, hist, hist, table, scan_scratch, nullptr));
-        hipLaunchKernelGGL(k_rs_scatter, dim3(ntiles), dim3(RS_THREADS), 0, ctx->stream, ki, vi, ko, vo, n, shifts[p], hist, ntiles);
+        JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, k_rs_scatter, dim3(ntiles), dim3(RS_THREADS), ki, vi, ko, vo, n, shifts[p], hist, ntiles);
         uint64_t *tk = ki; ki = ko; ko = tk;
         uint32_t *tv = vi; vi = vo; vo = tv;
     }

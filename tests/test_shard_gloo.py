@@ -1,0 +1,56 @@
+"""Multi-rank path on CPU: world_size 2, gloo.  Covers block ownership and the variable-size output gather that
+bench.py uses with RCCL on the GPU box."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jampack_amd import shard
+    nblocks = 5
+    mine = shard.my_blocks(nblocks, rank, world)
+    rng = np.random.default_rng(100)
+    payloads = [rng.integers(0, 256, 1000 + 377 * b, dtype=np.uint8) for b in range(nblocks)]
+    local = [torch.from_numpy(payloads[b]) for b in mine]
+    got = shard.gather_blocks(local, dst=0)
+    ok = True
+    if rank == 0:
+        for r in range(world):
+            owned = shard.my_blocks(nblocks, r, world)
+            ok = ok and len(got[r]) == len(owned)
+            for t, b in zip(got[r], owned):
+                ok = ok and np.array_equal(t.numpy(), payloads[b])
+    else:
+        ok = got is None
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_blocks_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 200
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
+
+
+def test_block_ownership_is_a_partition():
+    from jampack_amd import shard
+    for world in (1, 2, 4, 8):
+        seen = []
+        for r in range(world):
+            seen += shard.my_blocks(15, r, world)
+        assert sorted(seen) == list(range(15))
