@@ -479,8 +479,8 @@ __device__ __forceinline__ void for_each_cls(const uint8_t *__restrict__ p, uint
     if (t + 16 <= t1) {
         uint4 v = *reinterpret_cast<const uint4 *>(p + t);
         for (; t + 16 <= t1; t += 16) {
-            uint4 nv = v;
-            if (t + 32 <= t1) nv = *reinterpret_cast<const uint4 *>(p + t + 16);
+            const uint32_t tn = (t + 32 <= t1) ? t + 16 : t;          // clamped: the prefetch is unconditional
+            const uint4 nv = *reinterpret_cast<const uint4 *>(p + tn);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 16; k++) f(t + k, (w[k >> 2] >> (8 * (k & 3))) & 0xffu);
@@ -618,22 +618,29 @@ __global__ __launch_bounds__(64) void k_adapt_c(const uint8_t *__restrict__ cls8
 // rANS records in coding order.  Pair j = 2t (exponent) / 2t+1 (mantissa) belongs to state lane j & 3; the
 // records are stored lane-major (rec[lane][j >> 2]) so that every lane streams its own array.  A record is
 // {low | freq << 16, Alverson reciprocal of freq}: x / freq == mulhi(x, rcp) >> (ceil(log2 freq) - 1) for x < 2^31.
-// records per state lane, a multiple of 8 so that batched 16-byte loads/stores stay aligned
-__host__ __device__ __forceinline__ size_t rans_lane_stride(size_t rle_stride) { return (rle_stride / 2 + 8) & ~(size_t)7; }
+// records per state lane, a multiple of the 128-record staging tile
+__host__ __device__ __forceinline__ size_t rans_lane_stride(size_t rle_stride) { return (rle_stride / 2 + 128) & ~(size_t)127; }
 
-__device__ __forceinline__ uint2 rans_record(uint32_t lo, uint32_t fr)
+// 16-byte record {xmax, rcp, bias, cmpl | shift << 20}: everything a step needs that does not depend on the state
+// is computed here, in parallel (ryg's RansEncSymbolInit, rans_byte.hpp:188-246, restated for 16-bit frequencies):
+//   x / freq == mulhi(x, rcp) >> shift  with rcp = ceil(2^(31+s) / freq), s = ceil(log2 freq), shift = s - 1 (x < 2^31);
+//   freq == 1: rcp = 2^32 - 1, shift = 0 gives q = x - 1, compensated by bias += 65535.
+__device__ __forceinline__ uint4 rans_record(uint32_t lo, uint32_t fr)
 {
-    uint32_t rcp = 0;
+    uint32_t rcp, shift, bias = lo;
     if (fr >= 2) {
         const int sh = 32 - __clz((int)(fr - 1));
         rcp = (uint32_t)((((uint64_t)1 << (sh + 31)) + fr - 1) / fr);
+        shift = (uint32_t)(sh - 1);
+    } else {
+        rcp = 0xFFFFFFFFu; shift = 0; bias = lo + 65535u;
     }
-    return make_uint2(lo | (fr << 16), rcp);
+    return make_uint4(fr << 15, rcp, bias, (65536u - fr) | (shift << 20));
 }
 
 __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
                                              const uint16_t *__restrict__ explo, const uint16_t *__restrict__ exphi, const uint32_t *__restrict__ mantad,
-                                             const uint32_t *__restrict__ ord, const uint32_t *__restrict__ qcdf, uint2 *__restrict__ recs,
+                                             const uint32_t *__restrict__ ord, const uint32_t *__restrict__ qcdf, uint4 *__restrict__ recs,
                                              uint32_t *__restrict__ pairs_plain)
 {
     const uint32_t c = blockIdx.y;
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
     }
     // lane-major: pairs 2t, 2t+1 -> lanes (2t)&3, (2t+1)&3 at index t >> 1
     const size_t lane_stride = rans_lane_stride(rle_stride);
-    uint2 *rc = recs + (size_t)c * 4 * lane_stride;
+    uint4 *rc = recs + (size_t)c * 4 * lane_stride;
     const uint32_t j0 = 2 * t;
     rc[(size_t)(j0 & 3u) * lane_stride + (j0 >> 2)] = rans_record(l0, h0 - l0);
     rc[(size_t)((j0 + 1) & 3u) * lane_stride + (j0 >> 2)] = rans_record(l1, f1);
@@ -670,58 +677,92 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
 // rANS (ans.cpp:189-208): four independent sequential chains per chunk (state lane = pair index & 3), last pair
 // first.  Each step records the 0..2 renormalisation bytes it emits; their stream positions are a prefix sum.
 // ---------------------------------------------------------------------------------------------------------------
-// one encoder step; returns the new state, *em = emitted bytes | count << 16
-__device__ __forceinline__ uint32_t rans_step(uint32_t x, uint32_t lf, uint32_t rcp, uint32_t *em)
+// one encoder step (branch-free, 6 dependent levels); returns the new state, e = emitted bytes | count << 16
+__device__ __forceinline__ uint32_t rans_step(uint32_t x, const uint4 r, uint32_t &e)
 {
-    const uint32_t lo = lf & 0xffffu, fr = lf >> 16;
-    const uint32_t xmax = fr << 15;          // ((RANS_L >> 16) << 8) * freq
-    uint32_t e = 0;
-    if (x >= xmax) {
-        e = (x & 0xffu) | (1u << 16); x >>= 8;
-        if (x >= xmax) { e = (e & 0xffu) | ((x & 0xffu) << 8) | (2u << 16); x >>= 8; }
-    }
-    uint32_t q;
-    if (fr >= 2) q = __umulhi(x, rcp) >> (31 - __clz((int)(fr - 1)));    // ceil(log2 fr) - 1
-    else q = x;
-    *em = e;
-    return x + lo + q * (65536u - fr);        // == ((x / fr) << 16) + x % fr + lo
+    const uint32_t xmax = r.x;                // ((RANS_L >> 16) << 8) * freq
+    const uint32_t x8 = x >> 8, x16 = x >> 16;
+    const bool b1 = x >= xmax, b2 = x8 >= xmax;        // b2 implies b1
+    const uint32_t xr = b2 ? x16 : (b1 ? x8 : x);
+    e = b2 ? (((x & 0xffu) | ((x8 & 0xffu) << 8)) | (2u << 16)) : (b1 ? ((x & 0xffu) | (1u << 16)) : 0u);
+    const uint32_t q = __umulhi(xr, r.y) >> (r.w >> 20);
+    return xr + r.z + q * (r.w & 0xFFFFFu);   // == ((xr / freq) << 16) + xr % freq + low
 }
 
-// lanes = (chunk, state lane).  Records are consumed last-to-first in batches of 8 (four 16-byte loads, the next
-// batch requested before the current one is consumed); the 8 emit words of a batch leave as two 16-byte stores.
-__global__ __launch_bounds__(64) void k_rans_lanes(const uint2 *__restrict__ recs, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
+// One wave per chunk.  Lanes 0..3 run the four state chains (pair j -> lane j & 3), last record first.  All 64
+// lanes stage the records through LDS in tiles of 128 per chain: the global loads of the next tile are issued
+// before the 128 dependent steps of the current tile and only land in LDS afterwards, so HBM latency never sits on
+// the chain; emit words go back through LDS as coalesced 16-byte stores.
+constexpr int RANS_TILE = 128;
+
+__global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ recs, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
                                                   uint32_t *__restrict__ emit, uint32_t *__restrict__ fstate)
 {
-    const uint32_t g = blockIdx.x * 64 + threadIdx.x;
-    const uint32_t c = g >> 2, L = g & 3u;
-    if (c >= d.nch) return;
+    __shared__ uint4 rbuf[2][4][RANS_TILE];
+    __shared__ uint32_t ebuf[4][RANS_TILE];
+    const uint32_t c = blockIdx.x;
+    const int t = threadIdx.x;
     const uint32_t np = 2 * rlen[c];
-    const size_t lane_stride = rans_lane_stride(rle_stride);
-    const uint4 *rc = reinterpret_cast<const uint4 *>(recs + ((size_t)c * 4 + L) * lane_stride);
-    uint4 *em = reinterpret_cast<uint4 *>(emit + ((size_t)c * 4 + L) * lane_stride);
-    uint32_t x = RANS_L;
-    if (L < np) {
-        const int64_t kmax = (int64_t)((np - 1 - L) / 4);     // this lane's last record
-        int64_t kb = kmax & ~(int64_t)7;
-        uint4 v0 = rc[kb / 2], v1 = rc[kb / 2 + 1], v2 = rc[kb / 2 + 2], v3 = rc[kb / 2 + 3];
-        for (; kb >= 0; kb -= 8) {
-            uint4 n0 = v0, n1 = v1, n2 = v2, n3 = v3;
-            if (kb >= 8) { n0 = rc[kb / 2 - 4]; n1 = rc[kb / 2 - 3]; n2 = rc[kb / 2 - 2]; n3 = rc[kb / 2 - 1]; }
-            uint32_t e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kb + 7 <= kmax) x = rans_step(x, v3.z, v3.w, &e[7]);
-            if (kb + 6 <= kmax) x = rans_step(x, v3.x, v3.y, &e[6]);
-            if (kb + 5 <= kmax) x = rans_step(x, v2.z, v2.w, &e[5]);
-            if (kb + 4 <= kmax) x = rans_step(x, v2.x, v2.y, &e[4]);
-            if (kb + 3 <= kmax) x = rans_step(x, v1.z, v1.w, &e[3]);
-            if (kb + 2 <= kmax) x = rans_step(x, v1.x, v1.y, &e[2]);
-            if (kb + 1 <= kmax) x = rans_step(x, v0.z, v0.w, &e[1]);
-            x = rans_step(x, v0.x, v0.y, &e[0]);
-            em[kb / 4] = make_uint4(e[0], e[1], e[2], e[3]);
-            em[kb / 4 + 1] = make_uint4(e[4], e[5], e[6], e[7]);
-            v0 = n0; v1 = n1; v2 = n2; v3 = n3;
-        }
+    if (np == 0) {
+        if (t < 4) fstate[(size_t)c * 4 + t] = RANS_L;
+        return;
     }
-    fstate[(size_t)c * 4 + L] = x;
+    const size_t lane_stride = rans_lane_stride(rle_stride);
+    const int cl = t >> 4, part = t & 15;                       // staging role: chain cl, 16 lanes x 128 B = one tile row
+    const uint4 *src = recs + ((size_t)c * 4 + cl) * lane_stride + part * 8;
+    uint4 *dst = reinterpret_cast<uint4 *>(emit + ((size_t)c * 4 + cl) * lane_stride) + part * 2;
+    const int64_t kmax = (t < 4 && (uint32_t)t < np) ? (int64_t)((np - 1 - t) / 4) : -1;   // my chain's last record
+    const int64_t ntiles = (int64_t)(((np + 3) / 4 + RANS_TILE - 1) / RANS_TILE);
+    uint32_t x = RANS_L;
+    uint4 p[8];
+    {
+        const uint4 *s0 = src + (ntiles - 1) * RANS_TILE;
+#pragma unroll
+        for (int i = 0; i < 8; i++) p[i] = s0[i];
+    }
+    int buf = 0;
+    for (int64_t tt = ntiles - 1; tt >= 0; tt--) {
+        {   // land the prefetched tile in LDS
+            uint4 *ld = &rbuf[buf][cl][0] + part * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) ld[i] = p[i];
+        }
+        __syncthreads();
+        {   // request the next tile (clamped: unconditional)
+            const uint4 *s0 = src + (tt > 0 ? tt - 1 : 0) * RANS_TILE;
+#pragma unroll
+            for (int i = 0; i < 8; i++) p[i] = s0[i];
+        }
+        if (t < 4) {
+            const int64_t base = tt * RANS_TILE;
+            int k = (int)((kmax - base < RANS_TILE - 1) ? kmax - base : RANS_TILE - 1);
+            const uint4 *rb = &rbuf[buf][t][0];
+            uint32_t *eb = &ebuf[t][0];
+            for (; k >= 3; k -= 4) {
+                const uint4 r0 = rb[k], r1 = rb[k - 1], r2 = rb[k - 2], r3 = rb[k - 3];
+                uint32_t e0, e1, e2, e3;
+                x = rans_step(x, r0, e0);
+                x = rans_step(x, r1, e1);
+                x = rans_step(x, r2, e2);
+                x = rans_step(x, r3, e3);
+                eb[k] = e0; eb[k - 1] = e1; eb[k - 2] = e2; eb[k - 3] = e3;
+            }
+            for (; k >= 0; k--) {
+                const uint4 r0 = rb[k];
+                uint32_t e0;
+                x = rans_step(x, r0, e0);
+                eb[k] = e0;
+            }
+        }
+        __syncthreads();
+        {   // emit words of this tile: 4 chains x 512 B
+            const uint4 *es = reinterpret_cast<const uint4 *>(&ebuf[cl][0]) + part * 2;
+            uint4 *ed = dst + tt * (RANS_TILE / 4);
+            ed[0] = es[0]; ed[1] = es[1];
+        }
+        buf ^= 1;
+    }
+    if (t < 4) fstate[(size_t)c * 4 + t] = x;
 }
 
 // per chunk: exclusive prefix sum of the emit counts (forward pair order) -> byte positions; csize = 16 + total.
@@ -829,7 +870,7 @@ struct EncBufs {
     uint32_t *clscnt, *clstotal, *ord, *qhist, *qcdf;
     uint8_t *cls8;
     uint32_t *seg_flag; int32_t *seg_lo, *seg_end, *seg_start; uint16_t *seg_tab;
-    uint16_t *explo, *exphi; uint32_t *mantad, *pairs; uint2 *recs;
+    uint16_t *explo, *exphi; uint32_t *mantad, *pairs; uint4 *recs;
     uint32_t *emit, *epos, *fstate, *csize;
     uint8_t *hdr; uint32_t *hsize; uint64_t *outoff;
 };
@@ -872,7 +913,7 @@ void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what)
         b.seg_end = a.get<int32_t>(segs);
         b.seg_start = a.get<int32_t>(segs);
         b.seg_tab = a.get<uint16_t>(segs * 32);
-        b.recs = a.get<uint2>((size_t)d.nch * 4 * rans_lane_stride(stride));
+        b.recs = a.get<uint4>((size_t)d.nch * 4 * rans_lane_stride(stride));
         b.pairs = (what & LAY_PLAIN) ? a.get<uint32_t>((size_t)d.nch * stride * 2) : nullptr;
     }
     if (what & LAY_RANS) {
@@ -959,7 +1000,7 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     JPK_TRY(run_rle(ctx, b.ranks, d, b));
     JPK_TRY(run_model(ctx, b.rle, b.rlen, d, b));
     const size_t stride = d.chunk;
-    JPK_LAUNCH(ctx, PROF_ENC_RANS, 0, k_rans_lanes, dim3(jpk_grid((size_t)d.nch * 4, 64)), dim3(64), b.recs, stride, d, b.rlen, b.emit, b.fstate);
+    JPK_LAUNCH(ctx, PROF_ENC_RANS, 0, k_rans_lanes, dim3(d.nch), dim3(64), b.recs, stride, d, b.rlen, b.emit, b.fstate);
     JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_emit_scan, dim3(d.nch), dim3(1024), b.emit, stride, d, b.rlen, b.epos, b.csize);
     JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_headers, dim3(1), dim3(1024), d, b.freq, b.csize, b.rlen, b.hdr, b.hsize, b.outoff, ctx->d_mail);
     JPK_HIP(hipGetLastError());
