@@ -25,6 +25,26 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
+# algorithmic HBM bytes per processed unit of every timed kernel class
+ALG_BYTES_PER_UNIT = {
+    "k_rs_hist": (8, "sorted (key,value) pair"),
+    "k_rs_scatter": (24, "sorted (key,value) pair"),
+    "k_scan_*": (12, "u32 element"),
+    "k_init_keys/k_make_keys/k_win_heads": (12, "suffix"),
+    "k_seg_round": (28, "active suffix"),
+    "sa rerank kernels": (16, "suffix"),
+    "k_bwt_gather": (6, "block byte"),
+    "k_enc_hist/k_enc_prep": (1, "block byte"),
+    "k_enc_mtf": (2, "block byte"),
+    "k_rle_*": (2, "block byte"),
+    "k_cls_*/k_quasi_build": (9, "RLE0 symbol"),
+    "k_adaptive": (15, "RLE0 symbol"),
+    "k_pairs": (44, "RLE0 symbol"),
+    "k_rans_lanes": (20, "rANS pair"),
+    "k_emit_scan/k_put_*": (13, "rANS pair"),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -34,6 +54,7 @@ def parse():
     ap.add_argument("--block-mib", type=int, default=64)
     ap.add_argument("--limit-bytes", type=int, default=0, help="truncate the workload (debug only; marks the line invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--contexts", type=int, default=2, help="blocks in flight per GPU (one context + HIP stream each)")
     ap.add_argument("--cpu-sample-mib", type=int, default=24)
     return ap.parse_args()
 
@@ -99,17 +120,28 @@ def main():
     caps = [jam.ans_capacity(len(b) + jam.TRAILER) for b in blocks]
     d_out = [torch.empty(c, dtype=torch.uint8, device=dev) for c in caps]
     stream = torch.cuda.current_stream()
-    ctx = jam.Context(local_rank, stream.cuda_stream)
-    ctx.reserve(max(len(b) for b in blocks))
+    ctx = jam.Context(local_rank, stream.cuda_stream)           # stage breakdown / profiling context (torch's stream)
+    # blocks are independent (jampack.cpp:215: one Jampack instance per OpenMP thread): keep `--contexts` of them in
+    # flight, each on its own context = own HBM arena + own HIP stream, driven by one host thread each
+    import concurrent.futures as cf
+    nctx = max(1, min(args.contexts, len(blocks)))
+    ctxs = [jam.Context(local_rank, None) for _ in range(nctx)]
+    pool = cf.ThreadPoolExecutor(max_workers=nctx)
+    order = sorted(range(len(blocks)), key=lambda i: -len(blocks[i]))          # largest first
+    lanes = [order[k::nctx] for k in range(nctx)]
 
     sizes = [0] * len(blocks)
     max_comp = max(caps)
     gather_buf = torch.empty((world, max_comp), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
     pad_buf = torch.empty(max_comp, dtype=torch.uint8, device=dev) if world > 1 else None
 
+    def lane_work(k):
+        for i in lanes[k]:
+            sizes[i] = ctxs[k].block_compress(d_in[i], len(blocks[i]), d_out[i], caps[i])
+
     def compress_step():
-        for i, b in enumerate(blocks):
-            sizes[i] = ctx.block_compress(d_in[i], len(b), d_out[i], caps[i])
+        for f in [pool.submit(lane_work, k) for k in range(nctx)]:
+            f.result()
         if world > 1:
             # the only exchange of the path: compressed blocks -> rank 0 (sizes first, then payload), RCCL over xGMI
             sz = torch.tensor(sizes, dtype=torch.int64, device=dev)
@@ -182,14 +214,28 @@ def main():
         c = sum(comp_sizes) / batch_bytes
         alg = {"forward_bwt": 10.0, "ans_encode": 4.0 + c, "ans_decode": 4.0 + c, "inverse_bwt": 12.0}
         extra["stages_alg_GBps"] = {k: round(alg[k] * batch_bytes / 1e9 / (stage_ms[k] / 1e3), 2) for k in alg if stage_ms[k] > 0}
-        prof = ctx.profile() if hasattr(ctx, "profile") else None
-        if prof:
-            extra["roofline"] = prof
-        else:
-            # stage-level figure until the per-kernel HIP-event counters are wired (dominant stage = forward BWT)
-            a = alg["forward_bwt"] * batch_bytes / 1e9 / (stage_ms["forward_bwt"] / 1e3)
-            extra["roofline"] = {"bound": "hbm", "achieved": round(a, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(a / 8000.0, 5),
-                                 "traffic": None, "kernel": "forward_bwt stage (all kernels)", "note": "10 B per block byte / stage time"}
+        # per-kernel HIP-event timing (events recorded by the library on the launch stream) of one more compress pass
+        ctx.profile_enable(2)
+        for i, b in enumerate(blocks):
+            ctx.block_compress(d_in[i], len(b), d_out[i], caps[i])
+        tab = ctx.profile_table()
+        ctx.profile_enable(0)
+        rows = []
+        for r in tab:
+            bpu = ALG_BYTES_PER_UNIT.get(r["name"])
+            if not bpu or not r["units"] or r["ms"] <= 0:
+                continue
+            ach = bpu[0] * r["units"] / 1e9 / (r["ms"] / 1e3)
+            rows.append({"kernel": r["name"], "ms_total": round(r["ms"], 3), "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
+                         "alg_bytes_per_unit": bpu[0], "unit_is": bpu[1], "units": r["units"], "achieved": round(ach, 2), "frac": round(ach / 8000.0, 5)})
+        rows.sort(key=lambda r: -r["ms_total"])
+        if rows:
+            d0 = rows[0]
+            extra["roofline"] = {"bound": "hbm", "achieved": d0["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": d0["frac"], "traffic": None,
+                                 "kernel": d0["kernel"], "avg_launch_us": d0["avg_launch_us"], "launches": d0["launches"],
+                                 "alg_bytes_per_launch": round(d0["alg_bytes_per_unit"] * d0["units"] / d0["launches"]),
+                                 "note": "dominant kernel of the compress pass by total time; achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream)"}
+            extra["roofline_kernels"] = rows[:8]
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb, ref_enc = cpu_baseline(blocks[0], args.cpu_sample_mib)
@@ -212,10 +258,13 @@ def main():
             "dtype": "u8/int32", "data": "synthetic" if source == "synthetic" else source,
             "config": {"workload": f"{args.workload}-like {batch_bytes} B per GPU as {args.block_mib} MiB blocks ({len(blocks)} blocks), forward BWT + rANS encode, inputs resident in HBM"
                        + ("" if not args.limit_bytes else " [TRUNCATED: not a valid headline]"),
-                       "block_bytes": [len(b) for b in blocks], "parallelism": f"blocks sharded over {world} GPU(s), RCCL gather of compressed blocks" if world > 1 else "1 GPU"},
+                       "block_bytes": [len(b) for b in blocks], "parallelism": (f"blocks sharded over {world} GPU(s), RCCL gather of compressed blocks" if world > 1 else "1 GPU") + f", {nctx} blocks in flight per GPU"},
         }
         line.update(extra)
         print(json.dumps(line), flush=True)
+    pool.shutdown()
+    for c in ctxs:
+        c.close()
     ctx.close()
     if world > 1:
         dist.barrier()

@@ -379,9 +379,9 @@ int jpk_ans_decode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     uint32_t *status = ctx->d_mail + 8;
     JPK_HIP(hipMemsetAsync(status, 0, 4, st));
     JPK_HIP(hipMemsetAsync(d_out, 0, total_out, st));
-    JPK_LAUNCH(ctx, PROF_DEC_RANS, 0, k_dec_rans, dim3(nch), dim3(64), d_in, info, rle, status);
-    JPK_LAUNCH(ctx, PROF_DEC_RLE, 0, k_dec_rle, dim3(nch), dim3(1024), rle, info, d_out, status);
-    JPK_LAUNCH(ctx, PROF_DEC_RANK, 0, k_dec_rank, dim3(nch), dim3(64), d_out, info, freq, tmp, status);
+    JPK_LAUNCH(ctx, PROF_DEC_RANS, 2 * total_rle, k_dec_rans, dim3(nch), dim3(64), d_in, info, rle, status);
+    JPK_LAUNCH(ctx, PROF_DEC_RLE, total_rle, k_dec_rle, dim3(nch), dim3(1024), rle, info, d_out, status);
+    JPK_LAUNCH(ctx, PROF_DEC_RANK, total_out, k_dec_rank, dim3(nch), dim3(64), d_out, info, freq, tmp, status);
     JPK_HIP(hipGetLastError());
     JPK_HIP(hipMemcpyAsync(d_out, tmp, total_out, hipMemcpyDeviceToDevice, st));
     JPK_HIP(hipMemcpyAsync(ctx->d_mail, status, 4, hipMemcpyDeviceToDevice, st));

@@ -940,9 +940,9 @@ EncDims make_dims(uint32_t len, uint32_t chunk)
 int run_rank(jpk_ctx *ctx, const uint8_t *d_in, const EncDims &d, EncBufs &b)
 {
     hipStream_t st = ctx->stream;
-    JPK_LAUNCH(ctx, PROF_ENC_HIST, 0, k_enc_hist, dim3(d.tpc, d.nch), dim3(TB), d_in, d, b.tilecnt, b.lastpos);
-    JPK_LAUNCH(ctx, PROF_ENC_HIST, 0, k_enc_prep, dim3(d.nch), dim3(256), d, b.tilecnt, b.lastpos, b.freq, b.bstart);
-    JPK_LAUNCH(ctx, PROF_ENC_MTF, 0, k_enc_mtf, dim3((d.tpc + 3) / 4, d.nch), dim3(TB), d_in, d, b.tilecnt, b.lastpos, b.bstart, b.ranks);
+    JPK_LAUNCH(ctx, PROF_ENC_HIST, d.len, k_enc_hist, dim3(d.tpc, d.nch), dim3(TB), d_in, d, b.tilecnt, b.lastpos);
+    JPK_LAUNCH(ctx, PROF_ENC_HIST, d.len, k_enc_prep, dim3(d.nch), dim3(256), d, b.tilecnt, b.lastpos, b.freq, b.bstart);
+    JPK_LAUNCH(ctx, PROF_ENC_MTF, d.len, k_enc_mtf, dim3((d.tpc + 3) / 4, d.nch), dim3(TB), d_in, d, b.tilecnt, b.lastpos, b.bstart, b.ranks);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
 }
@@ -950,11 +950,11 @@ int run_rank(jpk_ctx *ctx, const uint8_t *d_in, const EncDims &d, EncBufs &b)
 int run_rle(jpk_ctx *ctx, const uint8_t *d_ranks, const EncDims &d, EncBufs &b)
 {
     hipStream_t st = ctx->stream;
-    JPK_LAUNCH(ctx, PROF_ENC_RLE, 0, k_rle_lz, dim3(d.tpc, d.nch), dim3(TB), d_ranks, d, b.lz);
-    JPK_LAUNCH(ctx, PROF_ENC_RLE, 0, k_rle_ext, dim3(jpk_grid(d.nch, 64)), dim3(64), d, b.lz, b.ext);
-    JPK_LAUNCH(ctx, PROF_ENC_RLE, 0, (k_rle_tiles<false>), dim3(d.tpc, d.nch), dim3(TB), d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
-    JPK_LAUNCH(ctx, PROF_ENC_RLE, 0, k_tile_prefix, dim3(jpk_grid(d.nch, 64)), dim3(64), d, b.tcount, b.toff, b.rlen, 1u, (const uint32_t *)nullptr);
-    JPK_LAUNCH(ctx, PROF_ENC_RLE, 0, (k_rle_tiles<true>), dim3(d.tpc, d.nch), dim3(TB), d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, k_rle_lz, dim3(d.tpc, d.nch), dim3(TB), d_ranks, d, b.lz);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, k_rle_ext, dim3(jpk_grid(d.nch, 64)), dim3(64), d, b.lz, b.ext);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, (k_rle_tiles<false>), dim3(d.tpc, d.nch), dim3(TB), d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, k_tile_prefix, dim3(jpk_grid(d.nch, 64)), dim3(64), d, b.tcount, b.toff, b.rlen, 1u, (const uint32_t *)nullptr);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, (k_rle_tiles<true>), dim3(d.tpc, d.nch), dim3(TB), d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
 }
@@ -1009,6 +1009,14 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     const uint64_t total = ((uint64_t)mail[1] << 32) | mail[0];
     ctx->stats.ans_chunks = d.nch;
     ctx->stats.ans_rle_symbols = (int64_t)(((uint64_t)mail[3] << 32) | mail[2]);
+    if (ctx->prof_on) {    // symbol-based kernels: units are only known now (RLE0 symbols / rANS pairs of this call)
+        const uint64_t rs = (uint64_t)ctx->stats.ans_rle_symbols;
+        ctx->prof_units[PROF_ENC_CLASS] += rs;
+        ctx->prof_units[PROF_ENC_ADAPTIVE] += rs;
+        ctx->prof_units[PROF_ENC_PAIRS] += rs;
+        ctx->prof_units[PROF_ENC_RANS] += 2 * rs;
+        ctx->prof_units[PROF_ENC_EMIT] += 2 * rs;
+    }
     if (total > (uint64_t)out_cap) return JPK_E_CAPACITY;
     JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_headers, dim3(d.nch), dim3(TB), d, b.hdr, b.hsize, b.outoff, b.fstate, d_out);
     JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_payload, dim3(jpk_grid(2 * stride, TB), d.nch), dim3(TB), stride, d, b.rlen, b.emit, b.epos, b.hsize,

@@ -281,15 +281,15 @@ int jpk_inv_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trail
     Arena real(ctx, false);
     inv_layout(real, n, b, ntiles, nsplit, max_slots);
 
-    JPK_LAUNCH(ctx, PROF_INV_HIST, 0, k_hist, dim3((unsigned)ntiles), dim3(TB), d_in, n, b.tilehist, (uint32_t)ntiles);
+    JPK_LAUNCH(ctx, PROF_INV_HIST, n, k_hist, dim3((unsigned)ntiles), dim3(TB), d_in, n, b.tilehist, (uint32_t)ntiles);
     JPK_TRY(jpk_exclusive_sum_u32(ctx, b.tilehist, b.tilehist, 256 * ntiles, b.scan_scratch, nullptr));
-    JPK_LAUNCH(ctx, PROF_INV_HIST, 0, k_cum, dim3(1), dim3(256), b.tilehist, (uint32_t)ntiles, n, b.cum);
-    JPK_LAUNCH(ctx, PROF_INV_BUILD, 0, k_build_nxt, dim3((unsigned)ntiles), dim3(TB), d_in, n, I, b.tilehist, (uint32_t)ntiles, b.nxt);
+    JPK_LAUNCH(ctx, PROF_INV_HIST, n, k_cum, dim3(1), dim3(256), b.tilehist, (uint32_t)ntiles, n, b.cum);
+    JPK_LAUNCH(ctx, PROF_INV_BUILD, n, k_build_nxt, dim3((unsigned)ntiles), dim3(TB), d_in, n, I, b.tilehist, (uint32_t)ntiles, b.nxt);
 
     JPK_HIP(hipMemsetAsync(ctx->d_mail, 0, 16, st));
     int lut_shift = 0;
     while (((uint64_t)(n - 1) >> lut_shift) >= LUT) lut_shift++;
-    JPK_LAUNCH(ctx, PROF_INV_WALK, 0, k_walk, dim3(jpk_grid(nsplit + 1, TB)), dim3(TB), b.nxt, b.cum, n, I, (uint32_t)nsplit, (uint32_t)lut_shift,
+    JPK_LAUNCH(ctx, PROF_INV_WALK, n, k_walk, dim3(jpk_grid(nsplit + 1, TB)), dim3(TB), b.nxt, b.cum, n, I, (uint32_t)nsplit, (uint32_t)lut_shift,
                        b.scratch, b.slot_len, b.slot_next, ctx->d_mail, (uint32_t)max_slots);
     uint32_t novf = 0;
     JPK_TRY(jpk_read_mail(ctx, &novf, 1));
@@ -308,8 +308,8 @@ int jpk_inv_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trail
         t = li; li = lo; lo = t;
     }
     JPK_LAUNCH(ctx, PROF_INV_RANK, 0, k_head_check, dim3(1), dim3(1), di, (uint32_t)nsplit, ctx->d_mail);
-    JPK_LAUNCH(ctx, PROF_INV_COPY, 0, k_copy_out, dim3(jpk_grid(nslots * 16, TB)), dim3(TB), b.scratch, b.slot_len, di, (uint32_t)nslots, n, d_out);
-    if (rem > 0) JPK_LAUNCH(ctx, PROF_INV_COPY, 0, k_inv_tail, dim3(1), dim3(128), d_in, n, (uint32_t)len, d_out);
+    JPK_LAUNCH(ctx, PROF_INV_COPY, n, k_copy_out, dim3(jpk_grid(nslots * 16, TB)), dim3(TB), b.scratch, b.slot_len, di, (uint32_t)nslots, n, d_out);
+    if (rem > 0) JPK_LAUNCH(ctx, PROF_INV_COPY, n, k_inv_tail, dim3(1), dim3(128), d_in, n, (uint32_t)len, d_out);
     JPK_HIP(hipGetLastError());
     uint32_t chk[2] = {0, 0};
     JPK_TRY(jpk_read_mail(ctx, chk, 2));

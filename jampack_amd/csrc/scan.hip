@@ -112,7 +112,7 @@ int run_scan(jpk_ctx *ctx, const uint32_t *in, uint32_t *out, size_t n, uint32_t
     size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     JPK_LAUNCH(ctx, PROF_SCAN, 0, (k_scan_reduce<Op>), dim3((unsigned)nb), dim3(SCAN_THREADS), in, n, scratch);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, (k_scan_partials<Op>), dim3(1), dim3(1024), scratch, nb, d_total);
-    JPK_LAUNCH(ctx, PROF_SCAN, 0, (k_scan_down<Op, EXCLUSIVE>), dim3((unsigned)nb), dim3(SCAN_THREADS), in, out, n, scratch);
+    JPK_LAUNCH(ctx, PROF_SCAN, n, (k_scan_down<Op, EXCLUSIVE>), dim3((unsigned)nb), dim3(SCAN_THREADS), in, out, n, scratch);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
 }
