@@ -105,8 +105,52 @@ __device__ __forceinline__ void quasi_rebuild(QuasiLds &q, int k, int A, int l)
     if (l == 0) { q.cdf[k][A] = 65536u; q.seen[k] = 0; q.expn[k] = (q.expn[k] < 65536u) ? q.expn[k] << 1 : 65536u; }
 }
 
-__global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in, const ChunkInfo *__restrict__ info, uint16_t *__restrict__ rle,
-                                                uint32_t *__restrict__ status)
+// 256-byte input window held across the wave (lane l = dword l), next window prefetched: the payload byte a
+// renormalisation needs is a v_readlane away instead of a dependent global load.
+struct ByteWindow {
+    const uint32_t *pw;       // dword-aligned base (payload start rounded down)
+    uint32_t a;               // payload start - aligned base (0..3)
+    int64_t gbase;            // byte offset of pw inside the whole input buffer
+    int64_t in_len;
+    const uint8_t *in;
+    uint32_t cur, nxt;        // my dword of the current / next window
+    uint32_t wi;              // index of the current window
+    int l;
+    __device__ __forceinline__ uint32_t load(uint32_t w) const
+    {
+        const int64_t g = gbase + ((int64_t)w * 64 + l) * 4;     // byte offset in the input buffer
+        if (g + 4 <= in_len) return pw[(size_t)w * 64 + l];
+        uint32_t v = 0;
+        for (int k = 0; k < 4; k++)
+            if (g + k < in_len) v |= (uint32_t)in[g + k] << (8 * k);
+        return v;
+    }
+    __device__ __forceinline__ void init(const uint8_t *input, int64_t input_len, const uint8_t *p, int lane)
+    {
+        in = input; in_len = input_len; l = lane;
+        a = (uint32_t)((uintptr_t)p & 3u);
+        pw = reinterpret_cast<const uint32_t *>(p - a);
+        gbase = (p - a) - input;
+        wi = 0;
+        cur = load(0);
+        nxt = load(1);
+    }
+    // byte at payload offset ptr (uniform); windows only move forward
+    __device__ __forceinline__ uint32_t get(uint32_t ptr)
+    {
+        const uint32_t o = ptr + a;
+        if ((o >> 8) != wi) {             // uniform
+            wi++;
+            cur = nxt;
+            nxt = load(wi + 1);
+        }
+        const uint32_t d = __builtin_amdgcn_readlane(cur, (o & 255u) >> 2);
+        return (d >> ((o & 3u) * 8u)) & 0xffu;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in, int64_t in_len, const ChunkInfo *__restrict__ info,
+                                                uint16_t *__restrict__ rle, uint32_t *__restrict__ status)
 {
     __shared__ QuasiLds q;
     const uint32_t c = blockIdx.x;
@@ -122,13 +166,19 @@ __global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in,
         if (l == 0) { q.seen[k] = 0; q.expn[k] = 8; }
     }
     __syncthreads();
+    ByteWindow bw;
+    bw.init(in, in_len, p, l);
     // exponent model: lane i holds cdf[i] (i <= 8); other lanes hold 65536 so they never count
     int32_t ex = (l <= 8) ? (int32_t)uniform_cdf(8, l) : 65536;
     int32_t a0 = 32768, a1 = 32768;          // cdf[1] of the two alphabet-2 mantissa models
     uint32_t R0, R1, R2, R3;
     {
-        auto rd = [&](int o) { return (uint32_t)p[o] | ((uint32_t)p[o + 1] << 8) | ((uint32_t)p[o + 2] << 16) | ((uint32_t)p[o + 3] << 24); };
-        R0 = rfl(rd(0)); R1 = rfl(rd(4)); R2 = rfl(rd(8)); R3 = rfl(rd(12));
+        uint32_t b[16];
+        for (int k = 0; k < 16; k++) b[k] = bw.get(k);
+        R0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        R1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        R2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+        R3 = b[12] | (b[13] << 8) | (b[14] << 16) | (b[15] << 24);
     }
     uint32_t ptr = 16;
     bool bad = false;
@@ -140,13 +190,13 @@ __global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in,
         const int e = __popcll(__ballot(l >= 1 && l <= 7 && (uint32_t)ex <= range));
         uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(ex, e);
         uint32_t hi = (uint32_t)__builtin_amdgcn_readlane(ex, e + 1);
+        if (l >= 1 && l <= 7) ex = adapt_step(ex, l, e, 8);
         x = (hi - lo) * (x >> 16) + range - lo;
         while (x < RANS_L) {
             if (ptr >= clen) { bad = true; break; }
-            x = (x << 8) | rfl((uint32_t)p[ptr]);
+            x = (x << 8) | bw.get(ptr);
             ptr++;
         }
-        if (l >= 1 && l <= 7) ex = adapt_step(ex, l, e, 8);
         R0 = R1; R1 = R2; R2 = R3; R3 = x;
         // ---- mantissa ----
         x = R0;
@@ -161,26 +211,26 @@ __global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in,
             if (e == 0) a0 = na; else a1 = na;
         } else {
             const int k = e - 2, A = class_alpha(e);
-            const uint32_t c1 = q.cdf[k][l + 1], c2 = q.cdf[k][l + 65];     // entries 1..128 (A-1 <= 128)
-            m = (uint32_t)__popcll(__ballot((l + 1 < A) && c1 <= range)) + (uint32_t)__popcll(__ballot((l + 65 < A) && c2 <= range));
+            const uint32_t c1 = q.cdf[k][l + 1];                                   // entries 1..64
+            m = (uint32_t)__popcll(__ballot((l + 1 < A) && c1 <= range));
+            if (A > 65) {                                                         // class 7 only: entries 65..128
+                const uint32_t c2 = q.cdf[k][l + 65];
+                m += (uint32_t)__popcll(__ballot((l + 65 < A) && c2 <= range));
+            }
             lo = q.cdf[k][m];
             hi = q.cdf[k][m + 1];
+            // QuasiModel::Update (model.cpp:160-204); a single wave: LDS operations complete in program order
+            const uint32_t seen = q.seen[k] + 1, expn = q.expn[k];
+            if (l == 0) { q.f[k][m] += 16u; q.seen[k] = seen; }
+            if (seen > expn) { __syncthreads(); quasi_rebuild(q, k, A, l); __syncthreads(); }
         }
         x = (hi - lo) * (x >> 16) + range - lo;
         while (x < RANS_L) {
             if (ptr >= clen) { bad = true; break; }
-            x = (x << 8) | rfl((uint32_t)p[ptr]);
+            x = (x << 8) | bw.get(ptr);
             ptr++;
         }
         R0 = R1; R1 = R2; R2 = R3; R3 = x;
-        if (e >= 2) {                                   // QuasiModel::Update (model.cpp:160-204)
-            const int k = e - 2;
-            uint32_t seen = q.seen[k] + 1, expn = q.expn[k];
-            __syncthreads();
-            if (l == 0) { q.f[k][m] += 16u; q.seen[k] = seen; }
-            __syncthreads();
-            if (seen > expn) { quasi_rebuild(q, k, class_alpha(e), l); __syncthreads(); }
-        }
         if (bad) break;
         const uint32_t sym = (uint32_t)class_base(e) + m;
         if ((t & 63u) == (uint32_t)l) mysym = sym;
@@ -252,10 +302,15 @@ __global__ __launch_bounds__(1024) void k_dec_rle(const uint16_t *__restrict__ r
 // sorted-rank decode (rank.cpp:96-151): one wave per chunk.
 // list: 256 byte positions held as one dword per lane (lane l = positions 4l..4l+3, little endian).
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v)        // lane i <- lane i+1 (lane 63 keeps its value): one DPP move
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+
 __device__ __forceinline__ uint32_t list_shift_insert(uint32_t v, int l, uint32_t r, uint32_t sym)
 {
     // positions < r take the value of position+1, position r takes sym, positions > r unchanged
-    const uint32_t nextv = __shfl_down(v, 1, 64);
+    const uint32_t nextv = wave_shl1(v);
     const uint32_t shifted = (v >> 8) | (nextv << 24);
     const int nb = (int)r - 4 * l;                      // bytes of this lane below position r
     uint32_t mask = nb <= 0 ? 0u : (nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u));
@@ -315,7 +370,7 @@ __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, con
             uniq--;
             // drop the front: positions < uniq shift down by one (rank.cpp:140-147; executes at least once)
             const uint32_t lim = uniq > 0 ? uniq : 1u;
-            const uint32_t nextv = __shfl_down(v, 1, 64);
+            const uint32_t nextv = wave_shl1(v);
             const uint32_t shifted = (v >> 8) | (nextv << 24);
             const int nb = (int)lim - 4 * l;
             const uint32_t mask = nb <= 0 ? 0u : (nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u));
@@ -379,7 +434,7 @@ int jpk_ans_decode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     uint32_t *status = ctx->d_mail + 8;
     JPK_HIP(hipMemsetAsync(status, 0, 4, st));
     JPK_HIP(hipMemsetAsync(d_out, 0, total_out, st));
-    JPK_LAUNCH(ctx, PROF_DEC_RANS, 2 * total_rle, k_dec_rans, dim3(nch), dim3(64), d_in, info, rle, status);
+    JPK_LAUNCH(ctx, PROF_DEC_RANS, 2 * total_rle, k_dec_rans, dim3(nch), dim3(64), d_in, (int64_t)len, info, rle, status);
     JPK_LAUNCH(ctx, PROF_DEC_RLE, total_rle, k_dec_rle, dim3(nch), dim3(1024), rle, info, d_out, status);
     JPK_LAUNCH(ctx, PROF_DEC_RANK, total_out, k_dec_rank, dim3(nch), dim3(64), d_out, info, freq, tmp, status);
     JPK_HIP(hipGetLastError());
