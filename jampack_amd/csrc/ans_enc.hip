@@ -677,14 +677,25 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
 // rANS (ans.cpp:189-208): four independent sequential chains per chunk (state lane = pair index & 3), last pair
 // first.  Each step records the 0..2 renormalisation bytes it emits; their stream positions are a prefix sum.
 // ---------------------------------------------------------------------------------------------------------------
-// one encoder step (branch-free, 6 dependent levels); returns the new state, e = emitted bytes | count << 16
+// (a >= b) ? t : f as v_cmp + v_cndmask.  hipcc turns the equivalent C++ selects of the renormalisation into
+// exec-mask branches (s_and_saveexec / s_xor / s_or per step), which doubles the length of the dependent chain.
+__device__ __forceinline__ uint32_t sel_ge(uint32_t a, uint32_t b, uint32_t t, uint32_t f)
+{
+    uint32_t r;
+    asm("v_cmp_ge_u32_e32 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %3, %4, vcc" : "=v"(r) : "v"(a), "v"(b), "v"(f), "v"(t) : "vcc");
+    return r;
+}
+
+// one encoder step (branch-free); returns the new state, e = emitted bytes | count << 16
 __device__ __forceinline__ uint32_t rans_step(uint32_t x, const uint4 r, uint32_t &e)
 {
     const uint32_t xmax = r.x;                // ((RANS_L >> 16) << 8) * freq
     const uint32_t x8 = x >> 8, x16 = x >> 16;
-    const bool b1 = x >= xmax, b2 = x8 >= xmax;        // b2 implies b1
-    const uint32_t xr = b2 ? x16 : (b1 ? x8 : x);
-    e = b2 ? (((x & 0xffu) | ((x8 & 0xffu) << 8)) | (2u << 16)) : (b1 ? ((x & 0xffu) | (1u << 16)) : 0u);
+    // b1 = x >= xmax (one byte leaves), b2 = x8 >= xmax (two bytes leave; implies b1)
+    const uint32_t t1 = sel_ge(x, xmax, x8, x);
+    const uint32_t xr = sel_ge(x8, xmax, x16, t1);
+    const uint32_t e1 = sel_ge(x, xmax, (x & 0xffu) | (1u << 16), 0u);
+    e = sel_ge(x8, xmax, (x & 0xffffu) | (2u << 16), e1);
     const uint32_t q = __umulhi(xr, r.y) >> (r.w >> 20);
     return xr + r.z + q * (r.w & 0xFFFFFu);   // == ((xr / freq) << 16) + xr % freq + low
 }
@@ -714,24 +725,22 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
     const int64_t kmax = (t < 4 && (uint32_t)t < np) ? (int64_t)((np - 1 - t) / 4) : -1;   // my chain's last record
     const int64_t ntiles = (int64_t)(((np + 3) / 4 + RANS_TILE - 1) / RANS_TILE);
     uint32_t x = RANS_L;
-    uint4 p[8];
+    uint4 p0, p1, p2, p3, p4, p5, p6, p7;          // named registers: an array here ends up in scratch
+#define JPK_TILE_LOAD(S) p0 = (S)[0]; p1 = (S)[1]; p2 = (S)[2]; p3 = (S)[3]; p4 = (S)[4]; p5 = (S)[5]; p6 = (S)[6]; p7 = (S)[7];
     {
         const uint4 *s0 = src + (ntiles - 1) * RANS_TILE;
-#pragma unroll
-        for (int i = 0; i < 8; i++) p[i] = s0[i];
+        JPK_TILE_LOAD(s0)
     }
     int buf = 0;
     for (int64_t tt = ntiles - 1; tt >= 0; tt--) {
         {   // land the prefetched tile in LDS
             uint4 *ld = &rbuf[buf][cl][0] + part * 8;
-#pragma unroll
-            for (int i = 0; i < 8; i++) ld[i] = p[i];
+            ld[0] = p0; ld[1] = p1; ld[2] = p2; ld[3] = p3; ld[4] = p4; ld[5] = p5; ld[6] = p6; ld[7] = p7;
         }
         __syncthreads();
         {   // request the next tile (clamped: unconditional)
             const uint4 *s0 = src + (tt > 0 ? tt - 1 : 0) * RANS_TILE;
-#pragma unroll
-            for (int i = 0; i < 8; i++) p[i] = s0[i];
+            JPK_TILE_LOAD(s0)
         }
         if (t < 4) {
             const int64_t base = tt * RANS_TILE;
