@@ -60,11 +60,10 @@ __global__ __launch_bounds__(TB) void k_round0_finish(const uint32_t *__restrict
     if (j >= n) return;
     uint32_t g = grp[j], s = sa[j];
     ISA0[s] = g;
-    ISA1[s] = g;
     bool head = (g == j);
     bool next_head = (j + 1 == n) || (grp[j + 1] == j + 1);
     bool single = head && next_head;
-    if (single) SA[j] = s;
+    if (single) { SA[j] = s; ISA1[s] = g; }      // finished: final rank in both buffers; the rest is rewritten by round 1
     keep[j] = single ? 0u : 1u;
 }
 
@@ -110,7 +109,8 @@ __global__ __launch_bounds__(TB) void k_win_heads(const uint32_t *__restrict__ a
 __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, uint32_t m, uint32_t n,
                                                  uint32_t h, int key_passes, const uint32_t *__restrict__ winscan /* inclusive max-scan of lasthead */,
                                                  const uint32_t *__restrict__ ISA_cur, uint32_t *__restrict__ ISA_nxt, uint32_t *__restrict__ SA,
-                                                 uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint32_t *__restrict__ lflag)
+                                                 uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint32_t *__restrict__ lflag, uint32_t *__restrict__ keep,
+                                                 uint32_t *__restrict__ large_count)
 {
     __shared__ uint32_t g[SEG_SPAN];          // group rank (abs SA position of the group head) per loaded element
     __shared__ uint32_t sv[SEG_SPAN];         // suffix index of the owned elements
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
     // ---- classify: size of the group of each position; owned = starts in my window and size <= SEG_TILE ----
     const uint32_t ph = (blockIdx.x > 0) ? winscan[blockIdx.x - 1] : 0u;          // 1 + last head before my window
     const uint32_t spill_start = ph > 0 ? ph - 1 : 0u;                              // global index
-    uint32_t my_fo = 0xFFFFFFFFu, my_oe = 0;
+    uint32_t my_fo = 0xFFFFFFFFu, my_oe = 0, my_large = 0;
 #pragma unroll
     for (int k = 0; k < SEG_ITEMS; k++) {
         uint32_t p = p0 + k;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
             else if (gs == 0xFFFFu) size = base + end - spill_start;
             else size = end - gs;
             const bool large = size > (uint32_t)SEG_TILE;
-            if (p < wlen) lflag[base + p] = large ? 1u : 0u;
+            if (p < wlen) { lflag[base + p] = large ? 1u : 0u; my_large += large ? 1u : 0u; }
             if (gs != 0xFFFFu && gs < (uint32_t)SEG_TILE && !large) {
                 if (p < my_fo) my_fo = p;
                 if (p + 1 > my_oe) my_oe = p + 1;
@@ -205,6 +205,8 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
         }
     }
     if (my_fo != 0xFFFFFFFFu) { atomicMin(&s_fo, my_fo); atomicMax(&s_oe, my_oe); }
+    my_large = wave_sum(my_large);
+    if (lane_id() == 0 && my_large) atomicAdd(large_count, my_large);
     __syncthreads();
     const uint32_t fo = s_fo, oe = s_oe;
     if (fo == 0xFFFFFFFFu) return;             // nothing owned
@@ -328,6 +330,7 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
             if (single) SA[ap[k]] = s;
             b_sa[base + fo + q] = s;
             b_grp[base + fo + q] = run | (single ? DONE : 0u);
+            keep[base + fo + q] = single ? 0u : 1u;
         }
     }
 }
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(TB) void k_abspos(const uint64_t *__restrict__ keys
 __global__ __launch_bounds__(TB) void k_large_finish(const uint32_t *__restrict__ abspos, const uint32_t *__restrict__ newrank,
                                                     const uint32_t *__restrict__ vals, const uint32_t *__restrict__ l_pos, uint32_t m,
                                                     uint32_t *__restrict__ ISA_nxt, uint32_t *__restrict__ SA, uint32_t *__restrict__ b_sa,
-                                                    uint32_t *__restrict__ b_grp)
+                                                    uint32_t *__restrict__ b_grp, uint32_t *__restrict__ keep)
 {
     uint32_t j = blockIdx.x * TB + threadIdx.x;
     if (j >= m) return;
@@ -392,20 +395,23 @@ __global__ __launch_bounds__(TB) void k_large_finish(const uint32_t *__restrict_
     uint32_t p = l_pos[j];
     b_sa[p] = s;
     b_grp[p] = r | (single ? DONE : 0u);
+    keep[p] = single ? 0u : 1u;
 }
 
-// keep flags of the round's output; finished suffixes also get their final rank in the buffer that was read
-// this round (it becomes the write buffer of the next round and is never rewritten for them)
-__global__ __launch_bounds__(TB) void k_round_keep(const uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint32_t m,
-                                                  uint32_t *__restrict__ ISA_cur, uint32_t *__restrict__ keep)
+// compaction of a round's output; finished suffixes also get their final rank in the buffer that was READ this
+// round (it becomes the write buffer of the next round and is never rewritten for them)
+__global__ __launch_bounds__(TB) void k_compact_round(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos,
+                                                     const uint32_t *__restrict__ b_sa, const uint32_t *__restrict__ b_grp, uint32_t m,
+                                                     uint32_t *__restrict__ ISA_cur, uint32_t *__restrict__ a_sa, uint32_t *__restrict__ a_grp)
 {
     uint32_t j = blockIdx.x * TB + threadIdx.x;
     if (j >= m) return;
-    uint32_t gv = b_grp[j];
-    if (gv & DONE) {
-        ISA_cur[b_sa[j]] = gv & ~DONE;
-        keep[j] = 0u;
-    } else keep[j] = 1u;
+    const uint32_t gv = b_grp[j], s = b_sa[j];
+    if (keep[j]) {
+        const uint32_t p = pos[j];
+        a_sa[p] = s;
+        a_grp[p] = gv;
+    } else ISA_cur[s] = gv & ~DONE;
 }
 
 // ---- BWT emission (bwt.cpp:44-61) -------------------------------------------------------------------
@@ -436,7 +442,7 @@ __global__ void k_bwt_trailer(const uint8_t *__restrict__ T, const uint32_t *__r
 
 struct SaBufs {
     uint64_t *keysA, *keysB;
-    uint32_t *valsA, *valsB, *ISA0, *ISA1, *SA, *a_sa, *a_grp, *b_sa, *b_grp, *t1, *t2, *t3, *l_pos, *win, *scratch;
+    uint32_t *valsA, *valsB, *ISA0, *ISA1, *SA, *a_sa, *a_grp, *b_sa, *b_grp, *t1, *t2, *t3, *keep, *l_pos, *win, *scratch;
 };
 
 void sa_layout(Arena &a, size_t n, SaBufs &b, bool need_sa_buf)
@@ -455,6 +461,7 @@ void sa_layout(Arena &a, size_t n, SaBufs &b, bool need_sa_buf)
     b.t1 = a.get<uint32_t>(n);
     b.t2 = a.get<uint32_t>(n);
     b.t3 = a.get<uint32_t>(n);
+    b.keep = a.get<uint32_t>(n);
     b.l_pos = a.get<uint32_t>(n);
     b.win = a.get<uint32_t>(n / SEG_TILE + 64);
     size_t sw = jpk_radix_scratch_words(n);
@@ -502,12 +509,14 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b, uint32_t **i
         // window bookkeeping: start of the group that spills into each window
         JPK_LAUNCH(ctx, PROF_SA_KEYS, m, k_win_heads, dim3(nwin), dim3(TB), b.a_grp, m, b.win);
         JPK_TRY(jpk_inclusive_max_u32(ctx, b.win, b.win, nwin, b.scratch));
+        JPK_HIP(hipMemsetAsync(ctx->d_mail + 4, 0, 4, st));
         JPK_LAUNCH(ctx, PROF_SA_SEG, m, k_seg_round, dim3(nwin), dim3(TB), b.a_sa, b.a_grp, m, n, (uint32_t)h, key_passes, b.win, isa_cur, isa_nxt,
-                   b.SA, b.b_sa, b.b_grp, b.t1);                                       // t1 = lflag
-        JPK_TRY(jpk_exclusive_sum_u32(ctx, b.t1, b.t2, m, b.scratch, ctx->d_mail));   // t2 = position in the large list
-        uint32_t lc = 0;
-        JPK_TRY(jpk_read_mail(ctx, &lc, 1));
+                   b.SA, b.b_sa, b.b_grp, b.t1, b.keep, ctx->d_mail + 4);              // t1 = lflag
+        uint32_t mailw[5];
+        JPK_TRY(jpk_read_mail(ctx, mailw, 5));
+        const uint32_t lc = mailw[4];
         if (lc > 0) {
+            JPK_TRY(jpk_exclusive_sum_u32(ctx, b.t1, b.t2, m, b.scratch, nullptr));      // t2 = position in the large list
             const unsigned g_l = jpk_grid(lc, TB);
             uint32_t *l_sa = b.valsB, *l_grp = b.t3;
             JPK_LAUNCH(ctx, PROF_SA_KEYS, lc, k_large_gather, dim3(g_m), dim3(TB), b.t1, b.t2, b.a_sa, b.a_grp, m, l_sa, l_grp, b.l_pos);
@@ -517,11 +526,11 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b, uint32_t **i
             ctx->stats.sa_sorted_elems += lc;
             JPK_LAUNCH(ctx, PROF_SA_RERANK, lc, k_abspos, dim3(g_l), dim3(TB), b.keysA, b.t2, lc, b.t1, b.t3);  // t1 = abspos, t3 = nh
             JPK_TRY(jpk_inclusive_max_u32(ctx, b.t3, b.t2, lc, b.scratch));               // t2 = newrank
-            JPK_LAUNCH(ctx, PROF_SA_RERANK, lc, k_large_finish, dim3(g_l), dim3(TB), b.t1, b.t2, b.valsA, b.l_pos, lc, isa_nxt, b.SA, b.b_sa, b.b_grp);
+            JPK_LAUNCH(ctx, PROF_SA_RERANK, lc, k_large_finish, dim3(g_l), dim3(TB), b.t1, b.t2, b.valsA, b.l_pos, lc, isa_nxt, b.SA, b.b_sa, b.b_grp,
+                       b.keep);
         }
-        JPK_LAUNCH(ctx, PROF_SA_RERANK, m, k_round_keep, dim3(g_m), dim3(TB), b.b_sa, b.b_grp, m, isa_cur, b.t1);   // t1 = keep
-        JPK_TRY(jpk_exclusive_sum_u32(ctx, b.t1, b.t3, m, b.scratch, ctx->d_mail));       // t3 = pos
-        JPK_LAUNCH(ctx, PROF_SA_RERANK, m, k_compact, dim3(g_m), dim3(TB), b.t1, b.t3, b.b_sa, b.b_grp, m, b.a_sa, b.a_grp);
+        JPK_TRY(jpk_exclusive_sum_u32(ctx, b.keep, b.t3, m, b.scratch, ctx->d_mail));     // t3 = pos
+        JPK_LAUNCH(ctx, PROF_SA_RERANK, m, k_compact_round, dim3(g_m), dim3(TB), b.keep, b.t3, b.b_sa, b.b_grp, m, isa_cur, b.a_sa, b.a_grp);
         uint32_t m2 = 0;
         JPK_TRY(jpk_read_mail(ctx, &m2, 1));
         m = m2;
