@@ -19,6 +19,14 @@ def _ensure_built():
 
 _ensure_built()
 
+# torch bundles its own HIP runtime: let it initialise first so that libjampack_amd.so (linked against the system
+# ROCm) and torch share one runtime instance in the GPU tests that use both (torch tensors as device buffers)
+try:
+    import torch
+    torch.cuda.is_available()
+except Exception:  # pragma: no cover - torch is optional for the CPU-only oracle tests
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
