@@ -1,0 +1,88 @@
+"""Full-size blocks (BASELINE.json configs 2, 3, 5) on the GPU: size-independent properties (round trip through every
+stage, trailer / length invariants, checksum of the concatenated stream) and -- when the reference build
+oracle/_ref is present -- byte equality with the reference itself on the same block.  -m gpu"""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _sha(t):
+    return hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import jampack_amd as jam
+    assert torch.cuda.is_available()
+    ctx = jam.Context(0, torch.cuda.current_stream().cuda_stream)
+    yield torch, jam, ctx
+    ctx.close()
+
+
+def _roundtrip(torch, jam, ctx, t):
+    n = len(t)
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(t).to(dev)
+    cap = jam.ans_capacity(n + 480)
+    d_bwt = torch.empty(n + 480, dtype=torch.uint8, device=dev)
+    d_enc = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_dec = torch.empty(n + 480, dtype=torch.uint8, device=dev)
+    d_back = torch.empty(n, dtype=torch.uint8, device=dev)
+    assert ctx.bwt_forward(d_in, n, d_bwt, n + 480) == n + 480
+    # invariants of the image: trailer[k] = ISA[k*step]+1 in [1, nlen], trailer values distinct, tail raw
+    nlen = n - n % 120
+    trailer = d_bwt[n:].cpu().numpy().view("<i4")
+    assert trailer.min() >= 1 and trailer.max() <= nlen and len(set(trailer.tolist())) == 120
+    assert torch.equal(d_bwt[nlen:n], d_in[nlen:n])
+    # the BWT is a permutation of the sorted part: byte histograms agree
+    assert torch.equal(torch.bincount(d_bwt[:nlen].int(), minlength=256), torch.bincount(d_in[:nlen].int(), minlength=256))
+    clen = ctx.ans_encode(d_bwt, n + 480, d_enc, cap)
+    assert ctx.ans_decode(d_enc, clen, d_dec, n + 480) == n + 480
+    assert torch.equal(d_dec, d_bwt)
+    assert ctx.bwt_inverse(d_dec, n + 480, d_back, n) == n
+    assert torch.equal(d_back, d_in)
+    # fused entry points give the same stream
+    d_enc2 = torch.empty(cap, dtype=torch.uint8, device=dev)
+    assert ctx.block_compress(d_in, n, d_enc2, cap) == clen
+    assert torch.equal(d_enc2[:clen], d_enc[:clen])
+    assert ctx.block_decompress(d_enc2, clen, d_back, n) == n
+    assert torch.equal(d_back, d_in)
+    return d_bwt, d_enc[:clen]
+
+
+def test_enwik8_like_64mib_block(gpu, ref):
+    torch, jam, ctx = gpu
+    t = jam.corpus.make("text", 100_000_000, 8)[: 64 << 20]
+    d_bwt, d_enc = _roundtrip(torch, jam, ctx, t)
+    # bit-exact against the reference on the full 64 MiB block
+    rb = ref.bwt_forward(t)
+    assert hashlib.sha256(rb.tobytes()).hexdigest() == _sha(d_bwt)
+    re_ = ref.ans_encode(rb)
+    assert len(re_) == d_enc.numel() and hashlib.sha256(re_.tobytes()).hexdigest() == _sha(d_enc)
+
+
+def test_enwik8_like_tail_block(gpu):
+    torch, jam, ctx = gpu
+    t = jam.corpus.make("text", 100_000_000, 8)[64 << 20:]
+    assert len(t) == 32_891_136
+    _roundtrip(torch, jam, ctx, t)
+
+
+def test_silesia_like_212mb_block(gpu):
+    """config 5: one mixed block (text, 16-bit samples, random, DNA, runs, 1 MiB segment repeated) of 211 938 580 B"""
+    torch, jam, ctx = gpu
+    t = jam.corpus.make("silesia", 211_938_580, 5)
+    _roundtrip(torch, jam, ctx, t)
+    s = ctx.stats()
+    assert s.sa_rounds >= 10          # the repeated 1 MiB segment needs log2(LCP) doubling rounds
+
+
+def test_worst_case_blocks_16mib(gpu, oracle):
+    torch, jam, ctx = gpu
+    for kind in ("zero", "repeat", "two"):
+        t = jam.corpus.make(kind, 16 << 20, 3)
+        d_bwt, _ = _roundtrip(torch, jam, ctx, t)
