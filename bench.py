@@ -45,6 +45,24 @@ ALG_BYTES_PER_UNIT = {
 }
 
 
+def pmc_traffic(kernel_class: str):
+    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; KiB counters; reads x2 for the gfx950
+    half-count of wide coalesced loads, MI355X_MICROARCH.md section HBM).  None if no PMC summary is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    tab = json.load(open(path))
+    names = [n.strip().rstrip("*") for n in kernel_class.split("/")]
+    fetch = write = launches = 0.0
+    for k, v in tab.items():
+        if any(k.startswith(n) for n in names if n.startswith("k_")):
+            fetch += 2.0 * v["fetch_KiB_raw"] * 1024
+            write += v["write_KiB"] * 1024
+            launches += v["launches"]
+    return round((fetch + write) / launches) if launches else None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,6 +144,8 @@ def main():
     import concurrent.futures as cf
     nctx = max(1, min(args.contexts, len(blocks)))
     ctxs = [jam.Context(local_rank, None) for _ in range(nctx)]
+    for c in [ctx] + ctxs:
+        c.reserve(max(len(b) for b in blocks))          # HBM arenas sized before anything is timed
     pool = cf.ThreadPoolExecutor(max_workers=nctx)
     order = sorted(range(len(blocks)), key=lambda i: -len(blocks[i]))          # largest first
     lanes = [order[k::nctx] for k in range(nctx)]
@@ -204,8 +224,31 @@ def main():
         mb = batch_bytes / 1e6
         extra["stages_ms"] = {k: round(v, 3) for k, v in stage_ms.items()}
         extra["stages_MBps"] = {k: round(mb / (v / 1e3), 1) for k, v in stage_ms.items() if v > 0}
-        extra["decompress"] = {"value": round(mb / ((stage_ms["ans_decode"] + stage_ms["inverse_bwt"]) / 1e3), 1), "unit": "MB/s",
+        # decompress leg (rANS decode -> inverse BWT, jampack.cpp:49-50) over the same batch, blocks in flight like compress
+        d_cmp = [d_out[i][: sizes[i]].clone() for i in range(len(blocks))]
+        d_dcm = [torch.empty(max(len(b), 1), dtype=torch.uint8, device=dev) for b in blocks]
+        dsz = [0] * len(blocks)
+
+        def dlane(k):
+            for i in lanes[k]:
+                dsz[i] = ctxs[k].block_decompress(d_cmp[i], sizes[i], d_dcm[i], len(blocks[i]))
+
+        def decompress_step():
+            for f in [pool.submit(dlane, k) for k in range(nctx)]:
+                f.result()
+
+        decompress_step()
+        torch.cuda.synchronize()
+        td0 = time.perf_counter()
+        decompress_step()
+        torch.cuda.synchronize()
+        td = time.perf_counter() - td0
+        ok = ok and all(dsz[i] == len(blocks[i]) and bool(torch.equal(d_dcm[i][: len(blocks[i])], d_in[i])) for i in range(len(blocks)))
+        extra["decompress"] = {"value": round(mb / td, 1), "unit": "MB/s", "ms_per_step": round(td * 1e3, 3),
+                               "one_block_at_a_time_MBps": round(mb / ((stage_ms["ans_decode"] + stage_ms["inverse_bwt"]) / 1e3), 1),
                                "inverse_bwt_MBps": round(mb / (stage_ms["inverse_bwt"] / 1e3), 1)}
+        extra["round_trip_ok"] = ok
+        del d_cmp, d_dcm
         extra["round_trip_ok"] = ok
         extra["compressed_bytes"] = int(sum(comp_sizes))
         extra["sa_rounds_last_block"] = int(st.sa_rounds)
@@ -231,10 +274,11 @@ def main():
         rows.sort(key=lambda r: -r["ms_total"])
         if rows:
             d0 = rows[0]
-            extra["roofline"] = {"bound": "hbm", "achieved": d0["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": d0["frac"], "traffic": None,
+            extra["roofline"] = {"bound": "hbm", "achieved": d0["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": d0["frac"],
+                                 "traffic": pmc_traffic(d0["kernel"]),
                                  "kernel": d0["kernel"], "avg_launch_us": d0["avg_launch_us"], "launches": d0["launches"],
                                  "alg_bytes_per_launch": round(d0["alg_bytes_per_unit"] * d0["units"] / d0["launches"]),
-                                 "note": "dominant kernel of the compress pass by total time; achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream)"}
+                                 "note": "dominant kernel of the compress pass by total time; achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream); traffic = PMC bytes per launch from profiles/r01_pmc_traffic.json; this kernel is bound by dependent-instruction latency (4 serial rANS chains per chunk), not by HBM"}
             extra["roofline_kernels"] = rows[:8]
         if world == 1 and not args.no_cpu_baseline:
             try:
