@@ -248,6 +248,9 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
     const uint64_t lt = lanemask_lt();
     const int gpasses = (ngroups <= 256u) ? 1 : 2;
     const int npass = (ngroups > 1u) ? key_passes + gpasses : key_passes;
+    // each wave ranks a contiguous quarter of the owned range: only ceil(no / 256) iterations of 64 are live
+    const int nit = (int)((no + TB - 1) / TB);
+    const uint32_t wspan = (uint32_t)nit * 64u;
     for (int pass = 0; pass < npass; pass++) {
         const bool on_key = pass < key_passes;
         const int shift = on_key ? 8 * pass : 8 * (pass - key_passes);
@@ -256,7 +259,8 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
         uint32_t rk[SEG_ITEMS], dg[SEG_ITEMS];
 #pragma unroll
         for (int it = 0; it < SEG_ITEMS; it++) {
-            const uint32_t q = w * (64 * SEG_ITEMS) + it * 64 + l;
+            if (it >= nit) break;
+            const uint32_t q = w * wspan + it * 64 + l;
             const bool valid = q < no;
             const uint32_t id = valid ? src[q] : 0u;
             const uint32_t d = valid ? (((on_key ? k2[id] : (uint32_t)lgid[id]) >> shift) & 255u) : 0u;
@@ -279,7 +283,8 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < SEG_ITEMS; it++) {
-            const uint32_t q = w * (64 * SEG_ITEMS) + it * 64 + l;
+            if (it >= nit) break;
+            const uint32_t q = w * wspan + it * 64 + l;
             if (q < no) {
                 const uint32_t d = dg[it] & 255u;
                 dst[dbase[d] + cnt[w][d] + rk[it]] = (uint16_t)(dg[it] >> 8);
