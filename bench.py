@@ -63,6 +63,9 @@ def pmc_traffic(kernel_class: str):
     return round((fetch + write) / launches) if launches else None
 
 
+FORCE_GATHER = bool(int(os.environ.get("JPK_FORCE_GATHER", "0")))      # exercise the RCCL gather with WORLD_SIZE=1 (test hook)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,7 +125,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or FORCE_GATHER:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -152,8 +155,8 @@ def main():
 
     sizes = [0] * len(blocks)
     max_comp = max(caps)
-    gather_buf = torch.empty((world, max_comp), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
-    pad_buf = torch.empty(max_comp, dtype=torch.uint8, device=dev) if world > 1 else None
+    gather_buf = torch.empty((world, max_comp), dtype=torch.uint8, device=dev) if ((world > 1 or FORCE_GATHER) and rank == 0) else None
+    pad_buf = torch.empty(max_comp, dtype=torch.uint8, device=dev) if (world > 1 or FORCE_GATHER) else None
 
     def lane_work(k):
         for i in lanes[k]:
@@ -162,7 +165,7 @@ def main():
     def compress_step():
         for f in [pool.submit(lane_work, k) for k in range(nctx)]:
             f.result()
-        if world > 1:
+        if world > 1 or FORCE_GATHER:
             # the only exchange of the path: compressed blocks -> rank 0 (sizes first, then payload), RCCL over xGMI
             sz = torch.tensor(sizes, dtype=torch.int64, device=dev)
             allsz = [torch.empty_like(sz) for _ in range(world)] if rank == 0 else None
@@ -172,7 +175,7 @@ def main():
                 dist.gather(pad_buf, list(gather_buf.unbind(0)) if rank == 0 else None, dst=0)
 
     def sync_all():
-        if world > 1:
+        if world > 1 or FORCE_GATHER:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -310,7 +313,7 @@ def main():
     for c in ctxs:
         c.close()
     ctx.close()
-    if world > 1:
+    if world > 1 or FORCE_GATHER:
         dist.barrier()
         dist.destroy_process_group()
 
