@@ -177,7 +177,7 @@ extern "C" int jpk_ctx_reserve(jpk_ctx *ctx, int64_t max_block_bytes)
 {
     if (!ctx || max_block_bytes < 0) return JPK_E_ARG;
     JPK_HIP(hipSetDevice(ctx->device));
-    return jpk_arena_ensure(ctx, (size_t)max_block_bytes * 56 + (64u << 20));
+    return jpk_arena_ensure(ctx, (size_t)max_block_bytes * 72 + (64u << 20));
 }
 
 extern "C" const char *jpk_strerror(int s)
