@@ -8,6 +8,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # see abi.hip: more than two blocks in flight need more HW queues
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libjampack_amd.so")
 

@@ -5,6 +5,12 @@
 
 #include "common.hpp"
 
+// Independent blocks run on separate contexts (= HIP streams).  ROCm multiplexes streams onto GPU_MAX_HW_QUEUES
+// hardware queues (default 4, of which two carried kernels concurrently in our measurements): with the default, more
+// than two blocks in flight serialise.  Ask for 16 queues unless the user has chosen a value; this runs when the library
+// is loaded, i.e. before the first HIP call of a program that links it.
+__attribute__((constructor)) static void jpk_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 // ---- arena / staging ---------------------------------------------------------------------------------------
 int jpk_arena_ensure(jpk_ctx *ctx, size_t bytes)
 {

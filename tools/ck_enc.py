@@ -1,5 +1,6 @@
 import os, sys, time
 sys.path.insert(0, os.getcwd())
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 import numpy as np, torch
 import jampack_amd as jam
 n = 64 << 20
