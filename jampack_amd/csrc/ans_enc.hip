@@ -13,6 +13,9 @@
 //                 per-interval histograms; the AdaptiveModel CDF entries are independent scalar recurrences.
 //   rANS          pair j lives in state lane j mod 4 -> four independent sequential chains per chunk that record
 //                 (bytes, count) per step; byte positions are a prefix sum; payload scattered afterwards.
+#include <algorithm>
+#include <vector>
+
 #include "ans_common.hpp"
 #include "common.hpp"
 
@@ -27,7 +30,11 @@ struct EncDims {
     uint32_t chunk;       // chunk size (ANS_CHUNK, or len for the stand-alone Postcoder entry)
     uint32_t nch;         // chunks
     uint32_t tpc;         // tiles per chunk
+    uint32_t ncl;         // chunks of this launch group (<= nch)
+    const uint32_t *cmap; // launch index -> chunk id (null: identity).  The densest chunks are launched first as their own
+                          // group so that their rANS chains start while the other chunks are still in the parallel stages.
 };
+__device__ __forceinline__ uint32_t chunk_of(const EncDims &d, uint32_t i) { return d.cmap ? d.cmap[i] : i; }
 __device__ __forceinline__ uint32_t chunk_len(const EncDims &d, uint32_t c)
 {
     uint64_t beg = (uint64_t)c * d.chunk;
@@ -41,7 +48,7 @@ __device__ __forceinline__ uint32_t chunk_len(const EncDims &d, uint32_t c)
 __global__ __launch_bounds__(TB) void k_enc_hist(const uint8_t *__restrict__ in, EncDims d, uint32_t *__restrict__ tilecnt,
                                                 int32_t *__restrict__ lastpos)
 {
-    const uint32_t c = blockIdx.y, t = blockIdx.x;
+    const uint32_t c = chunk_of(d, blockIdx.y), t = blockIdx.x;
     const uint32_t clen = chunk_len(d, c), ts = t * ATILE;
     if (ts >= clen) return;
     __shared__ uint32_t h[256];
@@ -70,7 +77,7 @@ __global__ __launch_bounds__(TB) void k_enc_hist(const uint8_t *__restrict__ in,
 __global__ __launch_bounds__(256) void k_enc_prep(EncDims d, uint32_t *__restrict__ tilecnt, int32_t *__restrict__ lastpos,
                                                  int32_t *__restrict__ freq, uint32_t *__restrict__ bstart)
 {
-    const uint32_t c = blockIdx.x, s = threadIdx.x;
+    const uint32_t c = chunk_of(d, blockIdx.x), s = threadIdx.x;
     const uint32_t clen = chunk_len(d, c);
     const uint32_t nt = (clen + ATILE - 1) / ATILE;
     uint32_t f = 0;
@@ -105,7 +112,7 @@ __global__ __launch_bounds__(TB) void k_enc_mtf(const uint8_t *__restrict__ in, 
                                                const int32_t *__restrict__ prevlast, const uint32_t *__restrict__ bstart,
                                                uint8_t *__restrict__ ranks)
 {
-    const uint32_t c = blockIdx.y;
+    const uint32_t c = chunk_of(d, blockIdx.y);
     const uint32_t t = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
     const uint32_t clen = chunk_len(d, c), ts = t * ATILE;
     if (ts >= clen) return;
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(TB) void k_enc_mtf(const uint8_t *__restrict__ in, 
 // leading zeros of every tile of the rank array
 __global__ __launch_bounds__(TB) void k_rle_lz(const uint8_t *__restrict__ ranks, EncDims d, uint32_t *__restrict__ lz)
 {
-    const uint32_t c = blockIdx.y, t = blockIdx.x;
+    const uint32_t c = chunk_of(d, blockIdx.y), t = blockIdx.x;
     const uint32_t clen = chunk_len(d, c), ts = t * ATILE;
     if (ts >= clen) return;
     const uint32_t tl = (clen - ts < (uint32_t)ATILE) ? clen - ts : (uint32_t)ATILE;
@@ -177,8 +184,9 @@ __global__ __launch_bounds__(TB) void k_rle_lz(const uint8_t *__restrict__ ranks
 // ext[t] = zeros that follow the end of tile t without interruption (within the chunk)
 __global__ void k_rle_ext(EncDims d, const uint32_t *__restrict__ lz, uint32_t *__restrict__ ext)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d.nch) return;
+    const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= d.ncl) return;
+    const uint32_t c = chunk_of(d, ci);
     const uint32_t clen = chunk_len(d, c);
     const uint32_t nt = (clen + ATILE - 1) / ATILE;
     uint32_t e = 0;
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(TB) void k_rle_tiles(const uint8_t *__restrict__ ra
                                                  uint32_t *__restrict__ tcount, const uint32_t *__restrict__ toff, uint16_t *__restrict__ rle,
                                                  size_t rle_stride)
 {
-    const uint32_t c = blockIdx.y, t = blockIdx.x;
+    const uint32_t c = chunk_of(d, blockIdx.y), t = blockIdx.x;
     const uint32_t clen = chunk_len(d, c), ts = t * ATILE;
     if (ts >= clen) return;
     const uint32_t tl = (clen - ts < (uint32_t)ATILE) ? clen - ts : (uint32_t)ATILE;
@@ -270,8 +278,9 @@ __global__ __launch_bounds__(TB) void k_rle_tiles(const uint8_t *__restrict__ ra
 __global__ void k_tile_prefix(EncDims d, const uint32_t *__restrict__ tcount, uint32_t *__restrict__ toff, uint32_t *__restrict__ total,
                               uint32_t unit_from_len /*1: tiles from chunk_len, 0: tiles from total_in*/, const uint32_t *__restrict__ count_in)
 {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d.nch) return;
+    const uint32_t ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= d.ncl) return;
+    const uint32_t c = chunk_of(d, ci);
     const uint32_t n = unit_from_len ? chunk_len(d, c) : count_in[c];
     const uint32_t nt = (n + ATILE - 1) / ATILE;
     uint32_t s = 0;
@@ -290,7 +299,7 @@ __global__ void k_tile_prefix(EncDims d, const uint32_t *__restrict__ tcount, ui
 __global__ __launch_bounds__(TB) void k_cls_count(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
                                                  uint32_t *__restrict__ clscnt)
 {
-    const uint32_t c = blockIdx.y, t = blockIdx.x;
+    const uint32_t c = chunk_of(d, blockIdx.y), t = blockIdx.x;
     const uint32_t n = rlen[c], ts = t * ATILE;
     if (ts >= n) return;
     __shared__ uint32_t h[8];
@@ -318,8 +327,9 @@ __global__ __launch_bounds__(TB) void k_cls_count(const uint16_t *__restrict__ r
 __global__ void k_cls_prefix(EncDims d, const uint32_t *__restrict__ rlen, uint32_t *__restrict__ clscnt, uint32_t *__restrict__ clstotal)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t c = g >> 3, k = g & 7u;
-    if (c >= d.nch) return;
+    const uint32_t k = g & 7u;
+    if ((g >> 3) >= d.ncl) return;
+    const uint32_t c = chunk_of(d, g >> 3);
     const uint32_t nt = (rlen[c] + ATILE - 1) / ATILE;
     uint32_t s = 0;
     for (uint32_t t = 0; t < nt; t++) {
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(TB) void k_cls_ord(const uint16_t *__restrict__ rle
                                                const uint32_t *__restrict__ clsbase, uint32_t *__restrict__ ord, uint32_t *__restrict__ qhist,
                                                uint8_t *__restrict__ cls8)
 {
-    const uint32_t c = blockIdx.y, t = blockIdx.x;
+    const uint32_t c = chunk_of(d, blockIdx.y), t = blockIdx.x;
     const uint32_t n = rlen[c], ts = t * ATILE;
     if (ts >= n) return;
     constexpr int W = TB / 64, IT = ATILE / TB;
@@ -395,7 +405,7 @@ __global__ __launch_bounds__(64) void k_quasi_build(EncDims d, const uint32_t *_
                                                    uint32_t *__restrict__ qcdf)
 {
     const int r = blockIdx.x, e = blockIdx.y + 2;
-    const uint32_t c = blockIdx.z;
+    const uint32_t c = chunk_of(d, blockIdx.z);
     const int A = class_alpha(e), l = lane_id();
     uint32_t *cdf = qcdf + (((size_t)c * 6 + (e - 2)) * NQ + r) * QSTRIDE;
     if (r == 0) {
@@ -521,7 +531,7 @@ __global__ __launch_bounds__(64) void k_adapt_a(const uint8_t *__restrict__ cls8
                                                uint32_t *__restrict__ mantad, uint32_t *__restrict__ seg_flag, int32_t *__restrict__ seg_lo,
                                                int32_t *__restrict__ seg_end, uint16_t *__restrict__ seg_tab)
 {
-    const uint32_t c = blockIdx.z, rec = blockIdx.y;
+    const uint32_t c = chunk_of(d, blockIdx.z), rec = blockIdx.y;
     const uint32_t k = blockIdx.x * 64 + threadIdx.x;
     const uint32_t n = rlen[c];
     const uint32_t nt = (n + ATILE - 1) / ATILE;
@@ -556,24 +566,35 @@ __global__ __launch_bounds__(64) void k_adapt_a(const uint8_t *__restrict__ cls8
         seg_end[so] = ad_run_write(r, c8p, t0, t1, lo, explo + (size_t)c * rle_stride, exphi + (size_t)c * rle_stride, mantad + (size_t)c * rle_stride);
         return;
     }
-    // transfer table of the 32 candidate start states lo .. lo+31 (hi - lo <= 31 after the warm-up)
+    // unresolved: k_adapt_tab tabulates the 32 candidate start states lo .. lo+31 (hi - lo <= 31 after the warm-up)
     seg_flag[so] = 0u;
     seg_lo[so] = lo;
-    int32_t x[32];
-#pragma unroll
-    for (int q = 0; q < 32; q++) x[q] = (lo + q < hi) ? lo + q : hi;
-    {
-        const int i = r.i, A = r.A;
-        for_each_cls(c8p, t0, t1, [&](uint32_t, uint32_t c8) {
-            if (r.hits(c8)) {
-                const int sy = r.sym(c8);
-#pragma unroll
-                for (int q = 0; q < 32; q++) x[q] = adapt_step(x[q], i, sy, A);
-            }
-        });
-    }
-#pragma unroll
-    for (int q = 0; q < 32; q++) seg_tab[so * 32 + q] = (uint16_t)(x[q] - 1);     // states are in [1, 65535+1)
+    seg_end[so] = hi;            // re-used as the interval's upper end until k_adapt_b has run
+}
+
+// transfer table of an unresolved segment: 32 lanes = 32 candidate start states walk the segment together (the
+// symbol loads are wave-uniform), instead of one lane walking it 32 times
+__global__ __launch_bounds__(64) void k_adapt_tab(const uint8_t *__restrict__ cls8, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
+                                                 const uint32_t *__restrict__ seg_flag, const int32_t *__restrict__ seg_lo,
+                                                 const int32_t *__restrict__ seg_end, uint16_t *__restrict__ seg_tab)
+{
+    const uint32_t c = chunk_of(d, blockIdx.z), rec = blockIdx.y;
+    const uint32_t k = blockIdx.x * 2 + (threadIdx.x >> 5);
+    const int q = threadIdx.x & 31;
+    const uint32_t n = rlen[c];
+    const uint32_t nt = (n + ATILE - 1) / ATILE;
+    if (k >= nt) return;
+    const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
+    if (seg_flag[so]) return;
+    const AdRec r(rec);
+    const uint32_t t0 = k * ATILE, t1 = (t0 + ATILE < n) ? t0 + ATILE : n;
+    const int32_t lo = seg_lo[so], hi = seg_end[so];
+    int32_t x = (lo + q < hi) ? lo + q : hi;
+    const int i = r.i, A = r.A;
+    for_each_cls(cls8 + (size_t)c * rle_stride, t0, t1, [&](uint32_t, uint32_t c8) {
+        if (r.hits(c8)) x = adapt_step(x, i, r.sym(c8), A);
+    });
+    seg_tab[so * 32 + q] = (uint16_t)(x - 1);     // states are in [1, 65535]
 }
 
 __global__ __launch_bounds__(64) void k_adapt_b(EncDims d, const uint32_t *__restrict__ rlen, const uint32_t *__restrict__ seg_flag,
@@ -581,8 +602,9 @@ __global__ __launch_bounds__(64) void k_adapt_b(EncDims d, const uint32_t *__res
                                                const uint16_t *__restrict__ seg_tab, int32_t *__restrict__ seg_start)
 {
     const uint32_t g = blockIdx.x * 64 + threadIdx.x;
-    const uint32_t c = g >> 4, rec = g & 15u;
-    if (c >= d.nch || rec >= 9) return;
+    const uint32_t rec = g & 15u;
+    if ((g >> 4) >= d.ncl || rec >= 9) return;
+    const uint32_t c = chunk_of(d, g >> 4);
     const AdRec r(rec);
     const uint32_t nt = (rlen[c] + ATILE - 1) / ATILE;
     int32_t x = r.init();
@@ -602,7 +624,7 @@ __global__ __launch_bounds__(64) void k_adapt_c(const uint8_t *__restrict__ cls8
                                                const uint32_t *__restrict__ seg_flag, const int32_t *__restrict__ seg_start,
                                                uint16_t *__restrict__ explo, uint16_t *__restrict__ exphi, uint32_t *__restrict__ mantad)
 {
-    const uint32_t c = blockIdx.z, rec = blockIdx.y;
+    const uint32_t c = chunk_of(d, blockIdx.z), rec = blockIdx.y;
     const uint32_t k = blockIdx.x * 64 + threadIdx.x;
     const uint32_t n = rlen[c];
     const uint32_t nt = (n + ATILE - 1) / ATILE;
@@ -643,7 +665,7 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
                                              const uint32_t *__restrict__ ord, const uint32_t *__restrict__ qcdf, uint4 *__restrict__ recs,
                                              uint32_t *__restrict__ pairs_plain)
 {
-    const uint32_t c = blockIdx.y;
+    const uint32_t c = chunk_of(d, blockIdx.y);
     const uint32_t t = blockIdx.x * TB + threadIdx.x;
     if (t >= rlen[c]) return;
     const size_t o = (size_t)c * rle_stride + t;
@@ -707,17 +729,22 @@ __device__ __forceinline__ uint32_t rans_step(uint32_t x, const uint4 r, uint32_
 constexpr int RANS_TILE = 128;
 
 __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ recs, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
-                                                  uint32_t *__restrict__ emit, uint32_t *__restrict__ fstate)
+                                                  uint32_t *__restrict__ emit, uint32_t *__restrict__ fstate, uint32_t *__restrict__ eend,
+                                                  uint32_t *__restrict__ csize)
 {
     __shared__ uint4 rbuf[2][4][RANS_TILE];
     __shared__ uint32_t ebuf[4][RANS_TILE];
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = chunk_of(d, blockIdx.x);
     const int t = threadIdx.x;
     const uint32_t np = 2 * rlen[c];
     if (np == 0) {
         if (t < 4) fstate[(size_t)c * 4 + t] = RANS_L;
+        if (t == 0) csize[c] = 16u;
         return;
     }
+    for (int i = t; i < 4 * RANS_TILE; i += 64) (&ebuf[0][0])[i] = 0;    // slots past a chain's last record must count 0 bytes
+    uint32_t *ee = eend + (size_t)c * 2 * rle_stride;
+    uint32_t carry = 0;                                                  // bytes emitted by all pairs of higher tiles
     const size_t lane_stride = rans_lane_stride(rle_stride);
     const int cl = t >> 4, part = t & 15;                       // staging role: chain cl, 16 lanes x 128 B = one tile row
     const uint4 *src = recs + ((size_t)c * 4 + cl) * lane_stride + part * 8;
@@ -769,48 +796,28 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
             uint4 *ed = dst + tt * (RANS_TILE / 4);
             ed[0] = es[0]; ed[1] = es[1];
         }
+        {   // bytes from the start of pair j's output to the end of the stream (pair order j = 4k + lane), all 64 lanes:
+            // lane t owns the 8 consecutive pairs 8t..8t+7 of this tile; inclusive suffix sums, higher tiles in `carry`
+            uint32_t cn[8];
+            uint32_t sum = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const int jl = t * 8 + i; cn[i] = ebuf[jl & 3][jl >> 2] >> 16; sum += cn[i]; }
+            uint32_t inc = wave_incl_sum(sum);                       // prefix over lanes <= t
+            const uint32_t tile_total = __shfl(inc, 63, 64);
+            uint32_t run = carry + (tile_total - inc);               // bytes of the pairs owned by lanes > t (and higher tiles)
+            const uint32_t jb = (uint32_t)tt * (4 * RANS_TILE) + (uint32_t)t * 8;
+#pragma unroll
+            for (int i = 7; i >= 0; i--) {
+                run += cn[i];
+                if (jb + i < np) ee[jb + i] = run;
+            }
+            carry += tile_total;
+        }
+        __syncthreads();
         buf ^= 1;
     }
     if (t < 4) fstate[(size_t)c * 4 + t] = x;
-}
-
-// per chunk: exclusive prefix sum of the emit counts (forward pair order) -> byte positions; csize = 16 + total.
-// emit words are lane-major: pair j sits at emit[j & 3][j >> 2].
-__global__ __launch_bounds__(1024) void k_emit_scan(const uint32_t *__restrict__ emit, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
-                                                   uint32_t *__restrict__ epos, uint32_t *__restrict__ csize)
-{
-    const uint32_t c = blockIdx.x;
-    const uint32_t np = 2 * rlen[c];
-    const size_t lane_stride = rans_lane_stride(rle_stride);
-    const uint32_t *em = emit + (size_t)c * 4 * lane_stride;
-    uint32_t *ep = epos + (size_t)c * 2 * rle_stride;
-    __shared__ uint32_t sm[1024 / 64 + 1];
-    __shared__ uint32_t carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t b0 = 0; b0 < np; b0 += 1024 * 8) {
-        const uint32_t p0 = b0 + threadIdx.x * 8;       // multiple of 8: pairs p0..p0+7 = records p0/4, p0/4+1 of each lane
-        uint32_t v[8];
-        uint32_t s = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t j = p0 + k;
-            v[k] = (j < np) ? (em[(size_t)(j & 3u) * lane_stride + (j >> 2)] >> 16) : 0u;
-            s += v[k];
-        }
-        uint32_t tot;
-        uint32_t inc = block_incl_scan<OpSum>(s, sm, &tot);
-        uint32_t run = carry_s + inc - s;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (p0 + k < np) ep[p0 + k] = run;
-            run += v[k];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) csize[c] = 16u + carry_s;
+    if (t == 0) csize[c] = 16u + carry;
 }
 
 constexpr int HDR_MAX = 259 * 5 + 1;   // 1296
@@ -858,8 +865,8 @@ __global__ __launch_bounds__(TB) void k_put_headers(EncDims d, const uint8_t *__
 }
 
 __global__ __launch_bounds__(TB) void k_put_payload(size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen, const uint32_t *__restrict__ emit,
-                                                   const uint32_t *__restrict__ epos, const uint32_t *__restrict__ hsize,
-                                                   const uint64_t *__restrict__ outoff, uint8_t *__restrict__ out)
+                                                   const uint32_t *__restrict__ eend, const uint32_t *__restrict__ csize,
+                                                   const uint32_t *__restrict__ hsize, const uint64_t *__restrict__ outoff, uint8_t *__restrict__ out)
 {
     const uint32_t c = blockIdx.y;
     const uint32_t j = blockIdx.x * TB + threadIdx.x;
@@ -867,7 +874,7 @@ __global__ __launch_bounds__(TB) void k_put_payload(size_t rle_stride, EncDims d
     const uint32_t e = emit[(size_t)c * 4 * rans_lane_stride(rle_stride) + (size_t)(j & 3u) * rans_lane_stride(rle_stride) + (j >> 2)];
     const uint32_t cnt = e >> 16;
     if (!cnt) return;
-    uint8_t *dst = out + outoff[c] + hsize[c] + 16 + epos[(size_t)c * 2 * rle_stride + j];
+    uint8_t *dst = out + outoff[c] + hsize[c] + csize[c] - eend[(size_t)c * 2 * rle_stride + j];
     if (cnt == 1) dst[0] = (uint8_t)e;
     else { dst[0] = (uint8_t)(e >> 8); dst[1] = (uint8_t)e; }   // the later (lower-address) byte of a step comes first in the stream
 }
@@ -876,7 +883,7 @@ struct EncBufs {
     uint32_t *tilecnt; int32_t *lastpos; int32_t *freq; uint32_t *bstart; uint8_t *ranks;
     uint32_t *lz, *ext, *tcount, *toff, *rlen;
     uint16_t *rle;
-    uint32_t *clscnt, *clstotal, *ord, *qhist, *qcdf;
+    uint32_t *clscnt, *clstotal, *ord, *qhist, *qcdf, *dens, *cmap;
     uint8_t *cls8;
     uint32_t *seg_flag; int32_t *seg_lo, *seg_end, *seg_start; uint16_t *seg_tab;
     uint16_t *explo, *exphi; uint32_t *mantad, *pairs; uint4 *recs;
@@ -907,6 +914,8 @@ void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what)
         b.rle = a.get<uint16_t>((size_t)d.nch * stride + 64);
     }
     if (what & LAY_MODEL) {
+        b.dens = a.get<uint32_t>(d.nch + 64);
+        b.cmap = a.get<uint32_t>(d.nch + 64);
         b.clscnt = a.get<uint32_t>(tiles * 8);
         b.clstotal = a.get<uint32_t>((size_t)d.nch * 8);
         b.ord = a.get<uint32_t>((size_t)d.nch * stride);
@@ -943,15 +952,34 @@ EncDims make_dims(uint32_t len, uint32_t chunk)
     d.chunk = chunk;
     d.nch = (len + chunk - 1) / chunk;
     d.tpc = (chunk + ATILE - 1) / ATILE;
+    d.ncl = d.nch;
+    d.cmap = nullptr;
     return d;
+}
+
+// symbol changes per chunk: a cheap proxy for the length of its rANS chain (used to launch the densest chunks first)
+__global__ __launch_bounds__(TB) void k_density(const uint8_t *__restrict__ in, EncDims d, uint32_t *__restrict__ dens)
+{
+    const uint32_t c = blockIdx.x;
+    const uint32_t clen = chunk_len(d, c);
+    const uint8_t *src = in + (size_t)c * d.chunk;
+    uint32_t n = 0;
+    for (uint32_t i = threadIdx.x * 16; i < clen; i += TB * 16) {
+        uint8_t prev = i ? src[i - 1] : 0;
+        for (uint32_t k = 0; k < 16 && i + k < clen; k++) { uint8_t v = src[i + k]; n += (v != prev); prev = v; }
+    }
+    __shared__ uint32_t sm[TB / 64 + 1];
+    uint32_t tot;
+    block_incl_scan<OpSum>(n, sm, &tot);
+    if (threadIdx.x == 0) dens[c] = tot;
 }
 
 int run_rank(jpk_ctx *ctx, const uint8_t *d_in, const EncDims &d, EncBufs &b)
 {
     hipStream_t st = ctx->stream;
-    JPK_LAUNCH(ctx, PROF_ENC_HIST, d.len, k_enc_hist, dim3(d.tpc, d.nch), dim3(TB), d_in, d, b.tilecnt, b.lastpos);
-    JPK_LAUNCH(ctx, PROF_ENC_HIST, d.len, k_enc_prep, dim3(d.nch), dim3(256), d, b.tilecnt, b.lastpos, b.freq, b.bstart);
-    JPK_LAUNCH(ctx, PROF_ENC_MTF, d.len, k_enc_mtf, dim3((d.tpc + 3) / 4, d.nch), dim3(TB), d_in, d, b.tilecnt, b.lastpos, b.bstart, b.ranks);
+    JPK_LAUNCH(ctx, PROF_ENC_HIST, d.len, k_enc_hist, dim3(d.tpc, d.ncl), dim3(TB), d_in, d, b.tilecnt, b.lastpos);
+    JPK_LAUNCH(ctx, PROF_ENC_HIST, d.len, k_enc_prep, dim3(d.ncl), dim3(256), d, b.tilecnt, b.lastpos, b.freq, b.bstart);
+    JPK_LAUNCH(ctx, PROF_ENC_MTF, d.len, k_enc_mtf, dim3((d.tpc + 3) / 4, d.ncl), dim3(TB), d_in, d, b.tilecnt, b.lastpos, b.bstart, b.ranks);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
 }
@@ -959,11 +987,11 @@ int run_rank(jpk_ctx *ctx, const uint8_t *d_in, const EncDims &d, EncBufs &b)
 int run_rle(jpk_ctx *ctx, const uint8_t *d_ranks, const EncDims &d, EncBufs &b)
 {
     hipStream_t st = ctx->stream;
-    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, k_rle_lz, dim3(d.tpc, d.nch), dim3(TB), d_ranks, d, b.lz);
-    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, k_rle_ext, dim3(jpk_grid(d.nch, 64)), dim3(64), d, b.lz, b.ext);
-    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, (k_rle_tiles<false>), dim3(d.tpc, d.nch), dim3(TB), d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
-    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, k_tile_prefix, dim3(jpk_grid(d.nch, 64)), dim3(64), d, b.tcount, b.toff, b.rlen, 1u, (const uint32_t *)nullptr);
-    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, (k_rle_tiles<true>), dim3(d.tpc, d.nch), dim3(TB), d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, k_rle_lz, dim3(d.tpc, d.ncl), dim3(TB), d_ranks, d, b.lz);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, k_rle_ext, dim3(jpk_grid(d.ncl, 64)), dim3(64), d, b.lz, b.ext);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, (k_rle_tiles<false>), dim3(d.tpc, d.ncl), dim3(TB), d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, k_tile_prefix, dim3(jpk_grid(d.ncl, 64)), dim3(64), d, b.tcount, b.toff, b.rlen, 1u, (const uint32_t *)nullptr);
+    JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, (k_rle_tiles<true>), dim3(d.tpc, d.ncl), dim3(TB), d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
 }
@@ -972,17 +1000,18 @@ int run_model(jpk_ctx *ctx, const uint16_t *d_rle, const uint32_t *d_rlen, const
 {
     hipStream_t st = ctx->stream;
     const size_t stride = d.chunk;
-    JPK_HIP(hipMemsetAsync(b.qhist, 0, (size_t)d.nch * 6 * NQ * QSTRIDE * 4, st));
-    JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_count, dim3(d.tpc, d.nch), dim3(TB), d_rle, stride, d, d_rlen, b.clscnt);
-    JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_prefix, dim3(jpk_grid((size_t)d.nch * 8, 64)), dim3(64), d, d_rlen, b.clscnt, b.clstotal);
-    JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_ord, dim3(d.tpc, d.nch), dim3(TB), d_rle, stride, d, d_rlen, b.clscnt, b.ord, b.qhist, b.cls8);
-    JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_quasi_build, dim3(NQ, 6, d.nch), dim3(64), d, b.clstotal, b.qhist, b.qcdf);
-    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_a, dim3((d.tpc + 63) / 64, 9, d.nch), dim3(64), b.cls8, stride, d, d_rlen, b.clscnt, b.explo, b.exphi, b.mantad,
+    JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_count, dim3(d.tpc, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.clscnt);
+    JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_prefix, dim3(jpk_grid((size_t)d.ncl * 8, 64)), dim3(64), d, d_rlen, b.clscnt, b.clstotal);
+    JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_ord, dim3(d.tpc, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.clscnt, b.ord, b.qhist, b.cls8);
+    JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_quasi_build, dim3(NQ, 6, d.ncl), dim3(64), d, b.clstotal, b.qhist, b.qcdf);
+    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_a, dim3((d.tpc + 63) / 64, 9, d.ncl), dim3(64), b.cls8, stride, d, d_rlen, b.clscnt, b.explo, b.exphi, b.mantad,
                        b.seg_flag, b.seg_lo, b.seg_end, b.seg_tab);
-    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_b, dim3(jpk_grid((size_t)d.nch * 16, 64)), dim3(64), d, d_rlen, b.seg_flag, b.seg_lo, b.seg_end, b.seg_tab, b.seg_start);
-    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_c, dim3((d.tpc + 63) / 64, 9, d.nch), dim3(64), b.cls8, stride, d, d_rlen, b.seg_flag, b.seg_start, b.explo, b.exphi,
+    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_tab, dim3((d.tpc + 1) / 2, 9, d.ncl), dim3(64), b.cls8, stride, d, d_rlen, b.seg_flag, b.seg_lo, b.seg_end,
+               b.seg_tab);
+    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_b, dim3(jpk_grid((size_t)d.ncl * 16, 64)), dim3(64), d, d_rlen, b.seg_flag, b.seg_lo, b.seg_end, b.seg_tab, b.seg_start);
+    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_c, dim3((d.tpc + 63) / 64, 9, d.ncl), dim3(64), b.cls8, stride, d, d_rlen, b.seg_flag, b.seg_start, b.explo, b.exphi,
                        b.mantad);
-    JPK_LAUNCH(ctx, PROF_ENC_PAIRS, 0, k_pairs, dim3(jpk_grid(stride, TB), d.nch), dim3(TB), d_rle, stride, d, d_rlen, b.explo, b.exphi, b.mantad, b.ord,
+    JPK_LAUNCH(ctx, PROF_ENC_PAIRS, 0, k_pairs, dim3(jpk_grid(stride, TB), d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.explo, b.exphi, b.mantad, b.ord,
                        b.qcdf, b.recs, b.pairs);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
@@ -1005,12 +1034,54 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     Arena real(ctx, false);
     enc_layout(real, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
 
-    JPK_TRY(run_rank(ctx, d_in, d, b));
-    JPK_TRY(run_rle(ctx, b.ranks, d, b));
-    JPK_TRY(run_model(ctx, b.rle, b.rlen, d, b));
     const size_t stride = d.chunk;
-    JPK_LAUNCH(ctx, PROF_ENC_RANS, 0, k_rans_lanes, dim3(d.nch), dim3(64), b.recs, stride, d, b.rlen, b.emit, b.fstate);
-    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_emit_scan, dim3(d.nch), dim3(1024), b.emit, stride, d, b.rlen, b.epos, b.csize);
+    JPK_HIP(hipMemsetAsync(b.qhist, 0, (size_t)d.nch * 6 * NQ * QSTRIDE * 4, st));
+    // The stage is bounded by the longest rANS chain (the densest chunk).  With enough chunks, the densest quarter is
+    // launched as its own group on the context's second stream so that its chains start after a quarter of the
+    // parallel work; the remaining chunks follow on the main stream and run beside those chains.
+    auto pre_chain = [&](const EncDims &g) -> int {
+        JPK_TRY(run_rank(ctx, d_in, g, b));
+        JPK_TRY(run_rle(ctx, b.ranks, g, b));
+        JPK_TRY(run_model(ctx, b.rle, b.rlen, g, b));
+        return JPK_OK;
+    };
+    auto chain = [&](const EncDims &g) -> int {
+        JPK_LAUNCH(ctx, PROF_ENC_RANS, 0, k_rans_lanes, dim3(g.ncl), dim3(64), b.recs, stride, g, b.rlen, b.emit, b.fstate, b.epos, b.csize);
+        return JPK_OK;
+    };
+    if (d.nch >= 8 && !getenv("JPK_NO_GROUPS")) {
+        JPK_LAUNCH(ctx, PROF_ENC_HIST, d.len, k_density, dim3(d.nch), dim3(TB), d_in, d, b.dens);
+        JPK_HIP(hipMemcpyAsync(ctx->h_map, b.dens, (size_t)d.nch * 4, hipMemcpyDeviceToHost, st));
+        JPK_HIP(hipStreamSynchronize(st));
+        std::vector<uint32_t> order(d.nch);
+        for (uint32_t c = 0; c < d.nch; c++) order[c] = c;
+        const uint32_t *dn = ctx->h_map;
+        std::vector<uint32_t> dcopy(dn, dn + d.nch);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return dcopy[x] > dcopy[y]; });
+        for (uint32_t c = 0; c < d.nch; c++) ctx->h_map[c] = order[c];
+        JPK_HIP(hipMemcpyAsync(b.cmap, ctx->h_map, (size_t)d.nch * 4, hipMemcpyHostToDevice, st));
+        JPK_HIP(hipEventRecord(ctx->ev_a, st));
+        const uint32_t na = (d.nch + 3) / 4;
+        EncDims ga = d, gb = d;
+        ga.ncl = na; ga.cmap = b.cmap;
+        gb.ncl = d.nch - na; gb.cmap = b.cmap + na;
+        // group A (densest) on the second stream; group B starts its parallel stages only when A's chains are launched
+        JPK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_a, 0));
+        ctx->stream = ctx->stream2;
+        int rc = pre_chain(ga);
+        if (rc == JPK_OK && hipEventRecord(ctx->ev_c, ctx->stream2) != hipSuccess) rc = JPK_E_DEVICE;
+        if (rc == JPK_OK) rc = chain(ga);
+        if (rc == JPK_OK && hipEventRecord(ctx->ev_b, ctx->stream2) != hipSuccess) rc = JPK_E_DEVICE;
+        ctx->stream = st;
+        JPK_TRY(rc);
+        JPK_HIP(hipStreamWaitEvent(st, ctx->ev_c, 0));
+        JPK_TRY(pre_chain(gb));
+        JPK_TRY(chain(gb));
+        JPK_HIP(hipStreamWaitEvent(st, ctx->ev_b, 0));
+    } else {
+        JPK_TRY(pre_chain(d));
+        JPK_TRY(chain(d));
+    }
     JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_headers, dim3(1), dim3(1024), d, b.freq, b.csize, b.rlen, b.hdr, b.hsize, b.outoff, ctx->d_mail);
     JPK_HIP(hipGetLastError());
     uint32_t mail[4];
@@ -1028,7 +1099,7 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     }
     if (total > (uint64_t)out_cap) return JPK_E_CAPACITY;
     JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_headers, dim3(d.nch), dim3(TB), d, b.hdr, b.hsize, b.outoff, b.fstate, d_out);
-    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_payload, dim3(jpk_grid(2 * stride, TB), d.nch), dim3(TB), stride, d, b.rlen, b.emit, b.epos, b.hsize,
+    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_payload, dim3(jpk_grid(2 * stride, TB), d.nch), dim3(TB), stride, d, b.rlen, b.emit, b.epos, b.csize, b.hsize,
                        b.outoff, d_out);
     JPK_HIP(hipGetLastError());
     JPK_HIP(hipStreamSynchronize(st));
@@ -1092,6 +1163,7 @@ int jpk_model_pairs_device(jpk_ctx *ctx, const uint16_t *d_rle, int32_t rlen, ui
     uint32_t n = (uint32_t)rlen;
     JPK_HIP(hipMemcpyAsync(b.rlen, &n, 4, hipMemcpyHostToDevice, ctx->stream));
     JPK_HIP(hipStreamSynchronize(ctx->stream));
+    JPK_HIP(hipMemsetAsync(b.qhist, 0, (size_t)d.nch * 6 * NQ * QSTRIDE * 4, ctx->stream));
     JPK_TRY(run_model(ctx, d_rle, b.rlen, d, b));
     JPK_HIP(hipMemcpyAsync(d_pairs, b.pairs, (size_t)rlen * 8, hipMemcpyDeviceToDevice, ctx->stream));
     JPK_HIP(hipStreamSynchronize(ctx->stream));

@@ -42,6 +42,9 @@ struct jpk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t stream2 = nullptr;   // second stream of the context (entropy stage: densest chunks first)
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
+    uint32_t *h_map = nullptr;       // pinned, 4096 words
     uint8_t *arena = nullptr;
     size_t arena_cap = 0;
     size_t arena_off = 0;

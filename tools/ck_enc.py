@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 import numpy as np, torch
 import jampack_amd as jam
