@@ -153,6 +153,7 @@ __global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in,
                                                 uint16_t *__restrict__ rle, uint32_t *__restrict__ status)
 {
     __shared__ QuasiLds q;
+    __builtin_amdgcn_s_setprio(3);         // serial chain: win the issue arbitration on a shared SIMD
     const uint32_t c = blockIdx.x;
     const int l = lane_id();
     const ChunkInfo ci = info[c];
@@ -322,6 +323,7 @@ __device__ __forceinline__ uint32_t list_shift_insert(uint32_t v, int l, uint32_
 __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, const ChunkInfo *__restrict__ info, const int32_t *__restrict__ freq,
                                                 uint8_t *__restrict__ tmp, uint32_t *__restrict__ status)
 {
+    __builtin_amdgcn_s_setprio(3);         // serial chain: win the issue arbitration on a shared SIMD
     const uint32_t c = blockIdx.x;
     const int l = lane_id();
     const ChunkInfo ci = info[c];

@@ -103,59 +103,62 @@ __global__ __launch_bounds__(256) void k_enc_prep(EncDims d, uint32_t *__restric
     bstart[(size_t)c * 256 + s] = b;
 }
 
-// v_writelane has no clang builtin on this toolchain: compare-and-select on the lane id instead
-#define JPK_WL(val, lane, old) (((uint32_t)l == (uint32_t)(lane)) ? (val) : (old))
-#define JPK_SEL4(q, a0, a1, a2, a3) ((q) == 0 ? (a0) : (q) == 1 ? (a1) : (q) == 2 ? (a2) : (a3))
-
-// one wave per tile: wave-sequential MTF by time stamps + bucket scatter (rank.cpp:69-87)
+// one wave per tile: wave-sequential MTF by time stamps + bucket scatter (rank.cpp:69-87).
+// The 256 time stamps live in 4 registers per lane for the rank (4 x v_cmp -> popcount); a per-wave LDS mirror
+// gives the previous occurrence of the current symbol, the bucket write positions and the (dest, rank) staging of a
+// 64-byte group with wave-uniform LDS accesses instead of register selects.
 __global__ __launch_bounds__(TB) void k_enc_mtf(const uint8_t *__restrict__ in, EncDims d, const uint32_t *__restrict__ tilebase,
                                                const int32_t *__restrict__ prevlast, const uint32_t *__restrict__ bstart,
                                                uint8_t *__restrict__ ranks)
 {
+    __shared__ int32_t s_last[TB / 64][256];
+    __shared__ uint32_t s_pos[TB / 64][256];
+    __shared__ uint32_t s_dst[TB / 64][64];
+    __shared__ uint32_t s_rk[TB / 64][64];
     const uint32_t c = chunk_of(d, blockIdx.y);
-    const uint32_t t = blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+    const int w = threadIdx.x >> 6;
+    const uint32_t t = blockIdx.x * (TB / 64) + w;
     const uint32_t clen = chunk_len(d, c), ts = t * ATILE;
     if (ts >= clen) return;
     const int l = lane_id();
     const size_t o = ((size_t)c * d.tpc + t) * 256;
     int32_t last0 = prevlast[o + l], last1 = prevlast[o + 64 + l], last2 = prevlast[o + 128 + l], last3 = prevlast[o + 192 + l];
     const uint32_t *bs = bstart + (size_t)c * 256;
-    uint32_t pos0 = bs[l] + tilebase[o + l], pos1 = bs[64 + l] + tilebase[o + 64 + l], pos2 = bs[128 + l] + tilebase[o + 128 + l],
-             pos3 = bs[192 + l] + tilebase[o + 192 + l];
+    int32_t *ll = s_last[w];
+    uint32_t *lp = s_pos[w], *ld = s_dst[w], *lr = s_rk[w];
+    ll[l] = last0; ll[64 + l] = last1; ll[128 + l] = last2; ll[192 + l] = last3;
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++) lp[qq * 64 + l] = bs[qq * 64 + l] + tilebase[o + qq * 64 + l];
     const uint8_t *src = in + (size_t)c * d.chunk;
     uint8_t *dst = ranks + (size_t)c * d.chunk;
     uint32_t prevc = 256;
     const uint32_t te = (ts + ATILE < clen) ? ts + ATILE : clen;
     for (uint32_t i0 = ts; i0 < te; i0 += 64) {
         const uint32_t nvalid = (te - i0 < 64u) ? te - i0 : 64u;
-        uint32_t b = ((uint32_t)l < nvalid) ? src[i0 + l] : 0u;
-        uint32_t mydest = 0, myrank = 0;
+        const uint32_t b = ((uint32_t)l < nvalid) ? src[i0 + l] : 0u;
         for (uint32_t k = 0; k < nvalid; k++) {
             const uint32_t cc = __builtin_amdgcn_readlane(b, k);
-            const uint32_t q = cc >> 6, ln = cc & 63u;
             uint32_t rank = 0;
-            if (cc != prevc) {
-                const int32_t lr = JPK_SEL4(q, last0, last1, last2, last3);
-                const int32_t own = __builtin_amdgcn_readlane(lr, ln);
+            if (cc != prevc) {                         // a repeat has rank 0 and leaves the recency order unchanged
+                const int32_t own = ll[cc];
                 rank = (uint32_t)__popcll(__ballot(last0 > own)) + (uint32_t)__popcll(__ballot(last1 > own)) +
                        (uint32_t)__popcll(__ballot(last2 > own)) + (uint32_t)__popcll(__ballot(last3 > own));
                 const int32_t nv = (int32_t)(i0 + k);
-                if (q == 0) last0 = JPK_WL(nv, ln, last0);
-                else if (q == 1) last1 = JPK_WL(nv, ln, last1);
-                else if (q == 2) last2 = JPK_WL(nv, ln, last2);
-                else last3 = JPK_WL(nv, ln, last3);
+                const uint32_t q = cc >> 6;
+                const bool mine = (uint32_t)l == (cc & 63u);
+                if (q == 0) last0 = mine ? nv : last0;
+                else if (q == 1) last1 = mine ? nv : last1;
+                else if (q == 2) last2 = mine ? nv : last2;
+                else last3 = mine ? nv : last3;
+                ll[cc] = nv;                           // every lane stores the same value
                 prevc = cc;
             }
-            const uint32_t pr = JPK_SEL4(q, pos0, pos1, pos2, pos3);
-            const uint32_t dpos = __builtin_amdgcn_readlane(pr, ln);
-            if (q == 0) pos0 = JPK_WL(dpos + 1, ln, pos0);
-            else if (q == 1) pos1 = JPK_WL(dpos + 1, ln, pos1);
-            else if (q == 2) pos2 = JPK_WL(dpos + 1, ln, pos2);
-            else pos3 = JPK_WL(dpos + 1, ln, pos3);
-            mydest = JPK_WL(dpos, k, mydest);
-            myrank = JPK_WL(rank, k, myrank);
+            const uint32_t dpos = lp[cc];
+            lp[cc] = dpos + 1;
+            ld[k] = dpos;
+            lr[k] = rank;
         }
-        if ((uint32_t)l < nvalid) dst[mydest] = (uint8_t)myrank;
+        if ((uint32_t)l < nvalid) dst[ld[l]] = (uint8_t)lr[l];
     }
 }
 
@@ -344,7 +347,7 @@ __global__ void k_cls_prefix(EncDims d, const uint32_t *__restrict__ rlen, uint3
 // ordinal of every symbol inside its class (stable) + per-interval mantissa histograms of the quasi classes
 __global__ __launch_bounds__(TB) void k_cls_ord(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
                                                const uint32_t *__restrict__ clsbase, uint32_t *__restrict__ ord, uint32_t *__restrict__ qhist,
-                                               uint8_t *__restrict__ cls8)
+                                               uint8_t *__restrict__ cls8, uint32_t *__restrict__ clist)
 {
     const uint32_t c = chunk_of(d, blockIdx.y), t = blockIdx.x;
     const uint32_t n = rlen[c], ts = t * ATILE;
@@ -377,8 +380,14 @@ __global__ __launch_bounds__(TB) void k_cls_ord(const uint16_t *__restrict__ rle
         if (valid && below == 0) cnt[w][e] = cc + (uint32_t)__popcll(m);
     }
     __syncthreads();
+    // mantissa histograms: the interval in which the tile starts (per class) is accumulated in LDS and flushed once;
+    // the few symbols that fall into later intervals go straight to global atomics
+    __shared__ uint32_t lh[6][QSTRIDE];
+    __shared__ int q0[8];
+    for (int i = threadIdx.x; i < 6 * QSTRIDE; i += TB) (&lh[0][0])[i] = 0;
     if (threadIdx.x < 8) {
         uint32_t s = clsbase[((size_t)c * d.tpc + t) * 8 + threadIdx.x];
+        q0[threadIdx.x] = qinterval(s);
 #pragma unroll
         for (int k = 0; k < W; k++) { uint32_t v = cnt[k][threadIdx.x]; cnt[k][threadIdx.x] = s; s += v; }
     }
@@ -392,10 +401,21 @@ __global__ __launch_bounds__(TB) void k_cls_ord(const uint16_t *__restrict__ rle
             uint32_t k = cnt[w][e] + rk[it];
             ord[(size_t)c * rle_stride + i] = k;
             cls8[(size_t)c * rle_stride + i] = (uint8_t)(e | ((s & 1u) << 3));      // class | mantissa bit of classes 0/1
-            if (e >= 2) {
-                int q = qinterval(k);
-                atomicAdd(&qhist[(((size_t)c * 6 + (e - 2)) * NQ + q) * QSTRIDE + (s - (uint32_t)class_base(e))], 1u);
+            if (e < 2) clist[((size_t)c * 2 + e) * ((rle_stride + 3) & ~(size_t)3) + k] = i | ((s & 1u) << 31);   // compact list of the class
+            else {
+                const int q = qinterval(k);
+                const uint32_t m = s - (uint32_t)class_base(e);
+                if (q == q0[e]) atomicAdd(&lh[e - 2][m], 1u);
+                else atomicAdd(&qhist[(((size_t)c * 6 + (e - 2)) * NQ + q) * QSTRIDE + m], 1u);
             }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 6 * QSTRIDE; i += TB) {
+        const uint32_t v = (&lh[0][0])[i];
+        if (v) {
+            const int e2 = i / QSTRIDE, m = i % QSTRIDE;
+            atomicAdd(&qhist[(((size_t)c * 6 + e2) * NQ + q0[e2 + 2]) * QSTRIDE + m], v);
         }
     }
 }
@@ -456,12 +476,15 @@ __global__ __launch_bounds__(64) void k_quasi_build(EncDims d, const uint32_t *_
 // Nine independent scalar recurrences per chunk: exponent model cdf[1..7] (alphabet 8) and cdf[1] of the two
 // alphabet-2 mantissa models.  One step is x += (mix - x) >> 5 with mix in {i, i + 65536 - A} (model.cpp:60-77):
 // a monotone map that shrinks any interval of states by >= floor(width/32) per update, so after >= ~500 updates
-// the set of reachable states is an interval of width <= 31 whatever the history was.  Per 4096-symbol segment:
-//   A  warm up the two extreme states over the preceding >= 1280 updates -> [lo, hi].  lo == hi: the start state
-//      is exact; run the segment, write the outputs, record the end state.  Otherwise run all 32 candidate
-//      start states lo..lo+31 through the segment and record their end states (a transfer table).
-//   B  one lane per (chunk, recurrence) walks the segments in order composing exact states through the tables.
-//   C  the unresolved segments are run again from their now exact start state, writing the outputs.
+// the set of reachable states is an interval of width <= 31 whatever the history was.
+// Item streams: the exponent entries see every symbol (class byte stream cls8); a mantissa model only sees the symbols
+// of its class, which k_cls_ord has compacted into a list (position | mantissa bit << 31), so its "time" is the
+// class ordinal and a warm-up is always the 1280 list entries in front of the segment.  Per 4096-item segment:
+//   A    warm up the two extreme states over the preceding 1280 items -> [lo, hi].  lo == hi: the start state is
+//        exact; run the segment, write the outputs, record the end state.  Otherwise record [lo, hi].
+//   tab  unresolved segments: 32 lanes walk the segment from the 32 candidate start states -> transfer table.
+//   B    one lane per (chunk, recurrence) walks the segments in order composing exact states through the tables.
+//   C    the unresolved segments are run again from their now exact start state, writing the outputs.
 // Every output is produced from an exact state: the result is bit-identical to the sequential reference.
 constexpr uint32_t AD_WARM = 1280;      // multiple of 16
 
@@ -474,167 +497,181 @@ struct AdRec {                          // one recurrence
     __device__ __forceinline__ int32_t init() const { return (int32_t)uniform_cdf(A, i); }
     __device__ __forceinline__ int32_t smin() const { return i; }
     __device__ __forceinline__ int32_t smax() const { return i + 65536 - A; }
-    // does symbol byte c8 update this recurrence, and with which coded symbol
-    __device__ __forceinline__ bool hits(uint32_t c8) const { return exp || (int)(c8 & 7u) == cls; }
-    __device__ __forceinline__ int sym(uint32_t c8) const { return exp ? (int)(c8 & 7u) : (int)((c8 >> 3) & 1u); }
 };
 
-// f(t, c8) for every symbol byte of [t0, t1); 16-byte loads where aligned, next load issued before the current
-// group is consumed
-template <class F>
-__device__ __forceinline__ void for_each_cls(const uint8_t *__restrict__ p, uint32_t t0, uint32_t t1, F f)
+// the item stream of a recurrence inside one chunk
+__host__ __device__ __forceinline__ size_t clist_stride(size_t rle_stride) { return (rle_stride + 3) & ~(size_t)3; }   // 16-byte rows
+
+struct AdStream {
+    const uint8_t *c8;        // exponent entries: class byte of every symbol
+    const uint32_t *list;     // mantissa models: compacted (position | bit << 31) of the class
+    uint32_t n;               // items
+};
+__device__ __forceinline__ AdStream ad_stream(const AdRec &r, uint32_t c, const uint8_t *cls8, const uint32_t *clist, size_t rle_stride,
+                                              const uint32_t *rlen, const uint32_t *clstotal)
 {
-    uint32_t t = t0;
-    while (t < t1 && (t & 15u)) { f(t, (uint32_t)p[t]); t++; }
-    if (t + 16 <= t1) {
-        uint4 v = *reinterpret_cast<const uint4 *>(p + t);
-        for (; t + 16 <= t1; t += 16) {
-            const uint32_t tn = (t + 32 <= t1) ? t + 16 : t;          // clamped: the prefetch is unconditional
-            const uint4 nv = *reinterpret_cast<const uint4 *>(p + tn);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 16; k++) f(t + k, (w[k >> 2] >> (8 * (k & 3))) & 0xffu);
-            v = nv;
-        }
-    }
-    while (t < t1) { f(t, (uint32_t)p[t]); t++; }
+    AdStream st;
+    st.c8 = cls8 + (size_t)c * rle_stride;
+    st.list = r.exp ? nullptr : clist + ((size_t)c * 2 + r.cls) * clist_stride(rle_stride);
+    st.n = r.exp ? rlen[c] : clstotal[(size_t)c * 8 + r.cls];
+    return st;
 }
 
-// run one exact trajectory over [t0,t1) writing the model outputs (ans.cpp:159-176)
-__device__ __forceinline__ int32_t ad_run_write(const AdRec &r, const uint8_t *__restrict__ c8p, uint32_t t0, uint32_t t1, int32_t x,
+// f(position, coded symbol) for the items [t0, t1) of a stream; 16-byte loads where aligned, the next load is
+// issued (unconditionally, clamped) before the current group is consumed
+template <class F>
+__device__ __forceinline__ void ad_for_each(const AdRec &r, const AdStream &st, uint32_t t0, uint32_t t1, F f)
+{
+    uint32_t t = t0;
+    if (r.exp) {
+        const uint8_t *p = st.c8;
+        while (t < t1 && (t & 15u)) { f(t, (int)(p[t] & 7u)); t++; }
+        if (t + 16 <= t1) {
+            uint4 v = *reinterpret_cast<const uint4 *>(p + t);
+            for (; t + 16 <= t1; t += 16) {
+                const uint32_t tn = (t + 32 <= t1) ? t + 16 : t;
+                const uint4 nv = *reinterpret_cast<const uint4 *>(p + tn);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 16; k++) f(t + k, (int)((w[k >> 2] >> (8 * (k & 3))) & 7u));
+                v = nv;
+            }
+        }
+        while (t < t1) { f(t, (int)(p[t] & 7u)); t++; }
+    } else {
+        const uint32_t *p = st.list;
+        while (t < t1 && (t & 3u)) { const uint32_t e = p[t]; f(e & 0x7FFFFFFFu, (int)(e >> 31)); t++; }
+        if (t + 4 <= t1) {
+            uint4 v = *reinterpret_cast<const uint4 *>(p + t);
+            for (; t + 4 <= t1; t += 4) {
+                const uint32_t tn = (t + 8 <= t1) ? t + 4 : t;
+                const uint4 nv = *reinterpret_cast<const uint4 *>(p + tn);
+                f(v.x & 0x7FFFFFFFu, (int)(v.x >> 31));
+                f(v.y & 0x7FFFFFFFu, (int)(v.y >> 31));
+                f(v.z & 0x7FFFFFFFu, (int)(v.z >> 31));
+                f(v.w & 0x7FFFFFFFu, (int)(v.w >> 31));
+                v = nv;
+            }
+        }
+        while (t < t1) { const uint32_t e = p[t]; f(e & 0x7FFFFFFFu, (int)(e >> 31)); t++; }
+    }
+}
+
+// run one exact trajectory over the items [t0,t1) writing the model outputs (ans.cpp:159-176)
+__device__ __forceinline__ int32_t ad_run_write(const AdRec &r, const AdStream &st, uint32_t t0, uint32_t t1, int32_t x,
                                                 uint16_t *__restrict__ lo, uint16_t *__restrict__ hi, uint32_t *__restrict__ ma)
 {
     if (r.exp) {
         const int i = r.i;
-        for_each_cls(c8p, t0, t1, [&](uint32_t t, uint32_t c8) {
-            const int e = (int)(c8 & 7u);
+        ad_for_each(r, st, t0, t1, [&](uint32_t t, int e) {
             if (e == i) lo[t] = (uint16_t)x;
             if (e + 1 == i) hi[t] = (uint16_t)(x - 1);
             x = adapt_step(x, i, e, 8);
         });
     } else {
-        const int cls = r.cls;
-        for_each_cls(c8p, t0, t1, [&](uint32_t t, uint32_t c8) {
-            if ((int)(c8 & 7u) == cls) {
-                const int m = (int)((c8 >> 3) & 1u);
-                const uint32_t l0 = m ? (uint32_t)x : 0u, fr = m ? 65536u - (uint32_t)x : (uint32_t)x;
-                ma[t] = l0 | (fr << 16);
-                x = adapt_step(x, 1, m, 2);
-            }
+        ad_for_each(r, st, t0, t1, [&](uint32_t t, int m) {
+            const uint32_t l0 = m ? (uint32_t)x : 0u, fr = m ? 65536u - (uint32_t)x : (uint32_t)x;
+            ma[t] = l0 | (fr << 16);
+            x = adapt_step(x, 1, m, 2);
         });
     }
     return x;
 }
 
-__global__ __launch_bounds__(64) void k_adapt_a(const uint8_t *__restrict__ cls8, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
-                                               const uint32_t *__restrict__ clsbase, uint16_t *__restrict__ explo, uint16_t *__restrict__ exphi,
-                                               uint32_t *__restrict__ mantad, uint32_t *__restrict__ seg_flag, int32_t *__restrict__ seg_lo,
-                                               int32_t *__restrict__ seg_end, uint16_t *__restrict__ seg_tab)
+struct AdArgs {
+    const uint8_t *cls8; const uint32_t *clist; size_t rle_stride; const uint32_t *rlen; const uint32_t *clstotal;
+    uint16_t *explo, *exphi; uint32_t *mantad;
+    uint32_t *seg_flag; int32_t *seg_lo, *seg_end, *seg_start; uint16_t *seg_tab;
+};
+
+// lanes = 4 segments x 16 recurrence slots (9 used)
+__global__ __launch_bounds__(64) void k_adapt_a(EncDims d, AdArgs a)
 {
-    const uint32_t c = chunk_of(d, blockIdx.z), rec = blockIdx.y;
-    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
-    const uint32_t n = rlen[c];
-    const uint32_t nt = (n + ATILE - 1) / ATILE;
-    if (k >= nt) return;
+    const uint32_t c = chunk_of(d, blockIdx.y), rec = threadIdx.x & 15u;
+    const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 4);
+    if (rec >= 9) return;
     const AdRec r(rec);
-    const uint8_t *c8p = cls8 + (size_t)c * rle_stride;
-    const uint32_t t0 = k * ATILE, t1 = (t0 + ATILE < n) ? t0 + ATILE : n;
+    const AdStream st = ad_stream(r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
+    const uint32_t nt = (st.n + ATILE - 1) / ATILE;
+    if (k >= nt) return;
+    const uint32_t t0 = k * ATILE, t1 = (t0 + ATILE < st.n) ? t0 + ATILE : st.n;
     int32_t lo, hi;
-    uint32_t ws;
-    if (r.exp) {
-        if (k == 0) { lo = hi = r.init(); ws = 0; }
-        else { ws = t0 - AD_WARM; lo = r.smin(); hi = r.smax(); }
-    } else {
-        // walk back over whole tiles until >= AD_WARM updates of this class lie between the warm start and t0
-        const uint32_t *cb = clsbase + (size_t)c * d.tpc * 8 + r.cls;
-        const uint32_t here = cb[(size_t)k * 8];
-        uint32_t w = k;
-        while (w > 0 && here - cb[(size_t)w * 8] < AD_WARM) w--;
-        ws = w * ATILE;
-        if (w == 0) lo = hi = r.init();
-        else { lo = r.smin(); hi = r.smax(); }
-    }
-    if (ws < t0) {
+    if (k == 0) lo = hi = r.init();
+    else {
+        lo = r.smin(); hi = r.smax();
         const int i = r.i, A = r.A;
-        for_each_cls(c8p, ws, t0, [&](uint32_t, uint32_t c8) {
-            if (r.hits(c8)) { const int sy = r.sym(c8); lo = adapt_step(lo, i, sy, A); hi = adapt_step(hi, i, sy, A); }
-        });
+        ad_for_each(r, st, t0 - AD_WARM, t0, [&](uint32_t, int sy) { lo = adapt_step(lo, i, sy, A); hi = adapt_step(hi, i, sy, A); });
     }
     const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
     if (lo == hi) {
-        seg_flag[so] = 1u;
-        seg_end[so] = ad_run_write(r, c8p, t0, t1, lo, explo + (size_t)c * rle_stride, exphi + (size_t)c * rle_stride, mantad + (size_t)c * rle_stride);
+        a.seg_flag[so] = 1u;
+        a.seg_end[so] = ad_run_write(r, st, t0, t1, lo, a.explo + (size_t)c * a.rle_stride, a.exphi + (size_t)c * a.rle_stride,
+                                     a.mantad + (size_t)c * a.rle_stride);
         return;
     }
     // unresolved: k_adapt_tab tabulates the 32 candidate start states lo .. lo+31 (hi - lo <= 31 after the warm-up)
-    seg_flag[so] = 0u;
-    seg_lo[so] = lo;
-    seg_end[so] = hi;            // re-used as the interval's upper end until k_adapt_b has run
+    a.seg_flag[so] = 0u;
+    a.seg_lo[so] = lo;
+    a.seg_end[so] = hi;          // re-used as the interval's upper end until k_adapt_b has run
 }
 
 // transfer table of an unresolved segment: 32 lanes = 32 candidate start states walk the segment together (the
-// symbol loads are wave-uniform), instead of one lane walking it 32 times
-__global__ __launch_bounds__(64) void k_adapt_tab(const uint8_t *__restrict__ cls8, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
-                                                 const uint32_t *__restrict__ seg_flag, const int32_t *__restrict__ seg_lo,
-                                                 const int32_t *__restrict__ seg_end, uint16_t *__restrict__ seg_tab)
+// item loads are wave-uniform), instead of one lane walking it 32 times
+__global__ __launch_bounds__(64) void k_adapt_tab(EncDims d, AdArgs a)
 {
     const uint32_t c = chunk_of(d, blockIdx.z), rec = blockIdx.y;
     const uint32_t k = blockIdx.x * 2 + (threadIdx.x >> 5);
     const int q = threadIdx.x & 31;
-    const uint32_t n = rlen[c];
-    const uint32_t nt = (n + ATILE - 1) / ATILE;
+    const AdRec r(rec);
+    const AdStream st = ad_stream(r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
+    const uint32_t nt = (st.n + ATILE - 1) / ATILE;
     if (k >= nt) return;
     const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
-    if (seg_flag[so]) return;
-    const AdRec r(rec);
-    const uint32_t t0 = k * ATILE, t1 = (t0 + ATILE < n) ? t0 + ATILE : n;
-    const int32_t lo = seg_lo[so], hi = seg_end[so];
+    if (a.seg_flag[so]) return;
+    const uint32_t t0 = k * ATILE, t1 = (t0 + ATILE < st.n) ? t0 + ATILE : st.n;
+    const int32_t lo = a.seg_lo[so], hi = a.seg_end[so];
     int32_t x = (lo + q < hi) ? lo + q : hi;
     const int i = r.i, A = r.A;
-    for_each_cls(cls8 + (size_t)c * rle_stride, t0, t1, [&](uint32_t, uint32_t c8) {
-        if (r.hits(c8)) x = adapt_step(x, i, r.sym(c8), A);
-    });
-    seg_tab[so * 32 + q] = (uint16_t)(x - 1);     // states are in [1, 65535]
+    ad_for_each(r, st, t0, t1, [&](uint32_t, int sy) { x = adapt_step(x, i, sy, A); });
+    a.seg_tab[so * 32 + q] = (uint16_t)(x - 1);     // states are in [1, 65535]
 }
 
-__global__ __launch_bounds__(64) void k_adapt_b(EncDims d, const uint32_t *__restrict__ rlen, const uint32_t *__restrict__ seg_flag,
-                                               const int32_t *__restrict__ seg_lo, const int32_t *__restrict__ seg_end,
-                                               const uint16_t *__restrict__ seg_tab, int32_t *__restrict__ seg_start)
+__global__ __launch_bounds__(64) void k_adapt_b(EncDims d, AdArgs a)
 {
     const uint32_t g = blockIdx.x * 64 + threadIdx.x;
     const uint32_t rec = g & 15u;
     if ((g >> 4) >= d.ncl || rec >= 9) return;
     const uint32_t c = chunk_of(d, g >> 4);
     const AdRec r(rec);
-    const uint32_t nt = (rlen[c] + ATILE - 1) / ATILE;
+    const AdStream st = ad_stream(r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
+    const uint32_t nt = (st.n + ATILE - 1) / ATILE;
     int32_t x = r.init();
     for (uint32_t k = 0; k < nt; k++) {
         const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
-        if (seg_flag[so]) x = seg_end[so];
+        if (a.seg_flag[so]) x = a.seg_end[so];
         else {
-            seg_start[so] = x;
-            int q = x - seg_lo[so];
+            a.seg_start[so] = x;
+            int q = x - a.seg_lo[so];
             q = q < 0 ? 0 : (q > 31 ? 31 : q);
-            x = (int32_t)seg_tab[so * 32 + q] + 1;
+            x = (int32_t)a.seg_tab[so * 32 + q] + 1;
         }
     }
 }
 
-__global__ __launch_bounds__(64) void k_adapt_c(const uint8_t *__restrict__ cls8, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
-                                               const uint32_t *__restrict__ seg_flag, const int32_t *__restrict__ seg_start,
-                                               uint16_t *__restrict__ explo, uint16_t *__restrict__ exphi, uint32_t *__restrict__ mantad)
+__global__ __launch_bounds__(64) void k_adapt_c(EncDims d, AdArgs a)
 {
-    const uint32_t c = chunk_of(d, blockIdx.z), rec = blockIdx.y;
-    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
-    const uint32_t n = rlen[c];
-    const uint32_t nt = (n + ATILE - 1) / ATILE;
+    const uint32_t c = chunk_of(d, blockIdx.y), rec = threadIdx.x & 15u;
+    const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 4);
+    if (rec >= 9) return;
+    const AdRec r(rec);
+    const AdStream st = ad_stream(r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
+    const uint32_t nt = (st.n + ATILE - 1) / ATILE;
     if (k >= nt) return;
     const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
-    if (seg_flag[so]) return;
-    const AdRec r(rec);
-    const uint32_t t0 = k * ATILE, t1 = (t0 + ATILE < n) ? t0 + ATILE : n;
-    ad_run_write(r, cls8 + (size_t)c * rle_stride, t0, t1, seg_start[so], explo + (size_t)c * rle_stride, exphi + (size_t)c * rle_stride,
-                 mantad + (size_t)c * rle_stride);
+    if (a.seg_flag[so]) return;
+    const uint32_t t0 = k * ATILE, t1 = (t0 + ATILE < st.n) ? t0 + ATILE : st.n;
+    ad_run_write(r, st, t0, t1, a.seg_start[so], a.explo + (size_t)c * a.rle_stride, a.exphi + (size_t)c * a.rle_stride,
+                 a.mantad + (size_t)c * a.rle_stride);
 }
 
 // rANS records in coding order.  Pair j = 2t (exponent) / 2t+1 (mantissa) belongs to state lane j & 3; the
@@ -734,6 +771,9 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
 {
     __shared__ uint4 rbuf[2][4][RANS_TILE];
     __shared__ uint32_t ebuf[4][RANS_TILE];
+    // this wave is a long dependent chain: let it win the issue arbitration against the wide kernels of other chunks /
+    // blocks that share its SIMD (priority, then age)
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t c = chunk_of(d, blockIdx.x);
     const int t = threadIdx.x;
     const uint32_t np = 2 * rlen[c];
@@ -884,7 +924,7 @@ struct EncBufs {
     uint32_t *lz, *ext, *tcount, *toff, *rlen;
     uint16_t *rle;
     uint32_t *clscnt, *clstotal, *ord, *qhist, *qcdf, *dens, *cmap;
-    uint8_t *cls8;
+    uint8_t *cls8; uint32_t *clist;
     uint32_t *seg_flag; int32_t *seg_lo, *seg_end, *seg_start; uint16_t *seg_tab;
     uint16_t *explo, *exphi; uint32_t *mantad, *pairs; uint4 *recs;
     uint32_t *emit, *epos, *fstate, *csize;
@@ -925,6 +965,7 @@ void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what)
         b.exphi = a.get<uint16_t>((size_t)d.nch * stride);
         b.mantad = a.get<uint32_t>((size_t)d.nch * stride);
         b.cls8 = a.get<uint8_t>((size_t)d.nch * stride + 64);
+        b.clist = a.get<uint32_t>((size_t)d.nch * 2 * ((stride + 3) & ~(size_t)3) + 64);
         const size_t segs = (size_t)d.nch * 9 * d.tpc;
         b.seg_flag = a.get<uint32_t>(segs);
         b.seg_lo = a.get<int32_t>(segs);
@@ -1002,15 +1043,16 @@ int run_model(jpk_ctx *ctx, const uint16_t *d_rle, const uint32_t *d_rlen, const
     const size_t stride = d.chunk;
     JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_count, dim3(d.tpc, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.clscnt);
     JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_prefix, dim3(jpk_grid((size_t)d.ncl * 8, 64)), dim3(64), d, d_rlen, b.clscnt, b.clstotal);
-    JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_ord, dim3(d.tpc, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.clscnt, b.ord, b.qhist, b.cls8);
+    JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_ord, dim3(d.tpc, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.clscnt, b.ord, b.qhist, b.cls8, b.clist);
     JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_quasi_build, dim3(NQ, 6, d.ncl), dim3(64), d, b.clstotal, b.qhist, b.qcdf);
-    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_a, dim3((d.tpc + 63) / 64, 9, d.ncl), dim3(64), b.cls8, stride, d, d_rlen, b.clscnt, b.explo, b.exphi, b.mantad,
-                       b.seg_flag, b.seg_lo, b.seg_end, b.seg_tab);
-    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_tab, dim3((d.tpc + 1) / 2, 9, d.ncl), dim3(64), b.cls8, stride, d, d_rlen, b.seg_flag, b.seg_lo, b.seg_end,
-               b.seg_tab);
-    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_b, dim3(jpk_grid((size_t)d.ncl * 16, 64)), dim3(64), d, d_rlen, b.seg_flag, b.seg_lo, b.seg_end, b.seg_tab, b.seg_start);
-    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_c, dim3((d.tpc + 63) / 64, 9, d.ncl), dim3(64), b.cls8, stride, d, d_rlen, b.seg_flag, b.seg_start, b.explo, b.exphi,
-                       b.mantad);
+    AdArgs aa;
+    aa.cls8 = b.cls8; aa.clist = b.clist; aa.rle_stride = stride; aa.rlen = d_rlen; aa.clstotal = b.clstotal;
+    aa.explo = b.explo; aa.exphi = b.exphi; aa.mantad = b.mantad;
+    aa.seg_flag = b.seg_flag; aa.seg_lo = b.seg_lo; aa.seg_end = b.seg_end; aa.seg_start = b.seg_start; aa.seg_tab = b.seg_tab;
+    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_a, dim3((d.tpc + 3) / 4, d.ncl), dim3(64), d, aa);
+    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_tab, dim3((d.tpc + 1) / 2, 9, d.ncl), dim3(64), d, aa);
+    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_b, dim3(jpk_grid((size_t)d.ncl * 16, 64)), dim3(64), d, aa);
+    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_c, dim3((d.tpc + 3) / 4, d.ncl), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_PAIRS, 0, k_pairs, dim3(jpk_grid(stride, TB), d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.explo, b.exphi, b.mantad, b.ord,
                        b.qcdf, b.recs, b.pairs);
     JPK_HIP(hipGetLastError());
