@@ -157,9 +157,8 @@ def main():
     lanes = [order[k::nctx] for k in range(nctx)]
 
     sizes = [0] * len(blocks)
-    max_comp = max(caps)
-    gather_buf = torch.empty((world, max_comp), dtype=torch.uint8, device=dev) if ((world > 1 or FORCE_GATHER) and rank == 0) else None
-    pad_buf = torch.empty(max_comp, dtype=torch.uint8, device=dev) if (world > 1 or FORCE_GATHER) else None
+    from jampack_amd import shard
+    gathered = [None]
 
     def lane_work(k):
         for i in lanes[k]:
@@ -169,13 +168,9 @@ def main():
         for f in [pool.submit(lane_work, k) for k in range(nctx)]:
             f.result()
         if world > 1 or FORCE_GATHER:
-            # the only exchange of the path: compressed blocks -> rank 0 (sizes first, then payload), RCCL over xGMI
-            sz = torch.tensor(sizes, dtype=torch.int64, device=dev)
-            allsz = [torch.empty_like(sz) for _ in range(world)] if rank == 0 else None
-            dist.gather(sz, allsz, dst=0)
-            for i in range(len(blocks)):
-                pad_buf[: sizes[i]].copy_(d_out[i][: sizes[i]])
-                dist.gather(pad_buf, list(gather_buf.unbind(0)) if rank == 0 else None, dst=0)
+            # the only exchange of the path: the compressed blocks of every rank -> rank 0 (all_gather of the sizes, one
+            # gather of a buffer padded to the largest rank total), RCCL over xGMI; jampack_amd/shard.py
+            gathered[0] = shard.gather_blocks([d_out[i][: sizes[i]] for i in range(len(blocks))], dst=0)
 
     def sync_all():
         if world > 1 or FORCE_GATHER:
@@ -257,6 +252,8 @@ def main():
         del d_cmp, d_dcm
         extra["round_trip_ok"] = ok
         extra["compressed_bytes"] = int(sum(comp_sizes))
+        if gathered[0] is not None:          # rank 0 holds every rank's compressed blocks: check its own against the source
+            extra["gather_ok"] = all(bool(torch.equal(gathered[0][0][i], d_out[i][: sizes[i]])) for i in range(len(blocks))) and len(gathered[0]) == world
         extra["sa_rounds_last_block"] = int(st.sa_rounds)
         extra["workspace_bytes"] = int(ctx.stats().workspace_bytes)
         # algorithmic HBM traffic of the stages: fwd BWT 10 B/B, ANS 4+c B/B, inverse BWT 12 B/B

@@ -9,7 +9,9 @@ idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 start = idx[-1]
 t0 = int(rows[start]["Start_Timestamp"])
 for r in rows[start:]:
-    n = r["Kernel_Name"].split("::")[-1].split("(")[0][:24]
+    import re
+    m = re.search(r"(k_\w+)", r["Kernel_Name"])
+    n = (m.group(1) if m else r["Kernel_Name"])[:24]
     s = (int(r["Start_Timestamp"]) - t0) / 1e6
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
     print("%-24s q=%3s start=%8.3f ms dur=%8.3f grid=%sx%sx%s" % (n, r["Queue_Id"], s, d, r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"]))
