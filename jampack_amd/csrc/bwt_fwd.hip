@@ -499,7 +499,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b, uint32_t **i
     ctx->stats.sa_rounds = 1;
 
     const int kbits = jpk_bits_for(n);     // key2 <= n, group rank < n
-    const int key_passes = (kbits + 7) / 8;
+    const int key_passes = getenv("JPK_DBG_NOSORT") ? 0 : (kbits + 7) / 8;   // debug: time k_seg_round without its LDS sort
     int shifts[8];
     int ns = 0;
     for (int s = 0; s < kbits; s += 8) shifts[ns++] = s;
