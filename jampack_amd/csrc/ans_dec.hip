@@ -356,33 +356,42 @@ __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, con
     __syncthreads();
     uint32_t v = lst[l];
     uint32_t sym = rfl(v) & 0xffu;
-    uint32_t mine = 0;        // 4 output bytes per lane per 256-step block are not worth it; accumulate 64 at a time
-    for (uint32_t i = 0; i < len; i++) {
-        if ((i & 63u) == (uint32_t)l) mine = sym;
-        if ((i & 63u) == 63u) T[i - 63 + l] = (uint8_t)mine;
-        const uint32_t bp = bpos[sym];
-        if (bp < bend[sym]) {
-            const uint32_t r = rfl((uint32_t)R[bp]);
-            if (l == 0) bpos[sym] = bp + 1;
-            if (r > 0) {
-                v = list_shift_insert(v, l, r, sym);
+    // One iteration = one run of the current symbol: the wave peeks the next 64 ranks of the symbol's bucket, z leading
+    // zero ranks mean z more copies of the symbol (rank 0 = "same symbol again"), which are written by z+1 lanes at once;
+    // the first non-zero rank (or the end of the bucket) then moves the symbol inside / out of the list.
+    uint32_t i = 0;
+    while (i < len) {
+        const uint32_t bp = bpos[sym], be = bend[sym];
+        const uint32_t rl = (bp + l < be) ? (uint32_t)R[bp + l] : 0xFFu;    // lanes past the bucket end count as non-zero
+        const uint64_t nz = __ballot(rl != 0);
+        const uint32_t z = nz ? (uint32_t)__builtin_ctzll(nz) : 64u;
+        uint32_t cnt = (z < 64u) ? z + 1u : 64u;
+        if (cnt > len - i) cnt = len - i;
+        if ((uint32_t)l < cnt) T[i + l] = (uint8_t)sym;
+        i += cnt;
+        if (z >= 64u) {                                  // 64 zero ranks consumed, the same symbol goes on
+            if (l == 0) bpos[sym] = bp + 64u;
+            continue;
+        }
+        if (bp + z < be) {
+            const uint32_t r = __builtin_amdgcn_readlane(rl, z);             // the non-zero rank that ends the run
+            if (l == 0) bpos[sym] = bp + z + 1u;
+            v = list_shift_insert(v, l, r, sym);
+            sym = rfl(v) & 0xffu;
+        } else {
+            if (l == 0) bpos[sym] = be;
+            if (uniq > 0) {
+                uniq--;
+                // drop the front: positions < uniq shift down by one (rank.cpp:140-147; executes at least once)
+                const uint32_t lim = uniq > 0 ? uniq : 1u;
+                const uint32_t nextv = wave_shl1(v);
+                const uint32_t shifted = (v >> 8) | (nextv << 24);
+                const int nb = (int)lim - 4 * l;
+                const uint32_t mask = nb <= 0 ? 0u : (nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u));
+                v = (shifted & mask) | (v & ~mask);
                 sym = rfl(v) & 0xffu;
             }
-        } else if (uniq > 0) {
-            uniq--;
-            // drop the front: positions < uniq shift down by one (rank.cpp:140-147; executes at least once)
-            const uint32_t lim = uniq > 0 ? uniq : 1u;
-            const uint32_t nextv = wave_shl1(v);
-            const uint32_t shifted = (v >> 8) | (nextv << 24);
-            const int nb = (int)lim - 4 * l;
-            const uint32_t mask = nb <= 0 ? 0u : (nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u));
-            v = (shifted & mask) | (v & ~mask);
-            sym = rfl(v) & 0xffu;
         }
-    }
-    if (len & 63u) {
-        const uint32_t base = len & ~63u;
-        if (base + l < len) T[base + l] = (uint8_t)mine;
     }
 }
 
