@@ -2,9 +2,9 @@
 // followed by the BWT gather and the 120 sampled ranks of BlockSort::Bwt::ForwardBwt (bwt.cpp:22-65).
 //
 // Suffix array = prefix doubling (Larsson-Sadakane ranks) with compaction of resolved suffixes:
-//   round 0   key = first 7 bytes (big-endian) | min(7, bytes left): one 64-bit LSD radix sort of all n suffixes
-//             (radix.hip).  A short suffix is a proper prefix of anything it ties with on the padded bytes, and
-//             its smaller length code puts it first -- plain suffix order even when the text contains 0x00.
+//   round 0   key = first 7 bytes (big-endian, zero padded): one LSD radix sort of all n suffixes, 7 passes (radix.hip),
+//             fed in descending text position so that a short suffix -- a proper prefix of anything it ties with on
+//             the padded bytes -- comes first: plain suffix order even when the text contains 0x00.
 //   round h   (h = 7, 14, 28, ...) active suffixes only.  The active list keeps groups of equal h-rank contiguous
 //             and in SA order, so a group is sorted by key2 = rank[sa + h] + 1 (0 past the end) independently:
 //               * groups of <= 1024 suffixes: k_seg_round -- one workgroup owns the groups that start in its
@@ -25,11 +25,16 @@ constexpr int TB = 256;
 constexpr uint32_t DONE = 0x80000000u;
 
 // ---- round 0 ----------------------------------------------------------------------------------------
+// key = first 7 bytes, big-endian in bits 63..8, zero padded past the end of the text.  Slot j holds suffix n-1-j:
+// the LSD sort is stable, so suffixes that tie on the padded bytes come out in DESCENDING text position, i.e. a
+// short suffix (a proper prefix of everything it ties with) lands in front -- plain suffix order even when the text
+// contains 0x00 -- and the low byte of the key needs no sort pass.
 __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T, uint32_t n, uint64_t *__restrict__ keys,
                                                  uint32_t *__restrict__ vals)
 {
-    uint32_t i = blockIdx.x * TB + threadIdx.x;
-    if (i >= n) return;
+    uint32_t j = blockIdx.x * TB + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t i = n - 1 - j;
     uint32_t left = n - i;
     uint64_t k = 0;
 #pragma unroll
@@ -37,17 +42,18 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
         uint64_t c = (b < (int)left) ? T[i + b] : 0;
         k |= c << (56 - 8 * b);
     }
-    k |= (left < 7u) ? left : 7u;
-    keys[i] = k;
-    vals[i] = i;
+    keys[j] = k;
+    vals[j] = i;
 }
 
-// head flags of equal-key runs -> hv[i] = head ? i : 0  (input of an inclusive max scan)
-__global__ __launch_bounds__(TB) void k_heads_u64(const uint64_t *__restrict__ keys, uint32_t m, uint32_t *__restrict__ hv)
+// head flags of equal-key runs -> hv[i] = head ? i : 0  (input of an inclusive max scan); a suffix with fewer than
+// 7 bytes is always a group of its own
+__global__ __launch_bounds__(TB) void k_heads_u64(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t m, uint32_t n,
+                                                 uint32_t *__restrict__ hv)
 {
     uint32_t j = blockIdx.x * TB + threadIdx.x;
     if (j >= m) return;
-    bool head = (j == 0) || (keys[j] != keys[j - 1]);
+    bool head = (j == 0) || (keys[j] != keys[j - 1]) || (sa[j] + 7u > n) || (sa[j - 1] + 7u > n);
     hv[j] = head ? j : 0u;
 }
 
@@ -482,14 +488,14 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b, uint32_t **i
     ctx->stats.sa_rounds = 0;
     ctx->stats.sa_sorted_elems = 0;
 
-    // round 0: sort by 7 bytes + length code
+    // round 0: sort by the first 7 bytes (7 passes; ties keep descending text position)
     JPK_LAUNCH(ctx, PROF_SA_KEYS, n, k_init_keys, dim3(g_n), dim3(TB), T, n, b.keysA, b.valsA);
     {
-        const int shifts[8] = {0, 8, 16, 24, 32, 40, 48, 56};
-        JPK_TRY(jpk_radix_sort_pairs_u64(ctx, b.keysA, b.valsA, b.keysB, b.valsB, n, shifts, 8, b.scratch));
+        const int shifts[7] = {8, 16, 24, 32, 40, 48, 56};
+        JPK_TRY(jpk_radix_sort_pairs_u64(ctx, b.keysA, b.valsA, b.keysB, b.valsB, n, shifts, 7, b.scratch));
         ctx->stats.sa_sorted_elems += n;
     }
-    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_heads_u64, dim3(g_n), dim3(TB), b.keysA, n, b.t1);
+    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_heads_u64, dim3(g_n), dim3(TB), b.keysA, b.valsA, n, n, b.t1);
     JPK_TRY(jpk_inclusive_max_u32(ctx, b.t1, b.t2, n, b.scratch));                     // t2 = grp
     JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_round0_finish, dim3(g_n), dim3(TB), b.t2, b.valsA, n, b.ISA0, b.ISA1, b.SA, b.t1);  // t1 = keep
     JPK_TRY(jpk_exclusive_sum_u32(ctx, b.t1, b.t3, n, b.scratch, ctx->d_mail));       // t3 = pos
