@@ -34,6 +34,9 @@ extern "C" {
 #define JPK_BWT_UNITS 120                 /* format.hpp:26  BWT_UNITS */
 #define JPK_TRAILER_BYTES (JPK_BWT_UNITS * 4)
 #define JPK_ANS_CHUNK (1 << 20)           /* ans.hpp:21     StackSize */
+#define JPK_MIN_BLOCKSIZE (1 << 20)       /* format.hpp:21  MIN_BLOCKSIZE */
+#define JPK_MAX_BLOCKSIZE (1000 << 20)    /* format.hpp:22  MAX_BLOCKSIZE */
+#define JPK_JAM_HEADER_BYTES 15           /* jampack.cpp:128-131: "JAM" + crc + payload size + BlockSize */
 
 typedef enum jpk_status {
     JPK_OK = 0,
@@ -96,6 +99,20 @@ JPK_API int jpk_rank_decode(uint8_t *ranks, const int32_t *freq256, int32_t len)
  * image kept in HBM between the two stages (jampack.cpp:40-41, 49-50). */
 JPK_API int jpk_block_compress(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len);
 JPK_API int jpk_block_decompress(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len);
+/* Checksum::IntegrityCheck(Buffer)                     checksum.hpp:15, checksum.cpp:12-36 */
+JPK_API int jpk_checksum(const uint8_t *in, int32_t in_len, uint32_t *crc);
+/* One framed block of a .jam stream: Jampack::Comp() (crc of the input, jampack.cpp:31) + CompWriteBlock
+ * (jampack.cpp:122-135):  "JAM" | u32 crc | i32 payload size | i32 BlockSize | payload   (15-byte header, LE).
+ * The payload is jpk_block_compress(in): the reference CLI additionally runs its LZ77 / filter / LPX pre-stages in
+ * front of the BWT (jampack.cpp:33-38), so frames interchange with a reference build whose Comp()/Decomp() call
+ * this path, not with the stock CLI.  block_size is Options.BlockSize and must lie in
+ * [JPK_MIN_BLOCKSIZE, JPK_MAX_BLOCKSIZE] with in_len <= block_size. */
+JPK_API int jpk_jam_block_write(const uint8_t *in, int32_t in_len, int32_t block_size, uint8_t *out, int32_t out_cap, int32_t *out_len);
+/* DecompReadBlock + Decomp() (jampack.cpp:140-164, 47-60): validates the header exactly as the reference does
+ * (magic, BlockSize range, 0 <= payload size <= MAX_BLOCKSIZE), decodes the payload and checks the crc.
+ * *consumed = 15 + payload size (where the next frame starts).  JPK_E_CORRUPT on a bad header, a payload that
+ * runs past in_len, or a crc mismatch ("Detected corrupt block!", jampack.cpp:59). */
+JPK_API int jpk_jam_block_read(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len, int32_t *consumed);
 
 /* ---- device-buffer entry points (all pointers except ctx/out_len are HBM addresses on ctx's device) ---- */
 JPK_API int jpk_dev_bwt_forward(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
@@ -106,6 +123,9 @@ JPK_API int jpk_dev_rank_encode(jpk_ctx *ctx, uint8_t *d_t, int32_t *d_freq256, 
 JPK_API int jpk_dev_rank_decode(jpk_ctx *ctx, uint8_t *d_ranks, const int32_t *d_freq256, int32_t len);
 JPK_API int jpk_dev_block_compress(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
 JPK_API int jpk_dev_block_decompress(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
+JPK_API int jpk_dev_checksum(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint32_t *crc);
+JPK_API int jpk_dev_jam_block_write(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, int32_t block_size, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
+JPK_API int jpk_dev_jam_block_read(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len, int32_t *consumed);
 
 /* ---- kernel-level probes used by tests/ (device buffers) ------------------------------------------------ */
 /* suffix array of d_t[0..n) into d_sa (int32[n]) -- the divsufsort() replacement, divsufsort.cpp:1721 */

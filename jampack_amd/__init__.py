@@ -3,6 +3,7 @@ bwt.hpp / ans.hpp / rank.hpp interface.  The compute path is libjampack_amd.so (
 importing this package loads it and fails loudly if it has not been built."""
 from . import corpus  # noqa: F401
 from ._lib import ABI_SYMBOLS, CHUNK, LIB_PATH, TRAILER, JampackError, lib  # noqa: F401
-from .api import Ans, Bwt, Context, Postcoder, ans_capacity, block_compress, block_decompress  # noqa: F401
+from .api import (Ans, Bwt, Checksum, Context, Postcoder, ans_capacity, block_compress, block_decompress,  # noqa: F401
+                  jam_block_read, jam_block_write, jam_compress, jam_decompress)
 
 lib()  # no lazy fallback: the HIP extension must be present

@@ -58,6 +58,9 @@ _SIGS = {
     "jpk_rank_decode": (C.c_int, [_vp, _vp, C.c_int32]),
     "jpk_block_compress": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_block_decompress": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_checksum": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_uint32)]),
+    "jpk_jam_block_write": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_jam_block_read": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p, _i32p]),
     "jpk_dev_bwt_forward": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_dev_bwt_inverse": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_dev_ans_encode": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
@@ -66,6 +69,9 @@ _SIGS = {
     "jpk_dev_rank_decode": (C.c_int, [_vp, _vp, _vp, C.c_int32]),
     "jpk_dev_block_compress": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_dev_block_decompress": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_dev_checksum": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(C.c_uint32)]),
+    "jpk_dev_jam_block_write": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_dev_jam_block_read": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p, _i32p]),
     "jpk_dev_suffix_array": (C.c_int, [_vp, _vp, C.c_int32, _vp]),
     "jpk_dev_sort_pairs_u64": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32]),
     "jpk_dev_exclusive_scan_u32": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(C.c_uint32)]),

@@ -107,6 +107,66 @@ def block_decompress(comp, cap: int) -> np.ndarray:
     return out[: n.value]
 
 
+JAM_HEADER = 15
+MIN_BLOCKSIZE = 1 << 20        # format.hpp:21
+MAX_BLOCKSIZE = 1000 << 20     # format.hpp:22
+
+
+class Checksum:
+    """Mirror of `class Checksum` (checksum.hpp:12-16)."""
+
+    def IntegrityCheck(self, buf) -> int:
+        t = _np_u8(buf)
+        crc = C.c_uint32(0)
+        _chk(lib().jpk_checksum(_ptr(t), len(t), C.byref(crc)), "Checksum::IntegrityCheck")
+        return crc.value
+
+
+def jam_block_write(block, block_size: int, cap: int | None = None) -> np.ndarray:
+    """One framed block: crc (jampack.cpp:31) + the 15-byte header of CompWriteBlock (jampack.cpp:122-135) +
+    the block_compress payload."""
+    t = _np_u8(block)
+    cap = JAM_HEADER + ans_capacity(len(t) + TRAILER) if cap is None else cap
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    n = C.c_int32(0)
+    _chk(lib().jpk_jam_block_write(_ptr(t), len(t), block_size, out.ctypes.data, cap, C.byref(n)), "jam_block_write")
+    return out[: n.value]
+
+
+def jam_block_read(stream, cap: int):
+    """DecompReadBlock + Decomp (jampack.cpp:140-164, 47-60) for the frame at the start of `stream`.
+    Returns (block bytes, bytes consumed); raises JampackError(CORRUPT) on a bad header or crc."""
+    c = _np_u8(stream)
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    n, used = C.c_int32(0), C.c_int32(0)
+    _chk(lib().jpk_jam_block_read(_ptr(c), len(c), out.ctypes.data, cap, C.byref(n), C.byref(used)), "jam_block_read")
+    return out[: n.value], used.value
+
+
+def jam_compress(data, block_size: int = 8 << 20) -> np.ndarray:
+    """Jampack::Compress's block loop (jampack.cpp:186-254) over an in-memory buffer: consecutive frames of
+    block_size input bytes (DEFAULT_BLOCKSIZE 8 MiB, format.hpp:20)."""
+    t = _np_u8(data)
+    frames = [jam_block_write(t[o: o + block_size], block_size) for o in range(0, len(t), block_size)]
+    return np.concatenate(frames) if frames else np.zeros(0, dtype=np.uint8)
+
+
+def jam_decompress(stream) -> np.ndarray:
+    """Jampack::Decompress's block loop (jampack.cpp:262-336): frames until the stream ends."""
+    c = _np_u8(stream)
+    out, o = [], 0
+    while o < len(c):
+        if len(c) - o < JAM_HEADER:
+            raise JampackError(-3, "jam_decompress: truncated header")
+        bs = int(np.frombuffer(c[o + 11: o + 15].tobytes(), dtype="<i4")[0])
+        if not (MIN_BLOCKSIZE <= bs <= MAX_BLOCKSIZE):
+            raise JampackError(-3, "jam_decompress: Refusing to read from corrupt header!")
+        blk, used = jam_block_read(c[o:], bs)
+        out.append(blk)
+        o += used
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.uint8)
+
+
 def _dptr(x):
     """device pointer of a torch CUDA tensor or a raw int"""
     if x is None:
@@ -179,6 +239,21 @@ class Context:
 
     def block_decompress(self, d_in, in_len, d_out, out_cap) -> int:
         return self._io(lib().jpk_dev_block_decompress, "jpk_dev_block_decompress", d_in, in_len, d_out, out_cap)
+
+    def checksum(self, d_in, in_len) -> int:
+        crc = C.c_uint32(0)
+        _chk(lib().jpk_dev_checksum(self._h, _dptr(d_in), in_len, C.byref(crc)), "jpk_dev_checksum")
+        return crc.value
+
+    def jam_block_write(self, d_in, in_len, block_size, d_out, out_cap) -> int:
+        n = C.c_int32(0)
+        _chk(lib().jpk_dev_jam_block_write(self._h, _dptr(d_in), in_len, block_size, _dptr(d_out), out_cap, C.byref(n)), "jpk_dev_jam_block_write")
+        return n.value
+
+    def jam_block_read(self, d_in, in_len, d_out, out_cap):
+        n, used = C.c_int32(0), C.c_int32(0)
+        _chk(lib().jpk_dev_jam_block_read(self._h, _dptr(d_in), in_len, _dptr(d_out), out_cap, C.byref(n), C.byref(used)), "jpk_dev_jam_block_read")
+        return n.value, used.value
 
     def rank_encode(self, d_t, d_freq, n):
         _chk(lib().jpk_dev_rank_encode(self._h, _dptr(d_t), _dptr(d_freq), n), "jpk_dev_rank_encode")

@@ -92,7 +92,7 @@ static const char *const PROF_NAMES[PROF_COUNT] = {
     "k_rs_hist", "k_rs_scatter", "k_scan_*", "k_init_keys/k_make_keys/k_win_heads", "k_seg_round", "sa rerank kernels", "k_bwt_gather",
     "k_hist", "k_build_nxt", "k_walk", "k_rank_jump", "k_copy_out",
     "k_enc_hist/k_enc_prep", "k_enc_mtf", "k_rle_*", "k_cls_*/k_quasi_build", "k_adaptive", "k_pairs", "k_rans_lanes", "k_emit_scan/k_put_*",
-    "k_dec_headers", "k_dec_rans", "k_dec_rle", "k_dec_rank"};
+    "k_dec_headers", "k_dec_rans", "k_dec_rle", "k_dec_rank", "k_chk_*"};
 
 extern "C" int jpk_ctx_profile(jpk_ctx *ctx, int enable)
 {
@@ -357,6 +357,68 @@ extern "C" int jpk_dev_model_pairs(jpk_ctx *ctx, const uint16_t *d_rle, int32_t 
     return jpk_model_pairs_device(ctx, d_rle, rlen, d_pairs);
 }
 
+// ---- block container: checksum + 15-byte frame (jampack.cpp:29-60, 122-164) ---------------------------------
+extern "C" int jpk_dev_checksum(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint32_t *crc)
+{
+    JPK_ENTER(ctx);
+    if (!crc || in_len < 0 || (in_len > 0 && !d_in)) return JPK_E_ARG;
+    JPK_TRY(jpk_checksum_device(ctx, d_in, in_len, ctx->d_mail));
+    return jpk_read_mail(ctx, crc, 1);
+}
+
+namespace {
+bool jam_block_size_ok(int32_t bs) { return bs >= JPK_MIN_BLOCKSIZE && bs <= JPK_MAX_BLOCKSIZE; }
+}
+
+extern "C" int jpk_dev_jam_block_write(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, int32_t block_size, uint8_t *d_out, int32_t out_cap,
+                                       int32_t *out_len)
+{
+    JPK_ENTER(ctx);
+    if (!d_out || !out_len || in_len < 0 || (in_len > 0 && !d_in)) return JPK_E_ARG;
+    if (!jam_block_size_ok(block_size) || in_len > block_size) return JPK_E_ARG;     // InitComp, jampack.cpp:70
+    if (out_cap < JPK_JAM_HEADER_BYTES) return JPK_E_CAPACITY;
+    uint32_t crc = 0;
+    JPK_TRY(jpk_dev_checksum(ctx, d_in, in_len, &crc));
+    int32_t n = 0;
+    JPK_TRY(jpk_dev_block_compress(ctx, d_in, in_len, d_out + JPK_JAM_HEADER_BYTES, out_cap - JPK_JAM_HEADER_BYTES, &n));
+    uint8_t *h = reinterpret_cast<uint8_t *>(ctx->h_mail + 128);    // pinned; words 128.. are not used by jpk_read_mail callers
+    memcpy(h, "JAM", 3);
+    memcpy(h + 3, &crc, 4);
+    memcpy(h + 7, &n, 4);
+    memcpy(h + 11, &block_size, 4);
+    JPK_HIP(hipMemcpyAsync(d_out, h, JPK_JAM_HEADER_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    *out_len = n + JPK_JAM_HEADER_BYTES;
+    return JPK_OK;
+}
+
+extern "C" int jpk_dev_jam_block_read(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len,
+                                      int32_t *consumed)
+{
+    JPK_ENTER(ctx);
+    if (!d_in || !d_out || !out_len || in_len < 0 || out_cap < 0) return JPK_E_ARG;
+    if (in_len < JPK_JAM_HEADER_BYTES) return JPK_E_CORRUPT;
+    uint8_t *h = reinterpret_cast<uint8_t *>(ctx->h_mail + 128);
+    JPK_HIP(hipMemcpyAsync(h, d_in, JPK_JAM_HEADER_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    uint32_t crc;
+    int32_t csize, block_size;
+    memcpy(&crc, h + 3, 4);
+    memcpy(&csize, h + 7, 4);
+    memcpy(&block_size, h + 11, 4);
+    // DecompReadBlock, jampack.cpp:150: "Refusing to read from corrupt header!"
+    if (memcmp(h, "JAM", 3) != 0 || !jam_block_size_ok(block_size) || csize < 0 || csize > JPK_MAX_BLOCKSIZE) return JPK_E_CORRUPT;
+    if ((int64_t)csize + JPK_JAM_HEADER_BYTES > in_len) return JPK_E_CORRUPT;
+    int32_t n = 0;
+    JPK_TRY(jpk_dev_block_decompress(ctx, d_in + JPK_JAM_HEADER_BYTES, csize, d_out, out_cap, &n));
+    uint32_t got = 0;
+    JPK_TRY(jpk_dev_checksum(ctx, d_out, n, &got));
+    if (got != crc) return JPK_E_CORRUPT;                            // "Detected corrupt block!", jampack.cpp:59
+    *out_len = n;
+    if (consumed) *consumed = csize + JPK_JAM_HEADER_BYTES;
+    return JPK_OK;
+}
+
 // ---- host-buffer (drop-in) entry points --------------------------------------------------------------------
 // One lazily created context per calling thread: re-entrant from the OpenMP block loop of jampack.cpp:215/313.
 namespace {
@@ -471,4 +533,48 @@ extern "C" int jpk_rank_decode(uint8_t *ranks, const int32_t *freq256, int32_t l
     if (len) JPK_HIP(hipMemcpyAsync(ranks, d_t, (size_t)len, hipMemcpyDeviceToHost, ctx->stream));
     JPK_HIP(hipStreamSynchronize(ctx->stream));
     return JPK_OK;
+}
+
+extern "C" int jpk_checksum(const uint8_t *in, int32_t in_len, uint32_t *crc)
+{
+    if (!crc || in_len < 0 || (in_len > 0 && !in)) return JPK_E_ARG;
+    jpk_ctx *ctx;
+    JPK_TRY(tls_ctx(&ctx));
+    JPK_HIP(hipSetDevice(ctx->device));
+    JPK_TRY(buf_ensure(ctx, &ctx->stage_in, &ctx->stage_in_cap, (size_t)in_len + 64));
+    if (in_len) JPK_HIP(hipMemcpyAsync(ctx->stage_in, in, (size_t)in_len, hipMemcpyHostToDevice, ctx->stream));
+    return jpk_dev_checksum(ctx, ctx->stage_in, in_len, crc);
+}
+
+namespace {
+thread_local int32_t tls_block_size = 0;
+thread_local int32_t tls_consumed = 0;
+int jam_write_tramp(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
+{
+    return jpk_dev_jam_block_write(ctx, d_in, in_len, tls_block_size, d_out, out_cap, out_len);
+}
+int jam_read_tramp(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
+{
+    return jpk_dev_jam_block_read(ctx, d_in, in_len, d_out, out_cap, out_len, &tls_consumed);
+}
+}  // namespace
+
+extern "C" int jpk_jam_block_write(const uint8_t *in, int32_t in_len, int32_t block_size, uint8_t *out, int32_t out_cap, int32_t *out_len)
+{
+    tls_block_size = block_size;
+    return staged(jam_write_tramp, in, in_len, out, out_cap, out_len, false);
+}
+
+extern "C" int jpk_jam_block_read(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len, int32_t *consumed)
+{
+    if (in_len >= JPK_JAM_HEADER_BYTES && in) {      // stage only this frame, not the rest of the stream
+        int32_t csize;
+        memcpy(&csize, in + 7, 4);
+        if (csize < 0 || csize > JPK_MAX_BLOCKSIZE || (int64_t)csize + JPK_JAM_HEADER_BYTES > in_len) return JPK_E_CORRUPT;
+        in_len = csize + JPK_JAM_HEADER_BYTES;
+    }
+    tls_consumed = 0;
+    int rc = staged(jam_read_tramp, in, in_len, out, out_cap, out_len, false);
+    if (rc == JPK_OK && consumed) *consumed = tls_consumed;
+    return rc;
 }

@@ -562,3 +562,39 @@ int orc_ans_decode(const uint8_t *in, int32_t len, uint8_t *out, int32_t cap, in
     free(rle);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* SURVEY section 8f rows 1 and 3 (block container): checksum.cpp:12-36 and the 15-byte block     */
+/* header of Jampack::CompWriteBlock / DecompReadBlock (jampack.cpp:122-164).                    */
+/* ------------------------------------------------------------------------------------------ */
+/* checksum.cpp:12-36: four lanes, S = {3,0,0,0}; 16 bytes per round while j + 16 < size, then the
+ * remaining bytes one at a time into lane 0. */
+uint32_t orc_checksum(const uint8_t *p, int32_t size)
+{
+    const uint32_t prime = 0x9E3779B1u;
+    uint32_t S[4] = {3u, 0u, 0u, 0u};
+    uint32_t j = 0;
+    while ((uint64_t)j + 16 < (uint64_t)(uint32_t)size) {
+        for (int k = 0; k < 4; k++) {
+            const uint8_t *q = p + j + 4 * k;
+            uint32_t w = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+            S[k] ^= (w + (1u << (S[k] & 7))) * prime;
+        }
+        j += 16;
+    }
+    while (j < (uint32_t)size) {
+        S[0] ^= ((uint32_t)p[j] + (1u << (S[0] & 7))) * prime;
+        j++;
+    }
+    return S[0] ^ S[1] ^ S[2] ^ S[3];
+}
+
+/* jampack.cpp:128-132: "JAM" | crc (4, native LE) | compressed size (4) | BlockSize (4) */
+int orc_block_header(uint32_t crc, int32_t comp_size, int32_t block_size, uint8_t *out15)
+{
+    out15[0] = 'J'; out15[1] = 'A'; out15[2] = 'M';
+    memcpy(out15 + 3, &crc, 4);
+    memcpy(out15 + 7, &comp_size, 4);
+    memcpy(out15 + 11, &block_size, 4);
+    return 15;
+}

@@ -149,6 +149,16 @@ class Oracle:
     def decompress_block(self, c: np.ndarray, cap: int) -> np.ndarray:
         return self.bwt_inverse(self.ans_decode(c, cap + TRAILER))
 
+    def checksum(self, t: np.ndarray) -> int:
+        t = np.ascontiguousarray(t, dtype=np.uint8)
+        self.lib.orc_checksum.restype = C.c_uint32
+        return int(self.lib.orc_checksum(_p(t, _u8p), C.c_int32(len(t))))
+
+    def block_header(self, crc: int, comp_size: int, block_size: int) -> bytes:
+        b = np.zeros(16, dtype=np.uint8)
+        self.lib.orc_block_header(C.c_uint32(crc), C.c_int32(comp_size), C.c_int32(block_size), _p(b, _u8p))
+        return bytes(b[:15])
+
 
 class Ref:
     """The real reference (oracle/_ref/libjamref.so).  Errors inside it call exit(-1) (format.cpp:6-10)."""
@@ -226,6 +236,11 @@ class Ref:
         v = C.c_int32(0)
         n = self.lib.ref_leb_decode(C.byref(v), _p(a, _u8p))
         return v.value, n
+
+    def checksum(self, t: np.ndarray) -> int:
+        t = np.array(t, dtype=np.uint8, copy=True)
+        self.lib.ref_checksum.restype = C.c_uint32
+        return int(self.lib.ref_checksum(_p(t, _u8p), C.c_int32(len(t))))
 
     def divsufsort(self, t: np.ndarray) -> np.ndarray:
         t = np.ascontiguousarray(t, dtype=np.uint8)

@@ -13,12 +13,14 @@
 //   RLE::encode / decode                      rle.hpp:9-10,  rle.cpp:22-74
 //   Utils::EncodeLeb128 / DecodeLeb128        utils.cpp:22-90
 //   divsufsort                                divsufsort.cpp:1721
+//   Checksum::IntegrityCheck                  checksum.hpp:15, checksum.cpp:12-36
 #include "bwt.hpp"
 #include "ans.hpp"
 #include "rank.hpp"
 #include "rle.hpp"
 #include "utils.hpp"
 #include "divsufsort.hpp"
+#include "checksum.hpp"
 
 static Options make_opt(int threads)
 {
@@ -117,6 +119,13 @@ int ref_leb_decode(int* val, unsigned char* buf)
 	int n = u->DecodeLeb128(val, buf);
 	delete u;
 	return n;
+}
+
+unsigned int ref_checksum(unsigned char* p, int size)
+{
+	Checksum c;
+	Buffer b{p, &size};
+	return c.IntegrityCheck(b);
 }
 
 int ref_divsufsort(const unsigned char* t, int* sa, int n)

@@ -46,7 +46,7 @@ def main():
             "name": name, "kind": kind, "n": n, "seed": seed, "input_sha256": sha(t), "bwt_sha256": sha(bwt),
             "bwt_len": int(len(bwt)), "ans_sha256": sha(ans), "ans_len": int(len(ans)),
             "rank0_sha256": sha(ranks), "freq0_sha256": sha(freq.astype("<i4")), "rle0_sha256": sha(rle.astype("<u2")),
-            "rle0_len": int(len(rle)), "raw": n <= 65536})
+            "rle0_len": int(len(rle)), "raw": n <= 65536, "crc": r.checksum(t)})
         if n <= 65536:
             small[name + ".in"] = t
             small[name + ".bwt"] = bwt
@@ -59,6 +59,9 @@ def main():
     for v in (0, 1, 126, 127, 128, 16509, 16510, 16511, 2113660, 2113661, 2113662, 270549115, 270549116, 1 << 20, 2147483647):
         leb[str(v)] = r.leb_encode(v).hex()
     manifest["leb128"] = leb
+    # Checksum::IntegrityCheck at the loop boundaries of checksum.cpp:18-33 (j + 16 < size) and odd lengths
+    manifest["checksum"] = [{"kind": k, "n": n, "seed": 5, "crc": r.checksum(corpus.make(k, n, 5))}
+                            for k in ("text", "random", "zero") for n in (0, 1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 4095, 65551, 1048577, 5000011)]
     np.savez_compressed(os.path.join(HERE, "golden_small.npz"), **small)
     with open(os.path.join(HERE, "golden_manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)

@@ -66,3 +66,13 @@ def test_rans_pairs_roundtrip(oracle):
     pairs = oracle.model_pairs(s)
     pay = oracle.rans_encode_pairs(pairs)
     assert np.array_equal(oracle.rans_decode_chunk(pay, len(s)), s)
+
+
+def test_checksum_matches_reference(oracle, ref):
+    from jampack_amd import corpus
+    t = corpus.make("text", 200_000, 41)
+    for n in list(range(0, 100)) + [4095, 4096, 4097, 65536, 65537, 199_999, 200_000]:
+        assert oracle.checksum(t[:n]) == ref.checksum(t[:n]), n
+    for kind in ("random", "zero", "two", "geometric"):
+        u = corpus.make(kind, 100_003, 42)
+        assert oracle.checksum(u) == ref.checksum(u), kind
