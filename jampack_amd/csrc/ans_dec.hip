@@ -68,14 +68,31 @@ __global__ void k_dec_headers(const uint8_t *__restrict__ in, uint32_t len, uint
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// rANS + model decode: one wave per chunk (ans.cpp:30-92)
+// rANS + model decode: one wave per chunk (ans.cpp:30-92).
+//
+// The loop is one long dependent chain, so it is written for the issue costs of a single gfx950 wave (measured with
+// tools/issuetest.hip): every VALU or SALU instruction costs 4 cycles, a SALU instruction that reads an SGPR a VALU
+// instruction has just written stalls ~16 cycles more, an LDS round trip is 50-60 cycles, a branch 13 (not taken)
+// to 26 (taken) cycles, and every value that is live across diverging arms costs a copy at the join.  Hence:
+//   * the four rANS states, the byte queue and the two alphabet-2 models are wave-uniform and live in SGPRs;
+//   * the 8-symbol exponent model and the mantissa models of classes 2..5 are register resident with "lane = symbol":
+//     lane j holds LO_j = cdf[j], HI_j = cdf[j+1], FR_j = HI_j - LO_j of its symbol (class e owns lanes
+//     [2^e, 2^(e+1)), which is exactly the RLE0 symbol numbering, tables.hpp:10).  All lanes form their candidate
+//     next state FR_j * (x >> 16) + (x & 0xffff) - LO_j at once; one v_cmp (HI_j > x & 0xffff), one s_ff1 and one
+//     v_readlane pick the coded symbol and its next state: no LDS, no search loop;
+//   * the rebuild countdowns of classes 2..5 and the 64-symbol output tile share one VGPR (lanes 0..3 and 8), so a
+//     symbol pays a single rarely-taken branch for all of them;
+//   * payload bytes come from a 64-bit SGPR queue refilled one dword at a time from a 256-byte window held across
+//     the wave (lane l = dword l, next window prefetched).
+// Classes 6 and 7 (64 and 129 symbols, rare outside incompressible data) keep their CDFs in LDS.
 // ---------------------------------------------------------------------------------------------------------------
-struct QuasiLds {
-    uint32_t cdf[6][QSTRIDE];
-    uint32_t f[6][QSTRIDE];
-    uint32_t seen[6], expn[6];
+struct QuasiLds {                 // classes 6 and 7
+    uint32_t cdf[2][QSTRIDE];
+    uint32_t f[2][QSTRIDE];
+    uint32_t seen[2], expn[2];
 };
 
+// QuasiModel rebuild (model.cpp:160-204) of an LDS-resident model
 __device__ __forceinline__ void quasi_rebuild(QuasiLds &q, int k, int A, int l)
 {
     uint32_t F[3];
@@ -105,49 +122,159 @@ __device__ __forceinline__ void quasi_rebuild(QuasiLds &q, int k, int A, int l)
     if (l == 0) { q.cdf[k][A] = 65536u; q.seen[k] = 0; q.expn[k] = (q.expn[k] < 65536u) ? q.expn[k] << 1 : 65536u; }
 }
 
-// 256-byte input window held across the wave (lane l = dword l), next window prefetched: the payload byte a
-// renormalisation needs is a v_readlane away instead of a dependent global load.
-struct ByteWindow {
+// 256-byte input window held across the wave (lane l = dword l), next window prefetched, drained through a 64-bit
+// scalar queue: a renormalisation byte is two scalar instructions away.
+struct ByteQueue {
     const uint32_t *pw;       // dword-aligned base (payload start rounded down)
-    uint32_t a;               // payload start - aligned base (0..3)
     int64_t gbase;            // byte offset of pw inside the whole input buffer
     int64_t in_len;
     const uint8_t *in;
     uint32_t cur, nxt;        // my dword of the current / next window
-    uint32_t wi;              // index of the current window
+    uint32_t di;              // next dword of the stream to enter the queue
+    uint64_t buf;             // queued bytes, next one in bits 7:0
+    uint32_t nb;              // bytes in the queue
+    uint32_t taken;           // payload bytes consumed so far
     int l;
     __device__ __forceinline__ uint32_t load(uint32_t w) const
     {
         const int64_t g = gbase + ((int64_t)w * 64 + l) * 4;     // byte offset in the input buffer
-        if (g + 4 <= in_len) return pw[(size_t)w * 64 + l];
+        if (g >= 0 && g + 4 <= in_len) return pw[(size_t)w * 64 + l];
         uint32_t v = 0;
         for (int k = 0; k < 4; k++)
-            if (g + k < in_len) v |= (uint32_t)in[g + k] << (8 * k);
+            if (g + k >= 0 && g + k < in_len) v |= (uint32_t)in[g + k] << (8 * k);
         return v;
+    }
+    __device__ __forceinline__ void refill()
+    {
+        if ((di & 63u) == 0u && di != 0u) { cur = nxt; nxt = load((di >> 6) + 1u); }      // uniform
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(di & 63u));
+        buf |= (uint64_t)d << (8u * nb);
+        nb += 4u;
+        di++;
     }
     __device__ __forceinline__ void init(const uint8_t *input, int64_t input_len, const uint8_t *p, int lane)
     {
         in = input; in_len = input_len; l = lane;
-        a = (uint32_t)((uintptr_t)p & 3u);
+        const uint32_t a = (uint32_t)((uintptr_t)p & 3u);
         pw = reinterpret_cast<const uint32_t *>(p - a);
         gbase = (p - a) - input;
-        wi = 0;
         cur = load(0);
         nxt = load(1);
+        di = 0; buf = 0; nb = 0; taken = 0;
+        refill();
+        buf >>= 8u * a;
+        nb -= a;
+        refill();
     }
-    // byte at payload offset ptr (uniform); windows only move forward
-    __device__ __forceinline__ uint32_t get(uint32_t ptr)
+    __device__ __forceinline__ void top_up() { if (__builtin_expect(nb < 4u, 0)) refill(); }      // leaves nb >= 4
+    __device__ __forceinline__ uint32_t take()
     {
-        const uint32_t o = ptr + a;
-        if ((o >> 8) != wi) {             // uniform
-            wi++;
-            cur = nxt;
-            nxt = load(wi + 1);
-        }
-        const uint32_t d = __builtin_amdgcn_readlane(cur, (o & 255u) >> 2);
-        return (d >> ((o & 3u) * 8u)) & 0xffu;
+        const uint32_t b = (uint32_t)buf & 0xffu;
+        buf >>= 8;
+        nb--;
+        taken++;
+        return b;
     }
 };
+
+__device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j <- lane j-1 inside a row of 16, lane 0 of a row <- 0
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+}
+
+#define JPK_ICMP_ULT 36     // llvm::CmpInst::ICMP_ULT
+
+#define JPK_RENORM(X)                                             \
+    if (__builtin_expect((X) < RANS_L, 0)) {                      \
+        (X) = ((X) << 8) | bq.take();                             \
+        if ((X) < RANS_L) (X) = ((X) << 8) | bq.take();           \
+    }
+
+// one RLE0 symbol: exponent from state RA, mantissa from state RB (the states rotate, ans.cpp:50-86)
+#define JPK_DEC_SYMBOL(RA, RB)                                                                            \
+    {                                                                                                     \
+        bq.top_up();                                                                                      \
+        uint32_t range = (RA) & 0xffffu, xs = (RA) >> 16;                                                 \
+        uint32_t x, e, sym;                                                                               \
+        {                                                                                                 \
+            const uint32_t cand = __umul24(efr, xs) + (range - elo);                                      \
+            e = (uint32_t)__builtin_ctz((uint32_t)__builtin_amdgcn_uicmp(range, ehi, JPK_ICMP_ULT));      \
+            x = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)e);                                   \
+            /* AdaptiveModel update (model.cpp:60-77): entry i = j + 1 lives in lane j */                 \
+            const int32_t mix = ((uint32_t)l < e) ? emix_lo : emix_hi;                                    \
+            ehi = (uint32_t)((int32_t)ehi + ((mix - (int32_t)ehi) >> 5));                                 \
+            elo = dpp_row_shr1_zero(ehi);                                                                 \
+            efr = ehi - elo;                                                                              \
+        }                                                                                                 \
+        JPK_RENORM(x)                                                                                     \
+        (RA) = x;                                                                                         \
+        range = (RB) & 0xffffu; xs = (RB) >> 16;                                                          \
+        /* countdowns: lane e - 2 for a register class, lane 8 for the output tile */                         \
+        rem -= (cls_of_lane == e) ? 1u : tile_dec;                                                        \
+        const bool event = __builtin_amdgcn_uicmp(rem, 0u, 32 /* ICMP_EQ */) != 0;                        \
+        if (e < 2u) {                                                                                     \
+            const int32_t a = (e == 0u) ? a0 : a1;                                                        \
+            const uint32_t m = (range >= (uint32_t)a) ? 1u : 0u;                                          \
+            const uint32_t lo = m ? (uint32_t)a : 0u;                                                     \
+            const uint32_t hi = m ? 65536u : (uint32_t)a;                                                 \
+            const int32_t na = adapt_step(a, 1, (int)m, 2);                                               \
+            a0 = (e == 0u) ? na : a0;                                                                     \
+            a1 = (e == 0u) ? a1 : na;                                                                     \
+            x = (hi - lo) * xs + range - lo;                                                              \
+            sym = 2u * e + m;                                                                             \
+        } else if (e < 6u) {                                                                              \
+            const uint32_t cand = __umul24(qfr, xs) + (range - qlo);                                      \
+            const uint64_t cls = ((1ull << (1u << e)) - 1ull) << (1u << e);       /* lanes [2^e, 2^(e+1)) */ \
+            sym = (uint32_t)__builtin_ctzll(__builtin_amdgcn_uicmp(range, qhi, JPK_ICMP_ULT) & cls);      \
+            x = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)sym);                                 \
+            qf += ((uint32_t)l == sym) ? 16u : 0u;                                                        \
+        } else {                                                                                          \
+            const int k = (int)e - 6, A = (e == 7u) ? 129 : 64;                                           \
+            const uint32_t c1 = q.cdf[k][l + 1];                                          /* entries 1..64 */  \
+            uint32_t m = (uint32_t)__popcll(__ballot((l + 1 < A) && c1 <= range));                        \
+            if (A > 65) {                                                                                 \
+                const uint32_t c2 = q.cdf[k][l + 65];                                     /* entries 65..128 */ \
+                m += (uint32_t)__popcll(__ballot((l + 65 < A) && c2 <= range));                           \
+            }                                                                                             \
+            const uint32_t lo = q.cdf[k][m], hi = q.cdf[k][m + 1];                                        \
+            const uint32_t seen = q.seen[k] + 1, expn = q.expn[k];                                        \
+            if (l == 0) { q.f[k][m] += 16u; q.seen[k] = seen; }                                           \
+            if (seen > expn) { __syncthreads(); quasi_rebuild(q, k, A, l); __syncthreads(); }             \
+            x = (hi - lo) * xs + range - lo;                                                              \
+            sym = (1u << e) + m;                                                                          \
+        }                                                                                                 \
+        JPK_RENORM(x)                                                                                     \
+        (RB) = x;                                                                                         \
+        mysym = ((t & 63u) == (uint32_t)l) ? sym : mysym;                                                 \
+        t++;                                                                                              \
+        if (__builtin_expect(event, 0)) {                                                                 \
+            if (__builtin_amdgcn_readlane((int)rem, 8) == 0) {          /* 64 symbols collected */        \
+                out[t - 64 + l] = (uint16_t)mysym;                                                        \
+                rem = (l == 8) ? 64u : rem;                                                               \
+            }                                                                                             \
+            const uint32_t kl = e - 2u;                                                                   \
+            if (kl < 4u && __builtin_amdgcn_readlane((int)rem, (int)(kl & 3u)) == 0) {                    \
+                /* QuasiModel rebuild (model.cpp:160-204) of class e in its lanes [2^e, 2^(e+1)) */       \
+                const uint32_t A = 1u << e;                                                               \
+                const bool mine = ((uint32_t)l >> e) == 1u;                                               \
+                uint32_t F = mine ? qf : 0u;                                                              \
+                const uint32_t tot = wave_sum(F);                                                         \
+                int lg = 0;                                                                               \
+                while ((tot >> lg) + A > 65536u) lg++;                                                    \
+                F = mine ? (F >> lg) + 1u : 0u;                                                           \
+                const uint32_t t2 = wave_sum(F);                                                          \
+                F = (65536u * F) / t2;                                                                    \
+                const uint32_t t3 = wave_sum(F);                                                          \
+                if ((uint32_t)l == A) F += 65536u - t3;                 /* first symbol of the class */   \
+                const uint32_t inc = wave_incl_sum(F);                                                    \
+                qhi = mine ? inc : qhi; qlo = mine ? inc - F : qlo; qfr = mine ? F : qfr; qf = mine ? 0u : qf; \
+                const uint32_t ex0 = (uint32_t)__builtin_amdgcn_readlane((int)qexpn, (int)kl);            \
+                const uint32_t ex1 = (ex0 < 65536u) ? ex0 << 1 : 65536u;                                  \
+                qexpn = ((uint32_t)l == kl) ? ex1 : qexpn;                                                \
+                rem = ((uint32_t)l == kl) ? ex1 + 1u : rem;                                               \
+            }                                                                                             \
+        }                                                                                                 \
+    }
 
 __global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in, int64_t in_len, const ChunkInfo *__restrict__ info,
                                                 uint16_t *__restrict__ rle, uint32_t *__restrict__ status)
@@ -161,89 +288,60 @@ __global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in,
     const uint32_t clen = ci.clen, rlen = ci.rlen;
     uint16_t *out = rle + ci.rle_off;
 
-    for (int k = 0; k < 6; k++) {
-        const int A = class_alpha(k + 2);
+    for (int k = 0; k < 2; k++) {
+        const int A = k ? 129 : 64;
         for (int i = l; i < QSTRIDE; i += 64) { q.cdf[k][i] = (i <= A) ? uniform_cdf(A, i) : 65536u; q.f[k][i] = 0; }
         if (l == 0) { q.seen[k] = 0; q.expn[k] = 8; }
     }
     __syncthreads();
-    ByteWindow bw;
-    bw.init(in, in_len, p, l);
-    // exponent model: lane i holds cdf[i] (i <= 8); other lanes hold 65536 so they never count
-    int32_t ex = (l <= 8) ? (int32_t)uniform_cdf(8, l) : 65536;
+    ByteQueue bq;
+    bq.init(in, in_len, p, l);
+    // exponent model (alphabet 8): lane j holds LO = cdf[j], HI = cdf[j+1]; lanes >= 7 keep HI = 65536
+    uint32_t elo = (l < 8) ? uniform_cdf(8, l) : 65536u;
+    uint32_t ehi = (l < 8) ? uniform_cdf(8, l + 1) : 65536u;
+    uint32_t efr = ehi - elo;
+    // mix targets of entry i = l + 1 (model.cpp:60-77): i when i <= symbol, i + 65536 - 8 otherwise; fixed lanes aim at 65536
+    const int32_t emix_lo = (l < 7) ? l + 1 : 65536;
+    const int32_t emix_hi = (l < 7) ? l + 1 + 65536 - 8 : 65536;
     int32_t a0 = 32768, a1 = 32768;          // cdf[1] of the two alphabet-2 mantissa models
+    // classes 2..5: symbol s = lane s (4 <= s < 64), class e = floor(log2 s), index inside the class s - 2^e
+    uint32_t qlo, qhi, qfr, qf = 0;
+    {
+        const int e = (l >= 4) ? 31 - __clz(l) : 2, A = 1 << e, i = l - A;
+        qlo = (l >= 4) ? uniform_cdf(A, i) : 65536u;
+        qhi = (l >= 4) ? uniform_cdf(A, i + 1) : 65536u;
+        qfr = qhi - qlo;
+    }
+    uint32_t qexpn = 8;                                          // lane k: EXP of class k + 2 (model.cpp:160-204)
+    uint32_t rem = (l < 4) ? 9u : (l == 8 ? 64u : 0x40000000u);  // lane k: symbols until the rebuild of class k + 2; lane 8: until the tile store
+    const uint32_t tile_dec = (l == 8) ? 1u : 0u;
+    const uint32_t cls_of_lane = (l < 4) ? (uint32_t)l + 2u : 99u;   // lane k counts down for class k + 2
     uint32_t R0, R1, R2, R3;
     {
         uint32_t b[16];
-        for (int k = 0; k < 16; k++) b[k] = bw.get(k);
+        for (int k = 0; k < 16; k++) { bq.top_up(); b[k] = bq.take(); }
         R0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
         R1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
         R2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
         R3 = b[12] | (b[13] << 8) | (b[14] << 16) | (b[15] << 24);
     }
-    uint32_t ptr = 16;
-    bool bad = false;
     uint32_t mysym = 0;
-    for (uint32_t t = 0; t < rlen; t++) {
-        // ---- exponent ----
-        uint32_t x = R0;
-        uint32_t range = x & 0xffffu;
-        const int e = __popcll(__ballot(l >= 1 && l <= 7 && (uint32_t)ex <= range));
-        uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(ex, e);
-        uint32_t hi = (uint32_t)__builtin_amdgcn_readlane(ex, e + 1);
-        if (l >= 1 && l <= 7) ex = adapt_step(ex, l, e, 8);
-        x = (hi - lo) * (x >> 16) + range - lo;
-        while (x < RANS_L) {
-            if (ptr >= clen) { bad = true; break; }
-            x = (x << 8) | bw.get(ptr);
-            ptr++;
-        }
-        R0 = R1; R1 = R2; R2 = R3; R3 = x;
-        // ---- mantissa ----
-        x = R0;
-        range = x & 0xffffu;
-        uint32_t m;
-        if (e < 2) {
-            const int32_t a = (e == 0) ? a0 : a1;
-            m = (range >= (uint32_t)a) ? 1u : 0u;
-            lo = m ? (uint32_t)a : 0u;
-            hi = m ? 65536u : (uint32_t)a;
-            const int32_t na = adapt_step(a, 1, (int)m, 2);
-            if (e == 0) a0 = na; else a1 = na;
-        } else {
-            const int k = e - 2, A = class_alpha(e);
-            const uint32_t c1 = q.cdf[k][l + 1];                                   // entries 1..64
-            m = (uint32_t)__popcll(__ballot((l + 1 < A) && c1 <= range));
-            if (A > 65) {                                                         // class 7 only: entries 65..128
-                const uint32_t c2 = q.cdf[k][l + 65];
-                m += (uint32_t)__popcll(__ballot((l + 65 < A) && c2 <= range));
-            }
-            lo = q.cdf[k][m];
-            hi = q.cdf[k][m + 1];
-            // QuasiModel::Update (model.cpp:160-204); a single wave: LDS operations complete in program order
-            const uint32_t seen = q.seen[k] + 1, expn = q.expn[k];
-            if (l == 0) { q.f[k][m] += 16u; q.seen[k] = seen; }
-            if (seen > expn) { __syncthreads(); quasi_rebuild(q, k, A, l); __syncthreads(); }
-        }
-        x = (hi - lo) * (x >> 16) + range - lo;
-        while (x < RANS_L) {
-            if (ptr >= clen) { bad = true; break; }
-            x = (x << 8) | bw.get(ptr);
-            ptr++;
-        }
-        R0 = R1; R1 = R2; R2 = R3; R3 = x;
-        if (bad) break;
-        const uint32_t sym = (uint32_t)class_base(e) + m;
-        if ((t & 63u) == (uint32_t)l) mysym = sym;
-        if ((t & 63u) == 63u) out[t - 63 + l] = (uint16_t)mysym;
+    uint32_t t = 0;
+    while (t + 2 <= rlen) {
+        JPK_DEC_SYMBOL(R0, R1)
+        JPK_DEC_SYMBOL(R2, R3)
     }
-    if (!bad && (rlen & 63u)) {
+    if (t < rlen) JPK_DEC_SYMBOL(R0, R1)
+    if (rlen & 63u) {
         const uint32_t base = rlen & ~63u;
         if (base + l < rlen) out[base + l] = (uint16_t)mysym;
     }
-    if (R0 != RANS_L || R1 != RANS_L || R2 != RANS_L || R3 != RANS_L) bad = true;     // ans.cpp:91-92
+    // ans.cpp:91-92 (all four states back at the lower bound) and no byte taken from beyond the chunk's payload
+    const bool bad = (R0 != RANS_L || R1 != RANS_L || R2 != RANS_L || R3 != RANS_L) || bq.taken > clen;
     if (bad && l == 0) atomicOr(status, 1u);
 }
+#undef JPK_DEC_SYMBOL
+#undef JPK_RENORM
 
 // ---------------------------------------------------------------------------------------------------------------
 // RLE0 decode: one workgroup per chunk.  Output is pre-zeroed, so only symbols > 1 are written; a digit group

@@ -694,7 +694,7 @@ __device__ __forceinline__ uint4 rans_record(uint32_t lo, uint32_t fr)
     } else {
         rcp = 0xFFFFFFFFu; shift = 0; bias = lo + 65535u;
     }
-    return make_uint4(fr << 15, rcp, bias, (65536u - fr) | (shift << 20));
+    return make_uint4(fr << 15, rcp, bias, (65536u - fr) | (shift << 24));
 }
 
 __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
@@ -745,18 +745,35 @@ __device__ __forceinline__ uint32_t sel_ge(uint32_t a, uint32_t b, uint32_t t, u
     return r;
 }
 
-// one encoder step (branch-free); returns the new state, e = emitted bytes | count << 16
-__device__ __forceinline__ uint32_t rans_step(uint32_t x, const uint4 r, uint32_t &e)
+// One encoder step (branch-free); returns the new state.  Cost on one wave: the 32-bit multiplies are quarter
+// rate (16 cycles per wave64 instruction against 4 for everything else), so the step keeps exactly one of them
+// (the reciprocal) and does the second product with the full-rate 24-bit multiply: after renormalisation
+// xr < freq << 15, so q = xr / freq < 2^15 and 65536 - freq < 2^16.  The bytes a step emits are NOT formed here:
+// the pre-renormalisation state goes to LDS and all 64 lanes rebuild the emit words per tile (emit_word).
+__device__ __forceinline__ uint32_t rans_step(uint32_t x, const uint4 r)
 {
     const uint32_t xmax = r.x;                // ((RANS_L >> 16) << 8) * freq
+    // b1 = x >= xmax: one byte leaves; b2 = (x >> 8) >= xmax: two leave (implies b1).  Both compares hang off x
+    // directly, so the dependent chain is  x>>8 -> cmp -> cndmask -> mul_hi -> shift -> mul24 -> add  (7 deep).
     const uint32_t x8 = x >> 8, x16 = x >> 16;
-    // b1 = x >= xmax (one byte leaves), b2 = x8 >= xmax (two bytes leave; implies b1)
-    const uint32_t t1 = sel_ge(x, xmax, x8, x);
-    const uint32_t xr = sel_ge(x8, xmax, x16, t1);
-    const uint32_t e1 = sel_ge(x, xmax, (x & 0xffu) | (1u << 16), 0u);
-    e = sel_ge(x8, xmax, (x & 0xffffu) | (2u << 16), e1);
-    const uint32_t q = __umulhi(xr, r.y) >> (r.w >> 20);
-    return xr + r.z + q * (r.w & 0xFFFFFu);   // == ((xr / freq) << 16) + xr % freq + low
+    uint64_t b1, b2;
+    uint32_t t1, xr;
+    asm("v_cmp_ge_u32_e64 %0, %1, %2" : "=s"(b1) : "v"(x), "v"(xmax));
+    asm("v_cmp_ge_u32_e64 %0, %1, %2" : "=s"(b2) : "v"(x8), "v"(xmax));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(t1) : "v"(x), "v"(x8), "s"(b1));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(xr) : "v"(t1), "v"(x16), "s"(b2));
+    const uint32_t q = __umulhi(xr, r.y) >> (r.w >> 24);
+    const uint32_t t = xr + r.z;              // off the chain: runs beside the reciprocal multiply
+    uint32_t xn;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(xn) : "v"(q), "v"(r.w), "v"(t));    // mul24 ignores the shift byte of r.w
+    return xn;                                // == ((xr / freq) << 16) + xr % freq + low
+}
+
+// emitted bytes | count << 16 of the step that started from state x with threshold xmax
+__device__ __forceinline__ uint32_t emit_word(uint32_t x, uint32_t xmax)
+{
+    const bool b1 = x >= xmax, b2 = (x >> 8) >= xmax;
+    return b2 ? ((x & 0xffffu) | (2u << 16)) : (b1 ? ((x & 0xffu) | (1u << 16)) : 0u);
 }
 
 // One wave per chunk.  Lanes 0..3 run the four state chains (pair j -> lane j & 3), last record first.  All 64
@@ -816,18 +833,32 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
             uint32_t *eb = &ebuf[t][0];
             for (; k >= 3; k -= 4) {
                 const uint4 r0 = rb[k], r1 = rb[k - 1], r2 = rb[k - 2], r3 = rb[k - 3];
-                uint32_t e0, e1, e2, e3;
-                x = rans_step(x, r0, e0);
-                x = rans_step(x, r1, e1);
-                x = rans_step(x, r2, e2);
-                x = rans_step(x, r3, e3);
-                eb[k] = e0; eb[k - 1] = e1; eb[k - 2] = e2; eb[k - 3] = e3;
+                const uint32_t x0 = x;
+                const uint32_t x1 = rans_step(x0, r0);
+                const uint32_t x2 = rans_step(x1, r1);
+                const uint32_t x3 = rans_step(x2, r2);
+                x = rans_step(x3, r3);
+                eb[k] = x0; eb[k - 1] = x1; eb[k - 2] = x2; eb[k - 3] = x3;
             }
             for (; k >= 0; k--) {
                 const uint4 r0 = rb[k];
-                uint32_t e0;
-                x = rans_step(x, r0, e0);
-                eb[k] = e0;
+                eb[k] = x;
+                x = rans_step(x, r0);
+            }
+        }
+        __syncthreads();
+        uint32_t cn[8];
+        uint32_t sum = 0;
+        const uint32_t jb = (uint32_t)tt * (4 * RANS_TILE) + (uint32_t)t * 8;
+        {   // all 64 lanes: lane t owns the 8 consecutive pairs 8t..8t+7 of this tile (pair j = 4k + chain); it turns
+            // the recorded states into emit words in place
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int jl = t * 8 + i;
+                const uint32_t e = (jb + i < np) ? emit_word(ebuf[jl & 3][jl >> 2], rbuf[buf][jl & 3][jl >> 2].x) : 0u;
+                ebuf[jl & 3][jl >> 2] = e;
+                cn[i] = e >> 16;
+                sum += cn[i];
             }
         }
         __syncthreads();
@@ -836,16 +867,11 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
             uint4 *ed = dst + tt * (RANS_TILE / 4);
             ed[0] = es[0]; ed[1] = es[1];
         }
-        {   // bytes from the start of pair j's output to the end of the stream (pair order j = 4k + lane), all 64 lanes:
-            // lane t owns the 8 consecutive pairs 8t..8t+7 of this tile; inclusive suffix sums, higher tiles in `carry`
-            uint32_t cn[8];
-            uint32_t sum = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) { const int jl = t * 8 + i; cn[i] = ebuf[jl & 3][jl >> 2] >> 16; sum += cn[i]; }
+        {   // bytes from the start of pair j's output to the end of the stream (pair order), inclusive suffix sums,
+            // higher tiles in `carry`
             uint32_t inc = wave_incl_sum(sum);                       // prefix over lanes <= t
             const uint32_t tile_total = __shfl(inc, 63, 64);
             uint32_t run = carry + (tile_total - inc);               // bytes of the pairs owned by lanes > t (and higher tiles)
-            const uint32_t jb = (uint32_t)tt * (4 * RANS_TILE) + (uint32_t)t * 8;
 #pragma unroll
             for (int i = 7; i >= 0; i--) {
                 run += cn[i];
