@@ -184,67 +184,76 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
 
 #define JPK_ICMP_ULT 36     // llvm::CmpInst::ICMP_ULT
 
+// refills inside the rare path keep >= 4 bytes queued, so the common path never looks at the queue
 #define JPK_RENORM(X)                                             \
     if (__builtin_expect((X) < RANS_L, 0)) {                      \
         (X) = ((X) << 8) | bq.take();                             \
         if ((X) < RANS_L) (X) = ((X) << 8) | bq.take();           \
+        bq.top_up();                                              \
     }
 
-// one RLE0 symbol: exponent from state RA, mantissa from state RB (the states rotate, ans.cpp:50-86)
+// one RLE0 symbol: exponent from state RA, mantissa from state RB (the states rotate, ans.cpp:50-86).
+// Instruction order matters on a single wave: the vector work that does not need the exponent (the mantissa
+// compare and candidates) and the model updates sit where the scalar unit would otherwise wait for a mask or a
+// v_readlane result; sched_barrier keeps the compiler from undoing that.
 #define JPK_DEC_SYMBOL(RA, RB)                                                                            \
     {                                                                                                     \
-        bq.top_up();                                                                                      \
-        uint32_t range = (RA) & 0xffffu, xs = (RA) >> 16;                                                 \
-        uint32_t x, e, sym;                                                                               \
-        {                                                                                                 \
-            const uint32_t cand = __umul24(efr, xs) + (range - elo);                                      \
-            e = (uint32_t)__builtin_ctz((uint32_t)__builtin_amdgcn_uicmp(range, ehi, JPK_ICMP_ULT));      \
-            x = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)e);                                   \
-            /* AdaptiveModel update (model.cpp:60-77): entry i = j + 1 lives in lane j */                 \
+        const uint32_t range = (RA) & 0xffffu, xs = (RA) >> 16;                                           \
+        const uint32_t range2 = (RB) & 0xffffu, xs2 = (RB) >> 16;                                         \
+        const uint64_t eabove = __builtin_amdgcn_uicmp(range, ehi, JPK_ICMP_ULT);                         \
+        const uint32_t ecand = __umul24(efr, xs) + (range - elo);                                         \
+        const uint64_t qabove = __builtin_amdgcn_uicmp(range2, qhi, JPK_ICMP_ULT);                        \
+        const uint32_t qcand = __umul24(qfr, xs2) + (range2 - qlo);                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        const uint32_t e = (uint32_t)__builtin_ctz((uint32_t)eabove);                                     \
+        uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)ecand, (int)e);                             \
+        /* symbol s = lane s; class e owns the lanes whose class is e.  For e >= 6 no lane matches: the guard bit      \
+           sends the (discarded) result to lane 0, whose count is never used, and the LDS block below takes over */    \
+        const bool mine = lane_cls == e;                                                                  \
+        const uint64_t minemask = __ballot(mine);                                                         \
+        {   /* AdaptiveModel update (model.cpp:60-77): entry i = j + 1 lives in lane j */                 \
             const int32_t mix = ((uint32_t)l < e) ? emix_lo : emix_hi;                                    \
             ehi = (uint32_t)((int32_t)ehi + ((mix - (int32_t)ehi) >> 5));                                 \
             elo = dpp_row_shr1_zero(ehi);                                                                 \
             efr = ehi - elo;                                                                              \
         }                                                                                                 \
-        JPK_RENORM(x)                                                                                     \
-        (RA) = x;                                                                                         \
-        range = (RB) & 0xffffu; xs = (RB) >> 16;                                                          \
-        /* countdowns: lane e - 2 for a register class, lane 8 for the output tile */                         \
+        /* countdowns: lane e - 2 for a register class, lane 8 for the output tile */                     \
         rem -= (cls_of_lane == e) ? 1u : tile_dec;                                                        \
         const bool event = __builtin_amdgcn_uicmp(rem, 0u, 32 /* ICMP_EQ */) != 0;                        \
-        if (e < 2u) {                                                                                     \
-            const int32_t a = (e == 0u) ? a0 : a1;                                                        \
-            const uint32_t m = (range >= (uint32_t)a) ? 1u : 0u;                                          \
-            const uint32_t lo = m ? (uint32_t)a : 0u;                                                     \
-            const uint32_t hi = m ? 65536u : (uint32_t)a;                                                 \
-            const int32_t na = adapt_step(a, 1, (int)m, 2);                                               \
-            a0 = (e == 0u) ? na : a0;                                                                     \
-            a1 = (e == 0u) ? a1 : na;                                                                     \
-            x = (hi - lo) * xs + range - lo;                                                              \
-            sym = 2u * e + m;                                                                             \
-        } else if (e < 6u) {                                                                              \
-            const uint32_t cand = __umul24(qfr, xs) + (range - qlo);                                      \
-            const uint64_t cls = ((1ull << (1u << e)) - 1ull) << (1u << e);       /* lanes [2^e, 2^(e+1)) */ \
-            sym = (uint32_t)__builtin_ctzll(__builtin_amdgcn_uicmp(range, qhi, JPK_ICMP_ULT) & cls);      \
-            x = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)sym);                                 \
-            qf += ((uint32_t)l == sym) ? 16u : 0u;                                                        \
-        } else {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        uint32_t sym = (uint32_t)__builtin_ctzll((qabove & minemask) | (uint64_t)((e + 2u) >> 3));        \
+        uint32_t x2 = (uint32_t)__builtin_amdgcn_readlane((int)qcand, (int)sym);                          \
+        JPK_RENORM(x)                                                                                     \
+        (RA) = x;                                                                                         \
+        {                                                                                                 \
+            qf += ((uint32_t)l == sym) ? 16u : 0u;                                         /* QuasiModel count */ \
+            /* AdaptiveModel update of the alphabet-2 pair (lanes 2e, 2e+1) when e < 2: both lanes carry a = cdf[1] */ \
+            const int32_t tgt = (sym & 1u) ? 1 : 65535;                                                   \
+            const int32_t d = mine ? (tgt - (int32_t)qa) >> 5 : 0;                                        \
+            qa += (uint32_t)d;                                                                            \
+            qhi = (uint32_t)(__mul24(d, even_lane) + (int32_t)qhi);                                       \
+            qlo = (uint32_t)(__mul24(d, odd_lane) + (int32_t)qlo);                                        \
+            qfr = (uint32_t)(__mul24(d, sign_lane) + (int32_t)qfr);                                       \
+        }                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        const uint32_t range_m = range2, xs_m = xs2;                                                      \
+        if (__builtin_expect(e >= 6u, 0)) {                                                               \
             const int k = (int)e - 6, A = (e == 7u) ? 129 : 64;                                           \
             const uint32_t c1 = q.cdf[k][l + 1];                                          /* entries 1..64 */  \
-            uint32_t m = (uint32_t)__popcll(__ballot((l + 1 < A) && c1 <= range));                        \
+            uint32_t m = (uint32_t)__popcll(__ballot((l + 1 < A) && c1 <= range_m));                      \
             if (A > 65) {                                                                                 \
                 const uint32_t c2 = q.cdf[k][l + 65];                                     /* entries 65..128 */ \
-                m += (uint32_t)__popcll(__ballot((l + 65 < A) && c2 <= range));                           \
+                m += (uint32_t)__popcll(__ballot((l + 65 < A) && c2 <= range_m));                         \
             }                                                                                             \
             const uint32_t lo = q.cdf[k][m], hi = q.cdf[k][m + 1];                                        \
             const uint32_t seen = q.seen[k] + 1, expn = q.expn[k];                                        \
             if (l == 0) { q.f[k][m] += 16u; q.seen[k] = seen; }                                           \
             if (seen > expn) { __syncthreads(); quasi_rebuild(q, k, A, l); __syncthreads(); }             \
-            x = (hi - lo) * xs + range - lo;                                                              \
+            x2 = (hi - lo) * xs_m + range_m - lo;                                                         \
             sym = (1u << e) + m;                                                                          \
         }                                                                                                 \
-        JPK_RENORM(x)                                                                                     \
-        (RB) = x;                                                                                         \
+        JPK_RENORM(x2)                                                                                    \
+        (RB) = x2;                                                                                        \
         mysym = ((t & 63u) == (uint32_t)l) ? sym : mysym;                                                 \
         t++;                                                                                              \
         if (__builtin_expect(event, 0)) {                                                                 \
@@ -268,7 +277,7 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
                 if ((uint32_t)l == A) F += 65536u - t3;                 /* first symbol of the class */   \
                 const uint32_t inc = wave_incl_sum(F);                                                    \
                 qhi = mine ? inc : qhi; qlo = mine ? inc - F : qlo; qfr = mine ? F : qfr; qf = mine ? 0u : qf; \
-                const uint32_t ex0 = (uint32_t)__builtin_amdgcn_readlane((int)qexpn, (int)kl);            \
+                const uint32_t ex0 = (uint32_t)__builtin_amdgcn_readlane((int)qexpn, (int)(kl & 3u));     \
                 const uint32_t ex1 = (ex0 < 65536u) ? ex0 << 1 : 65536u;                                  \
                 qexpn = ((uint32_t)l == kl) ? ex1 : qexpn;                                                \
                 rem = ((uint32_t)l == kl) ? ex1 + 1u : rem;                                               \
@@ -303,13 +312,17 @@ __global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in,
     // mix targets of entry i = l + 1 (model.cpp:60-77): i when i <= symbol, i + 65536 - 8 otherwise; fixed lanes aim at 65536
     const int32_t emix_lo = (l < 7) ? l + 1 : 65536;
     const int32_t emix_hi = (l < 7) ? l + 1 + 65536 - 8 : 65536;
-    int32_t a0 = 32768, a1 = 32768;          // cdf[1] of the two alphabet-2 mantissa models
-    // classes 2..5: symbol s = lane s (4 <= s < 64), class e = floor(log2 s), index inside the class s - 2^e
+    // mantissa models of classes 0..5: symbol s = lane s.  Lanes 0..3 hold the two alphabet-2 AdaptiveModels (class 0 =
+    // symbols 0,1; class 1 = symbols 2,3; cdf[1] = 32768), lanes 4..63 the QuasiModels of classes 2..5 (uniform start).
     uint32_t qlo, qhi, qfr, qf = 0;
+    const uint32_t lane_cls = (l < 2) ? 0u : (uint32_t)(31 - __clz(l));
+    const int32_t even_lane = (l < 4 && !(l & 1)) ? 1 : 0, odd_lane = (l < 4 && (l & 1)) ? 1 : 0;
+    const int32_t sign_lane = even_lane - odd_lane;
+    uint32_t qa = (l < 4) ? 32768u : 0u;                          // lanes 0..3: cdf[1] of the pair's AdaptiveModel
     {
-        const int e = (l >= 4) ? 31 - __clz(l) : 2, A = 1 << e, i = l - A;
-        qlo = (l >= 4) ? uniform_cdf(A, i) : 65536u;
-        qhi = (l >= 4) ? uniform_cdf(A, i + 1) : 65536u;
+        const int A = (l < 4) ? 2 : 1 << lane_cls, i = (l < 4) ? (l & 1) : l - A;
+        qlo = uniform_cdf(A, i);
+        qhi = uniform_cdf(A, i + 1);
         qfr = qhi - qlo;
     }
     uint32_t qexpn = 8;                                          // lane k: EXP of class k + 2 (model.cpp:160-204)
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in,
     uint32_t R0, R1, R2, R3;
     {
         uint32_t b[16];
-        for (int k = 0; k < 16; k++) { bq.top_up(); b[k] = bq.take(); }
+        for (int k = 0; k < 16; k++) { b[k] = bq.take(); bq.top_up(); }
         R0 = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
         R1 = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
         R2 = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
