@@ -421,14 +421,47 @@ __device__ __forceinline__ uint32_t wave_shl1(uint32_t v)        // lane i <- la
 
 __device__ __forceinline__ uint32_t list_shift_insert(uint32_t v, int l, uint32_t r, uint32_t sym)
 {
-    // positions < r take the value of position+1, position r takes sym, positions > r unchanged
+    // positions < r take the value of position+1, position r takes sym, positions > r unchanged.  Branch-free:
+    // keep = bytes of this lane at or above position r (two half shifts, so that 4 bytes below r give 0).
     const uint32_t nextv = wave_shl1(v);
-    const uint32_t shifted = (v >> 8) | (nextv << 24);
-    const int nb = (int)r - 4 * l;                      // bytes of this lane below position r
-    uint32_t mask = nb <= 0 ? 0u : (nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u));
-    uint32_t res = (shifted & mask) | (v & ~mask);
-    if (nb >= 0 && nb < 4) res = (res & ~(0xFFu << (8 * nb))) | (sym << (8 * nb));
-    return res;
+    const uint32_t shifted = __builtin_amdgcn_alignbyte(nextv, v, 1);      // (v >> 8) | (nextv << 24)
+    const int nb = (int)r - 4 * l;                                          // bytes of this lane below position r
+    const uint32_t h = 4u * (uint32_t)(nb < 0 ? 0 : (nb > 4 ? 4 : nb));
+    const uint32_t keep = (0xFFFFFFFFu << h) << h;
+    uint32_t res = (v & keep) | (shifted & ~keep);
+    const uint32_t ins = ((uint32_t)nb < 4u) ? 0xFFu << (8u * ((uint32_t)nb & 3u)) : 0u;
+    return (res & ~ins) | ((sym * 0x01010101u) & ins);
+}
+
+// Every symbol keeps the next 64 ranks of its bucket in an LDS row, one rank per dword (row[0] = the rank its next
+// occurrence reads), so the serial chain never waits for HBM: a run costs one LDS round trip, one ballot and one list
+// update.  Rows are consumed by shifting; a row that runs low is topped up by a direct-to-LDS load
+// (global_load_lds_ubyte: lane j's byte lands zero-extended in dword j behind the M0 base, no VGPR and therefore no
+// compiler-inserted wait).  Entries past the end of a bucket are 0xFF (non-zero: they end the zero run).
+//
+// The loop has a fast path for the common iteration -- a non-zero rank found inside the safe part of the row -- that
+// touches one counter of the row's metadata; everything else (end of a bucket, empty or low rows, landing a top-up,
+// the end of the chunk) goes through the general path, which also re-normalises the metadata.
+struct RankMeta {
+    uint32_t used;      // entries consumed by fast iterations since the last normalisation
+    uint32_t fast;      // fast iterations may consume this many entries (as of the last normalisation); 0 = row blocked
+    uint32_t nv;        // known entries in the row (as of the last normalisation)
+    uint32_t left;      // ranks of the bucket not yet consumed (as of the last normalisation)
+};
+struct RankSpan {
+    uint32_t gpos;      // offset in R of the first byte not yet requested
+    uint32_t gend;      // end of the bucket in R
+};
+constexpr uint32_t RANK_LOW = 24;          // top a row up when fewer known entries remain
+
+typedef const __attribute__((address_space(1))) void *jpk_gptr;
+typedef __attribute__((address_space(3))) void *jpk_lptr;
+
+__device__ __forceinline__ uint32_t rank_fast_limit(uint32_t nv, uint32_t left, bool all_loaded)
+{
+    const uint32_t slack = all_loaded ? 64u : (nv > RANK_LOW ? nv - RANK_LOW : 0u);
+    const uint32_t a = nv < left ? nv : left;
+    return a < slack ? a : slack;
 }
 
 __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, const ChunkInfo *__restrict__ info, const int32_t *__restrict__ freq,
@@ -442,67 +475,128 @@ __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, con
     if (len == 0) return;
     const uint8_t *R = data + ci.out_off;        // rank array
     uint8_t *T = tmp + ci.out_off;               // decoded symbols (copied back by the caller)
+    __shared__ uint32_t rows[256][64];
+    __shared__ RankMeta meta[256];
+    __shared__ RankSpan span[256];
     __shared__ uint32_t sf[256];
-    __shared__ uint32_t bpos[256], bend[256];
     __shared__ uint32_t lst[64];
     const int32_t *fq = freq + (size_t)c * 256;
     for (int s = l; s < 256; s += 64) sf[s] = (uint32_t)fq[s];
-    for (int i = l; i < 64; i += 64) lst[i] = 0;
+    lst[l] = 0;
     __syncthreads();
     uint32_t uniq = 0;
     // bucket layout in GenerateSortedMap order; list[R[bucket start]] = symbol (rank.cpp:114-123)
-    for (int s = l; s < 256; s += 64) {
+    uint32_t g4[4], e4[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int s = l + 64 * k;
         const uint32_t f = sf[s];
         uint32_t b = 0;
-        for (int k = 0; k < 256; k++) { uint32_t fk = sf[k]; if (fk > f || (fk == f && k < s)) b += fk; }
-        bpos[s] = b + 1;
-        bend[s] = b + f;
+        for (int j = 0; j < 256; j++) { uint32_t fj = sf[j]; if (fj > f || (fj == f && j < s)) b += fj; }
+        RankMeta m;
+        m.used = 0; m.nv = 64; m.left = f ? f - 1 : 0;
+        m.fast = rank_fast_limit(m.nv, m.left, b + 1 + 64 >= b + f);
+        meta[s] = m;
+        RankSpan sp;
+        sp.gpos = b + 1 + 64; sp.gend = b + f;
+        span[s] = sp;
+        g4[k] = b + 1; e4[k] = b + f;
         if (f > 0) {
             const uint32_t r0 = R[b];
             atomicOr(&lst[r0 >> 2], (uint32_t)s << (8 * (r0 & 3u)));
         }
         uniq += (f > 0);
     }
-    uniq = wave_sum(uniq);
+    uniq = rfl(wave_sum(uniq));
+    // first window of every bucket (the offsets come from registers so the 256 loads pipeline)
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        for (int j = 0; j < 64; j++) {
+            const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)g4[k], j), ge = (uint32_t)__builtin_amdgcn_readlane((int)e4[k], j);
+            rows[j + 64 * k][l] = (g + l < ge) ? (uint32_t)R[g + l] : 0xFFu;
+        }
     __syncthreads();
     uint32_t v = lst[l];
     uint32_t sym = rfl(v) & 0xffu;
-    // One iteration = one run of the current symbol: the wave peeks the next 64 ranks of the symbol's bucket, z leading
-    // zero ranks mean z more copies of the symbol (rank 0 = "same symbol again"), which are written by z+1 lanes at once;
-    // the first non-zero rank (or the end of the bucket) then moves the symbol inside / out of the list.
+    uint32_t psym = 256;                                         // row with a top-up in flight (256 = none); it is blocked (fast = 0)
     uint32_t i = 0;
     while (i < len) {
-        const uint32_t bp = bpos[sym], be = bend[sym];
-        const uint32_t rl = (bp + l < be) ? (uint32_t)R[bp + l] : 0xFFu;    // lanes past the bucket end count as non-zero
+        const uint32_t rl = rows[sym][l];
+        const RankMeta m = meta[sym];
+        const uint32_t used = rfl(m.used), room = rfl(m.fast) - used;
         const uint64_t nz = __ballot(rl != 0);
         const uint32_t z = nz ? (uint32_t)__builtin_ctzll(nz) : 64u;
-        uint32_t cnt = (z < 64u) ? z + 1u : 64u;
-        if (cnt > len - i) cnt = len - i;
-        if ((uint32_t)l < cnt) T[i + l] = (uint8_t)sym;
-        i += cnt;
-        if (z >= 64u) {                                  // 64 zero ranks consumed, the same symbol goes on
-            if (l == 0) bpos[sym] = bp + 64u;
-            continue;
-        }
-        if (bp + z < be) {
-            const uint32_t r = __builtin_amdgcn_readlane(rl, z);             // the non-zero rank that ends the run
-            if (l == 0) bpos[sym] = bp + z + 1u;
+        const uint32_t rest = len - i;
+        if (__builtin_expect(z < (room < rest ? room : rest), 1)) {
+            // ---- fast path: z zero ranks, then the real non-zero rank rl[z]; z + 1 outputs ----
+            const uint32_t cnt = z + 1u;
+            if ((uint32_t)l < cnt) T[i + l] = (uint8_t)sym;
+            i += cnt;
+            const uint32_t r = __builtin_amdgcn_readlane(rl, z);
+            const uint32_t shifted = ((uint32_t)l + cnt < 64u) ? rows[sym][(l + cnt) & 63u] : 0xFFu;
+            if (l == 0) meta[sym].used = used + cnt;
+            rows[sym][l] = shifted;
             v = list_shift_insert(v, l, r, sym);
             sym = rfl(v) & 0xffu;
-        } else {
-            if (l == 0) bpos[sym] = be;
-            if (uniq > 0) {
+            continue;
+        }
+        // ---- general path ----
+        if (psym < 256u) {                                       // land the top-up in flight and unblock its row
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const RankMeta pm = meta[psym];
+            const RankSpan ps = span[psym];
+            if (l == 0) { meta[psym].nv = 64u; meta[psym].fast = rank_fast_limit(64u, pm.left, ps.gpos >= ps.gend); }
+            psym = 256u;
+            __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
+            continue;                                            // start over with the rows as they are now
+        }
+        const RankSpan sp = span[sym];
+        const uint32_t gpos = rfl(sp.gpos), gend = rfl(sp.gend);
+        const uint32_t nv = rfl(m.nv) - used, left = rfl(m.left) - used;
+        const uint32_t rlk = ((uint32_t)l < nv) ? rl : 0xFFu;                // unknown entries stop the scan
+        const uint64_t nzk = __ballot(rlk != 0);
+        const uint32_t zk = nzk ? (uint32_t)__builtin_ctzll(nzk) : 64u;
+        const bool stop = zk < nv;                                           // a known non-zero entry ended the run
+        uint32_t cnt = stop ? zk + 1u : zk;                                  // outputs = ranks consumed
+        if (cnt > rest) cnt = rest;
+        if ((uint32_t)l < cnt) T[i + l] = (uint8_t)sym;
+        i += cnt;
+        const uint32_t shifted = ((uint32_t)l + cnt < 64u) ? rows[sym][(l + cnt) & 63u] : 0xFFu;   // vacated tail: 0xFF
+        const bool all_loaded = gpos >= gend;
+        const uint32_t nv2 = all_loaded ? 64u : nv - (cnt < nv ? cnt : nv);
+        const uint32_t left2 = left - (cnt < left ? cnt : left);
+        const uint32_t cur = sym;
+        if (stop) {
+            if (zk < left) {
+                const uint32_t r = __builtin_amdgcn_readlane(rlk, zk);       // the non-zero rank that ends the run
+                v = list_shift_insert(v, l, r, sym);
+                sym = rfl(v) & 0xffu;
+            } else if (uniq > 0) {                                           // bucket exhausted: drop the front
                 uniq--;
-                // drop the front: positions < uniq shift down by one (rank.cpp:140-147; executes at least once)
-                const uint32_t lim = uniq > 0 ? uniq : 1u;
+                const uint32_t lim = uniq > 0 ? uniq : 1u;                  // rank.cpp:140-147; executes at least once
                 const uint32_t nextv = wave_shl1(v);
-                const uint32_t shifted = (v >> 8) | (nextv << 24);
+                const uint32_t sh = (v >> 8) | (nextv << 24);
                 const int nb = (int)lim - 4 * l;
                 const uint32_t mask = nb <= 0 ? 0u : (nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u));
-                v = (shifted & mask) | (v & ~mask);
+                v = (sh & mask) | (v & ~mask);
                 sym = rfl(v) & 0xffu;
             }
         }
+        rows[cur][l] = shifted;
+        RankMeta w;
+        w.used = 0; w.nv = nv2; w.left = left2;
+        if (!all_loaded && nv2 < RANK_LOW + 8u) {                            // top the row up behind the shifted entries
+            const uint32_t want = 64u - nv2;
+            __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0): the shifted row is in LDS before the load may land
+            if ((uint32_t)l < want && gpos + l < gend)
+                __builtin_amdgcn_global_load_lds((jpk_gptr)(R + gpos + l), (jpk_lptr)(&rows[cur][nv2]), 1, 0, 0);
+            psym = cur;
+            w.fast = 0;                                                      // blocked until the top-up has landed
+            if (l == 0) span[cur].gpos = gpos + want;
+        } else {
+            w.fast = rank_fast_limit(nv2, left2, all_loaded);
+        }
+        if (l == 0) meta[cur] = w;
     }
 }
 
