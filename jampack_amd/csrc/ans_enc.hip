@@ -736,15 +736,6 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
 // rANS (ans.cpp:189-208): four independent sequential chains per chunk (state lane = pair index & 3), last pair
 // first.  Each step records the 0..2 renormalisation bytes it emits; their stream positions are a prefix sum.
 // ---------------------------------------------------------------------------------------------------------------
-// (a >= b) ? t : f as v_cmp + v_cndmask.  hipcc turns the equivalent C++ selects of the renormalisation into
-// exec-mask branches (s_and_saveexec / s_xor / s_or per step), which doubles the length of the dependent chain.
-__device__ __forceinline__ uint32_t sel_ge(uint32_t a, uint32_t b, uint32_t t, uint32_t f)
-{
-    uint32_t r;
-    asm("v_cmp_ge_u32_e32 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %3, %4, vcc" : "=v"(r) : "v"(a), "v"(b), "v"(f), "v"(t) : "vcc");
-    return r;
-}
-
 // One encoder step (branch-free); returns the new state.  Cost on one wave: the 32-bit multiplies are quarter
 // rate (16 cycles per wave64 instruction against 4 for everything else), so the step keeps exactly one of them
 // (the reciprocal) and does the second product with the full-rate 24-bit multiply: after renormalisation
@@ -754,14 +745,20 @@ __device__ __forceinline__ uint32_t rans_step(uint32_t x, const uint4 r)
 {
     const uint32_t xmax = r.x;                // ((RANS_L >> 16) << 8) * freq
     // b1 = x >= xmax: one byte leaves; b2 = (x >> 8) >= xmax: two leave (implies b1).  Both compares hang off x
-    // directly, so the dependent chain is  x>>8 -> cmp -> cndmask -> mul_hi -> shift -> mul24 -> add  (7 deep).
-    const uint32_t x8 = x >> 8, x16 = x >> 16;
+    // directly, so the dependent chain is  x>>8 -> cmp -> cndmask -> mul_hi -> shift -> mad  (6 deep).  One asm block:
+    // hipcc turns the C++ selects into exec-mask branches, and gfx940+ needs two wait states between a VALU write of an
+    // SGPR mask and the VALU that reads it -- the order below provides them (the s_nop covers the second mask).
+    uint32_t xr, x8, x16;
     uint64_t b1, b2;
-    uint32_t t1, xr;
-    asm("v_cmp_ge_u32_e64 %0, %1, %2" : "=s"(b1) : "v"(x), "v"(xmax));
-    asm("v_cmp_ge_u32_e64 %0, %1, %2" : "=s"(b2) : "v"(x8), "v"(xmax));
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(t1) : "v"(x), "v"(x8), "s"(b1));
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(xr) : "v"(t1), "v"(x16), "s"(b2));
+    asm("v_lshrrev_b32 %1, 8, %5\n\t"
+        "v_cmp_ge_u32_e64 %3, %5, %6\n\t"
+        "v_lshrrev_b32 %2, 16, %5\n\t"
+        "v_cmp_ge_u32_e64 %4, %1, %6\n\t"
+        "v_cndmask_b32_e64 %0, %5, %1, %3\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32_e64 %0, %0, %2, %4"
+        : "=&v"(xr), "=&v"(x8), "=&v"(x16), "=&s"(b1), "=&s"(b2)
+        : "v"(x), "v"(xmax));
     const uint32_t q = __umulhi(xr, r.y) >> (r.w >> 24);
     const uint32_t t = xr + r.z;              // off the chain: runs beside the reciprocal multiply
     uint32_t xn;
@@ -831,15 +828,33 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
             int k = (int)((kmax - base < RANS_TILE - 1) ? kmax - base : RANS_TILE - 1);
             const uint4 *rb = &rbuf[buf][t][0];
             uint32_t *eb = &ebuf[t][0];
+            // four steps from four records; the pre-renormalisation states go to LDS
+#define JPK_STEP4(K, A0, A1, A2, A3)                                                   \
+            {                                                                           \
+                const uint32_t x0 = x;                                                  \
+                const uint32_t x1 = rans_step(x0, A0);                                  \
+                const uint32_t x2 = rans_step(x1, A1);                                  \
+                const uint32_t x3 = rans_step(x2, A2);                                  \
+                x = rans_step(x3, A3);                                                  \
+                eb[(K)] = x0; eb[(K) - 1] = x1; eb[(K) - 2] = x2; eb[(K) - 3] = x3;     \
+            }
+            if (k >= 11) {
+                // software pipeline: the records of the next four steps are read from LDS while the current four run
+                uint4 a0 = rb[k], a1 = rb[k - 1], a2 = rb[k - 2], a3 = rb[k - 3];
+                for (; k >= 11; k -= 8) {
+                    const uint4 b0 = rb[k - 4], b1 = rb[k - 5], b2 = rb[k - 6], b3 = rb[k - 7];
+                    JPK_STEP4(k, a0, a1, a2, a3)
+                    a0 = rb[k - 8]; a1 = rb[k - 9]; a2 = rb[k - 10]; a3 = rb[k - 11];
+                    JPK_STEP4(k - 4, b0, b1, b2, b3)
+                }
+                JPK_STEP4(k, a0, a1, a2, a3)          // k >= 3 here: the group prefetched last
+                k -= 4;
+            }
             for (; k >= 3; k -= 4) {
                 const uint4 r0 = rb[k], r1 = rb[k - 1], r2 = rb[k - 2], r3 = rb[k - 3];
-                const uint32_t x0 = x;
-                const uint32_t x1 = rans_step(x0, r0);
-                const uint32_t x2 = rans_step(x1, r1);
-                const uint32_t x3 = rans_step(x2, r2);
-                x = rans_step(x3, r3);
-                eb[k] = x0; eb[k - 1] = x1; eb[k - 2] = x2; eb[k - 3] = x3;
+                JPK_STEP4(k, r0, r1, r2, r3)
             }
+#undef JPK_STEP4
             for (; k >= 0; k--) {
                 const uint4 r0 = rb[k];
                 eb[k] = x;
