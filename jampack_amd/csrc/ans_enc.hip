@@ -736,36 +736,6 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
 // rANS (ans.cpp:189-208): four independent sequential chains per chunk (state lane = pair index & 3), last pair
 // first.  Each step records the 0..2 renormalisation bytes it emits; their stream positions are a prefix sum.
 // ---------------------------------------------------------------------------------------------------------------
-// One encoder step (branch-free); returns the new state.  Cost on one wave: the 32-bit multiplies are quarter
-// rate (16 cycles per wave64 instruction against 4 for everything else), so the step keeps exactly one of them
-// (the reciprocal) and does the second product with the full-rate 24-bit multiply: after renormalisation
-// xr < freq << 15, so q = xr / freq < 2^15 and 65536 - freq < 2^16.  The bytes a step emits are NOT formed here:
-// the pre-renormalisation state goes to LDS and all 64 lanes rebuild the emit words per tile (emit_word).
-__device__ __forceinline__ uint32_t rans_step(uint32_t x, const uint4 r)
-{
-    const uint32_t xmax = r.x;                // ((RANS_L >> 16) << 8) * freq
-    // b1 = x >= xmax: one byte leaves; b2 = (x >> 8) >= xmax: two leave (implies b1).  Both compares hang off x
-    // directly, so the dependent chain is  x>>8 -> cmp -> cndmask -> mul_hi -> shift -> mad  (6 deep).  One asm block:
-    // hipcc turns the C++ selects into exec-mask branches, and gfx940+ needs two wait states between a VALU write of an
-    // SGPR mask and the VALU that reads it -- the order below provides them (the s_nop covers the second mask).
-    uint32_t xr, x8, x16;
-    uint64_t b1, b2;
-    asm("v_lshrrev_b32 %1, 8, %5\n\t"
-        "v_cmp_ge_u32_e64 %3, %5, %6\n\t"
-        "v_lshrrev_b32 %2, 16, %5\n\t"
-        "v_cmp_ge_u32_e64 %4, %1, %6\n\t"
-        "v_cndmask_b32_e64 %0, %5, %1, %3\n\t"
-        "s_nop 0\n\t"
-        "v_cndmask_b32_e64 %0, %0, %2, %4"
-        : "=&v"(xr), "=&v"(x8), "=&v"(x16), "=&s"(b1), "=&s"(b2)
-        : "v"(x), "v"(xmax));
-    const uint32_t q = __umulhi(xr, r.y) >> (r.w >> 24);
-    const uint32_t t = xr + r.z;              // off the chain: runs beside the reciprocal multiply
-    uint32_t xn;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(xn) : "v"(q), "v"(r.w), "v"(t));    // mul24 ignores the shift byte of r.w
-    return xn;                                // == ((xr / freq) << 16) + xr % freq + low
-}
-
 // emitted bytes | count << 16 of the step that started from state x with threshold xmax
 __device__ __forceinline__ uint32_t emit_word(uint32_t x, uint32_t xmax)
 {
@@ -773,18 +743,48 @@ __device__ __forceinline__ uint32_t emit_word(uint32_t x, uint32_t xmax)
     return b2 ? ((x & 0xffffu) | (2u << 16)) : (b1 ? ((x & 0xffu) | (1u << 16)) : 0u);
 }
 
-// One wave per chunk.  Lanes 0..3 run the four state chains (pair j -> lane j & 3), last record first.  All 64
-// lanes stage the records through LDS in tiles of 128 per chain: the global loads of the next tile are issued
-// before the 128 dependent steps of the current tile and only land in LDS afterwards, so HBM latency never sits on
-// the chain; emit words go back through LDS as coalesced 16-byte stores.
-constexpr int RANS_TILE = 128;
+// One encoder step on every lane at once (see k_rans_lanes): the state comes from the lane on the left (DPP row
+// rotate), keep = the state this lane had to start from once its turn came (captured when `turn` selects the lane).
+// Cost on one wave (tools/issuetest.hip): every VALU instruction is 4 cycles whatever it does, so the step is kept to
+// twelve of them, written as one block because the order carries the wait states gfx940+ needs and the compiler
+// cannot see into asm: two between a VALU write of an SGPR mask and the VALU reading it (cmp b2 .. select u,
+// cmp b1 .. select xr) and two between the write of the new state and the next step's DPP read (capture + s_nop).
+// After renormalisation xr < freq << 15, so q = xr / freq < 2^15 and 65536 - freq < 2^16: the second product fits the
+// 24-bit multiply-add, which also ignores the shift count kept in the top byte of r.w.
+__device__ __forceinline__ uint32_t rans_step_turn(uint32_t xprev, const uint4 r, uint32_t &keep, uint64_t turn)
+{
+    uint32_t xin, x8, x16, u, xr, q, t, xn;
+    uint64_t b1, b2;
+    asm("v_mov_b32_dpp %0, %11 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_lshrrev_b32 %1, 8, %0\n\t"
+        "v_cmp_ge_u32_e64 %9, %1, %12\n\t"             // b2 = (x >> 8) >= xmax: two bytes leave (implies b1)
+        "v_cmp_ge_u32_e64 %8, %0, %12\n\t"             // b1 = x >= xmax: one byte leaves
+        "v_lshrrev_b32 %2, 16, %0\n\t"
+        "v_cndmask_b32_e64 %3, %1, %2, %9\n\t"         // u = b2 ? x >> 16 : x >> 8
+        "v_cndmask_b32_e64 %4, %0, %3, %8\n\t"         // xr = b1 ? u : x
+        "v_mul_hi_u32 %5, %4, %13\n\t"
+        "v_lshrrev_b32_sdwa %5, %15, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+        "v_add_u32 %6, %4, %14\n\t"
+        "v_mad_u32_u24 %7, %5, %15, %6\n\t"            // == ((xr / freq) << 16) + xr % freq + low
+        "v_cndmask_b32_e64 %10, %10, %0, %16\n\t"      // my turn: remember the state I started from
+        "s_nop 0"
+        : "=&v"(xin), "=&v"(x8), "=&v"(x16), "=&v"(u), "=&v"(xr), "=&v"(q), "=&v"(t), "=&v"(xn), "=&s"(b1), "=&s"(b2), "+v"(keep)
+        : "v"(xprev), "v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w), "s"(turn));
+    return xn;
+}
 
+// One wave per chunk; no LDS.  The four chains of a chunk (pair j -> chain j & 3, ans.cpp:189-208) own one row of
+// 16 lanes each; lane s of a row holds the record of step K - s of the current batch of 16 steps (one coalesced
+// 16-byte global load per lane per batch, the next batch prefetched).  The state travels: every step all lanes run
+// the same eleven instructions on the state handed over by their left neighbour (DPP row rotate, no LDS, no
+// readlane), so after step t lane t holds the chain's true state and the others compute values nobody uses.  A lane
+// keeps the state it was handed on its own turn; after the 16 steps all 64 lanes turn those into emit words and
+// end-relative byte offsets at once (two ballots and per-lane popcounts instead of a scan).
+// Steps outside a chain (before its last pair, after its first) use an identity record.
 __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ recs, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
                                                   uint32_t *__restrict__ emit, uint32_t *__restrict__ fstate, uint32_t *__restrict__ eend,
                                                   uint32_t *__restrict__ csize)
 {
-    __shared__ uint4 rbuf[2][4][RANS_TILE];
-    __shared__ uint32_t ebuf[4][RANS_TILE];
     // this wave is a long dependent chain: let it win the issue arbitration against the wide kernels of other chunks /
     // blocks that share its SIMD (priority, then age)
     __builtin_amdgcn_s_setprio(3);
@@ -796,108 +796,52 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
         if (t == 0) csize[c] = 16u;
         return;
     }
-    for (int i = t; i < 4 * RANS_TILE; i += 64) (&ebuf[0][0])[i] = 0;    // slots past a chain's last record must count 0 bytes
-    uint32_t *ee = eend + (size_t)c * 2 * rle_stride;
-    uint32_t carry = 0;                                                  // bytes emitted by all pairs of higher tiles
+    const int chain = t >> 4, s = t & 15;
     const size_t lane_stride = rans_lane_stride(rle_stride);
-    const int cl = t >> 4, part = t & 15;                       // staging role: chain cl, 16 lanes x 128 B = one tile row
-    const uint4 *src = recs + ((size_t)c * 4 + cl) * lane_stride + part * 8;
-    uint4 *dst = reinterpret_cast<uint4 *>(emit + ((size_t)c * 4 + cl) * lane_stride) + part * 2;
-    const int64_t kmax = (t < 4 && (uint32_t)t < np) ? (int64_t)((np - 1 - t) / 4) : -1;   // my chain's last record
-    const int64_t ntiles = (int64_t)(((np + 3) / 4 + RANS_TILE - 1) / RANS_TILE);
-    uint32_t x = RANS_L;
-    uint4 p0, p1, p2, p3, p4, p5, p6, p7;          // named registers: an array here ends up in scratch
-#define JPK_TILE_LOAD(S) p0 = (S)[0]; p1 = (S)[1]; p2 = (S)[2]; p3 = (S)[3]; p4 = (S)[4]; p5 = (S)[5]; p6 = (S)[6]; p7 = (S)[7];
-    {
-        const uint4 *s0 = src + (ntiles - 1) * RANS_TILE;
-        JPK_TILE_LOAD(s0)
+    const uint4 *rc = recs + ((size_t)c * 4 + chain) * lane_stride;
+    uint32_t *em = emit + ((size_t)c * 4 + chain) * lane_stride;
+    uint32_t *ee = eend + (size_t)c * 2 * rle_stride;
+    const int32_t kmax = ((uint32_t)chain < np) ? (int32_t)((np - 1 - chain) / 4) : -1;    // my chain's last record
+    const int32_t nbatch = (int32_t)((np - 1) / 4) / 16 + 1;
+    // pair order inside a batch, last pair first: p = 4 * s + (3 - chain); before[] = lanes whose pair comes no later
+    const uint32_t myp = 4u * (uint32_t)s + (3u - (uint32_t)chain);
+    uint32_t before_lo = 0, before_hi = 0;
+    for (int q = 0; q < 64; q++) {
+        const uint32_t pq = 4u * (uint32_t)(q & 15) + (3u - (uint32_t)(q >> 4));
+        if (pq <= myp) { if (q < 32) before_lo |= 1u << q; else before_hi |= 1u << (q - 32); }
     }
-    int buf = 0;
-    for (int64_t tt = ntiles - 1; tt >= 0; tt--) {
-        {   // land the prefetched tile in LDS
-            uint4 *ld = &rbuf[buf][cl][0] + part * 8;
-            ld[0] = p0; ld[1] = p1; ld[2] = p2; ld[3] = p3; ld[4] = p4; ld[5] = p5; ld[6] = p6; ld[7] = p7;
-        }
-        __syncthreads();
-        {   // request the next tile (clamped: unconditional)
-            const uint4 *s0 = src + (tt > 0 ? tt - 1 : 0) * RANS_TILE;
-            JPK_TILE_LOAD(s0)
-        }
-        if (t < 4) {
-            const int64_t base = tt * RANS_TILE;
-            int k = (int)((kmax - base < RANS_TILE - 1) ? kmax - base : RANS_TILE - 1);
-            const uint4 *rb = &rbuf[buf][t][0];
-            uint32_t *eb = &ebuf[t][0];
-            // four steps from four records; the pre-renormalisation states go to LDS
-#define JPK_STEP4(K, A0, A1, A2, A3)                                                   \
-            {                                                                           \
-                const uint32_t x0 = x;                                                  \
-                const uint32_t x1 = rans_step(x0, A0);                                  \
-                const uint32_t x2 = rans_step(x1, A1);                                  \
-                const uint32_t x3 = rans_step(x2, A2);                                  \
-                x = rans_step(x3, A3);                                                  \
-                eb[(K)] = x0; eb[(K) - 1] = x1; eb[(K) - 2] = x2; eb[(K) - 3] = x3;     \
-            }
-            if (k >= 11) {
-                // software pipeline: the records of the next four steps are read from LDS while the current four run
-                uint4 a0 = rb[k], a1 = rb[k - 1], a2 = rb[k - 2], a3 = rb[k - 3];
-                for (; k >= 11; k -= 8) {
-                    const uint4 b0 = rb[k - 4], b1 = rb[k - 5], b2 = rb[k - 6], b3 = rb[k - 7];
-                    JPK_STEP4(k, a0, a1, a2, a3)
-                    a0 = rb[k - 8]; a1 = rb[k - 9]; a2 = rb[k - 10]; a3 = rb[k - 11];
-                    JPK_STEP4(k - 4, b0, b1, b2, b3)
-                }
-                JPK_STEP4(k, a0, a1, a2, a3)          // k >= 3 here: the group prefetched last
-                k -= 4;
-            }
-            for (; k >= 3; k -= 4) {
-                const uint4 r0 = rb[k], r1 = rb[k - 1], r2 = rb[k - 2], r3 = rb[k - 3];
-                JPK_STEP4(k, r0, r1, r2, r3)
-            }
-#undef JPK_STEP4
-            for (; k >= 0; k--) {
-                const uint4 r0 = rb[k];
-                eb[k] = x;
-                x = rans_step(x, r0);
-            }
-        }
-        __syncthreads();
-        uint32_t cn[8];
-        uint32_t sum = 0;
-        const uint32_t jb = (uint32_t)tt * (4 * RANS_TILE) + (uint32_t)t * 8;
-        {   // all 64 lanes: lane t owns the 8 consecutive pairs 8t..8t+7 of this tile (pair j = 4k + chain); it turns
-            // the recorded states into emit words in place
+    const uint4 ident = make_uint4(0x80000000u, 0u, 0u, 0u);       // xmax above every state, q * 0 + x + 0
+    int32_t K = 16 * nbatch - 1;                                   // step index of lane 0 in the current batch
+    auto load = [&](int32_t k) -> uint4 {
+        const int32_t kk = k < 0 ? 0 : (k > kmax ? (kmax < 0 ? 0 : kmax) : k);
+        const uint4 r = rc[kk];
+        return (k >= 0 && k <= kmax) ? r : ident;
+    };
+    uint4 rec = load(K - s);
+    uint32_t x = RANS_L;                                           // lane 15 of a row hands the start state to lane 0
+    uint32_t carry = 0;                                            // bytes emitted by all earlier batches
+    for (int32_t b = 0; b < nbatch; b++) {
+        const uint4 nrec = load(K - 16 - s);
+        uint32_t keep = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int jl = t * 8 + i;
-                const uint32_t e = (jb + i < np) ? emit_word(ebuf[jl & 3][jl >> 2], rbuf[buf][jl & 3][jl >> 2].x) : 0u;
-                ebuf[jl & 3][jl >> 2] = e;
-                cn[i] = e >> 16;
-                sum += cn[i];
-            }
+        for (int st = 0; st < 16; st++) {
+            x = rans_step_turn(x, rec, keep, 0x0001000100010001ull << st);
         }
-        __syncthreads();
-        {   // emit words of this tile: 4 chains x 512 B
-            const uint4 *es = reinterpret_cast<const uint4 *>(&ebuf[cl][0]) + part * 2;
-            uint4 *ed = dst + tt * (RANS_TILE / 4);
-            ed[0] = es[0]; ed[1] = es[1];
-        }
-        {   // bytes from the start of pair j's output to the end of the stream (pair order), inclusive suffix sums,
-            // higher tiles in `carry`
-            uint32_t inc = wave_incl_sum(sum);                       // prefix over lanes <= t
-            const uint32_t tile_total = __shfl(inc, 63, 64);
-            uint32_t run = carry + (tile_total - inc);               // bytes of the pairs owned by lanes > t (and higher tiles)
-#pragma unroll
-            for (int i = 7; i >= 0; i--) {
-                run += cn[i];
-                if (jb + i < np) ee[jb + i] = run;
-            }
-            carry += tile_total;
-        }
-        __syncthreads();
-        buf ^= 1;
+        const int32_t k = K - s;
+        const bool live = k >= 0 && k <= kmax;
+        const uint32_t e = live ? emit_word(keep, rec.x) : 0u;
+        if (live) em[k] = e;
+        const uint32_t cn = e >> 16;
+        const uint64_t m1 = __ballot(cn != 0), m2 = __ballot(cn == 2);
+        const uint32_t incl = __popc((uint32_t)m1 & before_lo) + __popc((uint32_t)(m1 >> 32) & before_hi) +
+                              __popc((uint32_t)m2 & before_lo) + __popc((uint32_t)(m2 >> 32) & before_hi);
+        // bytes from the start of pair j's output to the end of the stream (pair j = 4k + chain)
+        if (live) ee[4u * (uint32_t)k + (uint32_t)chain] = carry + incl;
+        carry += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
+        rec = nrec;
+        K -= 16;
     }
-    if (t < 4) fstate[(size_t)c * 4 + t] = x;
+    if (s == 15) fstate[(size_t)c * 4 + chain] = x;               // identity steps carried each chain's state to the end of its row
     if (t == 0) csize[c] = 16u + carry;
 }
 
