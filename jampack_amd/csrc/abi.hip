@@ -148,13 +148,17 @@ extern "C" int jpk_ctx_create(jpk_ctx **out, int device, void *hip_stream)
     }
     if (hipHostMalloc((void **)&c->h_mail, 256 * 4, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&c->h_map, 4096 * 4, hipHostMallocDefault) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_c, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&c->d_mail, 256 * 4) != hipSuccess) {
         jpk_ctx_destroy(c);
         return JPK_E_ALLOC;
+    }
+    for (int g = 0; g < jpk_ctx::ENC_GROUPS; g++) {
+        if ((g + 1 < jpk_ctx::ENC_GROUPS && hipStreamCreateWithFlags(&c->aux[g], hipStreamNonBlocking) != hipSuccess) ||
+            hipEventCreateWithFlags(&c->ev_pre[g], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_done[g], hipEventDisableTiming) != hipSuccess) {
+            jpk_ctx_destroy(c);
+            return JPK_E_ALLOC;
+        }
     }
     *out = c;
     return JPK_OK;
@@ -172,10 +176,11 @@ extern "C" void jpk_ctx_destroy(jpk_ctx *c)
     if (c->d_mail) (void)hipFree(c->d_mail);
     if (c->h_mail) (void)hipHostFree(c->h_mail);
     if (c->h_map) (void)hipHostFree(c->h_map);
-    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
-    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
-    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
-    if (c->ev_c) (void)hipEventDestroy(c->ev_c);
+    for (int g = 0; g < jpk_ctx::ENC_GROUPS; g++) {
+        if (g + 1 < jpk_ctx::ENC_GROUPS && c->aux[g]) { (void)hipStreamSynchronize(c->aux[g]); (void)hipStreamDestroy(c->aux[g]); }
+        if (c->ev_pre[g]) (void)hipEventDestroy(c->ev_pre[g]);
+        if (c->ev_done[g]) (void)hipEventDestroy(c->ev_done[g]);
+    }
     for (auto &p : c->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

@@ -1063,9 +1063,10 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
 
     const size_t stride = d.chunk;
     JPK_HIP(hipMemsetAsync(b.qhist, 0, (size_t)d.nch * 6 * NQ * QSTRIDE * 4, st));
-    // The stage is bounded by the longest rANS chain (the densest chunk).  With enough chunks, the densest quarter is
-    // launched as its own group on the context's second stream so that its chains start after a quarter of the
-    // parallel work; the remaining chunks follow on the main stream and run beside those chains.
+    // The stage is bounded by the longest rANS chain (the densest chunk), a single wave, and several of the parallel
+    // kernels in front of it are latency-bound per chunk as well.  The chunks are ordered by a density estimate and cut
+    // into up to four groups, densest first, and each group runs the whole stage on its own stream: the densest
+    // chains start after a quarter of the parallel work, beside the parallel stages of the other groups.
     auto pre_chain = [&](const EncDims &g) -> int {
         JPK_TRY(run_rank(ctx, d_in, g, b));
         JPK_TRY(run_rle(ctx, b.ranks, g, b));
@@ -1076,7 +1077,10 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
         JPK_LAUNCH(ctx, PROF_ENC_RANS, 0, k_rans_lanes, dim3(g.ncl), dim3(64), b.recs, stride, g, b.rlen, b.emit, b.fstate, b.epos, b.csize);
         return JPK_OK;
     };
-    if (d.nch >= 8 && !getenv("JPK_NO_GROUPS")) {
+    int ngroups = (int)(d.nch / 8u);
+    if (ngroups > jpk_ctx::ENC_GROUPS) ngroups = jpk_ctx::ENC_GROUPS;
+    if (const char *e = getenv("JPK_ENC_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= jpk_ctx::ENC_GROUPS && (uint32_t)v <= d.nch) ngroups = v; }
+    if (ngroups >= 2) {
         JPK_LAUNCH(ctx, PROF_ENC_HIST, d.len, k_density, dim3(d.nch), dim3(TB), d_in, d, b.dens);
         JPK_HIP(hipMemcpyAsync(ctx->h_map, b.dens, (size_t)d.nch * 4, hipMemcpyDeviceToHost, st));
         JPK_HIP(hipStreamSynchronize(st));
@@ -1087,24 +1091,25 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
         std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return dcopy[x] > dcopy[y]; });
         for (uint32_t c = 0; c < d.nch; c++) ctx->h_map[c] = order[c];
         JPK_HIP(hipMemcpyAsync(b.cmap, ctx->h_map, (size_t)d.nch * 4, hipMemcpyHostToDevice, st));
-        JPK_HIP(hipEventRecord(ctx->ev_a, st));
-        const uint32_t na = (d.nch + 3) / 4;
-        EncDims ga = d, gb = d;
-        ga.ncl = na; ga.cmap = b.cmap;
-        gb.ncl = d.nch - na; gb.cmap = b.cmap + na;
-        // group A (densest) on the second stream; group B starts its parallel stages only when A's chains are launched
-        JPK_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_a, 0));
-        ctx->stream = ctx->stream2;
-        int rc = pre_chain(ga);
-        if (rc == JPK_OK && hipEventRecord(ctx->ev_c, ctx->stream2) != hipSuccess) rc = JPK_E_DEVICE;
-        if (rc == JPK_OK) rc = chain(ga);
-        if (rc == JPK_OK && hipEventRecord(ctx->ev_b, ctx->stream2) != hipSuccess) rc = JPK_E_DEVICE;
-        ctx->stream = st;
+        JPK_HIP(hipEventRecord(ctx->ev_pre[0], st));           // histogram memset + chunk order are in place
+        uint32_t off = 0;
+        int rc = JPK_OK;
+        for (int g = 0; g < ngroups && rc == JPK_OK; g++) {
+            const uint32_t n = (d.nch - off + (uint32_t)(ngroups - g) - 1) / (uint32_t)(ngroups - g);
+            EncDims gd = d;
+            gd.ncl = n; gd.cmap = b.cmap + off;
+            off += n;
+            // every buffer of the stage is indexed by chunk, so the groups are independent: each runs on its own stream
+            hipStream_t gs = (g + 1 < ngroups) ? ctx->aux[g] : st;
+            if (gs != st && hipStreamWaitEvent(gs, ctx->ev_pre[0], 0) != hipSuccess) { rc = JPK_E_DEVICE; break; }
+            ctx->stream = gs;
+            rc = pre_chain(gd);
+            if (rc == JPK_OK) rc = chain(gd);
+            ctx->stream = st;
+            if (rc == JPK_OK && gs != st && hipEventRecord(ctx->ev_done[g], gs) != hipSuccess) rc = JPK_E_DEVICE;
+        }
         JPK_TRY(rc);
-        JPK_HIP(hipStreamWaitEvent(st, ctx->ev_c, 0));
-        JPK_TRY(pre_chain(gb));
-        JPK_TRY(chain(gb));
-        JPK_HIP(hipStreamWaitEvent(st, ctx->ev_b, 0));
+        for (int g = 0; g + 1 < ngroups; g++) JPK_HIP(hipStreamWaitEvent(st, ctx->ev_done[g], 0));
     } else {
         JPK_TRY(pre_chain(d));
         JPK_TRY(chain(d));

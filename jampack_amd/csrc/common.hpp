@@ -42,8 +42,11 @@ struct jpk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipStream_t stream2 = nullptr;   // second stream of the context (entropy stage: densest chunks first)
-    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
+    // entropy stage: chunk groups, densest first; group g's serial rANS kernel runs on aux[g] beside the parallel
+    // stages of the later groups (which stay on `stream`)
+    static constexpr int ENC_GROUPS = 4;
+    hipStream_t aux[ENC_GROUPS - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_pre[ENC_GROUPS] = {nullptr, nullptr, nullptr, nullptr}, ev_done[ENC_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t *h_map = nullptr;       // pinned, 4096 words
     uint8_t *arena = nullptr;
     size_t arena_cap = 0;
