@@ -812,35 +812,54 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
     }
     const uint4 ident = make_uint4(0x80000000u, 0u, 0u, 0u);       // xmax above every state, q * 0 + x + 0
     int32_t K = 16 * nbatch - 1;                                   // step index of lane 0 in the current batch
-    auto load = [&](int32_t k) -> uint4 {
+    auto load = [&](int32_t k) -> uint4 {                          // raw: steps outside the chain are replaced at the point of use
         const int32_t kk = k < 0 ? 0 : (k > kmax ? (kmax < 0 ? 0 : kmax) : k);
-        const uint4 r = rc[kk];
-        return (k >= 0 && k <= kmax) ? r : ident;
+        return rc[kk];
     };
-    uint4 rec = load(K - s);
     uint32_t x = RANS_L;                                           // lane 15 of a row hands the start state to lane 0
     uint32_t carry = 0;                                            // bytes emitted by all earlier batches
-    for (int32_t b = 0; b < nbatch; b++) {
-        const uint4 nrec = load(K - 16 - s);
-        uint32_t keep = 0;
-#pragma unroll
-        for (int st = 0; st < 16; st++) {
-            x = rans_step_turn(x, rec, keep, 0x0001000100010001ull << st);
-        }
-        const int32_t k = K - s;
-        const bool live = k >= 0 && k <= kmax;
-        const uint32_t e = live ? emit_word(keep, rec.x) : 0u;
-        if (live) em[k] = e;
-        const uint32_t cn = e >> 16;
-        const uint64_t m1 = __ballot(cn != 0), m2 = __ballot(cn == 2);
-        const uint32_t incl = __popc((uint32_t)m1 & before_lo) + __popc((uint32_t)(m1 >> 32) & before_hi) +
-                              __popc((uint32_t)m2 & before_lo) + __popc((uint32_t)(m2 >> 32) & before_hi);
-        // bytes from the start of pair j's output to the end of the stream (pair j = 4k + chain)
-        if (live) ee[4u * (uint32_t)k + (uint32_t)chain] = carry + incl;
-        carry += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);
-        rec = nrec;
-        K -= 16;
+    // one batch = 16 steps of every chain with the records REC (lane s: step KTOP - s), then the batch's emit words and offsets
+#define JPK_BATCH(REC, KTOP)                                                                               \
+    {                                                                                                      \
+        uint32_t keep = 0;                                                                                 \
+        const int32_t k = (KTOP) - s;                                                                      \
+        const bool live = k >= 0 && k <= kmax;                                                             \
+        const uint4 rr = live ? REC : ident;                                                               \
+        _Pragma("unroll") for (int st = 0; st < 16; st++) x = rans_step_turn(x, rr, keep, 0x0001000100010001ull << st); \
+        const uint32_t e = live ? emit_word(keep, rr.x) : 0u;                                              \
+        if (live) em[k] = e;                                                                               \
+        const uint32_t cn = e >> 16;                                                                       \
+        const uint64_t m1 = __ballot(cn != 0), m2 = __ballot(cn == 2);                                     \
+        const uint32_t incl = __popc((uint32_t)m1 & before_lo) + __popc((uint32_t)(m1 >> 32) & before_hi) + \
+                              __popc((uint32_t)m2 & before_lo) + __popc((uint32_t)(m2 >> 32) & before_hi); \
+        /* bytes from the start of pair j's output to the end of the stream (pair j = 4k + chain) */       \
+        if (live) ee[4u * (uint32_t)k + (uint32_t)chain] = carry + incl;                                   \
+        carry += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);                                          \
     }
+    // the records of eight batches are in flight: one batch is ~0.4 us of dependent steps, an HBM load takes longer, and
+    // the compiler's wait counts (loads and the batch's stores share vmcnt) give up part of the distance
+    uint4 r0 = load(K - s), r1 = load(K - 16 - s), r2 = load(K - 32 - s), r3 = load(K - 48 - s);
+    uint4 r4 = load(K - 64 - s), r5 = load(K - 80 - s), r6 = load(K - 96 - s), r7 = load(K - 112 - s);
+    for (int32_t b = 0; b < nbatch; b += 8) {                      // batches past the first pair run on identity records
+        JPK_BATCH(r0, K)
+        r0 = load(K - 128 - s);
+        JPK_BATCH(r1, K - 16)
+        r1 = load(K - 144 - s);
+        JPK_BATCH(r2, K - 32)
+        r2 = load(K - 160 - s);
+        JPK_BATCH(r3, K - 48)
+        r3 = load(K - 176 - s);
+        JPK_BATCH(r4, K - 64)
+        r4 = load(K - 192 - s);
+        JPK_BATCH(r5, K - 80)
+        r5 = load(K - 208 - s);
+        JPK_BATCH(r6, K - 96)
+        r6 = load(K - 224 - s);
+        JPK_BATCH(r7, K - 112)
+        r7 = load(K - 240 - s);
+        K -= 128;
+    }
+#undef JPK_BATCH
     if (s == 15) fstate[(size_t)c * 4 + chain] = x;               // identity steps carried each chain's state to the end of its row
     if (t == 0) csize[c] = 16u + carry;
 }

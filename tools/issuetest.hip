@@ -13,6 +13,7 @@ template <int MODE> __global__ void k(uint32_t *out, int iters, uint64_t *clk, u
     lds[threadIdx.x] = threadIdx.x;
     lds[threadIdx.x + 64] = threadIdx.x;
     uint4 q4 = {0, 0, 0, 0};
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0, w5 = 0, w6 = 0;
     uint32_t a = seed + threadIdx.x, b = seed * 3 + 1, c = seed * 5 + 2, d = seed * 7 + 3, m = 0x9E3779B1u;
     __syncthreads();
     uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -63,10 +64,15 @@ template <int MODE> __global__ void k(uint32_t *out, int iters, uint64_t *clk, u
         if (MODE == 45) { REP64(asm volatile("v_cmp_lt_u32 vcc, %0, %1\n s_ff1_i32_b64 s20, vcc\n v_readlane_b32 s21, %0, s20\n v_add_u32 %0, s21, %0" : "+v"(a) : "v"(m) : "vcc", "s20", "s21");) }
         if (MODE == 46) { REP64(asm volatile("v_cmp_lt_u32 vcc, %0, %1\n s_cbranch_vccz 1f\n v_add_u32 %0, %0, %1\n 1:\n v_add_u32 %0, %0, %1" : "+v"(a) : "v"(m) : "vcc");) }
         if (MODE == 47) { REP64(asm volatile("s_lshr_b64 s[20:21], s[20:21], 8\n s_add_u32 s22, s22, 1" ::: "s20", "s21", "s22", "scc");) }
+        if (MODE == 50) { REP64(asm volatile("v_mov_b32_dpp %0, %7 row_ror:1 row_mask:0xf bank_mask:0xf\n v_lshrrev_b32 %1, 8, %0\n v_cmp_ge_u32_e64 s[22:23], %1, %8\n v_cmp_ge_u32_e64 s[20:21], %0, %8\n v_lshrrev_b32 %2, 16, %0\n v_cndmask_b32_e64 %3, %1, %2, s[22:23]\n v_cndmask_b32_e64 %4, %0, %3, s[20:21]\n v_mul_hi_u32 %5, %4, %9\n v_lshrrev_b32_sdwa %5, %10, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n v_add_u32 %6, %4, %8\n v_mad_u32_u24 %7, %5, %10, %6\n v_cndmask_b32_e64 %11, %11, %0, s[24:25]\n s_nop 0" : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(w4), "=&v"(w5), "=&v"(w6), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(m) :: "s20", "s21", "s22", "s23", "s24", "s25");) }
+        if (MODE == 51) { REP64(asm volatile("v_mov_b32 %0, %7\n v_lshrrev_b32 %1, 8, %0\n v_cmp_ge_u32_e64 s[22:23], %1, %8\n v_cmp_ge_u32_e64 s[20:21], %0, %8\n v_lshrrev_b32 %2, 16, %0\n v_cndmask_b32_e64 %3, %1, %2, s[22:23]\n v_cndmask_b32_e64 %4, %0, %3, s[20:21]\n v_mul_hi_u32 %5, %4, %9\n v_lshrrev_b32_sdwa %5, %10, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n v_add_u32 %6, %4, %8\n v_mad_u32_u24 %7, %5, %10, %6\n v_cndmask_b32_e64 %11, %11, %0, s[24:25]\n s_nop 0" : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(w4), "=&v"(w5), "=&v"(w6), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(m) :: "s20", "s21", "s22", "s23", "s24", "s25");) }
+        if (MODE == 52) { REP64(asm volatile("v_mov_b32_dpp %0, %7 row_ror:1 row_mask:0xf bank_mask:0xf\n v_lshrrev_b32 %1, 8, %0\n v_cmp_ge_u32_e64 s[22:23], %1, %8\n v_cmp_ge_u32_e64 s[20:21], %0, %8\n v_lshrrev_b32 %2, 16, %0\n v_cndmask_b32_e64 %3, %1, %2, s[22:23]\n v_cndmask_b32_e64 %4, %0, %3, s[20:21]\n v_mul_hi_u32 %5, %4, %9\n v_lshrrev_b32 %5, 3, %5\n v_add_u32 %6, %4, %8\n v_mad_u32_u24 %7, %5, %10, %6\n v_cndmask_b32_e64 %11, %11, %0, s[24:25]\n s_nop 0" : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(w4), "=&v"(w5), "=&v"(w6), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(m) :: "s20", "s21", "s22", "s23", "s24", "s25");) }
+        if (MODE == 53) { REP64(asm volatile("v_mov_b32_dpp %0, %7 row_ror:1 row_mask:0xf bank_mask:0xf\n v_lshrrev_b32 %1, 8, %0\n v_cmp_ge_u32_e64 s[22:23], %1, %8\n v_cmp_ge_u32_e64 s[20:21], %0, %8\n v_lshrrev_b32 %2, 16, %0\n v_cndmask_b32_e64 %3, %1, %2, s[22:23]\n v_cndmask_b32_e64 %4, %0, %3, s[20:21]\n v_add_u32 %5, %4, %9\n v_lshrrev_b32_sdwa %5, %10, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n v_add_u32 %6, %4, %8\n v_mad_u32_u24 %7, %5, %10, %6\n v_cndmask_b32_e64 %11, %11, %0, s[24:25]\n s_nop 0" : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(w4), "=&v"(w5), "=&v"(w6), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(m) :: "s20", "s21", "s22", "s23", "s24", "s25");) }
+        if (MODE == 54) { REP64(asm volatile("v_mov_b32_dpp %0, %7 row_ror:1 row_mask:0xf bank_mask:0xf\n v_lshrrev_b32 %1, 8, %0\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %0, %8\n v_lshrrev_b32 %2, 16, %0\n v_xor_b32 %3, %1, %2\n v_xor_b32 %4, %0, %3\n v_mul_hi_u32 %5, %4, %9\n v_lshrrev_b32_sdwa %5, %10, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n v_add_u32 %6, %4, %8\n v_mad_u32_u24 %7, %5, %10, %6\n v_xor_b32 %11, %11, %0\n s_nop 0" : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3), "=&v"(w4), "=&v"(w5), "=&v"(w6), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(m) :: "s20", "s21", "s22", "s23", "s24", "s25");) }
         if (MODE == 17) { REP64(asm volatile("v_lshrrev_b32 %0, 1, %0\n v_or_b32 %0, %0, %1" : "+v"(a) : "v"(m));) }
     }
     uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    out[threadIdx.x] = a + b + c + d + q4.x;
+    out[threadIdx.x] = a + b + c + d + q4.x + w0 + w1 + w2 + w3 + w4 + w5 + w6;
     if (threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
 }
 
@@ -127,6 +133,11 @@ int main()
     run<45>("v_cmp, s_ff1(vcc), v_readlane(sel), v_add (quad)", 1, o, clk);
     run<46>("v_cmp vcc + s_cbranch_vccz not taken + 2 v_add", 1, o, clk);
     run<47>("s_lshr_b64 + s_add (pair)", 1, o, clk);
+    run<50>("rANS encoder step, as in k_rans_lanes (13 slots)", 1, o, clk);
+    run<51>("  same, plain v_mov instead of the DPP move", 1, o, clk);
+    run<52>("  same, plain shift instead of the SDWA shift", 1, o, clk);
+    run<53>("  same, v_add instead of v_mul_hi_u32", 1, o, clk);
+    run<54>("  same, no SGPR masks (add/xor instead of cmp/cndmask)", 1, o, clk);
     run<7>("v_readlane+v_add dependent (per pair)", 1, o, clk);
     run<15>("readfirstlane+s_add+v_mov (per triple)", 1, o, clk);
     run<10>("v_cmp+s_bcnt1+v_add (per triple)", 1, o, clk);
