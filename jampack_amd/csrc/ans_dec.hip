@@ -86,40 +86,39 @@ __global__ void k_dec_headers(const uint8_t *__restrict__ in, uint32_t len, uint
 //     the wave (lane l = dword l, next window prefetched).
 // Classes 6 and 7 (64 and 129 symbols, rare outside incompressible data) keep their CDFs in LDS.
 // ---------------------------------------------------------------------------------------------------------------
-struct QuasiLds {                 // classes 6 and 7
-    uint32_t cdf[2][QSTRIDE];
-    uint32_t f[2][QSTRIDE];
-    uint32_t seen[2], expn[2];
-};
-
-// QuasiModel rebuild (model.cpp:160-204) of an LDS-resident model
-__device__ __forceinline__ void quasi_rebuild(QuasiLds &q, int k, int A, int l)
+// QuasiModel rebuild (model.cpp:160-204) of a register-resident model of A <= 64 * NR symbols: symbol i = lane l of
+// register j (i = l + 64 j).  hi/lo/fr become the bounds and width of every symbol, the counts are cleared.
+template <int NR>
+__device__ __forceinline__ void quasi_rebuild_regs(int A, int l, uint32_t (&hi)[NR], uint32_t (&lo)[NR], uint32_t (&fr)[NR], uint32_t (&f)[NR],
+                                                   uint32_t &expn)
 {
-    uint32_t F[3];
+    uint32_t F[NR];
     uint32_t tot = 0;
 #pragma unroll
-    for (int j = 0; j < 3; j++) { int i = l + 64 * j; F[j] = (i < A) ? q.f[k][i] : 0u; tot += F[j]; }
+    for (int j = 0; j < NR; j++) { F[j] = (l + 64 * j < A) ? f[j] : 0u; tot += F[j]; }
     tot = wave_sum(tot);
     int lg = 0;
     while ((tot >> lg) + (uint32_t)A > 65536u) lg++;
     uint32_t t2 = 0;
 #pragma unroll
-    for (int j = 0; j < 3; j++) { int i = l + 64 * j; F[j] = (i < A) ? (F[j] >> lg) + 1u : 0u; t2 += F[j]; }
+    for (int j = 0; j < NR; j++) { F[j] = (l + 64 * j < A) ? (F[j] >> lg) + 1u : 0u; t2 += F[j]; }
     t2 = wave_sum(t2);
     uint32_t t3 = 0;
 #pragma unroll
-    for (int j = 0; j < 3; j++) { F[j] = (65536u * F[j]) / t2; t3 += F[j]; }
+    for (int j = 0; j < NR; j++) { F[j] = (65536u * F[j]) / t2; t3 += F[j]; }
     t3 = wave_sum(t3);
     if (l == 0) F[0] += 65536u - t3;
     uint32_t carry = 0;
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-        int i = l + 64 * j;
-        uint32_t inc = wave_incl_sum(F[j]);
-        if (i < A) { q.cdf[k][i] = carry + inc - F[j]; q.f[k][i] = 0; }
+    for (int j = 0; j < NR; j++) {
+        const uint32_t inc = wave_incl_sum(F[j]);
+        hi[j] = carry + inc;                         // symbols past the alphabet end at 65536 with width 0
+        lo[j] = carry + inc - F[j];
+        fr[j] = F[j];
+        f[j] = 0;
         carry += __shfl(inc, 63, 64);
     }
-    if (l == 0) { q.cdf[k][A] = 65536u; q.seen[k] = 0; q.expn[k] = (q.expn[k] < 65536u) ? q.expn[k] << 1 : 65536u; }
+    expn = (expn < 65536u) ? expn << 1 : 65536u;
 }
 
 // 256-byte input window held across the wave (lane l = dword l), next window prefetched, drained through a 64-bit
@@ -238,19 +237,35 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
         __builtin_amdgcn_sched_barrier(0);                                                                \
         const uint32_t range_m = range2, xs_m = xs2;                                                      \
         if (__builtin_expect(e >= 6u, 0)) {                                                               \
-            const int k = (int)e - 6, A = (e == 7u) ? 129 : 64;                                           \
-            const uint32_t c1 = q.cdf[k][l + 1];                                          /* entries 1..64 */  \
-            uint32_t m = (uint32_t)__popcll(__ballot((l + 1 < A) && c1 <= range_m));                      \
-            if (A > 65) {                                                                                 \
-                const uint32_t c2 = q.cdf[k][l + 65];                                     /* entries 65..128 */ \
-                m += (uint32_t)__popcll(__ballot((l + 65 < A) && c2 <= range_m));                         \
+            /* classes 6 (64 symbols) and 7 (129): same lane-per-symbol search over one / three registers */ \
+            if (e == 6u) {                                                                                \
+                const uint32_t cand = __umul24(fr6[0], xs_m) + (range_m - lo6[0]);                        \
+                const uint32_t m = (uint32_t)__builtin_ctzll(__builtin_amdgcn_uicmp(range_m, hi6[0], JPK_ICMP_ULT)); \
+                x2 = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)m);                              \
+                f6[0] += ((uint32_t)l == m) ? 16u : 0u;                                                   \
+                sym = 64u + m;                                                                            \
+                if (++seen6 > expn6) { quasi_rebuild_regs<1>(64, l, hi6, lo6, fr6, f6, expn6); seen6 = 0; } \
+            } else {                                                                                      \
+                const uint64_t a0 = __builtin_amdgcn_uicmp(range_m, hi7[0], JPK_ICMP_ULT);                \
+                const uint64_t a1 = __builtin_amdgcn_uicmp(range_m, hi7[1], JPK_ICMP_ULT);                \
+                uint32_t m;                                                                               \
+                if (a0) {                                                                                 \
+                    m = (uint32_t)__builtin_ctzll(a0);                                                    \
+                    x2 = (uint32_t)__builtin_amdgcn_readlane((int)(__umul24(fr7[0], xs_m) + (range_m - lo7[0])), (int)m); \
+                    f7[0] += ((uint32_t)l == m) ? 16u : 0u;                                               \
+                } else if (a1) {                                                                          \
+                    m = (uint32_t)__builtin_ctzll(a1);                                                    \
+                    x2 = (uint32_t)__builtin_amdgcn_readlane((int)(__umul24(fr7[1], xs_m) + (range_m - lo7[1])), (int)m); \
+                    f7[1] += ((uint32_t)l == m) ? 16u : 0u;                                               \
+                    m += 64u;                                                                             \
+                } else {                                             /* the 129th symbol: lane 0 of the third register */ \
+                    m = 128u;                                                                             \
+                    x2 = (uint32_t)__builtin_amdgcn_readlane((int)(__umul24(fr7[2], xs_m) + (range_m - lo7[2])), 0); \
+                    f7[2] += (l == 0) ? 16u : 0u;                                                         \
+                }                                                                                         \
+                sym = 128u + m;                                                                           \
+                if (++seen7 > expn7) { quasi_rebuild_regs<3>(129, l, hi7, lo7, fr7, f7, expn7); seen7 = 0; } \
             }                                                                                             \
-            const uint32_t lo = q.cdf[k][m], hi = q.cdf[k][m + 1];                                        \
-            const uint32_t seen = q.seen[k] + 1, expn = q.expn[k];                                        \
-            if (l == 0) { q.f[k][m] += 16u; q.seen[k] = seen; }                                           \
-            if (seen > expn) { __syncthreads(); quasi_rebuild(q, k, A, l); __syncthreads(); }             \
-            x2 = (hi - lo) * xs_m + range_m - lo;                                                         \
-            sym = (1u << e) + m;                                                                          \
         }                                                                                                 \
         JPK_RENORM(x2)                                                                                    \
         (RB) = x2;                                                                                        \
@@ -288,7 +303,6 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
 __global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in, int64_t in_len, const ChunkInfo *__restrict__ info,
                                                 uint16_t *__restrict__ rle, uint32_t *__restrict__ status)
 {
-    __shared__ QuasiLds q;
     __builtin_amdgcn_s_setprio(3);         // serial chain: win the issue arbitration on a shared SIMD
     const uint32_t c = blockIdx.x;
     const int l = lane_id();
@@ -297,12 +311,6 @@ __global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in,
     const uint32_t clen = ci.clen, rlen = ci.rlen;
     uint16_t *out = rle + ci.rle_off;
 
-    for (int k = 0; k < 2; k++) {
-        const int A = k ? 129 : 64;
-        for (int i = l; i < QSTRIDE; i += 64) { q.cdf[k][i] = (i <= A) ? uniform_cdf(A, i) : 65536u; q.f[k][i] = 0; }
-        if (l == 0) { q.seen[k] = 0; q.expn[k] = 8; }
-    }
-    __syncthreads();
     ByteQueue bq;
     bq.init(in, in_len, p, l);
     // exponent model (alphabet 8): lane j holds LO = cdf[j], HI = cdf[j+1]; lanes >= 7 keep HI = 65536
@@ -324,6 +332,17 @@ __global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in,
         qlo = uniform_cdf(A, i);
         qhi = uniform_cdf(A, i + 1);
         qfr = qhi - qlo;
+    }
+    // classes 6 and 7: symbol i of the class = lane l of register i / 64 (uniform start, model.cpp:85-95)
+    uint32_t hi6[1], lo6[1], fr6[1], f6[1] = {0}, seen6 = 0, expn6 = 8;
+    uint32_t hi7[3], lo7[3], fr7[3], f7[3] = {0, 0, 0}, seen7 = 0, expn7 = 8;
+    lo6[0] = uniform_cdf(64, l); hi6[0] = uniform_cdf(64, l + 1); fr6[0] = hi6[0] - lo6[0];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int i = l + 64 * j;
+        lo7[j] = (i < 129) ? uniform_cdf(129, i) : 65536u;
+        hi7[j] = (i < 129) ? uniform_cdf(129, i + 1) : 65536u;
+        fr7[j] = hi7[j] - lo7[j];
     }
     uint32_t qexpn = 8;                                          // lane k: EXP of class k + 2 (model.cpp:160-204)
     uint32_t rem = (l < 4) ? 9u : (l == 8 ? 64u : 0x40000000u);  // lane k: symbols until the rebuild of class k + 2; lane 8: until the tile store
