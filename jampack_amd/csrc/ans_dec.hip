@@ -539,24 +539,31 @@ __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, con
     uint32_t sym = rfl(v) & 0xffu;
     uint32_t psym = 256;                                         // row with a top-up in flight (256 = none); it is blocked (fast = 0)
     uint32_t i = 0;
+    // The row and metadata of the NEXT symbol are read one iteration ahead: a run that ends in a non-zero rank (or in
+    // the end of its bucket) always brings the second list entry to the front, whatever the rank is, so the only
+    // dependent chain from one fast iteration to the next is the list update itself.
+    uint32_t rl = rows[sym][l];                                  // physical order: entry (used + j) & 63 is the j-th unread rank
+    RankMeta m = meta[sym];
     while (i < len) {
-        const uint32_t rl = rows[sym][l];
-        const RankMeta m = meta[sym];
+        const uint32_t nsym = (rfl(v) >> 8) & 0xffu;
+        const uint32_t nrl = rows[nsym][l];
+        const RankMeta nm = meta[nsym];
         const uint32_t used = rfl(m.used), room = rfl(m.fast) - used;
-        const uint64_t nz = __ballot(rl != 0);
+        const uint64_t nzp = __ballot(rl != 0);
+        const uint32_t rot = used & 63u;
+        const uint64_t nz = (nzp >> rot) | (nzp << ((64u - rot) & 63u));
         const uint32_t z = nz ? (uint32_t)__builtin_ctzll(nz) : 64u;
         const uint32_t rest = len - i;
         if (__builtin_expect(z < (room < rest ? room : rest), 1)) {
-            // ---- fast path: z zero ranks, then the real non-zero rank rl[z]; z + 1 outputs ----
+            // ---- fast path: z zero ranks, then the real non-zero rank; z + 1 outputs.  The row itself is not touched:
+            // fast iterations only advance `used` (they never look past the entries known at the last normalisation)
             const uint32_t cnt = z + 1u;
             if ((uint32_t)l < cnt) T[i + l] = (uint8_t)sym;
             i += cnt;
-            const uint32_t r = __builtin_amdgcn_readlane(rl, z);
-            const uint32_t shifted = ((uint32_t)l + cnt < 64u) ? rows[sym][(l + cnt) & 63u] : 0xFFu;
-            if (l == 0) meta[sym].used = used + cnt;
-            rows[sym][l] = shifted;
+            const uint32_t r = __builtin_amdgcn_readlane(rl, (rot + z) & 63u);
+            meta[sym].used = used + cnt;                         // every lane stores the same word: cheaper than masking to one lane
             v = list_shift_insert(v, l, r, sym);
-            sym = rfl(v) & 0xffu;
+            sym = nsym; rl = nrl; m = nm;
             continue;
         }
         // ---- general path ----
@@ -567,12 +574,15 @@ __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, con
             if (l == 0) { meta[psym].nv = 64u; meta[psym].fast = rank_fast_limit(64u, pm.left, ps.gpos >= ps.gend); }
             psym = 256u;
             __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0)
-            continue;                                            // start over with the rows as they are now
+            rl = rows[sym][l];                                   // start over with the rows as they are now
+            m = meta[sym];
+            continue;
         }
         const RankSpan sp = span[sym];
         const uint32_t gpos = rfl(sp.gpos), gend = rfl(sp.gend);
         const uint32_t nv = rfl(m.nv) - used, left = rfl(m.left) - used;
-        const uint32_t rlk = ((uint32_t)l < nv) ? rl : 0xFFu;                // unknown entries stop the scan
+        const uint32_t rlog = rows[sym][(l + used) & 63u];                   // logical order from here on
+        const uint32_t rlk = ((uint32_t)l < nv) ? rlog : 0xFFu;             // unknown entries stop the scan
         const uint64_t nzk = __ballot(rlk != 0);
         const uint32_t zk = nzk ? (uint32_t)__builtin_ctzll(nzk) : 64u;
         const bool stop = zk < nv;                                           // a known non-zero entry ended the run
@@ -580,7 +590,8 @@ __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, con
         if (cnt > rest) cnt = rest;
         if ((uint32_t)l < cnt) T[i + l] = (uint8_t)sym;
         i += cnt;
-        const uint32_t shifted = ((uint32_t)l + cnt < 64u) ? rows[sym][(l + cnt) & 63u] : 0xFFu;   // vacated tail: 0xFF
+        // normalise: the unread entries move to the front of the row, unknown entries and the tail become 0xFF
+        const uint32_t shifted = ((uint32_t)l + cnt < nv) ? rows[sym][(l + used + cnt) & 63u] : 0xFFu;
         const bool all_loaded = gpos >= gend;
         const uint32_t nv2 = all_loaded ? 64u : nv - (cnt < nv ? cnt : nv);
         const uint32_t left2 = left - (cnt < left ? cnt : left);
@@ -616,6 +627,9 @@ __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, con
             w.fast = rank_fast_limit(nv2, left2, all_loaded);
         }
         if (l == 0) meta[cur] = w;
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                  // lgkmcnt(0): the normalised row and its metadata are in LDS
+        rl = rows[sym][l];
+        m = meta[sym];
     }
 }
 
