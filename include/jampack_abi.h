@@ -114,6 +114,20 @@ JPK_API int jpk_jam_block_write(const uint8_t *in, int32_t in_len, int32_t block
  * runs past in_len, or a crc mismatch ("Detected corrupt block!", jampack.cpp:59). */
 JPK_API int jpk_jam_block_read(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len, int32_t *consumed);
 
+/* ---- pre-stage decoders + frames of the stock CLI (host code, no GPU involved) ------------ */
+/* Lz77::Decompress(Buffer,Buffer)                      lz77.hpp:22, lz77.cpp:678-714 */
+JPK_API int jpk_lz77_decompress(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len);
+/* Lpx::Decode(Buffer,Buffer,Options)                   lpx.hpp:32, lpx.cpp:101-169 (output length = input length) */
+JPK_API int jpk_lpx_decode(const uint8_t *in, int32_t len, uint8_t *out);
+/* Filters::Decode(Buffer,Buffer)                       filters.hpp:44, filters.cpp:442-490 */
+JPK_API int jpk_filters_decode(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len);
+/* Checksum::IntegrityCheck on the host                 checksum.cpp:12-36 */
+JPK_API uint32_t jpk_checksum_host(const uint8_t *p, int32_t size);
+/* One frame written by an unmodified `jampack c` (any -m / -f setting): DecompReadBlock + the whole Jampack::Decomp()
+ * (jampack.cpp:47-60, 140-164) -- Ans::Decode and InverseBwt on the GPU, Lz77::Decompress, Lpx::Decode,
+ * Filters::Decode, Lz77::Decompress on the host, then the crc check.  *consumed = 15 + payload size. */
+JPK_API int jpk_jam_cli_block_read(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len, int32_t *consumed);
+
 /* ---- device-buffer entry points (all pointers except ctx/out_len are HBM addresses on ctx's device) ---- */
 JPK_API int jpk_dev_bwt_forward(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
 JPK_API int jpk_dev_bwt_inverse(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len_with_trailer, uint8_t *d_out, int32_t out_cap, int32_t *out_len);

@@ -61,6 +61,11 @@ _SIGS = {
     "jpk_checksum": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_uint32)]),
     "jpk_jam_block_write": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_jam_block_read": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p, _i32p]),
+    "jpk_lz77_decompress": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_lpx_decode": (C.c_int, [_vp, C.c_int32, _vp]),
+    "jpk_filters_decode": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_checksum_host": (C.c_uint32, [_vp, C.c_int32]),
+    "jpk_jam_cli_block_read": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p, _i32p]),
     "jpk_dev_bwt_forward": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_dev_bwt_inverse": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_dev_ans_encode": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),

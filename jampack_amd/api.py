@@ -167,6 +167,69 @@ def jam_decompress(stream) -> np.ndarray:
     return np.concatenate(out) if out else np.zeros(0, dtype=np.uint8)
 
 
+class Lz77:
+    """Decoder side of `class Lz77` (lz77.hpp:21-22); host code."""
+
+    def Decompress(self, buf, cap: int) -> np.ndarray:
+        t = _np_u8(buf)
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        n = C.c_int32(0)
+        _chk(lib().jpk_lz77_decompress(_ptr(t), len(t), out.ctypes.data, cap, C.byref(n)), "Lz77::Decompress")
+        return out[: n.value]
+
+
+class Lpx:
+    """Decoder side of `class Lpx` (lpx.hpp:31-32); host code."""
+
+    def Decode(self, buf) -> np.ndarray:
+        t = _np_u8(buf)
+        out = np.zeros(max(len(t), 1), dtype=np.uint8)
+        _chk(lib().jpk_lpx_decode(_ptr(t), len(t), out.ctypes.data), "Lpx::Decode")
+        return out[: len(t)]
+
+
+class Filters:
+    """Decoder side of `class Filters` (filters.hpp:43-44); host code."""
+
+    def Decode(self, buf, cap: int) -> np.ndarray:
+        t = _np_u8(buf)
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        n = C.c_int32(0)
+        _chk(lib().jpk_filters_decode(_ptr(t), len(t), out.ctypes.data, cap, C.byref(n)), "Filters::Decode")
+        return out[: n.value]
+
+
+def checksum_host(buf) -> int:
+    t = _np_u8(buf)
+    return int(lib().jpk_checksum_host(_ptr(t), len(t)))
+
+
+def jam_cli_block_read(stream, cap: int):
+    """One frame written by an unmodified `jampack c`: the whole Jampack::Decomp() (jampack.cpp:47-60), entropy decode and
+    inverse BWT on the GPU, the pre-stage decoders on the host.  Returns (block bytes, bytes consumed)."""
+    c = _np_u8(stream)
+    out = np.zeros(max(cap, 1), dtype=np.uint8)
+    n, used = C.c_int32(0), C.c_int32(0)
+    _chk(lib().jpk_jam_cli_block_read(_ptr(c), len(c), out.ctypes.data, cap, C.byref(n), C.byref(used)), "jam_cli_block_read")
+    return out[: n.value], used.value
+
+
+def jam_cli_decompress(stream) -> np.ndarray:
+    """`jampack d` over an in-memory .jam stream (Jampack::Decompress's block loop, jampack.cpp:262-336)."""
+    c = _np_u8(stream)
+    out, o = [], 0
+    while o < len(c):
+        if len(c) - o < JAM_HEADER:
+            raise JampackError(-3, "jam_cli_decompress: truncated header")
+        bs = int(np.frombuffer(c[o + 11: o + 15].tobytes(), dtype="<i4")[0])
+        if not (MIN_BLOCKSIZE <= bs <= MAX_BLOCKSIZE):
+            raise JampackError(-3, "jam_cli_decompress: Refusing to read from corrupt header!")
+        blk, used = jam_cli_block_read(c[o:], bs)
+        out.append(blk)
+        o += used
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.uint8)
+
+
 def _dptr(x):
     """device pointer of a torch CUDA tensor or a raw int"""
     if x is None:

@@ -2,6 +2,7 @@
 // host-buffer (drop-in) entry points, and the fused block pipeline.  No CPU fallback: without a gfx950 device
 // every entry point returns JPK_E_NODEVICE.
 #include <mutex>
+#include <vector>
 
 #include "common.hpp"
 
@@ -582,4 +583,35 @@ extern "C" int jpk_jam_block_read(const uint8_t *in, int32_t in_len, uint8_t *ou
     int rc = staged(jam_read_tramp, in, in_len, out, out_cap, out_len, false);
     if (rc == JPK_OK && consumed) *consumed = tls_consumed;
     return rc;
+}
+
+// One frame of the stock CLI: header (jampack.cpp:140-164), GPU stages, host pre-stage decoders in the order of
+// Jampack::Decomp() (jampack.cpp:47-57), crc check (jampack.cpp:58-59).
+extern "C" int jpk_jam_cli_block_read(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len, int32_t *consumed)
+{
+    if (!in || !out || !out_len || in_len < 0 || out_cap < 0) return JPK_E_ARG;
+    if (in_len < JPK_JAM_HEADER_BYTES) return JPK_E_CORRUPT;
+    uint32_t crc;
+    int32_t csize, block_size;
+    memcpy(&crc, in + 3, 4);
+    memcpy(&csize, in + 7, 4);
+    memcpy(&block_size, in + 11, 4);
+    if (memcmp(in, "JAM", 3) != 0 || !jam_block_size_ok(block_size) || csize < 0 || csize > JPK_MAX_BLOCKSIZE) return JPK_E_CORRUPT;
+    if ((int64_t)csize + JPK_JAM_HEADER_BYTES > in_len) return JPK_E_CORRUPT;
+    const int64_t cap64 = (int64_t)((double)block_size * 1.05) + 4096;             // the reference's stage buffers, jampack.cpp:156
+    if (cap64 > 0x7fffffff) return JPK_E_ARG;
+    const int32_t cap = (int32_t)cap64;
+    std::vector<uint8_t> a, b;
+    try { a.resize((size_t)cap); b.resize((size_t)cap); } catch (...) { return JPK_E_ALLOC; }
+    int32_t n = 0;
+    JPK_TRY(jpk_block_decompress(in + JPK_JAM_HEADER_BYTES, csize, a.data(), cap, &n));     // Ans::Decode + InverseBwt
+    int32_t m = 0;
+    JPK_TRY(jpk_lz77_decompress(a.data(), n, b.data(), cap, &m));                            // Lz->Decompress
+    JPK_TRY(jpk_lpx_decode(b.data(), m, a.data()));                                          // LocalModel->Decode
+    JPK_TRY(jpk_filters_decode(a.data(), m, b.data(), cap, &n));                             // Filter->Decode
+    JPK_TRY(jpk_lz77_decompress(b.data(), n, out, out_cap, &m));                             // Lz->Decompress
+    if (jpk_checksum_host(out, m) != crc) return JPK_E_CORRUPT;                              // "Detected corrupt block!"
+    *out_len = m;
+    if (consumed) *consumed = csize + JPK_JAM_HEADER_BYTES;
+    return JPK_OK;
 }

@@ -13,7 +13,6 @@ using namespace jpk;
 
 namespace {
 
-constexpr int TB = 256;
 
 struct ChunkInfo {          // one per chunk, written by the header walk
     uint64_t in_off;        // payload offset in the input

@@ -1021,7 +1021,6 @@ __global__ __launch_bounds__(TB) void k_density(const uint8_t *__restrict__ in, 
 
 int run_rank(jpk_ctx *ctx, const uint8_t *d_in, const EncDims &d, EncBufs &b)
 {
-    hipStream_t st = ctx->stream;
     JPK_LAUNCH(ctx, PROF_ENC_HIST, d.len, k_enc_hist, dim3(d.tpc, d.ncl), dim3(TB), d_in, d, b.tilecnt, b.lastpos);
     JPK_LAUNCH(ctx, PROF_ENC_HIST, d.len, k_enc_prep, dim3(d.ncl), dim3(256), d, b.tilecnt, b.lastpos, b.freq, b.bstart);
     JPK_LAUNCH(ctx, PROF_ENC_MTF, d.len, k_enc_mtf, dim3((d.tpc + 3) / 4, d.ncl), dim3(TB), d_in, d, b.tilecnt, b.lastpos, b.bstart, b.ranks);
@@ -1031,7 +1030,6 @@ int run_rank(jpk_ctx *ctx, const uint8_t *d_in, const EncDims &d, EncBufs &b)
 
 int run_rle(jpk_ctx *ctx, const uint8_t *d_ranks, const EncDims &d, EncBufs &b)
 {
-    hipStream_t st = ctx->stream;
     JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, k_rle_lz, dim3(d.tpc, d.ncl), dim3(TB), d_ranks, d, b.lz);
     JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, k_rle_ext, dim3(jpk_grid(d.ncl, 64)), dim3(64), d, b.lz, b.ext);
     JPK_LAUNCH(ctx, PROF_ENC_RLE, d.len, (k_rle_tiles<false>), dim3(d.tpc, d.ncl), dim3(TB), d_ranks, d, b.ext, b.tcount, b.toff, b.rle, (size_t)d.chunk);
@@ -1043,7 +1041,6 @@ int run_rle(jpk_ctx *ctx, const uint8_t *d_ranks, const EncDims &d, EncBufs &b)
 
 int run_model(jpk_ctx *ctx, const uint16_t *d_rle, const uint32_t *d_rlen, const EncDims &d, EncBufs &b)
 {
-    hipStream_t st = ctx->stream;
     const size_t stride = d.chunk;
     JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_count, dim3(d.tpc, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.clscnt);
     JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_prefix, dim3(jpk_grid((size_t)d.ncl * 8, 64)), dim3(64), d, d_rlen, b.clscnt, b.clstotal);

@@ -242,6 +242,52 @@ class Ref:
         self.lib.ref_checksum.restype = C.c_uint32
         return int(self.lib.ref_checksum(_p(t, _u8p), C.c_int32(len(t))))
 
+    # ---- pre-stages and the whole block codec of the stock CLI ----
+    def _stage(self, fn, t, cap, *extra):
+        x = np.array(t, dtype=np.uint8, copy=True)
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        n = fn(_p(x, _u8p), C.c_int32(len(x)), _p(out, _u8p), *extra)
+        if n < 0:
+            raise OracleError(f"reference stage failed ({n})")
+        return out[:n]
+
+    def lz77_compress(self, t, match_finder: int = 0, block_size: int = 8 << 20) -> np.ndarray:
+        return self._stage(self.lib.ref_lz77_compress, t, int(len(t) * 1.05) + 4096, C.c_int32(match_finder), C.c_int32(block_size))
+
+    def lz77_decompress(self, t, cap: int) -> np.ndarray:
+        return self._stage(self.lib.ref_lz77_decompress, t, cap + 64)
+
+    def lpx_encode(self, t) -> np.ndarray:
+        return self._stage(self.lib.ref_lpx_encode, t, len(t) + 64)
+
+    def lpx_decode(self, t) -> np.ndarray:
+        return self._stage(self.lib.ref_lpx_decode, t, len(t) + 64)
+
+    def filters_encode(self, t, filters: int = 1) -> np.ndarray:
+        return self._stage(self.lib.ref_filters_encode, t, int(len(t) * 1.05) + 4096, C.c_int32(filters))
+
+    def filters_decode(self, t, cap: int) -> np.ndarray:
+        return self._stage(self.lib.ref_filters_decode, t, cap + 64)
+
+    def jam_comp_block(self, t, block_size: int = 1 << 20, match_finder: int = 0, filters: int = 1) -> np.ndarray:
+        """one frame exactly as `jampack c` writes it: Comp() with all six stages + CompWriteBlock"""
+        x = np.array(t, dtype=np.uint8, copy=True)
+        cap = 15 + int(block_size * 1.05)
+        out = np.zeros(cap, dtype=np.uint8)
+        n = self.lib.ref_jam_comp_block(_p(x, _u8p), C.c_int32(len(x)), C.c_int32(block_size), C.c_int32(match_finder), C.c_int32(filters),
+                                        _p(out, _u8p), C.c_int32(cap))
+        if n < 0:
+            raise OracleError("reference frame does not fit")
+        return out[:n]
+
+    def jam_decomp_block(self, frame, cap: int) -> np.ndarray:
+        f = np.array(frame, dtype=np.uint8, copy=True)
+        out = np.zeros(max(cap, 1), dtype=np.uint8)
+        n = self.lib.ref_jam_decomp_block(_p(f, _u8p), C.c_int32(len(f)), _p(out, _u8p), C.c_int32(cap))
+        if n < 0:
+            raise OracleError(f"reference block decode failed ({n})")
+        return out[:n]
+
     def divsufsort(self, t: np.ndarray) -> np.ndarray:
         t = np.ascontiguousarray(t, dtype=np.uint8)
         sa = np.zeros(len(t), dtype=np.int32)

@@ -14,6 +14,10 @@
 //   Utils::EncodeLeb128 / DecodeLeb128        utils.cpp:22-90
 //   divsufsort                                divsufsort.cpp:1721
 //   Checksum::IntegrityCheck                  checksum.hpp:15, checksum.cpp:12-36
+//   Lz77::Compress / Decompress               lz77.hpp:21-22, lz77.cpp:100-714
+//   Lpx::Encode / Decode                      lpx.hpp:31-32,  lpx.cpp:146-170
+//   Filters::Encode / Decode                  filters.hpp:43-44, filters.cpp:287-490
+//   Jampack::Comp / Decomp + block frame      jampack.cpp:29-60, 122-164
 #include "bwt.hpp"
 #include "ans.hpp"
 #include "rank.hpp"
@@ -21,6 +25,20 @@
 #include "utils.hpp"
 #include "divsufsort.hpp"
 #include "checksum.hpp"
+#include "jampack.hpp"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static Options make_opt(int threads);
+static Options make_full_opt(int block_size, int match_finder, int filters, int threads)
+{
+	Options o = make_opt(threads);
+	o.BlockSize = block_size;
+	o.MatchFinder = (unsigned)match_finder;
+	o.Filters = (unsigned)filters;
+	return o;
+}
 
 static Options make_opt(int threads)
 {
@@ -126,6 +144,98 @@ unsigned int ref_checksum(unsigned char* p, int size)
 	Checksum c;
 	Buffer b{p, &size};
 	return c.IntegrityCheck(b);
+}
+
+// ---- pre-stages and the whole block codec of the stock CLI -------------------------
+int ref_lz77_compress(unsigned char* in, int len, unsigned char* out, int match_finder, int block_size)
+{
+	int isz = len, osz = 0;
+	Buffer I{in, &isz}, O{out, &osz};
+	Lz77 lz;
+	lz.Compress(I, O, make_full_opt(block_size, match_finder, 0, 1));
+	return osz;
+}
+
+int ref_lz77_decompress(unsigned char* in, int len, unsigned char* out)
+{
+	int isz = len, osz = 0;
+	Buffer I{in, &isz}, O{out, &osz};
+	Lz77 lz;
+	lz.Decompress(I, O);
+	return osz;
+}
+
+int ref_lpx_encode(unsigned char* in, int len, unsigned char* out)
+{
+	int isz = len, osz = 0;
+	Buffer I{in, &isz}, O{out, &osz};
+	Lpx p;
+	p.Encode(I, O, make_opt(1));
+	return osz;
+}
+
+int ref_lpx_decode(unsigned char* in, int len, unsigned char* out)
+{
+	int isz = len, osz = 0;
+	Buffer I{in, &isz}, O{out, &osz};
+	Lpx p;
+	p.Decode(I, O, make_opt(1));
+	return osz;
+}
+
+int ref_filters_encode(unsigned char* in, int len, unsigned char* out, int filters)
+{
+	int isz = len, osz = 0;
+	Buffer I{in, &isz}, O{out, &osz};
+	Filters f;
+	f.Encode(I, O, make_full_opt(8 << 20, 0, filters, 1));
+	return osz;
+}
+
+int ref_filters_decode(unsigned char* in, int len, unsigned char* out)
+{
+	int isz = len, osz = 0;
+	Buffer I{in, &isz}, O{out, &osz};
+	Filters f;
+	f.Decode(I, O);
+	return osz;
+}
+
+// One framed block exactly as the stock CLI writes it: Jampack::Comp() (all six stages) + CompWriteBlock.
+// len <= block_size; frame must hold 15 + 1.05 * block_size bytes.  Returns the frame length.
+int ref_jam_comp_block(unsigned char* in, int len, int block_size, int match_finder, int filters, unsigned char* frame, int frame_cap)
+{
+	Jampack j;
+	j.InitComp(make_full_opt(block_size, match_finder, filters, 1));
+	memcpy(j.Input.block, in, (size_t)len);
+	*j.Input.size = len;
+	j.Comp();
+	char* buf = NULL;
+	size_t n = 0;
+	FILE* f = open_memstream(&buf, &n);
+	j.CompWriteBlock(f);
+	fclose(f);
+	int r = -1;
+	if ((long)n <= (long)frame_cap) { memcpy(frame, buf, n); r = (int)n; }
+	free(buf);
+	j.Free();
+	return r;
+}
+
+// DecompReadBlock + Decomp() of one frame; returns the decoded length (the reference exits on a crc mismatch)
+int ref_jam_decomp_block(unsigned char* frame, int frame_len, unsigned char* out, int out_cap)
+{
+	Jampack j;
+	j.InitDecomp(make_opt(1));
+	FILE* f = fmemopen(frame, (size_t)frame_len, "rb");
+	int got = j.DecompReadBlock(f);
+	fclose(f);
+	if (got <= 0) { j.Free(); return -1; }
+	j.Decomp();
+	int n = *j.Output.size;
+	if (n <= out_cap) memcpy(out, j.Output.block, (size_t)n); else n = -2;
+	j.Free();
+	return n;
 }
 
 int ref_divsufsort(const unsigned char* t, int* sa, int n)
