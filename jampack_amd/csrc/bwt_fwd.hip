@@ -359,31 +359,41 @@ __global__ __launch_bounds__(TB) void k_large_gather(const uint32_t *__restrict_
     l_pos[p] = j;
 }
 
-__global__ __launch_bounds__(TB) void k_make_keys(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, uint32_t m, uint32_t n,
-                                                 uint32_t h, const uint32_t *__restrict__ ISA, uint64_t *__restrict__ keys,
-                                                 uint32_t *__restrict__ vals, uint32_t *__restrict__ hv)
+// old-group head positions in the large list (input of the max scan that gives every element its group's head)
+__global__ __launch_bounds__(TB) void k_large_heads(const uint32_t *__restrict__ a_grp, uint32_t m, uint32_t *__restrict__ hv)
 {
     uint32_t j = blockIdx.x * TB + threadIdx.x;
     if (j >= m) return;
-    uint32_t s = a_sa[j], g = a_grp[j];
-    uint64_t s2 = (uint64_t)s + h;
-    uint32_t k2 = (s2 < n) ? ISA[s2] + 1u : 0u;
-    keys[j] = ((uint64_t)g << 32) | k2;
-    vals[j] = s;
-    // old-group head positions in the list (groups stay contiguous through the sort)
-    bool head = (j == 0) || (a_grp[j - 1] != g);
+    bool head = (j == 0) || (a_grp[j - 1] != a_grp[j]);
     hv[j] = head ? j : 0u;
 }
 
-// abs position of element j after the sort = group rank + offset inside the (old) group;
-// new head flag from the full 64-bit key; nh[j] = newhead ? abspos : 0 (input of the max scan)
-__global__ __launch_bounds__(TB) void k_abspos(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ jhead, uint32_t m,
-                                              uint32_t *__restrict__ abspos, uint32_t *__restrict__ nh)
+// Sort key of a large-group element: (group id << 32) | rank of suffix + h.  Every group on this path has more than
+// 1024 elements, so its head position in the list divided by 1024 is a dense, order-preserving id: the group digits
+// need bits(list length / 1024) instead of bits(n) -- two radix passes instead of four on a 64 MiB block.
+__global__ __launch_bounds__(TB) void k_make_keys(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ jhead, uint32_t m, uint32_t n,
+                                                 uint32_t h, const uint32_t *__restrict__ ISA, uint64_t *__restrict__ keys,
+                                                 uint32_t *__restrict__ vals)
+{
+    uint32_t j = blockIdx.x * TB + threadIdx.x;
+    if (j >= m) return;
+    uint32_t s = a_sa[j];
+    uint64_t s2 = (uint64_t)s + h;
+    uint32_t k2 = (s2 < n) ? ISA[s2] + 1u : 0u;
+    keys[j] = ((uint64_t)(jhead[j] >> 10) << 32) | k2;
+    vals[j] = s;
+}
+
+// abs position of element j after the sort = group rank + offset inside the (old) group (groups keep their index
+// ranges through the sort, so the pre-sort group array still applies); new head flag from the full 64-bit key;
+// nh[j] = newhead ? abspos : 0 (input of the max scan).  grp and nh may alias.
+__global__ __launch_bounds__(TB) void k_abspos(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ jhead, const uint32_t *grp, uint32_t m,
+                                              uint32_t *__restrict__ abspos, uint32_t *nh)
 {
     uint32_t j = blockIdx.x * TB + threadIdx.x;
     if (j >= m) return;
     uint64_t k = keys[j];
-    uint32_t ap = (uint32_t)(k >> 32) + (j - jhead[j]);
+    uint32_t ap = grp[j] + (j - jhead[j]);
     abspos[j] = ap;
     bool head = (j == 0) || (keys[j - 1] != k);
     nh[j] = head ? ap : 0u;
@@ -506,11 +516,6 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b, uint32_t **i
 
     const int kbits = jpk_bits_for(n);     // key2 <= n, group rank < n
     const int key_passes = getenv("JPK_DBG_NOSORT") ? 0 : (kbits + 7) / 8;   // debug: time k_seg_round without its LDS sort
-    int shifts[8];
-    int ns = 0;
-    for (int s = 0; s < kbits; s += 8) shifts[ns++] = s;
-    for (int s = 0; s < kbits; s += 8) shifts[ns++] = 32 + s;
-
     uint32_t *isa_cur = b.ISA0, *isa_nxt = b.ISA1;
     uint64_t h = 7;
     while (m > 0) {
@@ -531,11 +536,17 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b, uint32_t **i
             const unsigned g_l = jpk_grid(lc, TB);
             uint32_t *l_sa = b.valsB, *l_grp = b.t3;
             JPK_LAUNCH(ctx, PROF_SA_KEYS, lc, k_large_gather, dim3(g_m), dim3(TB), b.t1, b.t2, b.a_sa, b.a_grp, m, l_sa, l_grp, b.l_pos);
-            JPK_LAUNCH(ctx, PROF_SA_KEYS, lc, k_make_keys, dim3(g_l), dim3(TB), l_sa, l_grp, lc, n, (uint32_t)h, isa_cur, b.keysA, b.valsA, b.t1);
+            JPK_LAUNCH(ctx, PROF_SA_KEYS, lc, k_large_heads, dim3(g_l), dim3(TB), l_grp, lc, b.t1);
             JPK_TRY(jpk_inclusive_max_u32(ctx, b.t1, b.t2, lc, b.scratch));               // t2 = jhead (old groups)
-            JPK_TRY(jpk_radix_sort_pairs_u64(ctx, b.keysA, b.valsA, b.keysB, b.valsB, lc, shifts, ns, b.scratch));
+            JPK_LAUNCH(ctx, PROF_SA_KEYS, lc, k_make_keys, dim3(g_l), dim3(TB), l_sa, b.t2, lc, n, (uint32_t)h, isa_cur, b.keysA, b.valsA);
+            int lshifts[8];
+            int lns = 0;
+            for (int s = 0; s < kbits && lns < key_passes; s += 8) lshifts[lns++] = s;
+            const int gbits = jpk_bits_for(lc >> 10);
+            for (int s = 0; s < gbits; s += 8) lshifts[lns++] = 32 + s;
+            JPK_TRY(jpk_radix_sort_pairs_u64(ctx, b.keysA, b.valsA, b.keysB, b.valsB, lc, lshifts, lns, b.scratch));
             ctx->stats.sa_sorted_elems += lc;
-            JPK_LAUNCH(ctx, PROF_SA_RERANK, lc, k_abspos, dim3(g_l), dim3(TB), b.keysA, b.t2, lc, b.t1, b.t3);  // t1 = abspos, t3 = nh
+            JPK_LAUNCH(ctx, PROF_SA_RERANK, lc, k_abspos, dim3(g_l), dim3(TB), b.keysA, b.t2, l_grp, lc, b.t1, b.t3);  // t1 = abspos, t3 = nh (over l_grp)
             JPK_TRY(jpk_inclusive_max_u32(ctx, b.t3, b.t2, lc, b.scratch));               // t2 = newrank
             JPK_LAUNCH(ctx, PROF_SA_RERANK, lc, k_large_finish, dim3(g_l), dim3(TB), b.t1, b.t2, b.valsA, b.l_pos, lc, isa_nxt, b.SA, b.b_sa, b.b_grp,
                        b.keep);
