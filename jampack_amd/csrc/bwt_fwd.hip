@@ -91,6 +91,9 @@ __global__ __launch_bounds__(TB) void k_compact(const uint32_t *__restrict__ kee
 constexpr int SEG_TILE = 1024;             // a workgroup owns the groups that START in its SEG_TILE window
 constexpr int SEG_SPAN = 2 * SEG_TILE;     // ... and therefore sees at most this many elements
 constexpr int SEG_ITEMS = SEG_SPAN / TB;   // 8
+constexpr int SEG_DBITS = 9;               // digit width of the LDS sort: (26-bit rank, 10-bit local group) = 36 bits = 4 passes
+constexpr int SEG_DIGITS = 1 << SEG_DBITS;
+static_assert(SEG_DIGITS == 2 * TB, "two digits per thread in the digit scan");
 
 // lasthead[w] = 1 + (largest group-head index inside window w), 0 if the window has no head
 __global__ __launch_bounds__(TB) void k_win_heads(const uint32_t *__restrict__ a_grp, uint32_t m, uint32_t *__restrict__ lasthead)
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(TB) void k_win_heads(const uint32_t *__restrict__ a
 
 // the sort / re-rank of all groups of <= SEG_TILE elements, one window per workgroup
 __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, uint32_t m, uint32_t n,
-                                                 uint32_t h, int key_passes, const uint32_t *__restrict__ winscan /* inclusive max-scan of lasthead */,
+                                                 uint32_t h, int key_bits, const uint32_t *__restrict__ winscan /* inclusive max-scan of lasthead */,
                                                  const uint32_t *__restrict__ ISA_cur, uint32_t *__restrict__ ISA_nxt, uint32_t *__restrict__ SA,
                                                  uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint32_t *__restrict__ lflag, uint32_t *__restrict__ keep,
                                                  uint32_t *__restrict__ large_count)
@@ -124,8 +127,8 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
     __shared__ uint16_t gsl[SEG_SPAN];        // group start (local position) per loaded element, 0xFFFF = spill-in
     __shared__ uint16_t lgid[SEG_SPAN];       // local group id of the owned elements
     __shared__ uint16_t idxA[SEG_SPAN], idxB[SEG_SPAN];
-    __shared__ uint32_t cnt[TB / 64][256];
-    __shared__ uint32_t dbase[256];
+    __shared__ uint32_t cnt[TB / 64][SEG_DIGITS];
+    __shared__ uint32_t dbase[SEG_DIGITS];
     __shared__ uint32_t sm[TB / 64 + 1];
     __shared__ uint32_t s_fo, s_oe;
 
@@ -248,19 +251,19 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
     __syncthreads();
     const uint32_t ngroups = (uint32_t)lgid[no - 1] + 1u;
 
-    // ---- LSD radix sort of the index permutation by (lgid, key2): key2 digits first, then group id ----
+    // ---- LSD radix sort of the index permutation by the composite key (lgid << key_bits) | key2, 9 bits per pass ----
     uint16_t *src = idxA, *dst = idxB;
     const int w = tid >> 6, l = tid & 63;
     const uint64_t lt = lanemask_lt();
-    const int gpasses = (ngroups <= 256u) ? 1 : 2;
-    const int npass = (ngroups > 1u) ? key_passes + gpasses : key_passes;
+    const int gbits = (ngroups > 1u) ? 32 - __clz((int)(ngroups - 1u)) : 0;
+    const int npass = key_bits > 0 ? (key_bits + gbits + SEG_DBITS - 1) / SEG_DBITS : 0;
     // each wave ranks a contiguous quarter of the owned range: only ceil(no / 256) iterations of 64 are live
     const int nit = (int)((no + TB - 1) / TB);
     const uint32_t wspan = (uint32_t)nit * 64u;
     for (int pass = 0; pass < npass; pass++) {
-        const bool on_key = pass < key_passes;
-        const int shift = on_key ? 8 * pass : 8 * (pass - key_passes);
-        for (int i = tid; i < (TB / 64) * 256; i += TB) (&cnt[0][0])[i] = 0;
+        const int shift = SEG_DBITS * pass;
+        const int part = (shift + SEG_DBITS <= key_bits) ? 0 : (shift >= key_bits ? 2 : 1);   // digit from key2 / both / group id
+        for (int i = tid; i < (TB / 64) * SEG_DIGITS; i += TB) (&cnt[0][0])[i] = 0;
         __syncthreads();
         uint32_t rk[SEG_ITEMS], dg[SEG_ITEMS];
 #pragma unroll
@@ -269,22 +272,32 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
             const uint32_t q = w * wspan + it * 64 + l;
             const bool valid = q < no;
             const uint32_t id = valid ? src[q] : 0u;
-            const uint32_t d = valid ? (((on_key ? k2[id] : (uint32_t)lgid[id]) >> shift) & 255u) : 0u;
-            dg[it] = d | (id << 8);
-            const uint64_t mm = match_any8(d, valid);
+            uint32_t d;
+            if (part == 0) d = k2[id] >> shift;
+            else if (part == 2) d = (uint32_t)lgid[id] >> (shift - key_bits);
+            else d = (k2[id] >> shift) | ((uint32_t)lgid[id] << (key_bits - shift));
+            d = valid ? (d & (uint32_t)(SEG_DIGITS - 1)) : 0u;
+            dg[it] = d | (id << SEG_DBITS);
+            const uint64_t mm = match_any<SEG_DBITS>(d, valid);
             const uint32_t below = (uint32_t)__popcll(mm & lt);
             const uint32_t c = valid ? cnt[w][d] : 0u;
             rk[it] = c + below;
             if (valid && below == 0) cnt[w][d] = c + (uint32_t)__popcll(mm);
         }
         __syncthreads();
-        {   // per digit: exclusive over waves, then exclusive over digits
-            const int d = tid;
-            uint32_t s = 0;
+        {   // per digit: exclusive over waves, then exclusive over digits (two digits per thread, in digit order)
+            uint32_t s2[2];
 #pragma unroll
-            for (int k = 0; k < TB / 64; k++) { uint32_t t = cnt[k][d]; cnt[k][d] = s; s += t; }
-            uint32_t inc = block_incl_scan<OpSum>(s, sm, nullptr);
-            dbase[d] = inc - s;
+            for (int e = 0; e < 2; e++) {
+                const int d = 2 * tid + e;
+                uint32_t s = 0;
+#pragma unroll
+                for (int k = 0; k < TB / 64; k++) { uint32_t t = cnt[k][d]; cnt[k][d] = s; s += t; }
+                s2[e] = s;
+            }
+            const uint32_t inc = block_incl_scan<OpSum>(s2[0] + s2[1], sm, nullptr);
+            dbase[2 * tid] = inc - s2[0] - s2[1];
+            dbase[2 * tid + 1] = inc - s2[1];
         }
         __syncthreads();
 #pragma unroll
@@ -292,8 +305,8 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
             if (it >= nit) break;
             const uint32_t q = w * wspan + it * 64 + l;
             if (q < no) {
-                const uint32_t d = dg[it] & 255u;
-                dst[dbase[d] + cnt[w][d] + rk[it]] = (uint16_t)(dg[it] >> 8);
+                const uint32_t d = dg[it] & (uint32_t)(SEG_DIGITS - 1);
+                dst[dbase[d] + cnt[w][d] + rk[it]] = (uint16_t)(dg[it] >> SEG_DBITS);
             }
         }
         __syncthreads();
@@ -526,7 +539,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b, uint32_t **i
         JPK_LAUNCH(ctx, PROF_SA_KEYS, m, k_win_heads, dim3(nwin), dim3(TB), b.a_grp, m, b.win);
         JPK_TRY(jpk_inclusive_max_u32(ctx, b.win, b.win, nwin, b.scratch));
         JPK_HIP(hipMemsetAsync(ctx->d_mail + 4, 0, 4, st));
-        JPK_LAUNCH(ctx, PROF_SA_SEG, m, k_seg_round, dim3(nwin), dim3(TB), b.a_sa, b.a_grp, m, n, (uint32_t)h, key_passes, b.win, isa_cur, isa_nxt,
+        JPK_LAUNCH(ctx, PROF_SA_SEG, m, k_seg_round, dim3(nwin), dim3(TB), b.a_sa, b.a_grp, m, n, (uint32_t)h, key_passes ? kbits : 0, b.win, isa_cur, isa_nxt,
                    b.SA, b.b_sa, b.b_grp, b.t1, b.keep, ctx->d_mail + 4);              // t1 = lflag
         uint32_t mailw[5];
         JPK_TRY(jpk_read_mail(ctx, mailw, 5));

@@ -80,18 +80,20 @@ __device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t *sm, ui
     return Op::f(prefix, inc);
 }
 
-// lanes of this wave whose 8-bit digit equals mine (valid lanes only)
-__device__ __forceinline__ uint64_t match_any8(uint32_t d, bool valid)
+// lanes of this wave whose BITS-bit digit equals mine (valid lanes only)
+template <int BITS>
+__device__ __forceinline__ uint64_t match_any(uint32_t d, bool valid)
 {
     uint64_t m = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
+    for (int b = 0; b < BITS; b++) {
         const bool bit = (d >> b) & 1u;
         const uint64_t bal = __ballot(bit);
         m &= bit ? bal : ~bal;
     }
     return m;
 }
+__device__ __forceinline__ uint64_t match_any8(uint32_t d, bool valid) { return match_any<8>(d, valid); }
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
