@@ -746,30 +746,35 @@ __device__ __forceinline__ uint32_t emit_word(uint32_t x, uint32_t xmax)
 // One encoder step on every lane at once (see k_rans_lanes): the state comes from the lane on the left (DPP row
 // rotate), keep = the state this lane had to start from once its turn came (captured when `turn` selects the lane).
 // Cost on one wave (tools/issuetest.hip): every VALU instruction is 4 cycles whatever it does, so the step is kept to
-// twelve of them, written as one block because the order carries the wait states gfx940+ needs and the compiler
+// twelve of them, written as one block (two steps per asm statement) because the order carries the wait states gfx940+ needs and the compiler
 // cannot see into asm: two between a VALU write of an SGPR mask and the VALU reading it (cmp b2 .. select u,
 // cmp b1 .. select xr) and two between the write of the new state and the next step's DPP read (capture + s_nop).
 // After renormalisation xr < freq << 15, so q = xr / freq < 2^15 and 65536 - freq < 2^16: the second product fits the
 // 24-bit multiply-add, which also ignores the shift count kept in the top byte of r.w.
-__device__ __forceinline__ uint32_t rans_step_turn(uint32_t xprev, const uint4 r, uint32_t &keep, uint64_t turn)
+// two consecutive steps (turns ta, tb) in one block: the compiler adds a wait state after every asm statement
+#define JPK_RANS_STEP_ASM(XIN, XPREV, XOUT, TURN)                                                        \
+        "v_mov_b32_dpp " XIN ", " XPREV " row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                       \
+        "v_lshrrev_b32 %[x8], 8, " XIN "\n\t"                                                             \
+        "v_cmp_ge_u32_e64 %[b2], %[x8], %[xmax]\n\t"    /* b2 = (x >> 8) >= xmax: two bytes leave (implies b1) */ \
+        "v_cmp_ge_u32_e64 %[b1], " XIN ", %[xmax]\n\t"  /* b1 = x >= xmax: one byte leaves */              \
+        "v_lshrrev_b32 %[x16], 16, " XIN "\n\t"                                                           \
+        "v_cndmask_b32_e64 %[u], %[x8], %[x16], %[b2]\n\t"     /* u = b2 ? x >> 16 : x >> 8 */            \
+        "v_cndmask_b32_e64 %[xr], " XIN ", %[u], %[b1]\n\t"    /* xr = b1 ? u : x */                      \
+        "v_mul_hi_u32 %[q], %[xr], %[rcp]\n\t"                                                            \
+        "v_lshrrev_b32_sdwa %[q], %[w], %[q] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t" \
+        "v_add_u32 %[t], %[xr], %[bias]\n\t"                                                              \
+        "v_mad_u32_u24 " XOUT ", %[q], %[w], %[t]\n\t"  /* == ((xr / freq) << 16) + xr % freq + low */     \
+        "v_cndmask_b32_e64 %[keep], %[keep], " XIN ", " TURN "\n\t"  /* my turn: remember the state I started from */ \
+        "s_nop 0\n\t"
+__device__ __forceinline__ uint32_t rans_step_turn2(uint32_t xprev, const uint4 r, uint32_t &keep, uint64_t ta, uint64_t tb)
 {
-    uint32_t xin, x8, x16, u, xr, q, t, xn;
+    uint32_t xin, x8, x16, u, xr, q, t, xm, xn;
     uint64_t b1, b2;
-    asm("v_mov_b32_dpp %0, %11 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_lshrrev_b32 %1, 8, %0\n\t"
-        "v_cmp_ge_u32_e64 %9, %1, %12\n\t"             // b2 = (x >> 8) >= xmax: two bytes leave (implies b1)
-        "v_cmp_ge_u32_e64 %8, %0, %12\n\t"             // b1 = x >= xmax: one byte leaves
-        "v_lshrrev_b32 %2, 16, %0\n\t"
-        "v_cndmask_b32_e64 %3, %1, %2, %9\n\t"         // u = b2 ? x >> 16 : x >> 8
-        "v_cndmask_b32_e64 %4, %0, %3, %8\n\t"         // xr = b1 ? u : x
-        "v_mul_hi_u32 %5, %4, %13\n\t"
-        "v_lshrrev_b32_sdwa %5, %15, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t"
-        "v_add_u32 %6, %4, %14\n\t"
-        "v_mad_u32_u24 %7, %5, %15, %6\n\t"            // == ((xr / freq) << 16) + xr % freq + low
-        "v_cndmask_b32_e64 %10, %10, %0, %16\n\t"      // my turn: remember the state I started from
-        "s_nop 0"
-        : "=&v"(xin), "=&v"(x8), "=&v"(x16), "=&v"(u), "=&v"(xr), "=&v"(q), "=&v"(t), "=&v"(xn), "=&s"(b1), "=&s"(b2), "+v"(keep)
-        : "v"(xprev), "v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w), "s"(turn));
+    asm(JPK_RANS_STEP_ASM("%[xin]", "%[xprev]", "%[xm]", "%[ta]")
+        JPK_RANS_STEP_ASM("%[xin]", "%[xm]", "%[xn]", "%[tb]")
+        : [xin] "=&v"(xin), [x8] "=&v"(x8), [x16] "=&v"(x16), [u] "=&v"(u), [xr] "=&v"(xr), [q] "=&v"(q), [t] "=&v"(t), [xm] "=&v"(xm),
+          [xn] "=&v"(xn), [b1] "=&s"(b1), [b2] "=&s"(b2), [keep] "+v"(keep)
+        : [xprev] "v"(xprev), [xmax] "v"(r.x), [rcp] "v"(r.y), [bias] "v"(r.z), [w] "v"(r.w), [ta] "s"(ta), [tb] "s"(tb));
     return xn;
 }
 
@@ -825,7 +830,8 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
         const int32_t k = (KTOP) - s;                                                                      \
         const bool live = k >= 0 && k <= kmax;                                                             \
         const uint4 rr = live ? REC : ident;                                                               \
-        _Pragma("unroll") for (int st = 0; st < 16; st++) x = rans_step_turn(x, rr, keep, 0x0001000100010001ull << st); \
+        _Pragma("unroll") for (int st = 0; st < 16; st += 2)                                               \
+            x = rans_step_turn2(x, rr, keep, 0x0001000100010001ull << st, 0x0001000100010001ull << (st + 1)); \
         const uint32_t e = live ? emit_word(keep, rr.x) : 0u;                                              \
         if (live) em[k] = e;                                                                               \
         const uint32_t cn = e >> 16;                                                                       \
