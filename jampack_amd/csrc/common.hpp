@@ -42,8 +42,7 @@ struct jpk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    // entropy stage: chunk groups, densest first; group g's serial rANS kernel runs on aux[g] beside the parallel
-    // stages of the later groups (which stay on `stream`)
+    // entropy stage: chunk groups, densest first; group g runs the whole stage on aux[g], the last group on `stream`
     static constexpr int ENC_GROUPS = 4;
     hipStream_t aux[ENC_GROUPS - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_pre[ENC_GROUPS] = {nullptr, nullptr, nullptr, nullptr}, ev_done[ENC_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
