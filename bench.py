@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- block hot path throughput on MI355X (see DESIGN.md section "Measurement").
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--workload enwik8|enwik9|...]
 
 A "step" = one pass of the compress hot path (forward BWT -> rANS encode, Jampack::Comp() tail, jampack.cpp:40-41)
-over one batch = the enwik8-like workload (100 000 000 B, BASELINE.json configs[1]) cut into 64 MiB blocks
-(67 108 864 + 32 891 136 B), inputs already resident in HBM.  For N > 1 every rank compresses its own batch
-(blocks are independent, jampack.cpp:215: weak scaling) and the compressed blocks are gathered on rank 0 with RCCL.
-value = uncompressed bytes of all ranks / max-over-ranks time, in MB/s (1e6 B/s).
+over one batch of 64 MiB blocks, inputs already resident in HBM.
 
-Extra keys on the same JSON line: `decompress` (rANS decode -> inverse BWT over the same batch), per-stage
-timings, `roofline` for the dominant kernel (HIP-event timed inside the library on the launch stream) and
-`cpu_baseline` (the real reference, oracle/_ref, on this box's host cores; rank 0, N = 1 only).
+  default (BASELINE.json configs[1], the configuration the metric is quoted on):  the enwik8-like workload
+      (100 000 000 B -> blocks of 67 108 864 + 32 891 136 B).  With N > 1 every rank compresses a batch of its own
+      (blocks are independent, jampack.cpp:215) and the compressed blocks are gathered on rank 0 with RCCL: weak scaling.
+  --workload enwik9 (BASELINE.json configs[3]):  ONE 1 000 000 000-B stream -> 15 blocks, block b owned by rank
+      b mod N (jampack_amd/shard.py), compressed blocks gathered on rank 0 in block order = the .jam payload order of
+      jampack.cpp:220-224: strong scaling.
+
+value = uncompressed bytes of the whole job / max-over-ranks time, in MB/s (1e6 B/s).
+
+N > 1 without a launcher: `python bench.py --gpus N` starts N child processes itself (one per GPU, before anything touches
+the GPU in the parent); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it uses the ranks it
+is given.  A --gpus that disagrees with WORLD_SIZE is an error, never a silent 1-GPU run.
+
+Extra keys on the same JSON line: `decompress` (rANS decode -> inverse BWT over the same batch), per-stage timings over
+warmed repetitions, `roofline` for the dominant kernel (HIP-event timed inside the library on the launch stream),
+`sa_rounds` (active suffixes per doubling round), `phrase_book_variant`, and `cpu_baseline` (the real reference,
+oracle/_ref, on this box's host cores; rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,34 +39,42 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 
+PROFILE_ROUND = "r02"
 
-# algorithmic HBM bytes per processed unit of every timed kernel class
+# algorithmic HBM bytes per processed unit of every timed kernel class, and what the class is
+# actually limited by ("hbm": streaming traffic; "hbm-random": 4-byte gathers/scatters, priced per 64-byte line in
+# DESIGN.md; "issue": instruction issue of single waves walking serial chains)
 ALG_BYTES_PER_UNIT = {
-    "k_rs_hist": (8, "sorted (key,value) pair"),
-    "k_rs_scatter": (24, "sorted (key,value) pair"),
-    "k_scan_*": (12, "u32 element"),
-    "k_init_keys/k_make_keys/k_win_heads": (12, "suffix"),
-    "k_seg_round": (28, "active suffix"),
-    "sa rerank kernels": (16, "suffix"),
-    "k_bwt_gather": (6, "block byte"),
-    "k_enc_hist/k_enc_prep": (1, "block byte"),
-    "k_enc_mtf": (2, "block byte"),
-    "k_rle_*": (2, "block byte"),
-    "k_cls_*/k_quasi_build": (9, "RLE0 symbol"),
-    "k_adaptive": (15, "RLE0 symbol"),
-    "k_pairs": (44, "RLE0 symbol"),
-    "k_rans_lanes": (20, "rANS pair"),
-    "k_emit_scan/k_put_*": (13, "rANS pair"),
+    "k_rs_hist": (8, "sorted (key,value) pair", "hbm"),
+    "k_rs_scatter": (24, "sorted (key,value) pair", "hbm"),
+    "k_scan_*": (12, "u32 element", "hbm"),
+    "k_init_keys/k_make_keys/k_win_heads": (12, "suffix", "hbm"),
+    "k_seg_round": (28, "active suffix", "hbm-random"),
+    "sa rerank kernels": (16, "suffix", "hbm-random"),
+    "k_bwt_gather": (6, "block byte", "hbm-random"),
+    "k_enc_hist/k_enc_prep": (1, "block byte", "hbm"),
+    "k_enc_mtf": (2, "block byte", "issue"),
+    "k_rle_*": (2, "block byte", "hbm"),
+    "k_cls_*/k_quasi_build": (9, "RLE0 symbol", "hbm"),
+    "k_adaptive": (15, "RLE0 symbol", "issue"),
+    "k_pairs": (44, "RLE0 symbol", "hbm"),
+    "k_rans_lanes": (20, "rANS pair", "issue"),
+    "k_emit_scan/k_put_*": (13, "rANS pair", "hbm"),
 }
+# algorithmic bytes per block byte of the four stages (c = compressed size / block size)
+STAGE_ALG = {"forward_bwt": lambda c: 10.0, "ans_encode": lambda c: 4.0 + c, "ans_decode": lambda c: 4.0 + c, "inverse_bwt": lambda c: 12.0}
 
 
 def pmc_traffic(kernel_class: str):
-    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (profiles/<round>_pmc_traffic.json:
     separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; KiB counters; reads x2 for the gfx950
     half-count of wide coalesced loads, MI355X_MICROARCH.md section HBM).  None if no PMC summary is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
+    for rnd in (PROFILE_ROUND, "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
+        if os.path.exists(path):
+            break
+    else:
+        return None, None
     tab = json.load(open(path))
     names = [n.strip().rstrip("*") for n in kernel_class.split("/")]
     fetch = write = launches = 0.0
@@ -63,7 +83,7 @@ def pmc_traffic(kernel_class: str):
             fetch += 2.0 * v["fetch_KiB_raw"] * 1024
             write += v["write_KiB"] * 1024
             launches += v["launches"]
-    return round((fetch + write) / launches) if launches else None
+    return (round((fetch + write) / launches) if launches else None), os.path.basename(path)
 
 
 FORCE_GATHER = bool(int(os.environ.get("JPK_FORCE_GATHER", "0")))      # exercise the RCCL gather with WORLD_SIZE=1 (test hook)
@@ -72,73 +92,151 @@ FORCE_GATHER = bool(int(os.environ.get("JPK_FORCE_GATHER", "0")))      # exercis
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="enwik8", choices=["enwik6", "enwik8", "enwik9", "silesia"])
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="enwik8", choices=["enwik6", "enwik8", "enwik8-phrase", "enwik9", "silesia"])
     ap.add_argument("--block-mib", type=int, default=64)
     ap.add_argument("--limit-bytes", type=int, default=0, help="truncate the workload (debug only; marks the line invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region (multi-GPU children print this anyway)")
     ap.add_argument("--contexts", type=int, default=2, help="blocks in flight per GPU (one context + HIP stream each)")
-    ap.add_argument("--cpu-sample-mib", type=int, default=24)
+    ap.add_argument("--cpu-sample-mib", type=int, default=64, help="bytes of block 0 the CPU reference is timed on")
+    ap.add_argument("--master-port", type=int, default=29511)
     return ap.parse_args()
 
 
-def cpu_baseline(block: np.ndarray, sample_mib: int):
-    """the reference itself (oracle/_ref/libjamref.so) on the host cores, bounded sample of the same block"""
+def launch_children(args) -> int:
+    """`python bench.py --gpus N` with no launcher: one fresh child per GPU.  The parent never initialises HIP/torch.cuda
+    (a process that has touched the GPU must not be replaced or forked on this pool); only rank 0 prints the JSON line."""
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(args.master_port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(blocks, sample_mib: int):
+    """The reference itself (oracle/_ref/libjamref_hot.so) on the host cores.  Sample = the first `sample_mib` MiB of
+    block 0 as one block (default: the whole 64 MiB block).  Three views, as SURVEY 8d asks:
+      Threads = nproc (`value`): ForwardBwt (divsufsort with OpenMP, divsufsort.cpp:1493) + Ans::Encode (single-threaded by
+      design, ans.cpp:113); Threads = 1; and blocks in parallel (jampack.cpp:215: one Jampack instance per thread), which is
+      the reference's own multi-core compress mode -- here every block of the batch on its own thread."""
+    import threading
     from oracle.pyoracle import Oracle, Ref
     cores = os.cpu_count() or 1
-    n = min(len(block), sample_mib << 20)
+    n = min(len(blocks[0]), sample_mib << 20)
     n -= n % 120
-    sample = np.ascontiguousarray(block[:n])
+    sample = np.ascontiguousarray(blocks[0][:n])
     kind = "reference" if Ref.available() else "port"
     impl = Ref() if kind == "reference" else Oracle()
-    t0 = time.perf_counter()
-    bwt = impl.bwt_forward(sample)
-    t1 = time.perf_counter()
-    enc = impl.ans_encode(bwt)
-    t2 = time.perf_counter()
-    if kind == "reference":
-        dec = impl.ans_decode(enc, len(bwt), threads=cores)
-        t3 = time.perf_counter()
-        back = impl.bwt_inverse(dec, threads=cores)
-    else:
-        dec = impl.ans_decode(enc, len(bwt))
-        t3 = time.perf_counter()
-        back = impl.bwt_inverse(dec)
-    t4 = time.perf_counter()
-    assert np.array_equal(back, sample)
     mb = n / 1e6
-    return {
-        "value": round(mb / (t2 - t0), 3), "unit": "MB/s", "cores": cores if kind == "reference" else 1, "kind": kind,
-        "sample": f"first {n} B of block 0 as one block: ForwardBwt (divsufsort, OpenMP {cores} threads) + Ans::Encode (single-threaded by design)",
-        "forward_bwt_MBps": round(mb / (t1 - t0), 3), "ans_encode_MBps": round(mb / (t2 - t1), 3),
-        "decompress_MBps": round(mb / (t4 - t2), 3), "ans_decode_MBps": round(mb / (t3 - t2), 3), "inverse_bwt_MBps": round(mb / (t4 - t3), 3),
-    }, enc
+    res = {"unit": "MB/s", "kind": kind, "cpu_model": cpu_model()}
+
+    def one_pass(threads):
+        if kind == "reference":
+            impl.set_threads(threads)
+        t0 = time.perf_counter()
+        bwt = impl.bwt_forward(sample)
+        t1 = time.perf_counter()
+        enc = impl.ans_encode(bwt)
+        t2 = time.perf_counter()
+        dec = impl.ans_decode(enc, len(bwt), threads=threads) if kind == "reference" else impl.ans_decode(enc, len(bwt))
+        t3 = time.perf_counter()
+        back = impl.bwt_inverse(dec, threads=threads) if kind == "reference" else impl.bwt_inverse(dec)
+        t4 = time.perf_counter()
+        assert np.array_equal(back, sample)
+        return enc, {"compress_MBps": round(mb / (t2 - t0), 3), "forward_bwt_MBps": round(mb / (t1 - t0), 3), "ans_encode_MBps": round(mb / (t2 - t1), 3),
+                     "decompress_MBps": round(mb / (t4 - t2), 3), "ans_decode_MBps": round(mb / (t3 - t2), 3), "inverse_bwt_MBps": round(mb / (t4 - t3), 3)}
+
+    enc, full = one_pass(cores if kind == "reference" else 1)
+    res.update({"value": full["compress_MBps"], "cores": cores if kind == "reference" else 1})
+    res.update({k: v for k, v in full.items() if k != "compress_MBps"})
+    res["sample"] = (f"first {n} B of block 0 as one block; value = ForwardBwt (divsufsort, OpenMP {cores} threads) + Ans::Encode "
+                     "(single-threaded by design, ans.cpp:113); threads_1 = the same with one thread; blocks_in_parallel = every block of "
+                     "the batch compressed at once, one thread team each (jampack.cpp:215)")
+    if kind == "reference":
+        _, one = one_pass(1)
+        res["threads_1"] = one
+        # blocks in parallel: the reference's -t mode.  Every block of the batch (bounded to the sample size) at once.
+        parts = [np.ascontiguousarray(b[: min(len(b), n) - (min(len(b), n) % 120)]) for b in blocks]
+        per = max(1, cores // len(parts))
+
+        def comp(p):
+            impl.set_threads(per)
+            impl.ans_encode(impl.bwt_forward(p))
+
+        th = [threading.Thread(target=comp, args=(p,)) for p in parts]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        res["blocks_in_parallel"] = {"compress_MBps": round(sum(len(p) for p in parts) / 1e6 / dt, 3), "blocks": len(parts), "threads_per_block": per}
+    return res, enc, n
 
 
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_children(args))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` (spawns the ranks itself) "
+                         f"or `python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or FORCE_GATHER:
+    use_dist = world > 1 or FORCE_GATHER
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import jampack_amd as jam
-    from jampack_amd import corpus
+    from jampack_amd import corpus, shard
 
-    # ---- workload: every rank gets its own batch of the same shape (weak scaling over independent blocks) ----
-    data, source = corpus.load_or_make(args.workload, limit=args.limit_bytes or None, seed_offset=1000 * rank)
-    blocks = corpus.split_blocks(data, args.block_mib << 20)
+    bs = args.block_mib << 20
+    stream_mode = args.workload == "enwik9"          # config 4: one stream, blocks owned b mod N (strong scaling)
+    if stream_mode:
+        total = min(corpus.workload_bytes(args.workload), args.limit_bytes or 1 << 62)
+        ranges = corpus.block_ranges(total, bs)
+        mine = shard.my_blocks(len(ranges), rank, world)
+        blocks, source = [], "synthetic"
+        for b in mine:
+            d, source = corpus.load_or_make(args.workload, limit=args.limit_bytes or None, start=ranges[b][0], count=ranges[b][1])
+            blocks.append(d)
+        job_bytes = total
+        nblocks_job = len(ranges)
+    else:
+        # every rank gets its own batch of the same shape (weak scaling over independent blocks)
+        data, source = corpus.load_or_make(args.workload, limit=args.limit_bytes or None, seed_offset=1000 * rank)
+        blocks = corpus.split_blocks(data, bs)
+        mine = list(range(len(blocks)))
+        job_bytes = world * int(sum(len(b) for b in blocks))
+        nblocks_job = world * len(blocks)
     batch_bytes = int(sum(len(b) for b in blocks))
     d_in = [torch.from_numpy(np.ascontiguousarray(b)).to(dev) for b in blocks]
     caps = [jam.ans_capacity(len(b) + jam.TRAILER) for b in blocks]
@@ -148,16 +246,15 @@ def main():
     # blocks are independent (jampack.cpp:215: one Jampack instance per OpenMP thread): keep `--contexts` of them in
     # flight, each on its own context = own HBM arena + own HIP stream, driven by one host thread each
     import concurrent.futures as cf
-    nctx = max(1, min(args.contexts, len(blocks)))
+    nctx = max(1, min(args.contexts, max(len(blocks), 1)))
     ctxs = [jam.Context(local_rank, None) for _ in range(nctx)]
     for c in [ctx] + ctxs:
-        c.reserve(max(len(b) for b in blocks))          # HBM arenas sized before anything is timed
+        c.reserve(max([len(b) for b in blocks] + [1]))          # HBM arenas sized before anything is timed
     pool = cf.ThreadPoolExecutor(max_workers=nctx)
     order = sorted(range(len(blocks)), key=lambda i: -len(blocks[i]))          # largest first
     lanes = [order[k::nctx] for k in range(nctx)]
 
     sizes = [0] * len(blocks)
-    from jampack_amd import shard
     gathered = [None]
 
     def lane_work(k):
@@ -167,13 +264,13 @@ def main():
     def compress_step():
         for f in [pool.submit(lane_work, k) for k in range(nctx)]:
             f.result()
-        if world > 1 or FORCE_GATHER:
+        if use_dist:
             # the only exchange of the path: the compressed blocks of every rank -> rank 0 (all_gather of the sizes, one
             # gather of a buffer padded to the largest rank total), RCCL over xGMI; jampack_amd/shard.py
-            gathered[0] = shard.gather_blocks([d_out[i][: sizes[i]] for i in range(len(blocks))], dst=0)
+            gathered[0] = shard.gather_blocks([d_out[i][: sizes[i]] for i in range(len(blocks))], dst=0, device=dev)
 
     def sync_all():
-        if world > 1 or FORCE_GATHER:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -190,14 +287,26 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * batch_bytes / 1e6 / (dt / args.steps)
+    value = job_bytes / 1e6 / (dt / args.steps)
 
-    # ---- un-timed extras on rank 0: stage breakdown, decompress leg, parity flags, roofline ----
     extra = {}
-    if rank == 0:
-        st = ctx.stats()
+    if rank == 0 and gathered[0] is not None:
+        # rank 0 holds every rank's compressed blocks; in stream mode they are put back into file order (what the in-order
+        # CompWriteBlock loop writes, jampack.cpp:220-224) and rank 0's own blocks are checked against their sources
+        per_rank = gathered[0]
+        ok = len(per_rank) == world and all(bool(torch.equal(per_rank[0][k], d_out[k][: sizes[k]])) for k in range(len(blocks)))
+        if stream_mode:
+            ordered = shard.assemble_in_block_order(per_rank, nblocks_job)
+            ok = ok and len(ordered) == nblocks_job and all(bool(torch.equal(ordered[b], d_out[k][: sizes[k]])) for k, b in enumerate(mine))
+            extra["gathered_payload_bytes"] = int(sum(t.numel() for t in ordered))
+        extra["gather_ok"] = bool(ok)
+
+    # ---- un-timed extras on rank 0 of a 1-GPU run: stage breakdown, decompress leg, parity flags, roofline, CPU baseline ----
+    if rank == 0 and world == 1 and not args.no_extras and blocks:
+        reps = max(3, min(args.steps, 10))
         ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731  (same stream as the library's launches)
-        stage_ms = {"forward_bwt": 0.0, "ans_encode": 0.0, "ans_decode": 0.0, "inverse_bwt": 0.0}
+        names = ("forward_bwt", "ans_encode", "ans_decode", "inverse_bwt")
+        stage_ms = dict.fromkeys(names, 0.0)
         comp_sizes = []
         ok = True
         for i, b in enumerate(blocks):
@@ -206,25 +315,37 @@ def main():
             d_enc = torch.empty(caps[i], dtype=torch.uint8, device=dev)
             d_dec = torch.empty(n + jam.TRAILER, dtype=torch.uint8, device=dev)
             d_back = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
-            e = [ev() for _ in range(5)]
-            e[0].record(stream)
-            ctx.bwt_forward(d_in[i], n, d_bwt, n + jam.TRAILER)
-            e[1].record(stream)
-            clen = ctx.ans_encode(d_bwt, n + jam.TRAILER, d_enc, caps[i])
-            e[2].record(stream)
-            dl = ctx.ans_decode(d_enc, clen, d_dec, n + jam.TRAILER)
-            e[3].record(stream)
-            bl = ctx.bwt_inverse(d_dec, dl, d_back, n)
-            e[4].record(stream)
-            torch.cuda.synchronize()
-            for k, name in enumerate(stage_ms):
-                stage_ms[name] += e[k].elapsed_time(e[k + 1])
+            acc = dict.fromkeys(names, 0.0)
+            for rep in range(reps + 1):                  # rep 0 warms every path of this context (arena growth, code load)
+                e = [ev() for _ in range(5)]
+                e[0].record(stream)
+                ctx.bwt_forward(d_in[i], n, d_bwt, n + jam.TRAILER)
+                e[1].record(stream)
+                clen = ctx.ans_encode(d_bwt, n + jam.TRAILER, d_enc, caps[i])
+                e[2].record(stream)
+                dl = ctx.ans_decode(d_enc, clen, d_dec, n + jam.TRAILER)
+                e[3].record(stream)
+                bl = ctx.bwt_inverse(d_dec, dl, d_back, n)
+                e[4].record(stream)
+                torch.cuda.synchronize()
+                if rep:
+                    for k, name in enumerate(names):
+                        acc[name] += e[k].elapsed_time(e[k + 1])
+            for name in names:
+                stage_ms[name] += acc[name] / reps
             comp_sizes.append(clen)
             ok = ok and bl == n and bool(torch.equal(d_back[:n], d_in[i])) and clen == sizes[i] and bool(torch.equal(d_enc[:clen], d_out[i][:clen]))
+            if i == 0:
+                st = ctx.stats()
+                nr = int(st.sa_rounds)
+                extra["sa_rounds"] = {"block_bytes": n, "rounds": nr, "active_suffixes": [int(x) for x in st.sa_round_active[:nr]],
+                                      "in_large_groups": [int(x) for x in st.sa_round_large[:nr]],
+                                      "note": "round 0 = radix sort on the first 7 bytes of every suffix; round r >= 1 sorts the still unresolved suffixes by the rank of the suffix 7*2^(r-1) bytes further"}
             del d_bwt, d_enc, d_dec, d_back
         mb = batch_bytes / 1e6
         extra["stages_ms"] = {k: round(v, 3) for k, v in stage_ms.items()}
         extra["stages_MBps"] = {k: round(mb / (v / 1e3), 1) for k, v in stage_ms.items() if v > 0}
+        extra["stages_reps"] = reps
         # decompress leg (rANS decode -> inverse BWT, jampack.cpp:49-50) over the same batch, blocks in flight like compress
         d_cmp = [d_out[i][: sizes[i]].clone() for i in range(len(blocks))]
         d_dcm = [torch.empty(max(len(b), 1), dtype=torch.uint8, device=dev) for b in blocks]
@@ -241,11 +362,12 @@ def main():
         decompress_step()
         torch.cuda.synchronize()
         td0 = time.perf_counter()
-        decompress_step()
+        for _ in range(reps):
+            decompress_step()
         torch.cuda.synchronize()
-        td = time.perf_counter() - td0
+        td = (time.perf_counter() - td0) / reps
         ok = ok and all(dsz[i] == len(blocks[i]) and bool(torch.equal(d_dcm[i][: len(blocks[i])], d_in[i])) for i in range(len(blocks)))
-        extra["decompress"] = {"value": round(mb / td, 1), "unit": "MB/s", "ms_per_step": round(td * 1e3, 3),
+        extra["decompress"] = {"value": round(mb / td, 1), "unit": "MB/s", "ms_per_step": round(td * 1e3, 3), "steps": reps,
                                "one_block_at_a_time_MBps": round(mb / ((stage_ms["ans_decode"] + stage_ms["inverse_bwt"]) / 1e3), 1),
                                "inverse_bwt_MBps": round(mb / (stage_ms["inverse_bwt"] / 1e3), 1)}
         extra["round_trip_ok"] = ok
@@ -283,14 +405,15 @@ def main():
                                                       "ms_per_pass": round(tsd / passes * 1e3, 3)}
         del d_cmp, d_dcm
         extra["compressed_bytes"] = int(sum(comp_sizes))
-        if gathered[0] is not None:          # rank 0 holds every rank's compressed blocks: check its own against the source
-            extra["gather_ok"] = all(bool(torch.equal(gathered[0][0][i], d_out[i][: sizes[i]])) for i in range(len(blocks))) and len(gathered[0]) == world
-        extra["sa_rounds_last_block"] = int(st.sa_rounds)
+        extra["compressed_ratio"] = round(sum(comp_sizes) / batch_bytes, 4)
         extra["workspace_bytes"] = int(ctx.stats().workspace_bytes)
         # algorithmic HBM traffic of the stages: fwd BWT 10 B/B, ANS 4+c B/B, inverse BWT 12 B/B
         c = sum(comp_sizes) / batch_bytes
-        alg = {"forward_bwt": 10.0, "ans_encode": 4.0 + c, "ans_decode": 4.0 + c, "inverse_bwt": 12.0}
-        extra["stages_alg_GBps"] = {k: round(alg[k] * batch_bytes / 1e9 / (stage_ms[k] / 1e3), 2) for k in alg if stage_ms[k] > 0}
+        sg = {k: STAGE_ALG[k](c) * batch_bytes / 1e9 / (stage_ms[k] / 1e3) for k in names if stage_ms[k] > 0}
+        extra["stages_alg_GBps"] = {k: {"achieved": round(v, 2), "frac": round(v / 8000.0, 5)} for k, v in sg.items()}
+        comp_ms = stage_ms["forward_bwt"] + stage_ms["ans_encode"]
+        extra["compress_alg"] = {"bytes_per_byte": round(14.0 + c, 2), "achieved_GBps": round((14.0 + c) * batch_bytes / 1e9 / (ms_per_step / 1e3), 2),
+                                 "frac": round((14.0 + c) * batch_bytes / 1e9 / (ms_per_step / 1e3) / 8000.0, 5), "one_block_at_a_time_ms": round(comp_ms, 3)}
         # per-kernel HIP-event timing (events recorded by the library on the launch stream) of one more compress pass
         ctx.profile_enable(2)
         for i, b in enumerate(blocks):
@@ -304,21 +427,47 @@ def main():
                 continue
             ach = bpu[0] * r["units"] / 1e9 / (r["ms"] / 1e3)
             rows.append({"kernel": r["name"], "ms_total": round(r["ms"], 3), "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
-                         "alg_bytes_per_unit": bpu[0], "unit_is": bpu[1], "units": r["units"], "achieved": round(ach, 2), "frac": round(ach / 8000.0, 5)})
+                         "alg_bytes_per_unit": bpu[0], "unit_is": bpu[1], "units": r["units"], "achieved": round(ach, 2), "frac": round(ach / 8000.0, 5),
+                         "limited_by": bpu[2]})
         rows.sort(key=lambda r: -r["ms_total"])
         if rows:
             d0 = rows[0]
-            extra["roofline"] = {"bound": "hbm", "achieved": d0["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": d0["frac"],
-                                 "traffic": pmc_traffic(d0["kernel"]),
-                                 "kernel": d0["kernel"], "avg_launch_us": d0["avg_launch_us"], "launches": d0["launches"],
+            traffic, pmc_file = pmc_traffic(d0["kernel"])
+            extra["roofline"] = {"bound": "hbm" if d0["limited_by"].startswith("hbm") else d0["limited_by"], "achieved": d0["achieved"], "peak": 8000.0, "unit": "GB/s",
+                                 "frac": d0["frac"], "traffic": traffic,
+                                 "kernel": d0["kernel"], "limited_by": d0["limited_by"], "avg_launch_us": d0["avg_launch_us"], "launches": d0["launches"],
                                  "alg_bytes_per_launch": round(d0["alg_bytes_per_unit"] * d0["units"] / d0["launches"]),
-                                 "note": "dominant kernel of the compress pass by total time; achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream); traffic = PMC bytes per launch from profiles/r01_pmc_traffic.json; this kernel is bound by dependent-instruction latency (4 serial rANS chains per chunk), not by HBM"}
+                                 "note": f"dominant kernel class of the compress pass by total time; achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream); traffic = PMC bytes per launch from profiles/{pmc_file}; peak = HBM spec; limited_by says what the class is really bound by (DESIGN.md section 4)"}
             extra["roofline_kernels"] = rows[:8]
-        if world == 1 and not args.no_cpu_baseline:
+        if args.workload == "enwik8" and not args.limit_bytes:
+            # the same step on the phrase-book text (deeper repeats, ratio ~10 %): round 1's headline corpus, kept for comparison
+            pdata, _ = corpus.load_or_make("enwik8-phrase")
+            pblocks = corpus.split_blocks(pdata, bs)
+            p_in = [torch.from_numpy(np.ascontiguousarray(b)).to(dev) for b in pblocks]
+            psz = [0] * len(pblocks)
+
+            def plane(k):
+                for i in lanes[k]:
+                    psz[i] = ctxs[k].block_compress(p_in[i], len(pblocks[i]), d_out[i], caps[i])
+
+            def pstep():
+                for f in [pool.submit(plane, k) for k in range(nctx)]:
+                    f.result()
+
+            pstep()
+            torch.cuda.synchronize()
+            tp0 = time.perf_counter()
+            for _ in range(3):
+                pstep()
+            torch.cuda.synchronize()
+            tp = (time.perf_counter() - tp0) / 3
+            extra["phrase_book_variant"] = {"value": round(batch_bytes / 1e6 / tp, 1), "unit": "MB/s", "ms_per_step": round(tp * 1e3, 3), "steps": 3,
+                                            "compressed_ratio": round(sum(psz) / batch_bytes, 4),
+                                            "workload": "same shape, text with a 200 000-phrase book (round 1's corpus)"}
+            del p_in
+        if not args.no_cpu_baseline:
             try:
-                cb, ref_enc = cpu_baseline(blocks[0], args.cpu_sample_mib)
-                n = min(len(blocks[0]), args.cpu_sample_mib << 20)
-                n -= n % 120
+                cb, ref_enc, n = cpu_baseline(blocks, args.cpu_sample_mib)
                 # bit-exact vs the CPU reference on the same sample block
                 d_s = d_in[0][:n].contiguous()
                 d_o = torch.empty(jam.ans_capacity(n + jam.TRAILER), dtype=torch.uint8, device=dev)
@@ -329,14 +478,21 @@ def main():
                 extra["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 0, "kind": "error", "sample": repr(ex)}
 
     if rank == 0:
+        if stream_mode:
+            wl = (f"{args.workload}-like: ONE {job_bytes} B stream as {args.block_mib} MiB blocks ({nblocks_job} blocks), block b on GPU b mod {world}, "
+                  "forward BWT + rANS encode, inputs resident in HBM, compressed blocks gathered on rank 0 in block order")
+            par = f"{nblocks_job} blocks sharded b mod {world} over {world} GPU(s)" + (", RCCL gather of compressed blocks" if use_dist else "")
+        else:
+            wl = (f"{args.workload}-like {batch_bytes} B per GPU as {args.block_mib} MiB blocks ({len(blocks)} blocks), forward BWT + rANS encode, inputs resident in HBM")
+            par = (f"one batch per GPU on {world} GPUs, RCCL gather of compressed blocks" if world > 1 else "1 GPU")
         line = {
             "metric": "MB/s compress (forward BWT + rANS encode) on 64 MiB blocks; bit-exact vs CPU ref",
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if stream_mode else "weak", "vs_baseline": None,
             "dtype": "u8/int32", "data": "synthetic" if source == "synthetic" else source,
-            "config": {"workload": f"{args.workload}-like {batch_bytes} B per GPU as {args.block_mib} MiB blocks ({len(blocks)} blocks), forward BWT + rANS encode, inputs resident in HBM"
-                       + ("" if not args.limit_bytes else " [TRUNCATED: not a valid headline]"),
-                       "block_bytes": [len(b) for b in blocks], "parallelism": (f"blocks sharded over {world} GPU(s), RCCL gather of compressed blocks" if world > 1 else "1 GPU") + f", {nctx} blocks in flight per GPU"},
+            "config": {"workload": wl + ("" if not args.limit_bytes else " [TRUNCATED: not a valid headline]"),
+                       "block_bytes": [len(b) for b in blocks] if not stream_mode else [r[1] for r in ranges],
+                       "parallelism": par + f", {nctx} blocks in flight per GPU"},
         }
         line.update(extra)
         print(json.dumps(line), flush=True)
@@ -344,7 +500,7 @@ def main():
     for c in ctxs:
         c.close()
     ctx.close()
-    if world > 1 or FORCE_GATHER:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

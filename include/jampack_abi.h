@@ -36,6 +36,7 @@ extern "C" {
 #define JPK_ANS_CHUNK (1 << 20)           /* ans.hpp:21     StackSize */
 #define JPK_MIN_BLOCKSIZE (1 << 20)       /* format.hpp:21  MIN_BLOCKSIZE */
 #define JPK_MAX_BLOCKSIZE (1000 << 20)    /* format.hpp:22  MAX_BLOCKSIZE */
+#define JPK_SA_MAX_ROUNDS 40               /* rounds reported in jpk_stats (h doubles: 7 * 2^31 > any block) */
 #define JPK_JAM_HEADER_BYTES 15           /* jampack.cpp:128-131: "JAM" + crc + payload size + BlockSize */
 
 typedef enum jpk_status {
@@ -60,6 +61,10 @@ typedef struct jpk_stats {
     int64_t workspace_bytes;      /* HBM arena currently held by the context */
     int64_t ans_chunks;           /* 1 MiB chunks in the last entropy call */
     int64_t ans_rle_symbols;      /* RLE0 symbols in the last entropy call */
+    /* per doubling round r (r = 0: the 7-byte radix round, r >= 1: h = 7 * 2^(r-1)) of the last forward BWT:
+     * suffixes still unresolved when the round starts / of those, members of groups too large for the LDS path */
+    int32_t sa_round_active[JPK_SA_MAX_ROUNDS];
+    int32_t sa_round_large[JPK_SA_MAX_ROUNDS];
 } jpk_stats;
 
 /* ---- contexts ------------------------------------------------------------------------------------------ */
@@ -80,6 +85,22 @@ JPK_API int jpk_device_count(void);
 JPK_API const char *jpk_strerror(int status);
 JPK_API const char *jpk_version(void);
 
+/* ---- process-wide set-up of the host-buffer entry points -------------------------------------- */
+/* Selects the devices the host-buffer entry points may use: bit d of device_mask = HIP device d, 0 = every visible
+ * gfx950 device.  Calling threads are dealt round robin over the selected devices and keep a persistent context
+ * (stream + HBM arena + staging) from a process-wide pool, so the OpenMP block loop of jampack.cpp:215/313 spreads
+ * its blocks over the node.  Returns the number of devices selected (> 0) or a negative jpk_status.  Optional: without
+ * it the first host-buffer call selects all devices (or the one named by the JPK_DEVICE environment variable).
+ * Replaces the reference's per-block cudaMalloc/cudaFree and its single-device choice (bwt.cpp:98-114, 189-239). */
+JPK_API int jpk_init(uint64_t device_mask);
+/* the devices selected by jpk_init (or by the implicit selection), in round-robin order; returns their count */
+JPK_API int jpk_init_devices(int32_t *devices, int32_t cap);
+/* device the calling thread has been dealt (creates its context if needed), or a negative jpk_status */
+JPK_API int jpk_thread_device(void);
+/* destroys every pooled context (arenas, streams, staging).  No host-buffer call may be in flight.  Threads that call
+ * again afterwards get fresh contexts. */
+JPK_API void jpk_shutdown(void);
+
 /* ---- host-buffer entry points (drop-in boundary) ------------------------------------------------------- */
 /* BlockSort::Bwt::ForwardBwt(Buffer,Buffer)            bwt.hpp:15, bwt.cpp:22-65.   *out_len = in_len + 480. */
 JPK_API int jpk_bwt_forward(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len);
@@ -92,6 +113,12 @@ JPK_API int jpk_bwt_inverse(const uint8_t *in, int32_t in_len_with_trailer, uint
 JPK_API int jpk_ans_encode(uint8_t *in_clobbered, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len);
 /* Ans::Decode(Buffer,Buffer,Options)                   ans.hpp:33, ans.cpp:236-270 */
 JPK_API int jpk_ans_decode(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len, int32_t threads);
+/* Header-only walk of an Ans stream (ReadHeader per chunk, ans.cpp:254-261, 287-302) on the host: the decoded length
+ * (sum of the chunks' original lengths) and the chunk count, with the reference's header sanity checks.  The reference's
+ * Ans::Decode has no capacity argument -- it trusts that the caller's buffer holds the frame (jampack.cpp:156-159) -- so the
+ * C++ shim uses this to bound jpk_ans_decode by what the stream itself declares instead of by Options.BlockSize, which on
+ * the decompress path is the CLI default, not the frame's block size (main.cpp:60, jampack.cpp:146-159). */
+JPK_API int jpk_ans_decoded_size(const uint8_t *in, int32_t in_len, int64_t *decoded_len, int32_t *chunks);
 /* Postcoder::Encode / Decode                           rank.hpp:12-13, rank.cpp:45-151 (in place) */
 JPK_API int jpk_rank_encode(uint8_t *t, int32_t *freq256, int32_t len);
 JPK_API int jpk_rank_decode(uint8_t *ranks, const int32_t *freq256, int32_t len);
@@ -141,7 +168,12 @@ JPK_API int jpk_dev_checksum(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, 
 JPK_API int jpk_dev_jam_block_write(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, int32_t block_size, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
 JPK_API int jpk_dev_jam_block_read(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len, int32_t *consumed);
 
-/* ---- kernel-level probes used by tests/ (device buffers) ------------------------------------------------ */
+/* ---- kernel-level probes used by tests/ and bench.py (device buffers) ------------------------------------ */
+/* Comparator for BASELINE config 3 ("120-way parallel LF-map"): the reference's own GPU kernel shape -- 120 threads, one per
+ * stored index, p = Map[p-1] (CUDAInverse<<<40,3>>>, bwt.cpp:8-19, 176-183, 226-229) -- on the same Map.  Same bytes as
+ * jpk_dev_bwt_inverse; *chase_ms = device time of the chase kernel alone.  A measured baseline, never a product path. */
+JPK_API int jpk_dev_bwt_inverse_chains120(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len_with_trailer, uint8_t *d_out, int32_t out_cap,
+                                  int32_t *out_len, float *chase_ms);
 /* suffix array of d_t[0..n) into d_sa (int32[n]) -- the divsufsort() replacement, divsufsort.cpp:1721 */
 JPK_API int jpk_dev_suffix_array(jpk_ctx *ctx, const uint8_t *d_t, int32_t n, int32_t *d_sa);
 /* stable LSD radix sort of (u64 key, u32 value) pairs on bits [bit_lo, bit_hi) */

@@ -29,7 +29,8 @@ class JampackError(RuntimeError):
 class Stats(C.Structure):
     _fields_ = [("sa_rounds", C.c_int32), ("reserved0", C.c_int32), ("sa_sorted_elems", C.c_int64),
                 ("inv_splitters", C.c_int64), ("inv_overflow_slots", C.c_int64), ("workspace_bytes", C.c_int64),
-                ("ans_chunks", C.c_int64), ("ans_rle_symbols", C.c_int64)]
+                ("ans_chunks", C.c_int64), ("ans_rle_symbols", C.c_int64),
+                ("sa_round_active", C.c_int32 * 40), ("sa_round_large", C.c_int32 * 40)]
 
 
 _lib = None
@@ -48,12 +49,17 @@ _SIGS = {
     "jpk_ctx_profile_name": (C.c_char_p, [C.c_int]),
     "jpk_ctx_profile_get": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "jpk_device_count": (C.c_int, []),
+    "jpk_init": (C.c_int, [C.c_uint64]),
+    "jpk_init_devices": (C.c_int, [_i32p, C.c_int32]),
+    "jpk_thread_device": (C.c_int, []),
+    "jpk_shutdown": (None, []),
     "jpk_strerror": (C.c_char_p, [C.c_int]),
     "jpk_version": (C.c_char_p, []),
     "jpk_bwt_forward": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_bwt_inverse": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p, C.c_int32, C.c_int32]),
     "jpk_ans_encode": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_ans_decode": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p, C.c_int32]),
+    "jpk_ans_decoded_size": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64), _i32p]),
     "jpk_rank_encode": (C.c_int, [_vp, _vp, C.c_int32]),
     "jpk_rank_decode": (C.c_int, [_vp, _vp, C.c_int32]),
     "jpk_block_compress": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p]),
@@ -68,6 +74,7 @@ _SIGS = {
     "jpk_jam_cli_block_read": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p, _i32p]),
     "jpk_dev_bwt_forward": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_dev_bwt_inverse": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_dev_bwt_inverse_chains120": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p, C.POINTER(C.c_float)]),
     "jpk_dev_ans_encode": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_dev_ans_decode": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_dev_rank_encode": (C.c_int, [_vp, _vp, _vp, C.c_int32]),

@@ -34,6 +34,34 @@ def ans_capacity(n: int) -> int:
     return int(n * 1.25) + 4096 + 1400 * (n // CHUNK + 1)
 
 
+def init(device_mask: int = 0) -> int:
+    """jpk_init: devices the host-buffer entry points may use (bit d = device d, 0 = all); returns how many were selected"""
+    n = lib().jpk_init(device_mask)
+    if n < 0:
+        raise JampackError(n, "jpk_init")
+    return n
+
+
+def shutdown() -> None:
+    lib().jpk_shutdown()
+
+
+def thread_device() -> int:
+    """device the calling thread's pooled context lives on"""
+    d = lib().jpk_thread_device()
+    if d < 0:
+        raise JampackError(d, "jpk_thread_device")
+    return d
+
+
+def ans_decoded_size(stream):
+    """(decoded bytes, chunks) declared by the chunk headers of an Ans stream (host-side header walk)"""
+    c = _np_u8(stream)
+    n, k = C.c_int64(0), C.c_int32(0)
+    _chk(lib().jpk_ans_decoded_size(_ptr(c), len(c), C.byref(n), C.byref(k)), "jpk_ans_decoded_size")
+    return n.value, k.value
+
+
 class Bwt:
     """BlockSort::Bwt (bwt.hpp:13-18)."""
 
@@ -290,6 +318,12 @@ class Context:
 
     def bwt_inverse(self, d_in, in_len, d_out, out_cap) -> int:
         return self._io(lib().jpk_dev_bwt_inverse, "jpk_dev_bwt_inverse", d_in, in_len, d_out, out_cap)
+
+    def bwt_inverse_chains120(self, d_in, in_len, d_out, out_cap):
+        """the reference's 120-chain chase (comparator); returns (bytes, chase kernel ms)"""
+        n, ms = C.c_int32(0), C.c_float(0)
+        _chk(lib().jpk_dev_bwt_inverse_chains120(self._h, _dptr(d_in), in_len, _dptr(d_out), out_cap, C.byref(n), C.byref(ms)), "jpk_dev_bwt_inverse_chains120")
+        return n.value, ms.value
 
     def ans_encode(self, d_in, in_len, d_out, out_cap) -> int:
         return self._io(lib().jpk_dev_ans_encode, "jpk_dev_ans_encode", d_in, in_len, d_out, out_cap)

@@ -101,6 +101,54 @@ def text(nbytes: int, seed: int) -> np.ndarray:
     return out
 
 
+SURVEY_PAGE = 4 << 20
+
+
+@functools.lru_cache(maxsize=4)
+def _survey_tables(seed: int):
+    letters, vstart, vlen = _vocab(seed)
+    nw = len(vlen)
+    pz = np.arange(1, nw + 1, dtype=np.float64) ** -1.05
+    return letters, vstart, vlen, np.cumsum(pz / pz.sum())
+
+
+def _survey_page(seed: int, page: int) -> np.ndarray:
+    """page `page` (SURVEY_PAGE bytes) of the survey text stream: pages are generated independently from (seed, page), so
+    any byte range of a long stream -- one 64 MiB block of the 1 GB workload -- costs only its own pages."""
+    letters, vstart, vlen, zcdf = _survey_tables(seed)
+    nw = len(vlen)
+    words = SURVEY_PAGE // 6                       # mean word + separator is 7.5 bytes: always enough
+    pseed = (seed * 0x9E3779B1 + 0x51 + page * 0x632BE5AB) & 0xFFFFFFFFFFFFFFFF
+    ids = np.minimum(np.searchsorted(zcdf, _uniform(pseed, 0, words)), nw - 1)
+    wl = vlen[ids] + 1
+    ends = np.cumsum(wl)
+    nwords = int(np.searchsorted(ends, SURVEY_PAGE)) + 1
+    ids, wl, ends = ids[:nwords], wl[:nwords], ends[:nwords]
+    begs = ends - wl
+    tot = int(ends[-1])
+    pos = np.arange(tot, dtype=np.int64) - np.repeat(begs, wl)
+    is_sep = pos == np.repeat(vlen[ids], wl)
+    src = np.where(is_sep, 0, np.repeat(vstart[ids], wl) + pos)
+    seg = np.where(is_sep, np.uint8(32), letters[src]).astype(np.uint8)
+    seg[ends[199999::200000] - 1] = 10             # newline every 200 000 words
+    return seg[:SURVEY_PAGE]
+
+
+def text_survey(nbytes: int, seed: int, start: int = 0) -> np.ndarray:
+    """SURVEY.md section 8d text model (no phrase book): 50 000-word vocabulary (lengths U[2,11], letters p ~ rank^-0.8),
+    word choice Zipf s=1.05, separator space, newline every 200 000 words.  Bytes [start, start + nbytes) of the stream."""
+    if nbytes <= 0:
+        return np.zeros(0, dtype=np.uint8)
+    out = np.empty(nbytes, dtype=np.uint8)
+    p0, p1 = start // SURVEY_PAGE, (start + nbytes - 1) // SURVEY_PAGE
+    for p in range(p0, p1 + 1):
+        page = _survey_page(seed, p)
+        lo = max(start, p * SURVEY_PAGE)
+        hi = min(start + nbytes, (p + 1) * SURVEY_PAGE)
+        out[lo - start: hi - start] = page[lo - p * SURVEY_PAGE: hi - p * SURVEY_PAGE]
+    return out
+
+
 def random_bytes(nbytes: int, seed: int) -> np.ndarray:
     n8 = (nbytes + 7) // 8
     return splitmix64(seed, 0, n8).view(np.uint8)[:nbytes].copy()
@@ -165,6 +213,8 @@ def make(kind: str, nbytes: int, seed: int) -> np.ndarray:
         return np.zeros(0, dtype=np.uint8)
     if kind == "text":
         return text(nbytes, seed)
+    if kind == "text_survey":
+        return text_survey(nbytes, seed)
     if kind == "random":
         return random_bytes(nbytes, seed)
     if kind == "dna":
@@ -188,27 +238,44 @@ def make(kind: str, nbytes: int, seed: int) -> np.ndarray:
     raise ValueError(f"unknown corpus kind {kind!r}")
 
 
-KINDS = ("text", "random", "dna", "two", "zero", "geometric", "samples16", "runs", "repeat", "repeat4k", "silesia")
+KINDS = ("text", "text_survey", "random", "dna", "two", "zero", "geometric", "samples16", "runs", "repeat", "repeat4k", "silesia")
 
+# name -> (kind, bytes, seed, real file under JAMPACK_CORPUS_DIR).  The enwik workloads use the SURVEY 8d text model
+# (ratio ~20 %, as enwik8's ~21 %); the *-phrase variants add a 200 000-phrase book (deeper repeats, ratio ~10 %) and are
+# reported beside them.
 WORKLOADS = {
-    "enwik6": ("text", 1_000_000, 6, "enwik6"),
-    "enwik8": ("text", 100_000_000, 8, "enwik8"),
-    "enwik9": ("text", 1_000_000_000, 9, "enwik9"),
+    "enwik6": ("text_survey", 1_000_000, 6, "enwik6"),
+    "enwik8": ("text_survey", 100_000_000, 8, "enwik8"),
+    "enwik9": ("text_survey", 1_000_000_000, 9, "enwik9"),
+    "enwik8-phrase": ("text", 100_000_000, 8, None),
     "silesia": ("silesia", 211_938_580, 5, "silesia.tar"),
 }
 
 
-def load_or_make(name: str, limit: int | None = None, seed_offset: int = 0):
-    """returns (bytes ndarray, source) where source is 'file:<path>' or 'synthetic'."""
+def workload_bytes(name: str) -> int:
+    return WORKLOADS[name][1]
+
+
+def load_or_make(name: str, limit: int | None = None, seed_offset: int = 0, start: int = 0, count: int | None = None):
+    """bytes [start, start+count) of a workload; returns (ndarray, source) where source is 'file:<path>' or 'synthetic'."""
     kind, nbytes, seed, fname = WORKLOADS[name]
     if limit is not None:
         nbytes = min(nbytes, limit)
+    start = min(start, nbytes)
+    count = nbytes - start if count is None else min(count, nbytes - start)
     d = os.environ.get("JAMPACK_CORPUS_DIR")
-    if d and seed_offset == 0:
+    if d and seed_offset == 0 and fname:
         p = os.path.join(d, fname)
         if os.path.isfile(p):
-            return np.fromfile(p, dtype=np.uint8, count=nbytes), f"file:{p}"
-    return make(kind, nbytes, seed + seed_offset), "synthetic"
+            return np.fromfile(p, dtype=np.uint8, count=count, offset=start), f"file:{p}"
+    if kind == "text_survey":
+        return text_survey(count, seed + seed_offset, start), "synthetic"
+    return make(kind, nbytes, seed + seed_offset)[start:start + count], "synthetic"
+
+
+def block_ranges(total: int, block_size: int):
+    """(start, length) of every block of a `total`-byte stream (jampack.cpp:205-213 reads BlockSize bytes per block)"""
+    return [(o, min(block_size, total - o)) for o in range(0, total, block_size)]
 
 
 def split_blocks(data: np.ndarray, block_size: int):

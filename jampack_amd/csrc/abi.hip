@@ -18,6 +18,8 @@ int jpk_arena_ensure(jpk_ctx *ctx, size_t bytes)
     bytes = jpk_align(bytes + 4096, 1 << 20);
     if (bytes <= ctx->arena_cap) return JPK_OK;
     JPK_HIP(hipStreamSynchronize(ctx->stream));
+    for (int g = 0; g + 1 < jpk_ctx::ENC_GROUPS; g++)
+        if (ctx->aux[g]) JPK_HIP(hipStreamSynchronize(ctx->aux[g]));
     if (ctx->arena) { JPK_HIP(hipFree(ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; }
     // grow geometrically so that a sequence of slightly larger blocks does not re-allocate every time
     size_t want = bytes + bytes / 8;
@@ -246,6 +248,18 @@ extern "C" int jpk_dev_bwt_inverse(jpk_ctx *ctx, const uint8_t *d_in, int32_t in
     return JPK_OK;
 }
 
+extern "C" int jpk_dev_bwt_inverse_chains120(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len,
+                                            float *chase_ms)
+{
+    JPK_ENTER(ctx);
+    if (!d_in || !d_out || !out_len || in_len < 0) return JPK_E_ARG;
+    if (in_len < JPK_TRAILER_BYTES) return JPK_E_CORRUPT;
+    if (in_len - JPK_TRAILER_BYTES > out_cap) return JPK_E_CAPACITY;
+    JPK_TRY(jpk_inv_bwt_chains120_device(ctx, d_in, in_len, d_out, chase_ms));
+    *out_len = in_len - JPK_TRAILER_BYTES;
+    return JPK_OK;
+}
+
 extern "C" int jpk_dev_ans_encode(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
 {
     JPK_ENTER(ctx);
@@ -426,26 +440,120 @@ extern "C" int jpk_dev_jam_block_read(jpk_ctx *ctx, const uint8_t *d_in, int32_t
 }
 
 // ---- host-buffer (drop-in) entry points --------------------------------------------------------------------
-// One lazily created context per calling thread: re-entrant from the OpenMP block loop of jampack.cpp:215/313.
+// Re-entrant from the OpenMP block loop of jampack.cpp:215/313: every calling thread works on a context of its own
+// (stream + HBM arena + staging buffers).  Contexts live in a process-wide pool: a thread borrows one on its first
+// call and hands it back when it exits, so the arenas persist across thread teams (the reference pays five
+// cudaMalloc/cudaFree per block instead, bwt.cpp:195-239).  Threads are dealt round robin over the devices selected
+// by jpk_init(device_mask) -- `jampack -t 8` on an 8-GPU node puts one block on each GPU.
 namespace {
+struct CtxPool {
+    std::mutex mu;
+    std::vector<int> devices;                       // selected devices (empty = not initialised yet)
+    std::vector<std::vector<jpk_ctx *>> idle;       // per selected device: contexts nobody holds
+    std::vector<jpk_ctx *> all;                     // every context the pool has created
+    uint64_t generation = 1;                        // bumped by jpk_shutdown: borrowed handles of older generations are dead
+    uint32_t next_thread = 0;
+    int init_rc = JPK_OK;
+};
+CtxPool &pool() { static CtxPool p; return p; }
+
+// caller holds pool().mu
+int pool_select(CtxPool &p, uint64_t mask)
+{
+    p.devices.clear();
+    p.idle.clear();
+    const int n = jpk_device_count();
+    if (n <= 0) return JPK_E_NODEVICE;
+    for (int d = 0; d < n && d < 64; d++) {
+        if (mask && !((mask >> d) & 1u)) continue;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) continue;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("JPK_ALLOW_ANY_ARCH")) continue;
+        p.devices.push_back(d);
+    }
+    if (p.devices.empty()) return JPK_E_NODEVICE;
+    p.idle.resize(p.devices.size());
+    return JPK_OK;
+}
+
 struct TlsCtx {
     jpk_ctx *ctx = nullptr;
-    int rc = JPK_OK;
-    ~TlsCtx() { if (ctx) jpk_ctx_destroy(ctx); }
+    uint64_t generation = 0;
+    size_t slot = 0;
+    ~TlsCtx()
+    {
+        if (!ctx) return;
+        CtxPool &p = pool();
+        std::lock_guard<std::mutex> g(p.mu);
+        if (generation == p.generation && slot < p.idle.size()) p.idle[slot].push_back(ctx);   // else: jpk_shutdown already destroyed it
+    }
 };
 thread_local TlsCtx tls;
 
 int tls_ctx(jpk_ctx **out)
 {
-    if (!tls.ctx) {
-        int dev = 0;
-        if (const char *e = getenv("JPK_DEVICE")) dev = atoi(e);
-        tls.rc = jpk_ctx_create(&tls.ctx, dev, nullptr);
+    CtxPool &p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    if (tls.ctx && tls.generation == p.generation) { *out = tls.ctx; return JPK_OK; }
+    tls.ctx = nullptr;
+    if (p.devices.empty()) {
+        // no jpk_init(): JPK_DEVICE pins one device, otherwise every visible gfx950 device takes part
+        uint64_t mask = 0;
+        if (const char *e = getenv("JPK_DEVICE")) { const int d = atoi(e); if (d < 0 || d >= 64) return JPK_E_NODEVICE; mask = 1ull << d; }
+        JPK_TRY(pool_select(p, mask));
     }
-    *out = tls.ctx;
-    return tls.ctx ? JPK_OK : tls.rc;
+    const size_t slot = (size_t)(p.next_thread++ % p.devices.size());
+    jpk_ctx *c = nullptr;
+    if (!p.idle[slot].empty()) { c = p.idle[slot].back(); p.idle[slot].pop_back(); }
+    else {
+        JPK_TRY(jpk_ctx_create(&c, p.devices[slot], nullptr));
+        p.all.push_back(c);
+    }
+    tls.ctx = c; tls.generation = p.generation; tls.slot = slot;
+    *out = c;
+    return JPK_OK;
+}
+}  // namespace
+
+extern "C" int jpk_init(uint64_t device_mask)
+{
+    CtxPool &p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    if (!p.all.empty()) return JPK_E_ARG;           // contexts exist: jpk_shutdown() first
+    JPK_TRY(pool_select(p, device_mask));
+    p.next_thread = 0;
+    return (int)p.devices.size();
 }
 
+extern "C" int jpk_init_devices(int32_t *devices, int32_t cap)
+{
+    CtxPool &p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    const int n = (int)p.devices.size();
+    for (int i = 0; i < n && i < cap && devices; i++) devices[i] = p.devices[(size_t)i];
+    return n;
+}
+
+extern "C" int jpk_thread_device(void)
+{
+    jpk_ctx *ctx;
+    int rc = tls_ctx(&ctx);
+    return rc == JPK_OK ? ctx->device : rc;
+}
+
+extern "C" void jpk_shutdown(void)
+{
+    CtxPool &p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    for (jpk_ctx *c : p.all) jpk_ctx_destroy(c);    // synchronises each context's streams first
+    p.all.clear();
+    p.idle.clear();
+    p.devices.clear();
+    p.generation++;
+    p.next_thread = 0;
+}
+
+namespace {
 typedef int (*dev_fn)(jpk_ctx *, const uint8_t *, int32_t, uint8_t *, int32_t, int32_t *);
 
 // H2D -> device entry -> D2H.  prefill_out: copy the caller's out bytes to the device first (used where the
@@ -495,6 +603,51 @@ extern "C" int jpk_ans_decode(const uint8_t *in, int32_t in_len, uint8_t *out, i
 {
     (void)threads;
     return staged(jpk_dev_ans_decode, in, in_len, out, out_cap, out_len, false);
+}
+
+namespace {
+// LEB128 "with carry" (utils.cpp:70-90), host side; returns bytes consumed or -1
+int leb_host(uint32_t *v, const uint8_t *b, int64_t avail)
+{
+    static const uint32_t C[4] = {127u, 16510u, 2113661u, 270549116u};
+    int d = 0;
+    uint32_t x = 0;
+    while (d < avail && !(b[d] & 0x80)) {
+        if (d >= 4) return -1;
+        x = (x << 7) | b[d++];
+    }
+    if (d >= avail) return -1;
+    x = (x << 7) | (b[d] & 0x7fu);
+    if (d > 0) x += C[d - 1];
+    *v = x;
+    return d + 1;
+}
+}  // namespace
+
+extern "C" int jpk_ans_decoded_size(const uint8_t *in, int32_t in_len, int64_t *decoded_len, int32_t *chunks)
+{
+    if (!decoded_len || in_len < 0 || (in_len > 0 && !in)) return JPK_E_ARG;
+    int64_t ip = 0, total = 0;
+    int32_t nch = 0;
+    while (ip < in_len) {
+        int64_t fsum = 0;
+        uint32_t v = 0;
+        for (int s = 0; s < 259; s++) {                 // 256 frequencies, olen, clen, rlen (ans.cpp:272-302)
+            const int n = leb_host(&v, in + ip, (int64_t)in_len - ip);
+            if (n < 0) return JPK_E_CORRUPT;
+            ip += n;
+            if (s < 256) { if (v > (uint32_t)JPK_ANS_CHUNK) return JPK_E_CORRUPT; fsum += v; }
+            else if (s == 256) { if (v > (uint32_t)JPK_ANS_CHUNK || (int64_t)v != fsum) return JPK_E_CORRUPT; total += v; }
+            else if (s == 257) { if (v < 16 || (int64_t)v > (int64_t)in_len - ip) return JPK_E_CORRUPT; fsum = v; }   // clen, payload follows rlen
+            else { if (v > (uint32_t)JPK_ANS_CHUNK) return JPK_E_CORRUPT; }
+        }
+        if (fsum > (int64_t)in_len - ip) return JPK_E_CORRUPT;
+        ip += fsum;                                      // skip the payload
+        nch++;
+    }
+    *decoded_len = total;
+    if (chunks) *chunks = nch;
+    return JPK_OK;
 }
 
 extern "C" int jpk_block_compress(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len)

@@ -1130,8 +1130,14 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
             ctx->stream = st;
             if (rc == JPK_OK && gs != st && hipEventRecord(ctx->ev_done[g], gs) != hipSuccess) rc = JPK_E_DEVICE;
         }
-        JPK_TRY(rc);
-        for (int g = 0; g + 1 < ngroups; g++) JPK_HIP(hipStreamWaitEvent(st, ctx->ev_done[g], 0));
+        for (int g = 0; g + 1 < ngroups && rc == JPK_OK; g++)
+            if (hipStreamWaitEvent(st, ctx->ev_done[g], 0) != hipSuccess) rc = JPK_E_DEVICE;
+        if (rc != JPK_OK) {
+            // groups already launched keep reading and writing the arena: join them before the caller may reuse it
+            for (int g = 0; g + 1 < jpk_ctx::ENC_GROUPS; g++) (void)hipStreamSynchronize(ctx->aux[g]);
+            (void)hipStreamSynchronize(st);
+            return rc;
+        }
     } else {
         JPK_TRY(pre_chain(d));
         JPK_TRY(chain(d));

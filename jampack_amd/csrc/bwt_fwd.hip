@@ -510,6 +510,9 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b, uint32_t **i
     const unsigned g_n = jpk_grid(n, TB);
     ctx->stats.sa_rounds = 0;
     ctx->stats.sa_sorted_elems = 0;
+    memset(ctx->stats.sa_round_active, 0, sizeof ctx->stats.sa_round_active);
+    memset(ctx->stats.sa_round_large, 0, sizeof ctx->stats.sa_round_large);
+    ctx->stats.sa_round_active[0] = (int32_t)n;
 
     // round 0: sort by the first 7 bytes (7 passes; ties keep descending text position)
     JPK_LAUNCH(ctx, PROF_SA_KEYS, n, k_init_keys, dim3(g_n), dim3(TB), T, n, b.keysA, b.valsA);
@@ -544,6 +547,10 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b, uint32_t **i
         uint32_t mailw[5];
         JPK_TRY(jpk_read_mail(ctx, mailw, 5));
         const uint32_t lc = mailw[4];
+        if (ctx->stats.sa_rounds < JPK_SA_MAX_ROUNDS) {
+            ctx->stats.sa_round_active[ctx->stats.sa_rounds] = (int32_t)m;
+            ctx->stats.sa_round_large[ctx->stats.sa_rounds] = (int32_t)lc;
+        }
         if (lc > 0) {
             JPK_TRY(jpk_exclusive_sum_u32(ctx, b.t1, b.t2, m, b.scratch, nullptr));      // t2 = position in the large list
             const unsigned g_l = jpk_grid(lc, TB);

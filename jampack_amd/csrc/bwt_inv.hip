@@ -229,6 +229,26 @@ __global__ void k_head_check(const uint32_t *__restrict__ dist, uint32_t head_sl
     mail[1] = dist[head_slot];
 }
 
+// ---- comparator: the reference's own GPU kernel shape (CUDAInverse<<<40,3>>>, bwt.cpp:8-19, 226-229) ----------------
+// 120 threads, one per stored index, each following p = Map[p-1]; T[k*step + i] = Bwt[p - (p >= idx)] for step = n/120
+// dependent iterations.  Not used by any product path: it is the measured baseline next to k_walk (bench.py extras), the
+// number behind "replaced, not hipified".
+__global__ void k_chase120(const int32_t *__restrict__ nxt, const uint8_t *__restrict__ B, uint32_t n, uint32_t len, uint32_t idx, uint8_t *__restrict__ T)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= JPK_BWT_UNITS) return;
+    const uint32_t step = n / JPK_BWT_UNITS;
+    const uint8_t *tr = B + len + 4 * k;
+    uint32_t p = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+    uint8_t *dst = T + (size_t)k * step;
+    for (uint32_t i = 0; i < step; i++) {
+        if (p < 1 || p > n) return;                      // corrupt index: stop (the probe is only meaningful on valid images)
+        p = (uint32_t)nxt[p - 1] + 1u;                   // Map[p-1]
+        if (p < 1 || p > n) return;
+        dst[i] = B[p - (p >= idx ? 1u : 0u)];
+    }
+}
+
 struct InvBufs {
     uint32_t *tilehist, *scan_scratch, *cum, *slot_len, *slot_next, *distA, *distB, *linkA, *linkB;
     int32_t *nxt;
@@ -314,5 +334,50 @@ int jpk_inv_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trail
     uint32_t chk[2] = {0, 0};
     JPK_TRY(jpk_read_mail(ctx, chk, 2));
     if (chk[1] != n) return JPK_E_CORRUPT;      // the chain from trailer[0] must cover the whole block
+    return JPK_OK;
+}
+
+// the 120-chain comparator: same Map build, then the literal chase.  *chase_ms = time of the chase kernel alone.
+int jpk_inv_bwt_chains120_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trailer, uint8_t *d_out, float *chase_ms)
+{
+    hipStream_t st = ctx->stream;
+    const int32_t len = len_with_trailer - JPK_TRAILER_BYTES;
+    if (len < 0) return JPK_E_CORRUPT;
+    const int32_t rem = len % JPK_BWT_UNITS;
+    const uint32_t n = (uint32_t)(len - rem);
+    if (chase_ms) *chase_ms = 0.f;
+    if (n == 0) {
+        if (rem > 0) JPK_HIP(hipMemcpyAsync(d_out, d_in, (size_t)rem, hipMemcpyDeviceToDevice, st));
+        return JPK_OK;
+    }
+    JPK_HIP(hipMemcpyAsync(ctx->h_mail, d_in + len, 4, hipMemcpyDeviceToHost, st));
+    JPK_HIP(hipStreamSynchronize(st));
+    const uint32_t I = ctx->h_mail[0];
+    if (I < 1 || I > n) return JPK_E_CORRUPT;
+    InvBufs b;
+    size_t ntiles, nsplit, max_slots;
+    Arena plan(ctx, true);
+    inv_layout(plan, n, b, ntiles, nsplit, max_slots);
+    JPK_TRY(jpk_arena_ensure(ctx, plan.need));
+    Arena real(ctx, false);
+    inv_layout(real, n, b, ntiles, nsplit, max_slots);
+    hipLaunchKernelGGL(k_hist, dim3((unsigned)ntiles), dim3(TB), 0, st, d_in, n, b.tilehist, (uint32_t)ntiles);
+    JPK_TRY(jpk_exclusive_sum_u32(ctx, b.tilehist, b.tilehist, 256 * ntiles, b.scan_scratch, nullptr));
+    hipLaunchKernelGGL(k_cum, dim3(1), dim3(256), 0, st, b.tilehist, (uint32_t)ntiles, n, b.cum);
+    hipLaunchKernelGGL(k_build_nxt, dim3((unsigned)ntiles), dim3(TB), 0, st, d_in, n, I, b.tilehist, (uint32_t)ntiles, b.nxt);
+    hipEvent_t e0, e1;
+    JPK_HIP(hipEventCreate(&e0));
+    JPK_HIP(hipEventCreate(&e1));
+    JPK_HIP(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(k_chase120, dim3(40), dim3(3), 0, st, b.nxt, d_in, n, (uint32_t)len, I, d_out);     // <<<40,3>>>, bwt.cpp:226-229
+    JPK_HIP(hipEventRecord(e1, st));
+    if (rem > 0) hipLaunchKernelGGL(k_inv_tail, dim3(1), dim3(128), 0, st, d_in, n, (uint32_t)len, d_out);
+    JPK_HIP(hipGetLastError());
+    JPK_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (chase_ms) *chase_ms = ms;
     return JPK_OK;
 }

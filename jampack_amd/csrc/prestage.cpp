@@ -44,7 +44,8 @@ extern "C" int jpk_lz77_decompress(const uint8_t *in, int32_t in_len, uint8_t *o
     int64_t pos = 0, op = 0;
     while (pos < in_len) {
         const uint32_t token = in[pos++];
-        int32_t off = 0, len = (int32_t)(token >> 3), lit = (int32_t)(token & 7u);
+        int32_t off = 0;
+        int64_t len = (int64_t)(token >> 3), lit = (int64_t)(token & 7u);   // 64-bit: the extensions are attacker-controlled int32
         int n = leb_read(in + pos, in_len - pos, &off);
         if (n < 0) return JPK_E_CORRUPT;
         pos += n;
@@ -70,14 +71,14 @@ extern "C" int jpk_lz77_decompress(const uint8_t *in, int32_t in_len, uint8_t *o
             op += rest;
             break;
         }
-        if (off < 0 || lit < 0 || len < 0 || pos + lit > in_len) return JPK_E_CORRUPT;
-        if (op + lit + (int64_t)len > out_cap) return JPK_E_CAPACITY;
+        if (off < 0 || lit > in_len - pos) return JPK_E_CORRUPT;
+        if (lit + len > (int64_t)out_cap - op) return JPK_E_CAPACITY;
         memcpy(out + op, in + pos, (size_t)lit);
         op += lit;
         pos += lit;
         if (off > op) return JPK_E_CORRUPT;
         const uint8_t *src = out + op - off;                           // may overlap the destination: byte order matters
-        for (int32_t k = 0; k < len; k++) out[op + k] = src[k];
+        for (int64_t k = 0; k < len; k++) out[op + k] = src[k];
         op += len;
     }
     *out_len = (int32_t)op;

@@ -44,8 +44,15 @@ void Ans::Encode(Buffer Input, Buffer Output, Options Opt)
 
 void Ans::Decode(Buffer Input, Buffer Output, Options Opt)
 {
+	// Not stage_capacity(Opt): on the decompress path Options.BlockSize is the CLI option (default 8 MiB, main.cpp:60),
+	// while the buffers were sized from the frame header (Jampack::BlockSize, jampack.cpp:146-159).  Like the reference
+	// the shim trusts that the caller's buffer holds what the stream declares; the declared size itself is validated.
+	int64_t need = 0;
+	int rc = jpk_ans_decoded_size(Input.block, *Input.size, &need, 0);
+	if (rc) fail("Ans", rc);
+	if (need > (int64_t)((double)JPK_MAX_BLOCKSIZE * 1.05)) fail("Ans", JPK_E_CORRUPT);
 	int n = 0;
-	int rc = jpk_ans_decode(Input.block, *Input.size, Output.block, stage_capacity(Opt), &n, (int)Opt.Threads);
+	rc = jpk_ans_decode(Input.block, *Input.size, Output.block, (int)need, &n, (int)Opt.Threads);
 	if (rc) fail("Ans", rc);
 	*Output.size = n;
 }

@@ -20,7 +20,19 @@ def my_blocks(nblocks: int, rank: int, world: int) -> list[int]:
     return [b for b in range(nblocks) if owner_of(b, world) == rank]
 
 
-def gather_blocks(local: list[torch.Tensor], dst: int = 0, group=None):
+def _collective_device(local, device, group) -> torch.device:
+    """device of the collective's tensors: explicit > the local blocks' > what the backend needs (a rank that owns no
+    block -- fewer blocks than ranks -- must still hand RCCL a CUDA tensor)"""
+    if device is not None:
+        return torch.device(device)
+    if local:
+        return local[0].device
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def gather_blocks(local: list[torch.Tensor], dst: int = 0, group=None, device=None):
     """Variable-size gather of 1-D uint8 tensors (one per local block) onto rank `dst`.
 
     Returns on dst a list (per rank) of lists of tensors in local block order, elsewhere None.
@@ -29,7 +41,7 @@ def gather_blocks(local: list[torch.Tensor], dst: int = 0, group=None):
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    dev = local[0].device if local else torch.device("cpu")
+    dev = _collective_device(local, device, group)
     nloc = torch.tensor([len(local)], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(nloc) for _ in range(world)]
     dist.all_gather(counts, nloc, group=group)
@@ -60,4 +72,15 @@ def gather_blocks(local: list[torch.Tensor], dst: int = 0, group=None):
             blocks.append(bufs[r][o:o + sz].clone())
             o += sz
         out.append(blocks)
+    return out
+
+
+def assemble_in_block_order(per_rank: list[list[torch.Tensor]], nblocks: int) -> list[torch.Tensor]:
+    """undo owner_of(): per_rank[r][k] is the k-th block owned by rank r = block r + k * world -> blocks 0..nblocks-1 in file
+    order (what CompWriteBlock's in-order loop produces, jampack.cpp:220-224)"""
+    world = len(per_rank)
+    out = []
+    for b in range(nblocks):
+        r = owner_of(b, world)
+        out.append(per_rank[r][b // world])
     return out

@@ -2,7 +2,7 @@
 
 Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never from
 jampack_amd/.  `Oracle` wraps oracle/libjamoracle.so (the C restatement, jam_oracle.c); `Ref` wraps
-oracle/_ref/libjamref.so (the real reference compiled from its own sources by oracle/Makefile).
+oracle/_ref/libjamref_hot.so / libjamref_cli.so (the real reference compiled from its own sources by oracle/Makefile).
 """
 from __future__ import annotations
 
@@ -161,17 +161,39 @@ class Oracle:
 
 
 class Ref:
-    """The real reference (oracle/_ref/libjamref.so).  Errors inside it call exit(-1) (format.cpp:6-10)."""
+    """The real reference.  `lib` = oracle/_ref/libjamref_hot.so (hot-path translation units, no macro stand-ins);
+    `cli` = oracle/_ref/libjamref_cli.so (adds the pre-stages and the Jampack class, built with the __min/__max stand-ins),
+    loaded only by the methods that need it.  Errors inside the reference call exit(-1) (format.cpp:6-10)."""
+
+    HOT = os.path.join(HERE, "_ref", "libjamref_hot.so")
+    CLI = os.path.join(HERE, "_ref", "libjamref_cli.so")
 
     def __init__(self, path: str | None = None):
-        path = path or os.path.join(HERE, "_ref", "libjamref.so")
+        path = path or self.HOT
         if not os.path.exists(path):
             raise FileNotFoundError(path)
         self.lib = C.CDLL(path)
+        self._cli = None
+
+    @property
+    def cli(self):
+        if self._cli is None:
+            if not os.path.exists(self.CLI):
+                raise FileNotFoundError(self.CLI)
+            self._cli = C.CDLL(self.CLI)
+        return self._cli
 
     @staticmethod
     def available() -> bool:
-        return os.path.exists(os.path.join(HERE, "_ref", "libjamref.so"))
+        return os.path.exists(Ref.HOT)
+
+    @staticmethod
+    def cli_available() -> bool:
+        return os.path.exists(Ref.CLI)
+
+    def set_threads(self, n: int):
+        """OpenMP team size of the reference (divsufsort.cpp:1493 and the decode loops pick it up)"""
+        self.lib.ref_set_threads(C.c_int32(n))
 
     def bwt_forward(self, t: np.ndarray, prefill: int = 0) -> np.ndarray:
         t = np.array(t, dtype=np.uint8, copy=True)
@@ -252,29 +274,29 @@ class Ref:
         return out[:n]
 
     def lz77_compress(self, t, match_finder: int = 0, block_size: int = 8 << 20) -> np.ndarray:
-        return self._stage(self.lib.ref_lz77_compress, t, int(len(t) * 1.05) + 4096, C.c_int32(match_finder), C.c_int32(block_size))
+        return self._stage(self.cli.ref_lz77_compress, t, int(len(t) * 1.05) + 4096, C.c_int32(match_finder), C.c_int32(block_size))
 
     def lz77_decompress(self, t, cap: int) -> np.ndarray:
-        return self._stage(self.lib.ref_lz77_decompress, t, cap + 64)
+        return self._stage(self.cli.ref_lz77_decompress, t, cap + 64)
 
     def lpx_encode(self, t) -> np.ndarray:
-        return self._stage(self.lib.ref_lpx_encode, t, len(t) + 64)
+        return self._stage(self.cli.ref_lpx_encode, t, len(t) + 64)
 
     def lpx_decode(self, t) -> np.ndarray:
-        return self._stage(self.lib.ref_lpx_decode, t, len(t) + 64)
+        return self._stage(self.cli.ref_lpx_decode, t, len(t) + 64)
 
     def filters_encode(self, t, filters: int = 1) -> np.ndarray:
-        return self._stage(self.lib.ref_filters_encode, t, int(len(t) * 1.05) + 4096, C.c_int32(filters))
+        return self._stage(self.cli.ref_filters_encode, t, int(len(t) * 1.05) + 4096, C.c_int32(filters))
 
     def filters_decode(self, t, cap: int) -> np.ndarray:
-        return self._stage(self.lib.ref_filters_decode, t, cap + 64)
+        return self._stage(self.cli.ref_filters_decode, t, cap + 64)
 
     def jam_comp_block(self, t, block_size: int = 1 << 20, match_finder: int = 0, filters: int = 1) -> np.ndarray:
         """one frame exactly as `jampack c` writes it: Comp() with all six stages + CompWriteBlock"""
         x = np.array(t, dtype=np.uint8, copy=True)
         cap = 15 + int(block_size * 1.05)
         out = np.zeros(cap, dtype=np.uint8)
-        n = self.lib.ref_jam_comp_block(_p(x, _u8p), C.c_int32(len(x)), C.c_int32(block_size), C.c_int32(match_finder), C.c_int32(filters),
+        n = self.cli.ref_jam_comp_block(_p(x, _u8p), C.c_int32(len(x)), C.c_int32(block_size), C.c_int32(match_finder), C.c_int32(filters),
                                         _p(out, _u8p), C.c_int32(cap))
         if n < 0:
             raise OracleError("reference frame does not fit")
@@ -283,7 +305,7 @@ class Ref:
     def jam_decomp_block(self, frame, cap: int) -> np.ndarray:
         f = np.array(frame, dtype=np.uint8, copy=True)
         out = np.zeros(max(cap, 1), dtype=np.uint8)
-        n = self.lib.ref_jam_decomp_block(_p(f, _u8p), C.c_int32(len(f)), _p(out, _u8p), C.c_int32(cap))
+        n = self.cli.ref_jam_decomp_block(_p(f, _u8p), C.c_int32(len(f)), _p(out, _u8p), C.c_int32(cap))
         if n < 0:
             raise OracleError(f"reference block decode failed ({n})")
         return out[:n]

@@ -2,8 +2,13 @@
 //
 // C-ABI driver around the *real* reference classes, compiled together with the reference's own
 // sources where they lie under /root/reference (see oracle/Makefile, target `ref`).  The output
-// (oracle/_ref/libjamref.so) is used (a) to pin the CPU restatement in oracle/jam_oracle.c,
-// (b) to generate tests/golden/, (c) as bench.py's cpu_baseline (kind "reference").
+// Two libraries are built from this file (oracle/Makefile, target `ref`):
+//   oracle/_ref/libjamref_hot.so  hot-path translation units only (ans bwt divsufsort format model rank rle sys_detect
+//                                 utils checksum), compiled with NO macro stand-ins: pins oracle/jam_oracle.c, generates
+//                                 tests/golden/, is bench.py's cpu_baseline (kind "reference");
+//   oracle/_ref/libjamref_cli.so  -DJAMREF_CLI: adds lz77 cyclichhm filters lpx jampack, which need the two MSVC macros
+//                                 __min/__max supplied on the command line -- only the pre-stage
+//                                  fixtures lean on it.
 // Nothing under jampack_amd/ links or loads it.
 //
 // Reference entry points wrapped here:
@@ -25,20 +30,12 @@
 #include "utils.hpp"
 #include "divsufsort.hpp"
 #include "checksum.hpp"
+#ifdef JAMREF_CLI
 #include "jampack.hpp"
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-
-static Options make_opt(int threads);
-static Options make_full_opt(int block_size, int match_finder, int filters, int threads)
-{
-	Options o = make_opt(threads);
-	o.BlockSize = block_size;
-	o.MatchFinder = (unsigned)match_finder;
-	o.Filters = (unsigned)filters;
-	return o;
-}
 
 static Options make_opt(int threads)
 {
@@ -49,6 +46,15 @@ static Options make_opt(int threads)
 	o.Filters = 0;
 	o.Gpu = false;
 	o.Multiblock = false;
+	return o;
+}
+
+static Options make_full_opt(int block_size, int match_finder, int filters, int threads)
+{
+	Options o = make_opt(threads);
+	o.BlockSize = block_size;
+	o.MatchFinder = (unsigned)match_finder;
+	o.Filters = (unsigned)filters;
 	return o;
 }
 
@@ -146,6 +152,7 @@ unsigned int ref_checksum(unsigned char* p, int size)
 	return c.IntegrityCheck(b);
 }
 
+#ifdef JAMREF_CLI
 // ---- pre-stages and the whole block codec of the stock CLI -------------------------
 int ref_lz77_compress(unsigned char* in, int len, unsigned char* out, int match_finder, int block_size)
 {
@@ -238,9 +245,15 @@ int ref_jam_decomp_block(unsigned char* frame, int frame_len, unsigned char* out
 	return n;
 }
 
+#endif // JAMREF_CLI
+
 int ref_divsufsort(const unsigned char* t, int* sa, int n)
 {
 	return divsufsort(t, sa, n);
 }
 
+// OpenMP team size the reference will use (divsufsort.cpp:1493, ans.cpp:262, bwt.cpp:92-132 read it through omp)
+void ref_set_threads(int n);
 } // extern "C"
+#include <omp.h>
+extern "C" void ref_set_threads(int n) { omp_set_num_threads(n < 1 ? 1 : n); }

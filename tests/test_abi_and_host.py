@@ -69,6 +69,65 @@ def test_shim_headers_compile_against_reference_call_pattern(tmp_path):
     assert os.path.exists(os.path.join(ROOT, "jampack_amd", "csrc", "shim", "jam_block_pipeline"))
 
 
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree absent (GPU box)")
+def test_integration_md_build_recipe_links_the_real_reference(tmp_path):
+    """Performs INTEGRATION.md section 1 literally: a scratch copy of the reference tree, its bwt.hpp / ans.hpp /
+    rank.hpp replaced by the shim headers, built with the documented g++ line (read from the document, so the two cannot
+    drift apart).  The unmodified main.cpp + jampack.cpp + pre-stages must link against shim.cpp + libjampack_amd.so."""
+    import glob
+    import shutil
+    import subprocess
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```\n\s*(g\+\+ -std=c\+\+14.*?)```", doc, re.S)
+    assert m, "INTEGRATION.md lost its build line"
+    cmdline = " ".join(m.group(1).replace("\\\n", " ").split())
+    assert "divsufsort.cpp" in cmdline, "lz77.cpp:141 calls divsufsort(): the recipe must keep divsufsort.cpp"
+    for f in glob.glob(os.path.join(REFERENCE, "*.[ch]pp")):
+        shutil.copy(f, tmp_path)
+    shim = os.path.join(ROOT, "jampack_amd", "csrc", "shim")
+    for h in ("bwt.hpp", "ans.hpp", "rank.hpp"):
+        shutil.copy(os.path.join(shim, h), tmp_path)
+    os.symlink(os.path.join(ROOT, "jampack_amd"), tmp_path / "jampack_amd")
+    os.symlink(os.path.join(ROOT, "include"), tmp_path / "include")
+    r = subprocess.run(cmdline + " -o jampack_gpu", shell=True, cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run(["nm", "-D", "--undefined-only", str(tmp_path / "jampack_gpu")], capture_output=True, text=True).stdout
+    for sym in ("jpk_bwt_forward", "jpk_bwt_inverse", "jpk_ans_encode", "jpk_ans_decode", "jpk_ans_decoded_size"):
+        assert sym in out, f"the drop-in binary does not bind {sym}"
+    assert "divsufsort" not in out            # defined in the binary, from the reference's own divsufsort.cpp
+
+
+def test_device_mask_api_without_gpu():
+    import jampack_amd
+    if jampack_amd.lib().jpk_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    assert jampack_amd.lib().jpk_init(0) == -6           # JPK_E_NODEVICE, never a silent CPU path
+    assert jampack_amd.lib().jpk_thread_device() == -6
+    jampack_amd.lib().jpk_shutdown()                     # harmless with nothing to destroy
+
+
+def test_bench_refuses_a_gpus_flag_that_disagrees_with_the_launcher():
+    """`--gpus N` must never silently run one GPU"""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_survey_corpus_is_seekable():
+    from jampack_amd import corpus
+    whole = corpus.text_survey(9_000_000, 9)
+    part = corpus.text_survey(2_500_000, 9, start=3_999_000)         # straddles a page boundary
+    assert np.array_equal(part, whole[3_999_000:6_499_000])
+    d, src = corpus.load_or_make("enwik9", start=14 * (64 << 20), count=64 << 20)
+    assert len(d) == 60_475_904 and src == "synthetic"               # the 15th block of the 1 GB stream (SURVEY 8)
+    assert corpus.block_ranges(1_000_000_000, 64 << 20)[-1] == (939_524_096, 60_475_904)
+
+
 def test_corpus_is_deterministic():
     from jampack_amd import corpus
     a = corpus.make("text", 100000, 8)

@@ -1,0 +1,119 @@
+"""The drop-in boundary end to end, on the GPU: the reference's UNMODIFIED command-line program (main.cpp, jampack.cpp,
+pre-stages) linked against the C++ shim + libjampack_amd.so (oracle/_ref/jampack_shim, built by oracle/Makefile with the
+recipe of INTEGRATION.md section 1) runs as a child process next to the stock build (oracle/_ref/jampack_ref).
+
+  * `jampack_shim c` writes the same archive, byte for byte, as `jampack c`        (jampack.cpp:186-254)
+  * each program decompresses the other's archive                                    (jampack.cpp:262-336)
+  * blocks larger than the decompressor's default Options.BlockSize (8 MiB, main.cpp:60) decode (Ans::Decode capacity)
+  * jam_block_pipeline (the Comp()/Decomp() tail through the shim) runs and verifies
+  * jpk_init(device_mask) / thread -> device round robin / jpk_shutdown
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_CLI = os.path.join(ROOT, "oracle", "_ref", "jampack_ref")
+SHIM_CLI = os.path.join(ROOT, "oracle", "_ref", "jampack_shim")
+PIPELINE = os.path.join(ROOT, "jampack_amd", "csrc", "shim", "jam_block_pipeline")
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import jampack_amd
+    if jampack_amd.lib().jpk_device_count() <= 0:
+        pytest.skip("no GPU")
+    return jampack_amd
+
+
+def _mixed(n, seed):
+    from jampack_amd import corpus
+    parts = [corpus.make("text", n // 2, seed), corpus.make("samples16", n // 4, seed + 1), corpus.make("runs", n // 8, seed + 2)]
+    parts.append(corpus.make("random", n - sum(len(p) for p in parts), seed + 3))
+    return np.concatenate(parts)
+
+
+def _run(cmd, timeout=600):
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, f"{' '.join(cmd)} -> {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}"
+    return r.stdout
+
+
+def _need(*paths):
+    for p in paths:
+        if not os.path.exists(p):
+            pytest.skip(f"{os.path.relpath(p, ROOT)} not built (reference tree was absent at build time)")
+
+
+@pytest.mark.parametrize("flags", [["-b1", "-t2"], ["-b2", "-t4", "-m1", "-f2"], ["-b1", "-t1", "-T"]])
+def test_stock_cli_through_the_shim_writes_the_reference_archive(gpu, tmp_path, flags):
+    _need(REF_CLI, SHIM_CLI)
+    src = tmp_path / "in.bin"
+    _mixed(3_300_000, 41).tofile(src)
+    _run([REF_CLI, "c", str(src), str(tmp_path / "ref.jam")] + flags)
+    _run([SHIM_CLI, "c", str(src), str(tmp_path / "gpu.jam")] + flags)
+    a, b = np.fromfile(tmp_path / "ref.jam", dtype=np.uint8), np.fromfile(tmp_path / "gpu.jam", dtype=np.uint8)
+    assert len(a) == len(b) and np.array_equal(a, b), "archive written through the shim differs from the stock CLI's"
+    _run([SHIM_CLI, "d", str(tmp_path / "ref.jam"), str(tmp_path / "back_gpu")] + flags[1:2])
+    _run([REF_CLI, "d", str(tmp_path / "gpu.jam"), str(tmp_path / "back_ref")] + flags[1:2])
+    orig = np.fromfile(src, dtype=np.uint8)
+    assert np.array_equal(np.fromfile(tmp_path / "back_gpu", dtype=np.uint8), orig)
+    assert np.array_equal(np.fromfile(tmp_path / "back_ref", dtype=np.uint8), orig)
+
+
+def test_blocks_larger_than_the_decoders_default_blocksize(gpu, tmp_path):
+    """`jampack d` never sees -b: Options.BlockSize stays 8 MiB (main.cpp:60) while the frame says 16 MiB.  The shim must not
+    derive Ans::Decode's capacity from Options.BlockSize."""
+    _need(SHIM_CLI)
+    from jampack_amd import corpus
+    src = tmp_path / "in.bin"
+    corpus.make("text", 20_000_000, 77).tofile(src)
+    _run([SHIM_CLI, "c", str(src), str(tmp_path / "a.jam"), "-b16", "-t2", "-f0"])
+    _run([SHIM_CLI, "d", str(tmp_path / "a.jam"), str(tmp_path / "back")])            # no -b on purpose
+    assert np.array_equal(np.fromfile(tmp_path / "back", dtype=np.uint8), np.fromfile(src, dtype=np.uint8))
+
+
+def test_block_pipeline_program_runs(gpu, tmp_path):
+    if not os.path.exists(PIPELINE):
+        subprocess.check_call(["make", "-C", os.path.dirname(PIPELINE)], stdout=subprocess.DEVNULL)
+    src = tmp_path / "in.bin"
+    _mixed(3_000_000, 5).tofile(src)
+    out = _run([PIPELINE, str(src), "1"])
+    assert "round trip ok" in out and "3000000 ->" in out, out
+
+
+def test_init_mask_round_robin_and_shutdown(gpu, oracle):
+    jam = gpu
+    lib = jam.lib()
+    lib.jpk_shutdown()
+    ndev = lib.jpk_device_count()
+    assert lib.jpk_init(1 << 40) == -6                   # no such device: JPK_E_NODEVICE, nothing selected
+    assert jam.init(0) == ndev
+    devs = (ctypes.c_int32 * 64)()
+    assert lib.jpk_init_devices(devs, 64) == ndev and list(devs[:ndev]) == list(range(ndev))
+    t = jam.corpus.make("text", 200_000, 3)
+    exp = oracle.ans_encode(oracle.bwt_forward(t))
+    got, where = {}, {}
+
+    def work(k):
+        where[k] = jam.thread_device()
+        got[k] = jam.block_compress(t)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert sorted(where.values()) == sorted(k % ndev for k in range(4))       # dealt round robin over the selected devices
+    assert all(np.array_equal(got[k], exp) for k in range(4))
+    assert lib.jpk_init(0) == -1                         # contexts exist: shut down first
+    jam.shutdown()
+    assert jam.init(1) == 1 and jam.thread_device() == 0  # explicit mask: device 0 only
+    assert np.array_equal(jam.block_compress(t), exp)     # fresh context after the shutdown
+    jam.shutdown()

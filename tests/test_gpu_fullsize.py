@@ -86,3 +86,20 @@ def test_worst_case_blocks_16mib(gpu, oracle):
     for kind in ("zero", "repeat", "two"):
         t = jam.corpus.make(kind, 16 << 20, 3)
         d_bwt, _ = _roundtrip(torch, jam, ctx, t)
+
+
+def test_120_chain_comparator_gives_the_same_text(gpu):
+    """BASELINE config 3's "120-way parallel LF-map": the reference's own kernel shape (CUDAInverse<<<40,3>>>, bwt.cpp:8-19)
+    kept as a measured comparator; same bytes as the list-ranking inverse, on a block small enough for 120 serial chains."""
+    torch, jam, ctx = gpu
+    n = 2_400_000 + 77
+    t = jam.corpus.make("text_survey", n, 4)
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(t).to(dev)
+    d_bwt = torch.empty(n + 480, dtype=torch.uint8, device=dev)
+    ctx.bwt_forward(d_in, n, d_bwt, n + 480)
+    a = torch.zeros(n, dtype=torch.uint8, device=dev)
+    b = torch.zeros(n, dtype=torch.uint8, device=dev)
+    assert ctx.bwt_inverse(d_bwt, n + 480, a, n) == n
+    m, ms = ctx.bwt_inverse_chains120(d_bwt, n + 480, b, n)
+    assert m == n and ms > 0 and torch.equal(a, b) and torch.equal(a, d_in)

@@ -9,7 +9,7 @@ from golden_util import case_input, cases, sha, small
 
 pytestmark = pytest.mark.gpu
 
-KINDS = ["text", "random", "dna", "two", "zero", "geometric", "samples16", "runs", "repeat4k", "silesia"]
+KINDS = ["text", "text_survey", "random", "dna", "two", "zero", "geometric", "samples16", "runs", "repeat4k", "silesia"]
 SIZES = [0, 1, 119, 120, 121, 240, 1207, 4097, 70_000, 300_000]
 
 

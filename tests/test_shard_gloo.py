@@ -9,12 +9,11 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, nblocks=5):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from jampack_amd import shard
-    nblocks = 5
     mine = shard.my_blocks(nblocks, rank, world)
     rng = np.random.default_rng(100)
     payloads = [rng.integers(0, 256, 1000 + 377 * b, dtype=np.uint8) for b in range(nblocks)]
@@ -27,6 +26,9 @@ def _worker(rank, world, port, q):
             ok = ok and len(got[r]) == len(owned)
             for t, b in zip(got[r], owned):
                 ok = ok and np.array_equal(t.numpy(), payloads[b])
+        # file order (jampack.cpp:220-224): block b comes back at index b whatever the ownership was
+        ordered = shard.assemble_in_block_order(got, nblocks)
+        ok = ok and len(ordered) == nblocks and all(np.array_equal(ordered[b].numpy(), payloads[b]) for b in range(nblocks))
     else:
         ok = got is None
     q.put((rank, ok))
@@ -34,11 +36,12 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gather_blocks_world2():
+@pytest.mark.parametrize("nblocks", [5, 1, 0])      # 1 and 0: a rank (or every rank) owns no block at all
+def test_gather_blocks_world2(nblocks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + os.getpid() % 200
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29600 + (os.getpid() + 7 * nblocks) % 200
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, nblocks)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
