@@ -243,8 +243,8 @@ __global__ void k_chase120(const int32_t *__restrict__ nxt, const uint8_t *__res
     uint8_t *dst = T + (size_t)k * step;
     for (uint32_t i = 0; i < step; i++) {
         if (p < 1 || p > n) return;                      // corrupt index: stop (the probe is only meaningful on valid images)
-        p = (uint32_t)nxt[p - 1] + 1u;                   // Map[p-1]
-        if (p < 1 || p > n) return;
+        p = (uint32_t)nxt[p - 1] + 1u;                   // Map[p-1]; 0 on the very last step of the last chain (row 0 = T[n-1])
+        if (p > n) return;
         dst[i] = B[p - (p >= idx ? 1u : 0u)];
     }
 }

@@ -52,12 +52,15 @@ def _need(*paths):
 
 
 # -f0: archive equality needs the pre-stages to be deterministic, and the reference's generic filter (on by default, -f1) is
-# not -- its heuristic for the last, partial 64 KiB piece of a block reads past the end of its 1.05 x BlockSize input buffer
-# (filters.cpp), so its choice depends on whatever the heap holds there.  The stock binary happens to see the same bytes every
-# run; any other library in the process (the HIP runtime here) changes them: with -f1 about a third of the runs of the shim
-# build differ from the stock archive in the last bytes of one block's filter output, BEFORE ForwardBwt is called
-# (tools/cli_dump.sh shows identical stage inputs otherwise, tools/cli_guard.sh that no stage call touches a byte outside its
-# output).  The default-filter archives are therefore checked by decoding, not by comparing bytes (next test).
+# not: its heuristic scores an UNINITIALISED 64 KiB malloc whenever the previous piece used no channel width ("pbuf",
+# filters.cpp:345-361: Reorder is skipped for PrevWidth == 0, the entropy of whatever the heap held is still computed and can
+# win, :363-364) and writes eScores[k][MAX_CHANNEL_WIDTH] one element past three small mallocs (filters.cpp:232-234 against
+# the `k <= MAX_CHANNEL_WIDTH` loops at :249-254, :374-378).  The stock binary happens to see the same heap every run; any
+# other library in the process (the HIP runtime here) changes it: with -f1 about a third of the runs of the shim build differ
+# from the stock archive in the last bytes of one block's FILTER output -- before ForwardBwt is called (tools/cli_dump.sh: all
+# other stage inputs identical; tools/cli_guard.sh: no stage call touches a byte outside its output; tools/cli_stock_repeat.sh:
+# stock 0/30, shim 11/30 with OMP_NUM_THREADS=1).  The default-filter archives are therefore checked by decoding, not by
+# comparing bytes (next test).
 @pytest.mark.parametrize("flags", [["-b1", "-t2", "-f0"], ["-b2", "-t4", "-m1", "-f0"], ["-b1", "-t1", "-T", "-f0"]])
 def test_stock_cli_through_the_shim_writes_the_reference_archive(gpu, tmp_path, flags):
     _need(REF_CLI, SHIM_CLI)
