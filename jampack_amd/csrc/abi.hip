@@ -155,6 +155,8 @@ extern "C" int jpk_ctx_create(jpk_ctx **out, int device, void *hip_stream)
         jpk_ctx_destroy(c);
         return JPK_E_ALLOC;
     }
+    for (int k = 0; k < 2; k++)
+        if (hipEventCreateWithFlags(&c->ev_sa[k], hipEventDisableTiming) != hipSuccess) { jpk_ctx_destroy(c); return JPK_E_ALLOC; }
     for (int g = 0; g < jpk_ctx::ENC_GROUPS; g++) {
         if ((g + 1 < jpk_ctx::ENC_GROUPS && hipStreamCreateWithFlags(&c->aux[g], hipStreamNonBlocking) != hipSuccess) ||
             hipEventCreateWithFlags(&c->ev_pre[g], hipEventDisableTiming) != hipSuccess ||
@@ -184,6 +186,8 @@ extern "C" void jpk_ctx_destroy(jpk_ctx *c)
         if (c->ev_pre[g]) (void)hipEventDestroy(c->ev_pre[g]);
         if (c->ev_done[g]) (void)hipEventDestroy(c->ev_done[g]);
     }
+    for (int k = 0; k < 2; k++)
+        if (c->ev_sa[k]) (void)hipEventDestroy(c->ev_sa[k]);
     for (auto &p : c->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -193,6 +197,11 @@ extern "C" void jpk_ctx_destroy(jpk_ctx *c)
 extern "C" int jpk_ctx_stats(jpk_ctx *ctx, jpk_stats *out)
 {
     if (!ctx || !out) return JPK_E_ARG;
+    if (ctx->sa_stats_pending) {
+        JPK_HIP(hipSetDevice(ctx->device));
+        JPK_HIP(hipStreamSynchronize(ctx->stream));
+        jpk_sa_stats_sync(ctx);
+    }
     *out = ctx->stats;
     return JPK_OK;
 }
@@ -232,6 +241,7 @@ extern "C" int jpk_dev_bwt_forward(jpk_ctx *ctx, const uint8_t *d_in, int32_t in
     if ((int64_t)in_len + JPK_TRAILER_BYTES > (int64_t)out_cap) return JPK_E_CAPACITY;
     JPK_TRY(jpk_fwd_bwt_device(ctx, d_in, in_len, d_out));
     JPK_HIP(hipStreamSynchronize(ctx->stream));
+    jpk_sa_stats_sync(ctx);
     *out_len = in_len + JPK_TRAILER_BYTES;
     return JPK_OK;
 }
@@ -300,7 +310,9 @@ extern "C" int jpk_dev_block_compress(jpk_ctx *ctx, const uint8_t *d_in, int32_t
     JPK_TRY(buf_ensure(ctx, &ctx->stage_out, &ctx->stage_out_cap, mid));
     if (in_len < JPK_BWT_UNITS) JPK_HIP(hipMemsetAsync(ctx->stage_out, 0, mid, ctx->stream));   // untouched trailer: defined bytes
     JPK_TRY(jpk_fwd_bwt_device(ctx, d_in, in_len, ctx->stage_out));
-    return jpk_ans_encode_device(ctx, ctx->stage_out, (int32_t)mid, d_out, out_cap, out_len);
+    const int rc = jpk_ans_encode_device(ctx, ctx->stage_out, (int32_t)mid, d_out, out_cap, out_len);    // synchronises the stream
+    if (rc == JPK_OK) jpk_sa_stats_sync(ctx);
+    return rc;
 }
 
 extern "C" int jpk_dev_block_decompress(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
@@ -325,6 +337,7 @@ extern "C" int jpk_dev_suffix_array(jpk_ctx *ctx, const uint8_t *d_t, int32_t n,
     if (n < 0 || (n > 0 && (!d_t || !d_sa))) return JPK_E_ARG;
     JPK_TRY(jpk_suffix_array_device(ctx, d_t, n, d_sa));
     JPK_HIP(hipStreamSynchronize(ctx->stream));
+    jpk_sa_stats_sync(ctx);
     return JPK_OK;
 }
 

@@ -1,19 +1,27 @@
 // bwt_fwd.hip -- forward BWT on gfx950: GPU suffix-array construction (replaces divsufsort, divsufsort.cpp:1721)
-// followed by the BWT gather and the 120 sampled ranks of BlockSort::Bwt::ForwardBwt (bwt.cpp:22-65).
+// followed by the BWT image and the 120 sampled ranks of BlockSort::Bwt::ForwardBwt (bwt.cpp:22-65).
 //
 // Suffix array = prefix doubling (Larsson-Sadakane ranks) with compaction of resolved suffixes:
 //   round 0   key = first 7 bytes (big-endian, zero padded): one LSD radix sort of all n suffixes, 7 passes (radix.hip),
 //             fed in descending text position so that a short suffix -- a proper prefix of anything it ties with on
 //             the padded bytes -- comes first: plain suffix order even when the text contains 0x00.
-//   round h   (h = 7, 14, 28, ...) active suffixes only.  The active list keeps groups of equal h-rank contiguous
-//             and in SA order, so a group is sorted by key2 = rank[sa + h] + 1 (0 past the end) independently:
-//               * groups of <= 1024 suffixes: k_seg_round -- one workgroup owns the groups that start in its
-//                 1024-element window, stages (sa, key2, group id) in LDS, LDS radix sort, re-ranks, writes ISA,
-//                 drops singletons into SA.  One read + one write of the active list per round.
-//               * larger groups: compacted and sent through the global radix sort on (group rank << 32 | key2).
-//             Ranks are double-buffered (read ISA_cur, write ISA_nxt) so that the gathers of a round never see
-//             ranks written by the same round.
-// Every array stays in HBM (T n, ISA 2 x 4n, SA 4n, sort ping-pong 24n, active lists 16n, temps 16n).
+//   round r   (h = 7, 14, 28, ...) unresolved suffixes only.  The active list keeps groups of equal h-rank contiguous and
+//             in SA order, so a group is sorted by key2 = rank[sa + h] + 1 (0 past the end) independently:
+//               * k_gather_win   key2 of every active suffix (the round's only random READ), head flags per 1024-slot window
+//               * groups of <= 1024 suffixes: k_seg_round -- one workgroup owns the groups that start in its window,
+//                 stages (sa, key2, group id) in LDS, LDS radix sort, re-ranks;
+//               * larger groups: segmented LSD radix sort IN PLACE on (key2, sa), tiles = the pieces a group cuts out of
+//                 the windows it crosses; per-group digit-major tables laid out in window order, so one flat exclusive
+//                 scan gives every piece its offsets inside its own group;
+//               * new ranks go to ISA (the round's only random WRITE); a suffix that has become a group of one is
+//                 finished: its BWT byte T[sa - 1] is emitted at its final SA position and it leaves the list;
+//               * compaction of the survivors (count / scan of tile totals / scatter).
+//   One ISA buffer: all reads of a round (k_gather_win) complete before its first write (kernel boundary), which is the
+//   condition under which parallel Larsson-Sadakane is exact.
+// No host round trip inside the loop: the number of active suffixes lives in device memory (SaState), every kernel is a
+// grid-stride loop that reads it, and the host only learns -- one round late, through an asynchronous copy -- when to stop
+// enqueueing rounds.
+// Every array stays in HBM: T n, ISA 4n, BWT-in-SA-order n, radix ping-pong 24n (re-used by the rounds), active list 8n.
 #include "common.hpp"
 #include "prims.hpp"
 
@@ -22,104 +30,381 @@ using namespace jpk;
 namespace {
 
 constexpr int TB = 256;
+constexpr int WAVES = TB / 64;
 constexpr uint32_t DONE = 0x80000000u;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
 
-// ---- round 0 ----------------------------------------------------------------------------------------
-// key = first 7 bytes, big-endian in bits 63..8, zero padded past the end of the text.  Slot j holds suffix n-1-j:
-// the LSD sort is stable, so suffixes that tie on the padded bytes come out in DESCENDING text position, i.e. a
-// short suffix (a proper prefix of everything it ties with) lands in front -- plain suffix order even when the text
-// contains 0x00 -- and the low byte of the key needs no sort pass.
-__global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T, uint32_t n, uint64_t *__restrict__ keys,
-                                                 uint32_t *__restrict__ vals)
-{
-    uint32_t j = blockIdx.x * TB + threadIdx.x;
-    if (j >= n) return;
-    const uint32_t i = n - 1 - j;
-    uint32_t left = n - i;
-    uint64_t k = 0;
-#pragma unroll
-    for (int b = 0; b < 7; b++) {
-        uint64_t c = (b < (int)left) ? T[i + b] : 0;
-        k |= c << (56 - 8 * b);
-    }
-    keys[j] = k;
-    vals[j] = i;
-}
-
-// head flags of equal-key runs -> hv[i] = head ? i : 0  (input of an inclusive max scan); a suffix with fewer than
-// 7 bytes is always a group of its own
-__global__ __launch_bounds__(TB) void k_heads_u64(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t m, uint32_t n,
-                                                 uint32_t *__restrict__ hv)
-{
-    uint32_t j = blockIdx.x * TB + threadIdx.x;
-    if (j >= m) return;
-    bool head = (j == 0) || (keys[j] != keys[j - 1]) || (sa[j] + 7u > n) || (sa[j - 1] + 7u > n);
-    hv[j] = head ? j : 0u;
-}
-
-// round 0: grp[] (= index of the run head) -> both rank buffers, singletons -> SA, keep flags for compaction
-__global__ __launch_bounds__(TB) void k_round0_finish(const uint32_t *__restrict__ grp, const uint32_t *__restrict__ sa, uint32_t n,
-                                                     uint32_t *__restrict__ ISA0, uint32_t *__restrict__ ISA1, uint32_t *__restrict__ SA,
-                                                     uint32_t *__restrict__ keep)
-{
-    uint32_t j = blockIdx.x * TB + threadIdx.x;
-    if (j >= n) return;
-    uint32_t g = grp[j], s = sa[j];
-    ISA0[s] = g;
-    bool head = (g == j);
-    bool next_head = (j + 1 == n) || (grp[j + 1] == j + 1);
-    bool single = head && next_head;
-    if (single) { SA[j] = s; ISA1[s] = g; }      // finished: final rank in both buffers; the rest is rewritten by round 1
-    keep[j] = single ? 0u : 1u;
-}
-
-// stream compaction of the survivors: (sa, grp) -> active lists
-__global__ __launch_bounds__(TB) void k_compact(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ sa,
-                                               const uint32_t *__restrict__ grp, uint32_t m, uint32_t *__restrict__ a_sa,
-                                               uint32_t *__restrict__ a_grp)
-{
-    uint32_t j = blockIdx.x * TB + threadIdx.x;
-    if (j >= m) return;
-    if (keep[j]) {
-        uint32_t p = pos[j];
-        a_sa[p] = sa[j];
-        a_grp[p] = grp[j];
-    }
-}
-
-// ---- doubling rounds: window bookkeeping -----------------------------------------------------------------
+constexpr int CT = 4096;                   // slots per tile of the streaming kernels (count / scatter), 16 per thread
+constexpr int CT_ITEMS = CT / TB;          // 16: slot(w, k, l) = tile * CT + w * 1024 + k * 64 + l  -> ballot = one 64-bit word
 constexpr int SEG_TILE = 1024;             // a workgroup owns the groups that START in its SEG_TILE window
 constexpr int SEG_SPAN = 2 * SEG_TILE;     // ... and therefore sees at most this many elements
 constexpr int SEG_ITEMS = SEG_SPAN / TB;   // 8
-constexpr int SEG_DBITS = 9;               // digit width of the LDS sort: (26-bit rank, 10-bit local group) = 36 bits = 4 passes
+constexpr int SEG_DBITS = 9;               // digit width of the LDS sort: (<= 31-bit rank, 10-bit local group) = at most 5 passes
 constexpr int SEG_DIGITS = 1 << SEG_DBITS;
+constexpr int WIN_ITEMS = SEG_TILE / TB;   // 4: slot(w, k, l) = window * 1024 + w * 256 + k * 64 + l
 static_assert(SEG_DIGITS == 2 * TB, "two digits per thread in the digit scan");
 
-// lasthead[w] = 1 + (largest group-head index inside window w), 0 if the window has no head
-__global__ __launch_bounds__(TB) void k_win_heads(const uint32_t *__restrict__ a_grp, uint32_t m, uint32_t *__restrict__ lasthead)
+// device-resident bookkeeping of one suffix sort (lives in the arena; the host reads it asynchronously)
+struct SaState {
+    uint32_t m[2];                         // unresolved suffixes: round r reads m[r & 1] and writes m[(r + 1) & 1]
+    uint32_t npieces;                      // pieces of large groups in the current round
+    uint32_t lc;                           // members of large groups in the current round
+    uint32_t round_m[JPK_SA_MAX_ROUNDS];   // per round: unresolved suffixes when it starts
+    uint32_t round_lc[JPK_SA_MAX_ROUNDS];  // per round: of those, members of groups > SEG_TILE
+};
+
+// one piece of a large group: the part of the group that lies inside one 1024-slot window of the active list
+struct Piece {
+    uint32_t begin, count;                 // slots [begin, begin + count) of the active list
+    uint32_t gs, ge;                       // the group: slots [gs, ge)
+    uint32_t fp, nt, tl, pad;              // index of the group's first piece, pieces in the group, this piece's ordinal
+};
+
+__device__ __forceinline__ uint64_t mask_below(int l) { return (1ull << l) - 1ull; }              // lanes < l
+__device__ __forceinline__ uint64_t mask_upto(int l) { return (l >= 63) ? ~0ull : ((2ull << l) - 1ull); }   // lanes <= l
+__device__ __forceinline__ uint32_t top_bit(uint64_t v) { return 63u - (uint32_t)__clzll((long long)v); }   // v != 0
+
+// ---- single-workgroup scans over small per-tile / per-window arrays (1024 threads) -----------------------------------
+constexpr int WG1 = 1024;
+constexpr int WG1_ITEMS = 8;
+// out[i] = scan of in[0..i] (inclusive) or in[0..i-1] (exclusive) starting from `init`; REV walks the array backwards
+// (suffix scan).  Returns the reduction of everything (all threads).  in == out is allowed.
+template <class Op, bool EXCL, bool REV>
+__device__ __forceinline__ uint32_t wg_scan(const uint32_t *in, uint32_t *out, uint32_t n, uint32_t init, uint32_t *sm)
 {
-    __shared__ uint32_t sm[TB / 64 + 1];
-    const uint32_t base = blockIdx.x * SEG_TILE;
-    uint32_t best = 0;
+    uint32_t carry = init;
+    for (uint32_t c0 = 0; c0 < n; c0 += WG1 * WG1_ITEMS) {
+        const uint32_t i0 = c0 + threadIdx.x * WG1_ITEMS;
+        uint32_t v[WG1_ITEMS];
+        uint32_t acc = Op::id();
 #pragma unroll
-    for (int k = 0; k < SEG_TILE / TB; k++) {
-        uint32_t j = base + k * TB + threadIdx.x;
-        if (j < m) {
-            bool head = (j == 0) || (a_grp[j] != a_grp[j - 1]);
-            if (head) best = j + 1;
+        for (int k = 0; k < WG1_ITEMS; k++) {
+            const uint32_t i = i0 + k;
+            v[k] = (i < n) ? in[REV ? n - 1 - i : i] : Op::id();
+            acc = Op::f(acc, v[k]);
         }
+        uint32_t tot;
+        const uint32_t inc = block_incl_scan<Op>(acc, sm, &tot);
+        uint32_t prev = __shfl_up(inc, 1, 64);
+        if (lane_id() == 0) prev = (threadIdx.x == 0) ? Op::id() : sm[(threadIdx.x >> 6) - 1];
+        uint32_t run = Op::f(carry, prev);
+#pragma unroll
+        for (int k = 0; k < WG1_ITEMS; k++) {
+            const uint32_t i = i0 + k;
+            uint32_t o;
+            if (EXCL) { o = run; run = Op::f(run, v[k]); }
+            else { run = Op::f(run, v[k]); o = run; }
+            if (i < n) out[REV ? n - 1 - i : i] = o;
+        }
+        carry = Op::f(carry, tot);
+        __syncthreads();                    // sm is reused by the next chunk; the stores above are visible to the workgroup
     }
-    uint32_t tot;
-    block_incl_scan<OpMax>(best, sm, &tot);
-    if (threadIdx.x == 0) lasthead[blockIdx.x] = tot;
+    return carry;
 }
 
-// the sort / re-rank of all groups of <= SEG_TILE elements, one window per workgroup
-__global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, uint32_t m, uint32_t n,
-                                                 uint32_t h, int key_bits, const uint32_t *__restrict__ winscan /* inclusive max-scan of lasthead */,
-                                                 const uint32_t *__restrict__ ISA_cur, uint32_t *__restrict__ ISA_nxt, uint32_t *__restrict__ SA,
-                                                 uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint32_t *__restrict__ lflag, uint32_t *__restrict__ keep,
-                                                 uint32_t *__restrict__ large_count)
+// ---- round 0 ---------------------------------------------------------------------------------------------------------
+// Round 0 sorts slot j = suffix n-1-j by key = first 7 bytes, big-endian in bits 63..8, zero padded past the end of the text
+// (radix.hip builds the keys from the text in its first pass).  The LSD sort is stable, so suffixes that tie on the padded
+// bytes come out in DESCENDING text position, i.e. a short suffix (a proper prefix of everything it ties with) lands in
+// front -- plain suffix order even when the text contains 0x00 -- and the low byte of the key needs no sort pass.
+
+// head of an equal-key run; a suffix with fewer than 7 bytes is always a group of its own
+__device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t j, uint32_t n)
+{
+    if (j == 0) return true;
+    return keys[j] != keys[j - 1] || sa[j] + 7u > n || sa[j - 1] + 7u > n;
+}
+
+// head words of one 4096-slot tile: HE[word] = heads | slots past the end (so that "the next slot is a head" is one shift),
+// HE[64] bit 0 = head flag of the first slot of the next tile
+__device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n, uint32_t base, uint64_t *HE)
+{
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll 4
+    for (int k = 0; k < CT_ITEMS; k++) {
+        const uint32_t j = base + w * (64 * CT_ITEMS) + k * 64 + l;
+        const bool he = (j >= n) || r0_head(keys, sa, j, n);
+        const uint64_t b = __ballot(he);
+        if (l == 0) HE[w * CT_ITEMS + k] = b;
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t jn = base + CT;
+        HE[64] = (jn >= n || r0_head(keys, sa, jn, n)) ? 1ull : 0ull;
+    }
+}
+__device__ __forceinline__ uint64_t valid_word(uint32_t word_base, uint32_t n)
+{
+    if (word_base >= n) return 0ull;
+    const uint32_t left = n - word_base;
+    return left >= 64u ? ~0ull : ((1ull << left) - 1ull);
+}
+
+// per tile: 1 + position of its last head (0: none), number of suffixes that stay unresolved
+__global__ __launch_bounds__(TB) void k_r0_count(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n,
+                                                uint32_t *__restrict__ tLast, uint32_t *__restrict__ tSurv)
+{
+    __shared__ uint64_t HE[65];
+    const uint32_t ntiles = (n + CT - 1) / CT;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * CT;
+        __syncthreads();
+        r0_tile_heads(keys, sa, n, base, HE);
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            const uint64_t he = HE[l], vm = valid_word(base + l * 64, n);
+            const uint64_t hv = he & vm;
+            const uint64_t nexth = (he >> 1) | (HE[l + 1] << 63);
+            const uint64_t single = hv & nexth;
+            uint32_t cnt = (uint32_t)__popcll(vm & ~single);
+            uint32_t last = hv ? base + l * 64 + top_bit(hv) + 1u : 0u;
+            cnt = wave_sum(cnt);
+            last = wave_incl_max(last);
+            if (l == 63) { tSurv[tile] = cnt; tLast[tile] = last; }
+        }
+    }
+}
+
+// one workgroup: carry-in head per tile (exclusive prefix max), output offset per tile (exclusive prefix sum), total -> state
+__global__ __launch_bounds__(WG1) void k_r0_scan(uint32_t *__restrict__ tLast, uint32_t *__restrict__ tSurv, uint32_t n, SaState *__restrict__ st)
+{
+    __shared__ uint32_t sm[WG1 / 64 + 1];
+    const uint32_t ntiles = (n + CT - 1) / CT;
+    wg_scan<OpMax, true, false>(tLast, tLast, ntiles, 0u, sm);
+    const uint32_t total = wg_scan<OpSum, true, false>(tSurv, tSurv, ntiles, 0u, sm);
+    if (threadIdx.x == 0) {
+        st->m[1] = total;
+        st->round_m[0] = n;
+        st->round_m[1] = total;
+        st->npieces = 0;
+        st->lc = 0;
+    }
+}
+
+// group rank (= index of the run head) -> ISA; singletons are finished: BWT byte at their SA position (and SA itself for the
+// suffix-array probe); the rest is compacted into the active list
+__global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n,
+                                                 const uint32_t *__restrict__ tCarry, const uint32_t *__restrict__ tOff, const uint8_t *__restrict__ T,
+                                                 uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
+                                                 uint32_t *__restrict__ a_sa, uint32_t *__restrict__ a_grp)
+{
+    __shared__ uint64_t HE[65];
+    __shared__ uint64_t SV[64];            // survivor bits per word
+    __shared__ uint32_t LHW[64];           // 1 + last head position at or before the end of word l (carry included)
+    __shared__ uint32_t SW[64];            // output position of the first survivor of word l
+    const uint32_t ntiles = (n + CT - 1) / CT;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * CT;
+        __syncthreads();
+        r0_tile_heads(keys, sa, n, base, HE);
+        __syncthreads();
+        const uint32_t carry = tCarry[tile];
+        if (threadIdx.x < 64) {
+            const uint64_t he = HE[l], vm = valid_word(base + l * 64, n);
+            const uint64_t hv = he & vm;
+            const uint64_t nexth = (he >> 1) | (HE[l + 1] << 63);
+            const uint64_t surv = vm & ~(hv & nexth);
+            SV[l] = surv;
+            const uint32_t cnt = (uint32_t)__popcll(surv);
+            const uint32_t inc = wave_incl_sum(cnt);
+            SW[l] = tOff[tile] + inc - cnt;
+            uint32_t last = hv ? base + l * 64 + top_bit(hv) + 1u : 0u;
+            last = wave_incl_max(last);
+            LHW[l] = last > carry ? last : carry;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < CT_ITEMS; k++) {
+            const int word = w * CT_ITEMS + k;
+            const uint32_t j = base + word * 64 + l;
+            if (j < n) {
+                const uint64_t hv = HE[word] & valid_word(base + word * 64, n);
+                const uint64_t le = hv & mask_upto(l);
+                const uint32_t grp = le ? base + word * 64 + top_bit(le) : (word ? LHW[word - 1] : carry) - 1u;
+                const uint32_t s = sa[j];
+                ISA[s] = grp;
+                const uint64_t sv = SV[word];
+                if (!((sv >> l) & 1ull)) {
+                    bwt[j] = s ? T[s - 1] : (uint8_t)0;
+                    if (SA) SA[j] = s;
+                } else {
+                    const uint32_t pos = SW[word] + (uint32_t)__popcll(sv & mask_below(l));
+                    a_sa[pos] = s;
+                    a_grp[pos] = grp;
+                }
+            }
+        }
+    }
+}
+
+// ---- doubling rounds -------------------------------------------------------------------------------------------------
+// key2 of every active suffix + head words per window -> FH / LH = 1 + first / last head position of the window (0: none)
+__global__ __launch_bounds__(TB) void k_gather_win(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const SaState *__restrict__ st,
+                                                  int par, uint32_t n, uint32_t h, const uint32_t *__restrict__ ISA, uint32_t *__restrict__ k2,
+                                                  uint32_t *__restrict__ FH, uint32_t *__restrict__ LH)
+{
+    __shared__ uint64_t H[16];
+    const uint32_t m = st->m[par];
+    const uint32_t nwin = (m + SEG_TILE - 1) / SEG_TILE;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (uint32_t win = blockIdx.x; win < nwin; win += gridDim.x) {
+        const uint32_t base = win * SEG_TILE;
+        __syncthreads();
+        uint32_t s[WIN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l;
+            s[k] = (j < m) ? a_sa[j] : NONE;
+        }
+        uint32_t kv[WIN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const uint64_t s2 = (uint64_t)s[k] + h;
+            kv[k] = (s[k] != NONE && s2 < n) ? ISA[s2] + 1u : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l;
+            bool head = false;
+            if (j < m) {
+                head = (j == 0) || (a_grp[j] != a_grp[j - 1]);
+                k2[j] = kv[k];
+            }
+            const uint64_t b = __ballot(head);
+            if (l == 0) H[w * WIN_ITEMS + k] = b;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint64_t hv = (l < 16) ? H[l] : 0ull;
+            uint32_t first = hv ? base + l * 64 + (uint32_t)__builtin_ctzll(hv) + 1u : NONE;
+            uint32_t last = hv ? base + l * 64 + top_bit(hv) + 1u : 0u;
+            first = wave_incl_min(first);
+            last = wave_incl_max(last);
+            if (l == 63) { FH[win] = (first == NONE) ? 0u : first; LH[win] = last; }
+        }
+    }
+}
+
+// Geometry of the (at most two) pieces that groups larger than SEG_TILE cut out of window w: A = the tail of the group that
+// spills in, B = the head of the window's last group.  PH = 1 + last head at or before the end of window w, NH = first head
+// position after window w (m if none).
+__device__ __forceinline__ void win_geometry(uint32_t w, uint32_t m, const uint32_t *FH, const uint32_t *LH, const uint32_t *PH, const uint32_t *NH,
+                                             bool &hasA, uint32_t &a_end, uint32_t &a_gs, uint32_t &a_ge, bool &hasB, uint32_t &b_gs, uint32_t &b_ge)
+{
+    const uint32_t base = w * SEG_TILE;
+    const uint32_t wend = (base + SEG_TILE < m) ? base + SEG_TILE : m;
+    const uint32_t fh = FH[w], lh = LH[w];
+    hasA = (fh != base + 1u);                         // the first slot of the window is not a head (then w > 0: slot 0 is one)
+    a_gs = 0; a_ge = 0; a_end = 0;
+    if (hasA) {
+        a_gs = PH[w - 1] - 1u;
+        a_end = fh ? fh - 1u : wend;
+        a_ge = fh ? fh - 1u : NH[w];
+        hasA = (a_ge - a_gs > (uint32_t)SEG_TILE);
+    }
+    hasB = (lh != 0u);
+    b_gs = 0; b_ge = 0;
+    if (hasB) {
+        b_gs = lh - 1u;
+        b_ge = NH[w];
+        hasB = (b_ge - b_gs > (uint32_t)SEG_TILE);
+    }
+}
+
+// window metadata in four small kernels: (1) one workgroup: PH, NH by scans; (2) all windows: piece counts; (3) one workgroup:
+// exclusive prefix of the counts; (4) all windows: piece descriptors
+__global__ __launch_bounds__(WG1) void k_win_scan1(const uint32_t *__restrict__ FH, const uint32_t *__restrict__ LH, uint32_t *PH, uint32_t *NH,
+                                                  SaState *__restrict__ st, int par)
+{
+    __shared__ uint32_t sm[WG1 / 64 + 1];
+    const uint32_t m = st->m[par];
+    const uint32_t nwin = (m + SEG_TILE - 1) / SEG_TILE;
+    if (threadIdx.x == 0) { st->npieces = 0; st->lc = 0; }
+    if (nwin == 0) return;
+    wg_scan<OpMax, false, false>(LH, PH, nwin, 0u, sm);
+    // NH: exclusive suffix min of the first-head positions (FH holds position + 1, 0 = none)
+    for (uint32_t w = threadIdx.x; w < nwin; w += WG1) NH[w] = FH[w] ? FH[w] - 1u : NONE;
+    __syncthreads();
+    wg_scan<OpMin, true, true>(NH, NH, nwin, m, sm);
+}
+
+__global__ __launch_bounds__(TB) void k_win_count(const uint32_t *__restrict__ FH, const uint32_t *__restrict__ LH, const uint32_t *__restrict__ PH,
+                                                 const uint32_t *__restrict__ NH, uint32_t *__restrict__ PC, SaState *__restrict__ st, int par)
+{
+    const uint32_t m = st->m[par];
+    const uint32_t nwin = (m + SEG_TILE - 1) / SEG_TILE;
+    uint32_t lsum = 0;
+    for (uint32_t w = blockIdx.x * TB + threadIdx.x; w < nwin; w += gridDim.x * TB) {
+        bool hasA, hasB;
+        uint32_t a_end, a_gs, a_ge, b_gs, b_ge;
+        win_geometry(w, m, FH, LH, PH, NH, hasA, a_end, a_gs, a_ge, hasB, b_gs, b_ge);
+        const uint32_t base = w * SEG_TILE;
+        const uint32_t wend = (base + SEG_TILE < m) ? base + SEG_TILE : m;
+        PC[w] = (hasA ? 1u : 0u) + (hasB ? 1u : 0u);
+        lsum += (hasA ? a_end - base : 0u) + (hasB ? wend - b_gs : 0u);
+    }
+    lsum = wave_sum(lsum);
+    if (lane_id() == 0 && lsum) atomicAdd(&st->lc, lsum);
+}
+
+__global__ __launch_bounds__(WG1) void k_win_scan2(uint32_t *PC, SaState *__restrict__ st, int par, int round)
+{
+    __shared__ uint32_t sm[WG1 / 64 + 1];
+    const uint32_t m = st->m[par];
+    const uint32_t nwin = (m + SEG_TILE - 1) / SEG_TILE;
+    const uint32_t np = wg_scan<OpSum, true, false>(PC, PC, nwin, 0u, sm);
+    if (threadIdx.x == 0) {
+        st->npieces = np;
+        if (round < JPK_SA_MAX_ROUNDS) st->round_lc[round] = st->lc;
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_win_pieces(const uint32_t *__restrict__ FH, const uint32_t *__restrict__ LH, const uint32_t *__restrict__ PH,
+                                                  const uint32_t *__restrict__ NH, const uint32_t *__restrict__ PC, Piece *__restrict__ pieces,
+                                                  const SaState *__restrict__ st, int par)
+{
+    if (st->npieces == 0) return;
+    const uint32_t m = st->m[par];
+    const uint32_t nwin = (m + SEG_TILE - 1) / SEG_TILE;
+    for (uint32_t w = blockIdx.x * TB + threadIdx.x; w < nwin; w += gridDim.x * TB) {
+        bool hasA, hasB;
+        uint32_t a_end, a_gs, a_ge, b_gs, b_ge;
+        win_geometry(w, m, FH, LH, PH, NH, hasA, a_end, a_gs, a_ge, hasB, b_gs, b_ge);
+        const uint32_t base = w * SEG_TILE;
+        const uint32_t wend = (base + SEG_TILE < m) ? base + SEG_TILE : m;
+        uint32_t p = PC[w];
+        if (hasA) {
+            // the group's first piece is piece B of the window that holds its head
+            const uint32_t w0 = a_gs / SEG_TILE;
+            bool hA0, hB0;
+            uint32_t t0, t1, t2, t3, t4;
+            win_geometry(w0, m, FH, LH, PH, NH, hA0, t0, t1, t2, hB0, t3, t4);
+            Piece q;
+            q.begin = base; q.count = a_end - base; q.gs = a_gs; q.ge = a_ge;
+            q.fp = PC[w0] + (hA0 ? 1u : 0u);
+            q.nt = (a_ge - 1u) / SEG_TILE - w0 + 1u;
+            q.tl = w - w0;
+            q.pad = 0;
+            pieces[p++] = q;
+        }
+        if (hasB) {
+            Piece q;
+            q.begin = b_gs; q.count = wend - b_gs; q.gs = b_gs; q.ge = b_ge;
+            q.fp = p;
+            q.nt = (b_ge - 1u) / SEG_TILE - w + 1u;
+            q.tl = 0;
+            q.pad = 0;
+            pieces[p] = q;
+        }
+    }
+}
+
+// the sort / re-rank of all groups of <= SEG_TILE elements, one window per workgroup iteration
+__global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const uint32_t *__restrict__ k2g,
+                                                 const SaState *__restrict__ st, int par, int key_bits, const uint32_t *__restrict__ PH,
+                                                 const uint8_t *__restrict__ T, uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
+                                                 uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp)
 {
     __shared__ uint32_t g[SEG_SPAN];          // group rank (abs SA position of the group head) per loaded element
     __shared__ uint32_t sv[SEG_SPAN];         // suffix index of the owned elements
@@ -131,335 +416,570 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
     __shared__ uint32_t dbase[SEG_DIGITS];
     __shared__ uint32_t sm[TB / 64 + 1];
     __shared__ uint32_t s_fo, s_oe;
-
-    const uint32_t base = blockIdx.x * SEG_TILE;
-    const uint32_t avail = (m - base < (uint32_t)SEG_SPAN) ? m - base : (uint32_t)SEG_SPAN;
-    const bool list_ends = (base + avail == m);
-    const uint32_t wlen = avail < (uint32_t)SEG_TILE ? avail : (uint32_t)SEG_TILE;    // elements of my own window
-    const int tid = threadIdx.x;
-
-    for (uint32_t p = tid; p < avail; p += TB) g[p] = a_grp[base + p];
-    const uint32_t gprev = (base > 0) ? a_grp[base - 1] : 0xFFFFFFFFu;
-    __syncthreads();
-
-    // ---- group starts (max-scan of head positions) and group ends (next head), blocked 8 per thread ----
-    const uint32_t p0 = tid * SEG_ITEMS;
-    uint32_t hd = 0;                           // head bits of my 8 positions
-    uint32_t lasth = 0;                        // 1 + last head position in my segment
-#pragma unroll
-    for (int k = 0; k < SEG_ITEMS; k++) {
-        uint32_t p = p0 + k;
-        if (p < avail) {
-            bool head = (p == 0) ? (base == 0 || g[0] != gprev) : (g[p] != g[p - 1]);
-            if (head) { hd |= 1u << k; lasth = p + 1; }
-        }
-    }
-    uint32_t incl = block_incl_scan<OpMax>(lasth, sm, nullptr);
-    uint32_t prev = __shfl_up(incl, 1, 64);
-    if (lane_id() == 0) prev = (tid == 0) ? 0u : sm[(tid >> 6) - 1];
-    // next head after my segment: suffix-min over the first-head positions of later threads
-    uint32_t firsth = 0xFFFFFFFFu;
-#pragma unroll
-    for (int k = SEG_ITEMS - 1; k >= 0; k--)
-        if (hd & (1u << k)) firsth = p0 + k;
     __shared__ uint32_t fz[TB], rz[TB];
-    fz[tid] = firsth;
-    __syncthreads();
-    uint32_t rv = fz[TB - 1 - tid];
-    uint32_t rinc = block_incl_scan<OpMin>(rv, sm, nullptr);
-    rz[tid] = rinc;
-    __syncthreads();
-    uint32_t after = (tid == TB - 1) ? 0xFFFFFFFFu : rz[TB - 2 - tid];
-    // per position: group start / end
-    uint32_t ge[SEG_ITEMS];
-    {
-        uint32_t nn = after;
-#pragma unroll
-        for (int k = SEG_ITEMS - 1; k >= 0; k--) {
-            ge[k] = nn;                        // first head strictly after position p0+k (or none)
-            if (hd & (1u << k)) nn = p0 + k;
-        }
-        uint32_t run = prev;                   // 1 + start of the current group, 0 = spill-in
-#pragma unroll
-        for (int k = 0; k < SEG_ITEMS; k++) {
-            uint32_t p = p0 + k;
-            if (hd & (1u << k)) run = p + 1;
-            if (p < avail) gsl[p] = run ? (uint16_t)(run - 1) : (uint16_t)0xFFFF;
-        }
-    }
-    if (tid == 0) { s_fo = 0xFFFFFFFFu; s_oe = 0; }
-    __syncthreads();
-    // ---- classify: size of the group of each position; owned = starts in my window and size <= SEG_TILE ----
-    const uint32_t ph = (blockIdx.x > 0) ? winscan[blockIdx.x - 1] : 0u;          // 1 + last head before my window
-    const uint32_t spill_start = ph > 0 ? ph - 1 : 0u;                              // global index
-    uint32_t my_fo = 0xFFFFFFFFu, my_oe = 0, my_large = 0;
-#pragma unroll
-    for (int k = 0; k < SEG_ITEMS; k++) {
-        uint32_t p = p0 + k;
-        if (p < avail) {
-            const uint32_t gs = gsl[p];
-            uint32_t end = ge[k];
-            bool end_known = true;
-            if (end == 0xFFFFFFFFu) { end = avail; end_known = list_ends; }
-            uint32_t size;
-            if (!end_known) size = 0xFFFFFFFFu;
-            else if (gs == 0xFFFFu) size = base + end - spill_start;
-            else size = end - gs;
-            const bool large = size > (uint32_t)SEG_TILE;
-            if (p < wlen) { lflag[base + p] = large ? 1u : 0u; my_large += large ? 1u : 0u; }
-            if (gs != 0xFFFFu && gs < (uint32_t)SEG_TILE && !large) {
-                if (p < my_fo) my_fo = p;
-                if (p + 1 > my_oe) my_oe = p + 1;
-            }
-        }
-    }
-    if (my_fo != 0xFFFFFFFFu) { atomicMin(&s_fo, my_fo); atomicMax(&s_oe, my_oe); }
-    my_large = wave_sum(my_large);
-    if (lane_id() == 0 && my_large) atomicAdd(large_count, my_large);
-    __syncthreads();
-    const uint32_t fo = s_fo, oe = s_oe;
-    if (fo == 0xFFFFFFFFu) return;             // nothing owned
-    const uint32_t no = oe - fo;               // owned elements: a contiguous range of whole groups
+    __shared__ uint8_t firstflag[TB + 1];
 
-    // ---- stage owned elements: suffix, key2, local group id ----
-    // local group id = number of heads in [fo, p] - 1  (block scan over head counts, blocked layout)
-    uint32_t hc = 0;
-#pragma unroll
-    for (int k = 0; k < SEG_ITEMS; k++) {
-        uint32_t p = p0 + k;
-        if (p >= fo && p < oe && (hd & (1u << k))) hc++;
-    }
-    uint32_t hinc = block_incl_scan<OpSum>(hc, sm, nullptr);
-    {
-        uint32_t run = hinc - hc;
-#pragma unroll
-        for (int k = 0; k < SEG_ITEMS; k++) {
-            uint32_t p = p0 + k;
-            if (p >= fo && p < oe) {
-                if (hd & (1u << k)) run++;
-                lgid[p - fo] = (uint16_t)(run - 1);
-            }
-        }
-    }
-    for (uint32_t q = tid; q < no; q += TB) {
-        const uint32_t s = a_sa[base + fo + q];
-        sv[q] = s;
-        const uint64_t s2 = (uint64_t)s + h;
-        k2[q] = (s2 < n) ? ISA_cur[s2] + 1u : 0u;
-        idxA[q] = (uint16_t)q;
-    }
-    __syncthreads();
-    const uint32_t ngroups = (uint32_t)lgid[no - 1] + 1u;
+    const uint32_t m = st->m[par];
+    const uint32_t nwin = (m + SEG_TILE - 1) / SEG_TILE;
+    const int tid = threadIdx.x;
+    for (uint32_t win = blockIdx.x; win < nwin; win += gridDim.x) {
+        __syncthreads();                      // the LDS of the previous window is free
+        const uint32_t base = win * SEG_TILE;
+        const uint32_t avail = (m - base < (uint32_t)SEG_SPAN) ? m - base : (uint32_t)SEG_SPAN;
+        const bool list_ends = (base + avail == m);
 
-    // ---- LSD radix sort of the index permutation by the composite key (lgid << key_bits) | key2, 9 bits per pass ----
-    uint16_t *src = idxA, *dst = idxB;
-    const int w = tid >> 6, l = tid & 63;
-    const uint64_t lt = lanemask_lt();
-    const int gbits = (ngroups > 1u) ? 32 - __clz((int)(ngroups - 1u)) : 0;
-    const int npass = key_bits > 0 ? (key_bits + gbits + SEG_DBITS - 1) / SEG_DBITS : 0;
-    // each wave ranks a contiguous quarter of the owned range: only ceil(no / 256) iterations of 64 are live
-    const int nit = (int)((no + TB - 1) / TB);
-    const uint32_t wspan = (uint32_t)nit * 64u;
-    for (int pass = 0; pass < npass; pass++) {
-        const int shift = SEG_DBITS * pass;
-        const int part = (shift + SEG_DBITS <= key_bits) ? 0 : (shift >= key_bits ? 2 : 1);   // digit from key2 / both / group id
-        for (int i = tid; i < (TB / 64) * SEG_DIGITS; i += TB) (&cnt[0][0])[i] = 0;
+        for (uint32_t p = tid; p < avail; p += TB) g[p] = a_grp[base + p];
+        const uint32_t gprev = (base > 0) ? a_grp[base - 1] : 0xFFFFFFFFu;
+        if (tid == 0) { s_fo = 0xFFFFFFFFu; s_oe = 0; }
         __syncthreads();
-        uint32_t rk[SEG_ITEMS], dg[SEG_ITEMS];
+
+        // ---- group starts (max-scan of head positions) and group ends (next head), blocked 8 per thread ----
+        const uint32_t p0 = tid * SEG_ITEMS;
+        uint32_t hd = 0;                           // head bits of my 8 positions
+        uint32_t lasth = 0;                        // 1 + last head position in my segment
 #pragma unroll
-        for (int it = 0; it < SEG_ITEMS; it++) {
-            if (it >= nit) break;
-            const uint32_t q = w * wspan + it * 64 + l;
-            const bool valid = q < no;
-            const uint32_t id = valid ? src[q] : 0u;
-            uint32_t d;
-            if (part == 0) d = k2[id] >> shift;
-            else if (part == 2) d = (uint32_t)lgid[id] >> (shift - key_bits);
-            else d = (k2[id] >> shift) | ((uint32_t)lgid[id] << (key_bits - shift));
-            d = valid ? (d & (uint32_t)(SEG_DIGITS - 1)) : 0u;
-            dg[it] = d | (id << SEG_DBITS);
-            const uint64_t mm = match_any<SEG_DBITS>(d, valid);
+        for (int k = 0; k < SEG_ITEMS; k++) {
+            uint32_t p = p0 + k;
+            if (p < avail) {
+                bool head = (p == 0) ? (base == 0 || g[0] != gprev) : (g[p] != g[p - 1]);
+                if (head) { hd |= 1u << k; lasth = p + 1; }
+            }
+        }
+        uint32_t incl = block_incl_scan<OpMax>(lasth, sm, nullptr);
+        uint32_t prev = __shfl_up(incl, 1, 64);
+        if (lane_id() == 0) prev = (tid == 0) ? 0u : sm[(tid >> 6) - 1];
+        // next head after my segment: suffix-min over the first-head positions of later threads
+        uint32_t firsth = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = SEG_ITEMS - 1; k >= 0; k--)
+            if (hd & (1u << k)) firsth = p0 + k;
+        fz[tid] = firsth;
+        __syncthreads();
+        uint32_t rv = fz[TB - 1 - tid];
+        uint32_t rinc = block_incl_scan<OpMin>(rv, sm, nullptr);
+        rz[tid] = rinc;
+        __syncthreads();
+        uint32_t after = (tid == TB - 1) ? 0xFFFFFFFFu : rz[TB - 2 - tid];
+        // per position: group start / end
+        uint32_t ge[SEG_ITEMS];
+        {
+            uint32_t nn = after;
+#pragma unroll
+            for (int k = SEG_ITEMS - 1; k >= 0; k--) {
+                ge[k] = nn;                        // first head strictly after position p0+k (or none)
+                if (hd & (1u << k)) nn = p0 + k;
+            }
+            uint32_t run = prev;                   // 1 + start of the current group, 0 = spill-in
+#pragma unroll
+            for (int k = 0; k < SEG_ITEMS; k++) {
+                uint32_t p = p0 + k;
+                if (hd & (1u << k)) run = p + 1;
+                if (p < avail) gsl[p] = run ? (uint16_t)(run - 1) : (uint16_t)0xFFFF;
+            }
+        }
+        __syncthreads();
+        // ---- classify: size of the group of each position; owned = starts in my window and size <= SEG_TILE.  A group whose
+        // end lies beyond the loaded span is larger than SEG_TILE by construction (it starts inside the first half) ----
+        const uint32_t ph = (win > 0) ? PH[win - 1] : 0u;                              // 1 + last head before my window
+        const uint32_t spill_start = ph > 0 ? ph - 1 : 0u;                              // global index
+        uint32_t my_fo = 0xFFFFFFFFu, my_oe = 0;
+#pragma unroll
+        for (int k = 0; k < SEG_ITEMS; k++) {
+            uint32_t p = p0 + k;
+            if (p < avail) {
+                const uint32_t gs = gsl[p];
+                uint32_t end = ge[k];
+                bool end_known = true;
+                if (end == 0xFFFFFFFFu) { end = avail; end_known = list_ends; }
+                uint32_t size;
+                if (!end_known) size = 0xFFFFFFFFu;
+                else if (gs == 0xFFFFu) size = base + end - spill_start;
+                else size = end - gs;
+                const bool large = size > (uint32_t)SEG_TILE;
+                if (gs != 0xFFFFu && gs < (uint32_t)SEG_TILE && !large) {
+                    if (p < my_fo) my_fo = p;
+                    if (p + 1 > my_oe) my_oe = p + 1;
+                }
+            }
+        }
+        if (my_fo != 0xFFFFFFFFu) { atomicMin(&s_fo, my_fo); atomicMax(&s_oe, my_oe); }
+        __syncthreads();
+        const uint32_t fo = s_fo, oe = s_oe;
+        if (fo == 0xFFFFFFFFu) continue;           // nothing owned (uniform)
+        const uint32_t no = oe - fo;               // owned elements: a contiguous range of whole groups
+
+        // ---- stage owned elements: suffix, key2, local group id ----
+        // local group id = number of heads in [fo, p] - 1  (block scan over head counts, blocked layout)
+        uint32_t hc = 0;
+#pragma unroll
+        for (int k = 0; k < SEG_ITEMS; k++) {
+            uint32_t p = p0 + k;
+            if (p >= fo && p < oe && (hd & (1u << k))) hc++;
+        }
+        uint32_t hinc = block_incl_scan<OpSum>(hc, sm, nullptr);
+        {
+            uint32_t run = hinc - hc;
+#pragma unroll
+            for (int k = 0; k < SEG_ITEMS; k++) {
+                uint32_t p = p0 + k;
+                if (p >= fo && p < oe) {
+                    if (hd & (1u << k)) run++;
+                    lgid[p - fo] = (uint16_t)(run - 1);
+                }
+            }
+        }
+        for (uint32_t q = tid; q < no; q += TB) {
+            sv[q] = a_sa[base + fo + q];
+            k2[q] = k2g[base + fo + q];
+            idxA[q] = (uint16_t)q;
+        }
+        __syncthreads();
+        const uint32_t ngroups = (uint32_t)lgid[no - 1] + 1u;
+
+        // ---- LSD radix sort of the index permutation by the composite key (lgid << key_bits) | key2, 9 bits per pass ----
+        uint16_t *src = idxA, *dst = idxB;
+        const int w = tid >> 6, l = tid & 63;
+        const uint64_t lt = lanemask_lt();
+        const int gbits = (ngroups > 1u) ? 32 - __clz((int)(ngroups - 1u)) : 0;
+        const int npass = (key_bits + gbits + SEG_DBITS - 1) / SEG_DBITS;
+        // each wave ranks a contiguous quarter of the owned range: only ceil(no / 256) iterations of 64 are live
+        const int nit = (int)((no + TB - 1) / TB);
+        const uint32_t wspan = (uint32_t)nit * 64u;
+        for (int pass = 0; pass < npass; pass++) {
+            const int shift = SEG_DBITS * pass;
+            const int part = (shift + SEG_DBITS <= key_bits) ? 0 : (shift >= key_bits ? 2 : 1);   // digit from key2 / both / group id
+            for (int i = tid; i < (TB / 64) * SEG_DIGITS; i += TB) (&cnt[0][0])[i] = 0;
+            __syncthreads();
+            uint32_t rk[SEG_ITEMS], dg[SEG_ITEMS];
+#pragma unroll
+            for (int it = 0; it < SEG_ITEMS; it++) {
+                if (it >= nit) break;
+                const uint32_t q = w * wspan + it * 64 + l;
+                const bool valid = q < no;
+                const uint32_t id = valid ? src[q] : 0u;
+                uint32_t d;
+                if (part == 0) d = k2[id] >> shift;
+                else if (part == 2) d = (uint32_t)lgid[id] >> (shift - key_bits);
+                else d = (k2[id] >> shift) | ((uint32_t)lgid[id] << (key_bits - shift));
+                d = valid ? (d & (uint32_t)(SEG_DIGITS - 1)) : 0u;
+                dg[it] = d | (id << SEG_DBITS);
+                const uint64_t mm = match_any<SEG_DBITS>(d, valid);
+                const uint32_t below = (uint32_t)__popcll(mm & lt);
+                const uint32_t c = valid ? cnt[w][d] : 0u;
+                rk[it] = c + below;
+                if (valid && below == 0) cnt[w][d] = c + (uint32_t)__popcll(mm);
+            }
+            __syncthreads();
+            {   // per digit: exclusive over waves, then exclusive over digits (two digits per thread, in digit order)
+                uint32_t s2[2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int d = 2 * tid + e;
+                    uint32_t s = 0;
+#pragma unroll
+                    for (int k = 0; k < TB / 64; k++) { uint32_t t = cnt[k][d]; cnt[k][d] = s; s += t; }
+                    s2[e] = s;
+                }
+                const uint32_t inc = block_incl_scan<OpSum>(s2[0] + s2[1], sm, nullptr);
+                dbase[2 * tid] = inc - s2[0] - s2[1];
+                dbase[2 * tid + 1] = inc - s2[1];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < SEG_ITEMS; it++) {
+                if (it >= nit) break;
+                const uint32_t q = w * wspan + it * 64 + l;
+                if (q < no) {
+                    const uint32_t d = dg[it] & (uint32_t)(SEG_DIGITS - 1);
+                    dst[dbase[d] + cnt[w][d] + rk[it]] = (uint16_t)(dg[it] >> SEG_DBITS);
+                }
+            }
+            __syncthreads();
+            uint16_t *t = src; src = dst; dst = t;
+        }
+
+        // ---- re-rank (blocked 8 per thread over the sorted order) ----
+        uint32_t ap[SEG_ITEMS], nh[SEG_ITEMS];
+        uint32_t hmax = 0;
+#pragma unroll
+        for (int k = 0; k < SEG_ITEMS; k++) {
+            const uint32_t q = p0 + k;
+            ap[k] = 0; nh[k] = 0;
+            if (q < no) {
+                const uint32_t id = src[q];
+                const uint32_t pos = fo + q;                        // groups keep their positions through the sort
+                ap[k] = g[pos] + (pos - (uint32_t)gsl[pos]);
+                bool head = (q == 0);
+                if (!head) {
+                    const uint32_t pid = src[q - 1];
+                    head = (lgid[pid] != lgid[id]) || (k2[pid] != k2[id]);
+                }
+                nh[k] = head ? 1u : 0u;
+                if (head) hmax = ap[k];
+            }
+        }
+        uint32_t rincl = block_incl_scan<OpMax>(hmax, sm, nullptr);
+        uint32_t rprev = __shfl_up(rincl, 1, 64);
+        if (lane_id() == 0) rprev = (tid == 0) ? 0u : sm[(tid >> 6) - 1];
+        // next-head flag of the element after my segment
+        firstflag[tid] = (uint8_t)(nh[0] | (p0 >= no ? 1u : 0u));
+        if (tid == 0) firstflag[TB] = 1;
+        __syncthreads();
+        uint32_t run = rprev;
+#pragma unroll
+        for (int k = 0; k < SEG_ITEMS; k++) {
+            const uint32_t q = p0 + k;
+            if (q < no) {
+                if (nh[k]) run = ap[k];
+                const bool next_head = (q + 1 >= no) ? true : (k + 1 < SEG_ITEMS ? (nh[k + 1] != 0) : (firstflag[tid + 1] != 0));
+                const bool single = nh[k] && next_head;
+                const uint32_t s = sv[src[q]];
+                ISA[s] = run;
+                if (single) {
+                    bwt[ap[k]] = s ? T[s - 1] : (uint8_t)0;
+                    if (SA) SA[ap[k]] = s;
+                }
+                b_sa[base + fo + q] = s;
+                b_grp[base + fo + q] = run | (single ? DONE : 0u);
+            }
+        }
+    }
+}
+
+// ---- large groups: segmented LSD radix sort in place on (key2, sa), tiles = pieces -----------------------------------------
+// table layout: entry of (group, digit d, piece t of the group) = fp * NB + d * nt + t  -- group-major in list order, so the flat
+// exclusive scan S gives  S[entry] - S[fp * NB] = offset inside the group
+template <int DB>
+__global__ __launch_bounds__(TB) void k_lg_hist(const uint32_t *__restrict__ key, const Piece *__restrict__ pieces, const SaState *__restrict__ st, int shift,
+                                               uint32_t *__restrict__ table)
+{
+    constexpr int NB = 1 << DB;
+    __shared__ uint32_t h[WAVES][NB];
+    const uint32_t np = st->npieces;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
+        const Piece q = pieces[p];
+        __syncthreads();
+        for (int i = threadIdx.x; i < WAVES * NB; i += TB) (&h[0][0])[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const uint32_t e = w * (64 * WIN_ITEMS) + k * 64 + l;
+            if (e < q.count) atomicAdd(&h[w][(key[q.begin + e] >> shift) & (uint32_t)(NB - 1)], 1u);
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d < NB; d += TB) {
+            uint32_t s = 0;
+#pragma unroll
+            for (int k = 0; k < WAVES; k++) s += h[k][d];
+            table[(size_t)q.fp * NB + (size_t)d * q.nt + q.tl] = s;
+        }
+    }
+}
+
+template <int DB>
+__global__ __launch_bounds__(TB) void k_lg_scatter(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint32_t *__restrict__ kout,
+                                                  uint32_t *__restrict__ vout, const Piece *__restrict__ pieces, const SaState *__restrict__ st, int shift,
+                                                  const uint32_t *__restrict__ S)
+{
+    constexpr int NB = 1 << DB;
+    __shared__ uint32_t cnt[WAVES][NB];
+    __shared__ uint32_t gbase[NB];
+    const uint32_t np = st->npieces;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const uint64_t lt = lanemask_lt();
+    for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
+        const Piece q = pieces[p];
+        __syncthreads();
+        for (int i = threadIdx.x; i < WAVES * NB; i += TB) (&cnt[0][0])[i] = 0;
+        const uint32_t s0 = S[(size_t)q.fp * NB];
+        for (int d = threadIdx.x; d < NB; d += TB) gbase[d] = q.gs + (S[(size_t)q.fp * NB + (size_t)d * q.nt + q.tl] - s0);
+        __syncthreads();
+        uint32_t key[WIN_ITEMS], val[WIN_ITEMS], rnk[WIN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const uint32_t e = w * (64 * WIN_ITEMS) + k * 64 + l;
+            const bool valid = e < q.count;
+            key[k] = valid ? kin[q.begin + e] : 0u;
+            val[k] = valid ? vin[q.begin + e] : 0u;
+            const uint32_t d = (key[k] >> shift) & (uint32_t)(NB - 1);
+            const uint64_t mm = match_any<DB>(d, valid);
             const uint32_t below = (uint32_t)__popcll(mm & lt);
             const uint32_t c = valid ? cnt[w][d] : 0u;
-            rk[it] = c + below;
+            rnk[k] = c + below;
             if (valid && below == 0) cnt[w][d] = c + (uint32_t)__popcll(mm);
         }
         __syncthreads();
-        {   // per digit: exclusive over waves, then exclusive over digits (two digits per thread, in digit order)
-            uint32_t s2[2];
+        for (int d = threadIdx.x; d < NB; d += TB) {
+            uint32_t s = 0;
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const int d = 2 * tid + e;
-                uint32_t s = 0;
-#pragma unroll
-                for (int k = 0; k < TB / 64; k++) { uint32_t t = cnt[k][d]; cnt[k][d] = s; s += t; }
-                s2[e] = s;
-            }
-            const uint32_t inc = block_incl_scan<OpSum>(s2[0] + s2[1], sm, nullptr);
-            dbase[2 * tid] = inc - s2[0] - s2[1];
-            dbase[2 * tid + 1] = inc - s2[1];
+            for (int k = 0; k < WAVES; k++) { uint32_t t = cnt[k][d]; cnt[k][d] = s; s += t; }
         }
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < SEG_ITEMS; it++) {
-            if (it >= nit) break;
-            const uint32_t q = w * wspan + it * 64 + l;
-            if (q < no) {
-                const uint32_t d = dg[it] & (uint32_t)(SEG_DIGITS - 1);
-                dst[dbase[d] + cnt[w][d] + rk[it]] = (uint16_t)(dg[it] >> SEG_DBITS);
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const uint32_t e = w * (64 * WIN_ITEMS) + k * 64 + l;
+            if (e < q.count) {
+                const uint32_t d = (key[k] >> shift) & (uint32_t)(NB - 1);
+                const uint32_t dst = gbase[d] + cnt[w][d] + rnk[k];
+                kout[dst] = key[k];
+                vout[dst] = val[k];
             }
+        }
+    }
+}
+
+// head words of a piece in the sorted order: a new group starts where key2 changes (and at the group's first slot);
+// H[16] bit 0 = the slot after the piece starts a group (or the old group ends there)
+__device__ __forceinline__ void lg_piece_heads(const uint32_t *__restrict__ key, const Piece &q, uint64_t *H)
+{
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < WIN_ITEMS; k++) {
+        const uint32_t e = w * (64 * WIN_ITEMS) + k * 64 + l;
+        bool head = false;
+        if (e < q.count) {
+            const uint32_t j = q.begin + e;
+            head = (j == q.gs) || (key[j] != key[j - 1]);
+        }
+        const uint64_t b = __ballot(head);
+        if (l == 0) H[w * WIN_ITEMS + k] = b;
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t jn = q.begin + q.count;
+        H[16] = (jn >= q.ge || key[jn] != key[jn - 1]) ? 1ull : 0ull;
+    }
+}
+
+// 1 + position of the last new head inside every piece (0: none)
+__global__ __launch_bounds__(TB) void k_lg_heads(const uint32_t *__restrict__ key, const Piece *__restrict__ pieces, const SaState *__restrict__ st,
+                                                uint32_t *__restrict__ pLast)
+{
+    __shared__ uint64_t H[17];
+    const uint32_t np = st->npieces;
+    for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
+        const Piece q = pieces[p];
+        __syncthreads();
+        lg_piece_heads(key, q, H);
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            const uint64_t hv = (l < 16) ? H[l] : 0ull;
+            uint32_t last = hv ? q.begin + l * 64 + top_bit(hv) + 1u : 0u;
+            last = wave_incl_max(last);
+            if (l == 63) pLast[p] = last;
+        }
+    }
+}
+
+__global__ __launch_bounds__(WG1) void k_lg_scan(uint32_t *__restrict__ pLast, const SaState *__restrict__ st)
+{
+    __shared__ uint32_t sm[WG1 / 64 + 1];
+    wg_scan<OpMax, true, false>(pLast, pLast, st->npieces, 0u, sm);
+}
+
+// new ranks of the members of large groups -> ISA, finished suffixes -> BWT byte, everything back to the b-list
+__global__ __launch_bounds__(TB) void k_lg_finish(const uint32_t *__restrict__ key, const uint32_t *__restrict__ val, const uint32_t *__restrict__ a_grp,
+                                                 const Piece *__restrict__ pieces, const SaState *__restrict__ st, const uint32_t *__restrict__ pCarry,
+                                                 const uint8_t *__restrict__ T, uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
+                                                 uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp)
+{
+    __shared__ uint64_t H[17];
+    __shared__ uint32_t LHW[16];
+    const uint32_t np = st->npieces;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
+        const Piece q = pieces[p];
+        __syncthreads();
+        lg_piece_heads(key, q, H);
+        __syncthreads();
+        const uint32_t carry = pCarry[p];
+        if (threadIdx.x < 64) {
+            const uint64_t hv = (l < 16) ? H[l] : 0ull;
+            uint32_t last = hv ? q.begin + l * 64 + top_bit(hv) + 1u : 0u;
+            last = wave_incl_max(last);
+            if (l < 16) LHW[l] = last > carry ? last : carry;
         }
         __syncthreads();
-        uint16_t *t = src; src = dst; dst = t;
-    }
-
-    // ---- re-rank (blocked 8 per thread over the sorted order) ----
-    uint32_t ap[SEG_ITEMS], nh[SEG_ITEMS];
-    uint32_t hmax = 0;
+        const uint32_t G = a_grp[q.gs] & ~DONE;            // rank of the old group = SA position of its first member
 #pragma unroll
-    for (int k = 0; k < SEG_ITEMS; k++) {
-        const uint32_t q = p0 + k;
-        ap[k] = 0; nh[k] = 0;
-        if (q < no) {
-            const uint32_t id = src[q];
-            const uint32_t pos = fo + q;                        // groups keep their positions through the sort
-            ap[k] = g[pos] + (pos - (uint32_t)gsl[pos]);
-            bool head = (q == 0);
-            if (!head) {
-                const uint32_t pid = src[q - 1];
-                head = (lgid[pid] != lgid[id]) || (k2[pid] != k2[id]);
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const int word = w * WIN_ITEMS + k;
+            const uint32_t e = word * 64 + l;
+            if (e < q.count) {
+                const uint32_t j = q.begin + e;
+                const uint64_t hv = H[word];
+                const uint64_t le = hv & mask_upto(l);
+                const uint32_t hp = le ? q.begin + word * 64 + top_bit(le) : (word ? LHW[word - 1] : carry) - 1u;
+                const uint32_t rank = G + (hp - q.gs);
+                const bool head = (hv >> l) & 1ull;
+                bool nh;
+                if (e + 1 == q.count) nh = H[16] & 1ull;
+                else nh = (l < 63) ? ((hv >> (l + 1)) & 1ull) : (H[word + 1] & 1ull);
+                const bool single = head && nh;
+                const uint32_t s = val[j];
+                ISA[s] = rank;
+                if (single) {
+                    const uint32_t ap = G + (j - q.gs);
+                    bwt[ap] = s ? T[s - 1] : (uint8_t)0;
+                    if (SA) SA[ap] = s;
+                }
+                b_sa[j] = s;
+                b_grp[j] = rank | (single ? DONE : 0u);
             }
-            nh[k] = head ? 1u : 0u;
-            if (head) hmax = ap[k];
         }
     }
-    uint32_t rincl = block_incl_scan<OpMax>(hmax, sm, nullptr);
-    uint32_t rprev = __shfl_up(rincl, 1, 64);
-    if (lane_id() == 0) rprev = (tid == 0) ? 0u : sm[(tid >> 6) - 1];
-    // next-head flag of the element after my segment
-    __shared__ uint8_t firstflag[TB + 1];
-    firstflag[tid] = (uint8_t)(nh[0] | (p0 >= no ? 1u : 0u));
-    if (tid == 0) firstflag[TB] = 1;
-    __syncthreads();
-    uint32_t run = rprev;
+}
+
+// ---- flat exclusive scan of the piece tables (size known on the device only) ---------------------------------------------
+constexpr int SC_ITEMS = 16, SC_TILE = TB * SC_ITEMS;
+__global__ __launch_bounds__(TB) void k_tab_reduce(const uint32_t *__restrict__ in, const SaState *__restrict__ st, uint32_t nb, uint32_t *__restrict__ partial)
+{
+    __shared__ uint32_t sm[TB / 64 + 1];
+    const size_t n = (size_t)st->npieces * nb;
+    const size_t ntiles = (n + SC_TILE - 1) / SC_TILE;
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t base = tile * SC_TILE + (size_t)threadIdx.x * SC_ITEMS;
+        uint32_t acc = 0;
+        if (base + SC_ITEMS <= n) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(in + base);
 #pragma unroll
-    for (int k = 0; k < SEG_ITEMS; k++) {
-        const uint32_t q = p0 + k;
-        if (q < no) {
-            if (nh[k]) run = ap[k];
-            const bool next_head = (q + 1 >= no) ? true : (k + 1 < SEG_ITEMS ? (nh[k + 1] != 0) : (firstflag[tid + 1] != 0));
-            const bool single = nh[k] && next_head;
-            const uint32_t s = sv[src[q]];
-            ISA_nxt[s] = run;
-            if (single) SA[ap[k]] = s;
-            b_sa[base + fo + q] = s;
-            b_grp[base + fo + q] = run | (single ? DONE : 0u);
-            keep[base + fo + q] = single ? 0u : 1u;
+            for (int k = 0; k < SC_ITEMS / 4; k++) { uint4 v = p[k]; acc += v.x + v.y + v.z + v.w; }
+        } else {
+            for (int k = 0; k < SC_ITEMS; k++) if (base + k < n) acc += in[base + k];
+        }
+        uint32_t tot;
+        block_incl_scan<OpSum>(acc, sm, &tot);
+        if (threadIdx.x == 0) partial[tile] = tot;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(WG1) void k_tab_partials(uint32_t *__restrict__ partial, const SaState *__restrict__ st, uint32_t nb)
+{
+    __shared__ uint32_t sm[WG1 / 64 + 1];
+    const size_t n = (size_t)st->npieces * nb;
+    wg_scan<OpSum, true, false>(partial, partial, (uint32_t)((n + SC_TILE - 1) / SC_TILE), 0u, sm);
+}
+__global__ __launch_bounds__(TB) void k_tab_down(const uint32_t *in, uint32_t *out, const SaState *__restrict__ st, uint32_t nb, const uint32_t *__restrict__ partial)
+{
+    __shared__ uint32_t sm[TB / 64 + 1];
+    const size_t n = (size_t)st->npieces * nb;
+    const size_t ntiles = (n + SC_TILE - 1) / SC_TILE;
+    for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t base = tile * SC_TILE + (size_t)threadIdx.x * SC_ITEMS;
+        uint32_t v[SC_ITEMS];
+        if (base + SC_ITEMS <= n) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(in + base);
+#pragma unroll
+            for (int k = 0; k < SC_ITEMS / 4; k++) { uint4 q = p[k]; v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < SC_ITEMS; k++) v[k] = (base + k < n) ? in[base + k] : 0u;
+        }
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < SC_ITEMS; k++) acc += v[k];
+        const uint32_t inc = block_incl_scan<OpSum>(acc, sm, nullptr);
+        uint32_t prev = __shfl_up(inc, 1, 64);
+        if (lane_id() == 0) prev = (threadIdx.x == 0) ? 0u : sm[(threadIdx.x >> 6) - 1];
+        uint32_t run = partial[tile] + prev;
+        uint32_t o[SC_ITEMS];
+#pragma unroll
+        for (int k = 0; k < SC_ITEMS; k++) { o[k] = run; run += v[k]; }
+        if (base + SC_ITEMS <= n) {
+            uint4 *p = reinterpret_cast<uint4 *>(out + base);
+#pragma unroll
+            for (int k = 0; k < SC_ITEMS / 4; k++) p[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < SC_ITEMS; k++) if (base + k < n) out[base + k] = o[k];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- compaction of a round's output: the unresolved suffixes, in order, become the next round's active list -------------
+__global__ __launch_bounds__(TB) void k_cmp_count(const uint32_t *__restrict__ b_grp, const SaState *__restrict__ st, int par, uint32_t *__restrict__ tSurv)
+{
+    const uint32_t m = st->m[par];
+    const uint32_t ntiles = (m + CT - 1) / CT;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __shared__ uint32_t ws[WAVES];
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * CT;
+        uint32_t c = 0;
+#pragma unroll 4
+        for (int k = 0; k < CT_ITEMS; k++) {
+            const uint32_t j = base + w * (64 * CT_ITEMS) + k * 64 + l;
+            c += (j < m && !(b_grp[j] & DONE)) ? 1u : 0u;
+        }
+        c = wave_sum(c);
+        __syncthreads();
+        if (l == 0) ws[w] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) tSurv[tile] = ws[0] + ws[1] + ws[2] + ws[3];
+    }
+}
+__global__ __launch_bounds__(WG1) void k_cmp_scan(uint32_t *__restrict__ tSurv, SaState *__restrict__ st, int par, int round)
+{
+    __shared__ uint32_t sm[WG1 / 64 + 1];
+    const uint32_t m = st->m[par];
+    const uint32_t total = wg_scan<OpSum, true, false>(tSurv, tSurv, (m + CT - 1) / CT, 0u, sm);
+    if (threadIdx.x == 0) {
+        st->m[par ^ 1] = total;
+        if (round + 1 < JPK_SA_MAX_ROUNDS) st->round_m[round + 1] = total;
+    }
+}
+__global__ __launch_bounds__(TB) void k_cmp_scatter(const uint32_t *__restrict__ b_sa, const uint32_t *__restrict__ b_grp, const SaState *__restrict__ st, int par,
+                                                   const uint32_t *__restrict__ tOff, uint32_t *__restrict__ a_sa, uint32_t *__restrict__ a_grp)
+{
+    __shared__ uint64_t SV[64];
+    __shared__ uint32_t SW[64];
+    const uint32_t m = st->m[par];
+    const uint32_t ntiles = (m + CT - 1) / CT;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * CT;
+        __syncthreads();
+        uint32_t gv[CT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < CT_ITEMS; k++) {
+            const uint32_t j = base + w * (64 * CT_ITEMS) + k * 64 + l;
+            gv[k] = (j < m) ? b_grp[j] : DONE;
+            const uint64_t b = __ballot(!(gv[k] & DONE));
+            if (l == 0) SV[w * CT_ITEMS + k] = b;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint32_t cnt = (uint32_t)__popcll(SV[l]);
+            const uint32_t inc = wave_incl_sum(cnt);
+            SW[l] = tOff[tile] + inc - cnt;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CT_ITEMS; k++) {
+            const int word = w * CT_ITEMS + k;
+            const uint32_t j = base + word * 64 + l;
+            if (!(gv[k] & DONE)) {
+                const uint32_t pos = SW[word] + (uint32_t)__popcll(SV[word] & mask_below(l));
+                a_sa[pos] = b_sa[j];
+                a_grp[pos] = gv[k];
+            }
         }
     }
 }
 
-// ---- large groups: compaction into a side list, global sort, write back ---------------------------------
-__global__ __launch_bounds__(TB) void k_large_gather(const uint32_t *__restrict__ lflag, const uint32_t *__restrict__ lpos_scan,
-                                                    const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, uint32_t m,
-                                                    uint32_t *__restrict__ l_sa, uint32_t *__restrict__ l_grp, uint32_t *__restrict__ l_pos)
+// ---- BWT image (bwt.cpp:44-61) -------------------------------------------------------------------------------------
+// bwt_sa[i] = T[SA[i] - 1] was emitted when suffix SA[i] was resolved; the image drops the row of suffix 0 (index idx = ISA[0])
+// and starts with T[n-1]
+__global__ __launch_bounds__(TB) void k_bwt_image(const uint8_t *__restrict__ T, const uint8_t *__restrict__ bwt_sa, const uint32_t *__restrict__ ISA,
+                                                 uint32_t n, uint8_t *__restrict__ out)
 {
-    uint32_t j = blockIdx.x * TB + threadIdx.x;
-    if (j >= m || !lflag[j]) return;
-    uint32_t p = lpos_scan[j];
-    l_sa[p] = a_sa[j];
-    l_grp[p] = a_grp[j];
-    l_pos[p] = j;
-}
-
-// old-group head positions in the large list (input of the max scan that gives every element its group's head)
-__global__ __launch_bounds__(TB) void k_large_heads(const uint32_t *__restrict__ a_grp, uint32_t m, uint32_t *__restrict__ hv)
-{
-    uint32_t j = blockIdx.x * TB + threadIdx.x;
-    if (j >= m) return;
-    bool head = (j == 0) || (a_grp[j - 1] != a_grp[j]);
-    hv[j] = head ? j : 0u;
-}
-
-// Sort key of a large-group element: (group id << 32) | rank of suffix + h.  Every group on this path has more than
-// 1024 elements, so its head position in the list divided by 1024 is a dense, order-preserving id: the group digits
-// need bits(list length / 1024) instead of bits(n) -- two radix passes instead of four on a 64 MiB block.
-__global__ __launch_bounds__(TB) void k_make_keys(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ jhead, uint32_t m, uint32_t n,
-                                                 uint32_t h, const uint32_t *__restrict__ ISA, uint64_t *__restrict__ keys,
-                                                 uint32_t *__restrict__ vals)
-{
-    uint32_t j = blockIdx.x * TB + threadIdx.x;
-    if (j >= m) return;
-    uint32_t s = a_sa[j];
-    uint64_t s2 = (uint64_t)s + h;
-    uint32_t k2 = (s2 < n) ? ISA[s2] + 1u : 0u;
-    keys[j] = ((uint64_t)(jhead[j] >> 10) << 32) | k2;
-    vals[j] = s;
-}
-
-// abs position of element j after the sort = group rank + offset inside the (old) group (groups keep their index
-// ranges through the sort, so the pre-sort group array still applies); new head flag from the full 64-bit key;
-// nh[j] = newhead ? abspos : 0 (input of the max scan).  grp and nh may alias.
-__global__ __launch_bounds__(TB) void k_abspos(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ jhead, const uint32_t *grp, uint32_t m,
-                                              uint32_t *__restrict__ abspos, uint32_t *nh)
-{
-    uint32_t j = blockIdx.x * TB + threadIdx.x;
-    if (j >= m) return;
-    uint64_t k = keys[j];
-    uint32_t ap = grp[j] + (j - jhead[j]);
-    abspos[j] = ap;
-    bool head = (j == 0) || (keys[j - 1] != k);
-    nh[j] = head ? ap : 0u;
-}
-
-// new ranks -> ISA_nxt; singletons -> SA; sorted elements back to their slots of the active list
-__global__ __launch_bounds__(TB) void k_large_finish(const uint32_t *__restrict__ abspos, const uint32_t *__restrict__ newrank,
-                                                    const uint32_t *__restrict__ vals, const uint32_t *__restrict__ l_pos, uint32_t m,
-                                                    uint32_t *__restrict__ ISA_nxt, uint32_t *__restrict__ SA, uint32_t *__restrict__ b_sa,
-                                                    uint32_t *__restrict__ b_grp, uint32_t *__restrict__ keep)
-{
-    uint32_t j = blockIdx.x * TB + threadIdx.x;
-    if (j >= m) return;
-    uint32_t ap = abspos[j], r = newrank[j], s = vals[j];
-    ISA_nxt[s] = r;
-    bool head = (r == ap);
-    bool next_head = (j + 1 == m) || (newrank[j + 1] == abspos[j + 1]);
-    bool single = head && next_head;
-    if (single) SA[ap] = s;
-    uint32_t p = l_pos[j];
-    b_sa[p] = s;
-    b_grp[p] = r | (single ? DONE : 0u);
-    keep[p] = single ? 0u : 1u;
-}
-
-// compaction of a round's output; finished suffixes also get their final rank in the buffer that was READ this
-// round (it becomes the write buffer of the next round and is never rewritten for them)
-__global__ __launch_bounds__(TB) void k_compact_round(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos,
-                                                     const uint32_t *__restrict__ b_sa, const uint32_t *__restrict__ b_grp, uint32_t m,
-                                                     uint32_t *__restrict__ ISA_cur, uint32_t *__restrict__ a_sa, uint32_t *__restrict__ a_grp)
-{
-    uint32_t j = blockIdx.x * TB + threadIdx.x;
-    if (j >= m) return;
-    const uint32_t gv = b_grp[j], s = b_sa[j];
-    if (keep[j]) {
-        const uint32_t p = pos[j];
-        a_sa[p] = s;
-        a_grp[p] = gv;
-    } else ISA_cur[s] = gv & ~DONE;
-}
-
-// ---- BWT emission (bwt.cpp:44-61) -------------------------------------------------------------------
-__global__ __launch_bounds__(TB) void k_bwt_gather(const uint8_t *__restrict__ T, const uint32_t *__restrict__ SA, const uint32_t *__restrict__ ISA,
-                                                  uint32_t n, uint8_t *__restrict__ out)
-{
-    uint32_t i = blockIdx.x * TB + threadIdx.x;
-    if (i >= n) return;
     const uint32_t idx = ISA[0];
-    uint32_t s = SA[i];
-    if (i == 0) out[0] = T[n - 1];
-    if (i == idx) return;                       // the row whose predecessor is the sentinel is dropped
-    uint32_t o = (i < idx) ? i + 1 : i;
-    out[o] = T[s - 1];
+    for (uint32_t i = blockIdx.x * TB + threadIdx.x; i < n; i += gridDim.x * TB) {
+        if (i == 0) out[0] = T[n - 1];
+        if (i != idx) out[(i < idx) ? i + 1 : i] = bwt_sa[i];
+    }
 }
 
 __global__ void k_bwt_trailer(const uint8_t *__restrict__ T, const uint32_t *__restrict__ ISA, uint32_t n, uint32_t len, uint8_t *__restrict__ out)
@@ -474,131 +994,204 @@ __global__ void k_bwt_trailer(const uint8_t *__restrict__ T, const uint32_t *__r
     if (t < len - n) out[n + t] = T[n + t];      // raw tail (bwt.cpp:32-33), at most 119 bytes
 }
 
+// ---- host side -------------------------------------------------------------------------------------------------------
 struct SaBufs {
     uint64_t *keysA, *keysB;
-    uint32_t *valsA, *valsB, *ISA0, *ISA1, *SA, *a_sa, *a_grp, *b_sa, *b_grp, *t1, *t2, *t3, *keep, *l_pos, *win, *scratch;
+    uint32_t *valsA, *valsB, *ISA, *SA, *a_sa, *a_grp, *b_sa, *b_grp, *k2, *k2alt, *sa_alt, *table;
+    uint32_t *tA, *tB;          // per-tile scalars
+    uint32_t *FH, *LH, *PH, *NH, *PC, *pLast, *partial, *scratch;
+    uint8_t *bwt;
+    Piece *pieces;
+    SaState *state;
 };
 
-void sa_layout(Arena &a, size_t n, SaBufs &b, bool need_sa_buf)
+int lg_digit_bits(uint32_t n, int *npass)
 {
+    const int kbits = jpk_bits_for(n);             // key2 <= n
+    int np = (kbits + 7) / 8;
+    if (np < 1) np = 1;
+    int db = (kbits + np - 1) / np;
+    if (db < 4) db = 4;
+    *npass = np;
+    return db;                                     // 4..8
+}
+
+void sa_layout(Arena &a, size_t n, SaBufs &b)
+{
+    const size_t nwin = n / SEG_TILE + 2, ntile = n / CT + 2;
+    memset(&b, 0, sizeof b);
     b.keysA = a.get<uint64_t>(n);
     b.keysB = a.get<uint64_t>(n);
     b.valsA = a.get<uint32_t>(n);
     b.valsB = a.get<uint32_t>(n);
-    b.ISA0 = a.get<uint32_t>(n);
-    b.ISA1 = a.get<uint32_t>(n);
-    b.SA = need_sa_buf ? a.get<uint32_t>(n) : nullptr;
+    b.ISA = a.get<uint32_t>(n);
     b.a_sa = a.get<uint32_t>(n);
     b.a_grp = a.get<uint32_t>(n);
-    b.b_sa = a.get<uint32_t>(n);
-    b.b_grp = a.get<uint32_t>(n);
-    b.t1 = a.get<uint32_t>(n);
-    b.t2 = a.get<uint32_t>(n);
-    b.t3 = a.get<uint32_t>(n);
-    b.keep = a.get<uint32_t>(n);
-    b.l_pos = a.get<uint32_t>(n);
-    b.win = a.get<uint32_t>(n / SEG_TILE + 64);
-    size_t sw = jpk_radix_scratch_words(n);
-    size_t sc = jpk_scan_scratch_words(n);
-    b.scratch = a.get<uint32_t>(sw > sc ? sw : sc);
+    b.bwt = a.get<uint8_t>(n);
+    const size_t nbmax = 256;
+    b.table = a.get<uint32_t>(nbmax * 2 * nwin);
+    b.partial = a.get<uint32_t>(nbmax * 2 * nwin / SC_TILE + 64);
+    b.tA = a.get<uint32_t>(ntile);
+    b.tB = a.get<uint32_t>(ntile);
+    b.FH = a.get<uint32_t>(nwin);
+    b.LH = a.get<uint32_t>(nwin);
+    b.PH = a.get<uint32_t>(nwin);
+    b.NH = a.get<uint32_t>(nwin);
+    b.PC = a.get<uint32_t>(nwin);
+    b.pLast = a.get<uint32_t>(2 * nwin);
+    b.pieces = a.get<Piece>(2 * nwin);
+    b.state = a.get<SaState>(1);
+    b.scratch = a.get<uint32_t>(jpk_radix_scratch_words(n));
 }
 
-// builds SA (uint32) for T[0..n); on return *isa_final points at the buffer holding the complete inverse SA
-int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b, uint32_t **isa_final)
+inline unsigned cap_grid(size_t work, unsigned per_block, unsigned cap)
+{
+    size_t g = (work + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (unsigned)(g > cap ? cap : g);
+}
+
+template <int DB>
+void launch_lg_pass(jpk_ctx *ctx, SaBufs &b, const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int shift, unsigned gp, unsigned gt)
+{
+    constexpr uint32_t NB = 1u << DB;
+    JPK_LAUNCH(ctx, PROF_RS_HIST, 0, (k_lg_hist<DB>), dim3(gp), dim3(TB), kin, b.pieces, b.state, shift, b.table);
+    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_tab_reduce, dim3(gt), dim3(TB), b.table, b.state, NB, b.partial);
+    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_tab_partials, dim3(1), dim3(WG1), b.partial, b.state, NB);
+    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_tab_down, dim3(gt), dim3(TB), b.table, b.table, b.state, NB, b.partial);
+    JPK_LAUNCH(ctx, PROF_RS_SCATTER, 0, (k_lg_scatter<DB>), dim3(gp), dim3(TB), kin, vin, kout, vout, b.pieces, b.state, shift, b.table);
+}
+
+// builds the BWT-in-SA-order bytes (b.bwt), the complete inverse suffix array (b.ISA) and, if b.SA is set, the suffix array
+int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
 {
     hipStream_t st = ctx->stream;
-    const unsigned g_n = jpk_grid(n, TB);
     ctx->stats.sa_rounds = 0;
     ctx->stats.sa_sorted_elems = 0;
     memset(ctx->stats.sa_round_active, 0, sizeof ctx->stats.sa_round_active);
     memset(ctx->stats.sa_round_large, 0, sizeof ctx->stats.sa_round_large);
-    ctx->stats.sa_round_active[0] = (int32_t)n;
+    // One workgroup per tile / window / piece of the host's (one round old) upper bound; the surplus workgroups of a shrunken
+    // list read the true count and leave.  Not persistent on purpose: a workgroup that has issued its random stores exits and
+    // its slot is refilled at once, whereas a grid-stride loop would wait for those stores at its next barrier (measured:
+    // k_seg_round 9.5 ms persistent against 8.1 ms).  The loops inside the kernels only matter beyond 2^20 tiles.
+    constexpr unsigned CAP = 1u << 20;
+    constexpr unsigned CAP_SEG = 1u << 20;
 
     // round 0: sort by the first 7 bytes (7 passes; ties keep descending text position)
-    JPK_LAUNCH(ctx, PROF_SA_KEYS, n, k_init_keys, dim3(g_n), dim3(TB), T, n, b.keysA, b.valsA);
-    {
-        const int shifts[7] = {8, 16, 24, 32, 40, 48, 56};
-        JPK_TRY(jpk_radix_sort_pairs_u64(ctx, b.keysA, b.valsA, b.keysB, b.valsB, n, shifts, 7, b.scratch));
-        ctx->stats.sa_sorted_elems += n;
-    }
-    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_heads_u64, dim3(g_n), dim3(TB), b.keysA, b.valsA, n, n, b.t1);
-    JPK_TRY(jpk_inclusive_max_u32(ctx, b.t1, b.t2, n, b.scratch));                     // t2 = grp
-    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_round0_finish, dim3(g_n), dim3(TB), b.t2, b.valsA, n, b.ISA0, b.ISA1, b.SA, b.t1);  // t1 = keep
-    JPK_TRY(jpk_exclusive_sum_u32(ctx, b.t1, b.t3, n, b.scratch, ctx->d_mail));       // t3 = pos
-    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_compact, dim3(g_n), dim3(TB), b.t1, b.t3, b.valsA, b.t2, n, b.a_sa, b.a_grp);
-    uint32_t m = 0;
-    JPK_TRY(jpk_read_mail(ctx, &m, 1));
+    JPK_HIP(hipMemsetAsync(b.state, 0, sizeof(SaState), st));
+    uint64_t *ks = b.keysA;
+    uint32_t *vs = b.valsA;
+    JPK_TRY(jpk_radix_sort_suffix_keys7(ctx, T, n, b.keysA, b.valsA, b.keysB, b.valsB, b.scratch, &ks, &vs));
+    ctx->stats.sa_sorted_elems += n;
+    // The sorted pairs sit in (ks, vs).  The other pair of radix buffers is free from here on, the pair that holds the result
+    // once k_r0_finish has read it: the doubling rounds live in them.
+    uint64_t *kfree = (ks == b.keysA) ? b.keysB : b.keysA;
+    uint32_t *vfree = (vs == b.valsA) ? b.valsB : b.valsA;
+    b.b_sa = vfree;
+    b.b_grp = reinterpret_cast<uint32_t *>(kfree);
+    b.k2 = reinterpret_cast<uint32_t *>(kfree) + n;
+    b.k2alt = reinterpret_cast<uint32_t *>(ks);
+    b.sa_alt = reinterpret_cast<uint32_t *>(ks) + n;
+
+    const unsigned g_ct = cap_grid(n, CT, CAP);
+    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_count, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB);
+    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_r0_scan, dim3(1), dim3(WG1), b.tA, b.tB, n, b.state);
+    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, T, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp);
     ctx->stats.sa_rounds = 1;
 
-    const int kbits = jpk_bits_for(n);     // key2 <= n, group rank < n
-    const int key_passes = getenv("JPK_DBG_NOSORT") ? 0 : (kbits + 7) / 8;   // debug: time k_seg_round without its LDS sort
-    uint32_t *isa_cur = b.ISA0, *isa_nxt = b.ISA1;
+    const int kbits = jpk_bits_for(n);             // key2 <= n, group rank < n
+    int lg_pass = 0;
+    const int lg_db = lg_digit_bits(n, &lg_pass);
+    // The host learns the number of unresolved suffixes one round late: round r is enqueued with the grid bound of round r-2's
+    // result while the GPU is still busy with round r-1.  A round that starts with m == 0 is a handful of empty launches.
+    uint32_t *h_m = ctx->h_mail + 16;              // pinned: h_m[r & 1] receives the count round r leaves behind
+    JPK_HIP(hipMemcpyAsync(&h_m[0], &b.state->m[1], 4, hipMemcpyDeviceToHost, st));
+    JPK_HIP(hipEventRecord(ctx->ev_sa[0], st));
+    uint32_t bound = n;                            // upper bound of the active count of the round being enqueued
     uint64_t h = 7;
-    while (m > 0) {
-        if (h >= n) return JPK_E_DEVICE;   // cannot happen: every suffix is unique once h >= n
-        const unsigned g_m = jpk_grid(m, TB);
-        const unsigned nwin = jpk_grid(m, SEG_TILE);
-        // window bookkeeping: start of the group that spills into each window
-        JPK_LAUNCH(ctx, PROF_SA_KEYS, m, k_win_heads, dim3(nwin), dim3(TB), b.a_grp, m, b.win);
-        JPK_TRY(jpk_inclusive_max_u32(ctx, b.win, b.win, nwin, b.scratch));
-        JPK_HIP(hipMemsetAsync(ctx->d_mail + 4, 0, 4, st));
-        JPK_LAUNCH(ctx, PROF_SA_SEG, m, k_seg_round, dim3(nwin), dim3(TB), b.a_sa, b.a_grp, m, n, (uint32_t)h, key_passes ? kbits : 0, b.win, isa_cur, isa_nxt,
-                   b.SA, b.b_sa, b.b_grp, b.t1, b.keep, ctx->d_mail + 4);              // t1 = lflag
-        uint32_t mailw[5];
-        JPK_TRY(jpk_read_mail(ctx, mailw, 5));
-        const uint32_t lc = mailw[4];
-        if (ctx->stats.sa_rounds < JPK_SA_MAX_ROUNDS) {
-            ctx->stats.sa_round_active[ctx->stats.sa_rounds] = (int32_t)m;
-            ctx->stats.sa_round_large[ctx->stats.sa_rounds] = (int32_t)lc;
+    for (int round = 1;; round++) {
+        const int par = round & 1;
+        const unsigned g_win = cap_grid(bound, SEG_TILE, CAP);
+        const unsigned g_seg = cap_grid(bound, SEG_TILE, CAP_SEG);
+        const unsigned g_cmp = cap_grid(bound, CT, CAP);
+        const size_t pc_bound = 2 * ((size_t)bound / SEG_TILE + 1);
+        const unsigned g_pc = cap_grid(pc_bound, 1, CAP);
+        const unsigned g_tab = cap_grid(pc_bound << lg_db, SC_TILE, CAP);
+        const uint32_t hh = (h < n) ? (uint32_t)h : n;
+        JPK_LAUNCH(ctx, PROF_SA_KEYS, bound, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, hh, b.ISA, b.k2, b.FH, b.LH);
+        const unsigned g_wm = cap_grid((size_t)bound / SEG_TILE + 1, TB, 256);
+        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan1, dim3(1), dim3(WG1), b.FH, b.LH, b.PH, b.NH, b.state, par);
+        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_count, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.state, par);
+        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan2, dim3(1), dim3(WG1), b.PC, b.state, par, round);
+        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_pieces, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.pieces, b.state, par);
+        JPK_LAUNCH(ctx, PROF_SA_SEG, bound, k_seg_round, dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, kbits, b.PH, T, b.ISA, b.bwt, b.SA,
+                   b.b_sa, b.b_grp);
+        {   // large groups: lg_pass LSD passes over (key2, sa), ping-pong between (k2, a_sa) and (k2alt, sa_alt)
+            uint32_t *kin = b.k2, *vin = b.a_sa, *kout = b.k2alt, *vout = b.sa_alt;
+            for (int p = 0; p < lg_pass; p++) {
+                const int shift = p * lg_db;
+                switch (lg_db) {
+                case 4: launch_lg_pass<4>(ctx, b, kin, vin, kout, vout, shift, g_pc, g_tab); break;
+                case 5: launch_lg_pass<5>(ctx, b, kin, vin, kout, vout, shift, g_pc, g_tab); break;
+                case 6: launch_lg_pass<6>(ctx, b, kin, vin, kout, vout, shift, g_pc, g_tab); break;
+                case 7: launch_lg_pass<7>(ctx, b, kin, vin, kout, vout, shift, g_pc, g_tab); break;
+                default: launch_lg_pass<8>(ctx, b, kin, vin, kout, vout, shift, g_pc, g_tab); break;
+                }
+                uint32_t *tk = kin; kin = kout; kout = tk;
+                uint32_t *tv = vin; vin = vout; vout = tv;
+            }
+            JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_lg_heads, dim3(g_pc), dim3(TB), kin, b.pieces, b.state, b.pLast);
+            JPK_LAUNCH(ctx, PROF_SCAN, 0, k_lg_scan, dim3(1), dim3(WG1), b.pLast, b.state);
+            JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_lg_finish, dim3(g_pc), dim3(TB), kin, vin, b.a_grp, b.pieces, b.state, b.pLast, T, b.ISA, b.bwt, b.SA, b.b_sa,
+                       b.b_grp);
         }
-        if (lc > 0) {
-            JPK_TRY(jpk_exclusive_sum_u32(ctx, b.t1, b.t2, m, b.scratch, nullptr));      // t2 = position in the large list
-            const unsigned g_l = jpk_grid(lc, TB);
-            uint32_t *l_sa = b.valsB, *l_grp = b.t3;
-            JPK_LAUNCH(ctx, PROF_SA_KEYS, lc, k_large_gather, dim3(g_m), dim3(TB), b.t1, b.t2, b.a_sa, b.a_grp, m, l_sa, l_grp, b.l_pos);
-            JPK_LAUNCH(ctx, PROF_SA_KEYS, lc, k_large_heads, dim3(g_l), dim3(TB), l_grp, lc, b.t1);
-            JPK_TRY(jpk_inclusive_max_u32(ctx, b.t1, b.t2, lc, b.scratch));               // t2 = jhead (old groups)
-            JPK_LAUNCH(ctx, PROF_SA_KEYS, lc, k_make_keys, dim3(g_l), dim3(TB), l_sa, b.t2, lc, n, (uint32_t)h, isa_cur, b.keysA, b.valsA);
-            int lshifts[8];
-            int lns = 0;
-            for (int s = 0; s < kbits && lns < key_passes; s += 8) lshifts[lns++] = s;
-            const int gbits = jpk_bits_for(lc >> 10);
-            for (int s = 0; s < gbits; s += 8) lshifts[lns++] = 32 + s;
-            JPK_TRY(jpk_radix_sort_pairs_u64(ctx, b.keysA, b.valsA, b.keysB, b.valsB, lc, lshifts, lns, b.scratch));
-            ctx->stats.sa_sorted_elems += lc;
-            JPK_LAUNCH(ctx, PROF_SA_RERANK, lc, k_abspos, dim3(g_l), dim3(TB), b.keysA, b.t2, l_grp, lc, b.t1, b.t3);  // t1 = abspos, t3 = nh (over l_grp)
-            JPK_TRY(jpk_inclusive_max_u32(ctx, b.t3, b.t2, lc, b.scratch));               // t2 = newrank
-            JPK_LAUNCH(ctx, PROF_SA_RERANK, lc, k_large_finish, dim3(g_l), dim3(TB), b.t1, b.t2, b.valsA, b.l_pos, lc, isa_nxt, b.SA, b.b_sa, b.b_grp,
-                       b.keep);
-        }
-        JPK_TRY(jpk_exclusive_sum_u32(ctx, b.keep, b.t3, m, b.scratch, ctx->d_mail));     // t3 = pos
-        JPK_LAUNCH(ctx, PROF_SA_RERANK, m, k_compact_round, dim3(g_m), dim3(TB), b.keep, b.t3, b.b_sa, b.b_grp, m, isa_cur, b.a_sa, b.a_grp);
-        uint32_t m2 = 0;
-        JPK_TRY(jpk_read_mail(ctx, &m2, 1));
-        m = m2;
+        JPK_LAUNCH(ctx, PROF_SA_RERANK, bound, k_cmp_count, dim3(g_cmp), dim3(TB), b.b_grp, b.state, par, b.tA);
+        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_cmp_scan, dim3(1), dim3(WG1), b.tA, b.state, par, round);
+        JPK_LAUNCH(ctx, PROF_SA_RERANK, bound, k_cmp_scatter, dim3(g_cmp), dim3(TB), b.b_sa, b.b_grp, b.state, par, b.tA, b.a_sa, b.a_grp);
+        JPK_HIP(hipGetLastError());
+        JPK_HIP(hipMemcpyAsync(&h_m[par], &b.state->m[par ^ 1], 4, hipMemcpyDeviceToHost, st));
+        JPK_HIP(hipEventRecord(ctx->ev_sa[par], st));
+        // what the PREVIOUS round (or round 0) left behind: known without draining the queue
+        JPK_HIP(hipEventSynchronize(ctx->ev_sa[par ^ 1]));
+        const uint32_t m_start = h_m[par ^ 1];      // = the active count this round started with
+        if (m_start == 0) break;                    // this round was empty: done
+        ctx->stats.sa_rounds = round + 1;
+        bound = m_start;
         h <<= 1;
-        uint32_t *t = isa_cur; isa_cur = isa_nxt; isa_nxt = t;
-        ctx->stats.sa_rounds++;
+        if (round >= 2 * JPK_SA_MAX_ROUNDS) return JPK_E_DEVICE;     // cannot happen: h doubles, every suffix is unique once h >= n
     }
-    JPK_HIP(hipGetLastError());
-    *isa_final = isa_cur;                  // after the last swap isa_cur holds the ranks written by the last round
+    // statistics: one small copy, read by sa_collect_stats() after the caller has synchronised the stream
+    JPK_HIP(hipMemcpyAsync(ctx->h_mail + 32, b.state->round_m, sizeof(uint32_t) * 2 * JPK_SA_MAX_ROUNDS, hipMemcpyDeviceToHost, st));
+    ctx->sa_stats_pending = true;
     return JPK_OK;
 }
 
 }  // namespace
+
+void jpk_sa_stats_sync(jpk_ctx *ctx)
+{
+    if (!ctx->sa_stats_pending) return;
+    ctx->sa_stats_pending = false;
+    const uint32_t *rm = ctx->h_mail + 32, *rl = ctx->h_mail + 32 + JPK_SA_MAX_ROUNDS;
+    for (int r = 0; r < JPK_SA_MAX_ROUNDS; r++) {
+        const bool live = r < ctx->stats.sa_rounds;
+        ctx->stats.sa_round_active[r] = live ? (int32_t)rm[r] : 0;
+        ctx->stats.sa_round_large[r] = live ? (int32_t)rl[r] : 0;
+        if (r >= 1 && live) ctx->stats.sa_sorted_elems += rm[r];
+    }
+}
 
 int jpk_suffix_array_device(jpk_ctx *ctx, const uint8_t *d_t, int32_t n, int32_t *d_sa)
 {
     if (n <= 0) return JPK_OK;
     SaBufs b;
     Arena plan(ctx, true);
-    sa_layout(plan, (size_t)n, b, false);
+    sa_layout(plan, (size_t)n, b);
     JPK_TRY(jpk_arena_ensure(ctx, plan.need));
     Arena real(ctx, false);
-    sa_layout(real, (size_t)n, b, false);
+    sa_layout(real, (size_t)n, b);
     b.SA = reinterpret_cast<uint32_t *>(d_sa);
-    uint32_t *isa;
-    return build_sa(ctx, d_t, (uint32_t)n, b, &isa);
+    return build_sa(ctx, d_t, (uint32_t)n, b);
 }
 
 int jpk_fwd_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out)
@@ -611,14 +1204,13 @@ int jpk_fwd_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *
     }
     SaBufs b;
     Arena plan(ctx, true);
-    sa_layout(plan, (size_t)nlen, b, true);
+    sa_layout(plan, (size_t)nlen, b);
     JPK_TRY(jpk_arena_ensure(ctx, plan.need));
     Arena real(ctx, false);
-    sa_layout(real, (size_t)nlen, b, true);
-    uint32_t *isa;
-    JPK_TRY(build_sa(ctx, d_in, (uint32_t)nlen, b, &isa));
-    JPK_LAUNCH(ctx, PROF_BWT_GATHER, nlen, k_bwt_gather, dim3(jpk_grid(nlen, TB)), dim3(TB), d_in, b.SA, isa, (uint32_t)nlen, d_out);
-    hipLaunchKernelGGL(k_bwt_trailer, dim3(1), dim3(128), 0, ctx->stream, d_in, isa, (uint32_t)nlen, (uint32_t)len, d_out);
+    sa_layout(real, (size_t)nlen, b);
+    JPK_TRY(build_sa(ctx, d_in, (uint32_t)nlen, b));
+    JPK_LAUNCH(ctx, PROF_BWT_GATHER, nlen, k_bwt_image, dim3(cap_grid((size_t)nlen, TB * 16, 4096)), dim3(TB), d_in, b.bwt, b.ISA, (uint32_t)nlen, d_out);
+    hipLaunchKernelGGL(k_bwt_trailer, dim3(1), dim3(128), 0, ctx->stream, d_in, b.ISA, (uint32_t)nlen, (uint32_t)len, d_out);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
 }

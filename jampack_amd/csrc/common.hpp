@@ -46,6 +46,8 @@ struct jpk_ctx {
     static constexpr int ENC_GROUPS = 4;
     hipStream_t aux[ENC_GROUPS - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_pre[ENC_GROUPS] = {nullptr, nullptr, nullptr, nullptr}, ev_done[ENC_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_sa[2] = {nullptr, nullptr};      // suffix sort: "the count round r left behind has reached the host"
+    bool sa_stats_pending = false;   // per-round statistics of the last suffix sort are still in the pinned mailbox
     uint32_t *h_map = nullptr;       // pinned, 4096 words
     uint8_t *arena = nullptr;
     size_t arena_cap = 0;
@@ -119,6 +121,12 @@ size_t jpk_radix_scratch_words(size_t n);
 // LSD radix sort on bit ranges; result is left in keys/vals (alt buffers used for ping-pong)
 int jpk_radix_sort_pairs_u64(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_alt, uint32_t *vals_alt, size_t n,
                              const int *shifts, int nshifts, uint32_t *scratch);
+int jpk_radix_sort_pairs_u64_nocopy(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_alt, uint32_t *vals_alt, size_t n,
+                                    const int *shifts, int nshifts, uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out);
+int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n, uint64_t *keysA, uint32_t *valsA, uint64_t *keysB, uint32_t *valsB,
+                                uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out);
+// moves the per-round statistics of the last suffix sort from the pinned mailbox into ctx->stats (call after a stream sync)
+void jpk_sa_stats_sync(jpk_ctx *ctx);
 
 // ---- stage drivers (device buffers) -----------------------------------------------------------------
 int jpk_fwd_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out);

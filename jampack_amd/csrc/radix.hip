@@ -19,7 +19,29 @@ constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
 
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *__restrict__ keys, size_t n, int shift,
+// Pass 0 of the suffix sort reads its (key, value) pairs straight from the text: slot j holds suffix i = n-1-j, key = the
+// first 7 bytes of the suffix, big-endian in bits 63..8, zero padded past the end (bwt_fwd.hip, round 0).  Three aligned dword
+// loads per slot (neighbouring lanes share them), a funnel shift and a byte swap; nothing beyond the dword that holds
+// T[n-1] is touched.
+struct TextSrc {
+    const uint32_t *tb;      // T rounded down to a dword boundary
+    uint32_t off;            // T - tb (0..3)
+    uint32_t n;
+};
+__device__ __forceinline__ uint64_t text_key7(const TextSrc &t, uint32_t i)
+{
+    const uint32_t a = i + t.off, wi = a >> 2, sh = (a & 3u) * 8u;
+    const uint32_t lastw = (t.n - 1u + t.off) >> 2;
+    const uint32_t w0 = t.tb[wi], w1 = t.tb[wi + 1 < lastw ? wi + 1 : lastw], w2 = t.tb[wi + 2 < lastw ? wi + 2 : lastw];
+    const uint64_t lo = ((uint64_t)w1 << 32) | w0;
+    uint64_t v = sh ? (lo >> sh) | ((uint64_t)w2 << (64u - sh)) : lo;            // bytes i .. i+7, little endian
+    const uint32_t left = t.n - i;                                                  // >= 1
+    if (left < 8u) v &= (1ull << (8u * left)) - 1ull;
+    return __builtin_bswap64(v) & ~0xFFull;
+}
+
+template <bool TEXT>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *__restrict__ keys, TextSrc txt, size_t n, int shift,
                                                        uint32_t *__restrict__ tilehist, uint32_t ntiles)
 {
     __shared__ uint32_t h[RS_WAVES][256];
@@ -30,7 +52,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *__restri
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++) {
         size_t i = base + (size_t)it * 64;
-        if (i < n) atomicAdd(&h[w][(uint32_t)(keys[i] >> shift) & 255u], 1u);
+        if (i < n) {
+            uint32_t d;
+            if (TEXT) {                                // digit of byte (56 - shift) / 8 of the suffix: one text byte
+                const uint32_t pos = (uint32_t)(n - 1 - i) + (uint32_t)((56 - shift) >> 3);
+                d = (pos < txt.n) ? reinterpret_cast<const uint8_t *>(txt.tb)[pos + txt.off] : 0u;
+            } else d = (uint32_t)(keys[i] >> shift) & 255u;
+            atomicAdd(&h[w][d], 1u);
+        }
     }
     __syncthreads();
     for (int d = threadIdx.x; d < 256; d += RS_THREADS) {
@@ -41,7 +70,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *__restri
     }
 }
 
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+template <bool TEXT>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, TextSrc txt,
                                                           uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n, int shift,
                                                           const uint32_t *__restrict__ tileoff, uint32_t ntiles)
 {
@@ -60,8 +90,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *__res
     for (int it = 0; it < RS_ITEMS; it++) {
         size_t i = base + (size_t)it * 64;
         bool valid = i < n;
-        key[it] = valid ? kin[i] : 0;
-        val[it] = valid ? vin[i] : 0;
+        if (TEXT) {
+            val[it] = valid ? (uint32_t)(n - 1 - i) : 0u;
+            key[it] = valid ? text_key7(txt, val[it]) : 0;
+        } else {
+            key[it] = valid ? kin[i] : 0;
+            val[it] = valid ? vin[i] : 0;
+        }
         uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
         uint64_t m = match_any8(d, valid);
         uint32_t below = (uint32_t)__popcll(m & lt);
@@ -99,9 +134,13 @@ size_t jpk_radix_scratch_words(size_t n)
     return table + jpk_scan_scratch_words(table) + 64;
 }
 
-int jpk_radix_sort_pairs_u64(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_alt, uint32_t *vals_alt, size_t n,
-                             const int *shifts, int nshifts, uint32_t *scratch)
+// the sorted pairs end up in (*keys_out, *vals_out): the caller's buffers after an even number of passes, the alt buffers after an
+// odd number -- no copy back
+int jpk_radix_sort_pairs_u64_nocopy(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_alt, uint32_t *vals_alt, size_t n,
+                                    const int *shifts, int nshifts, uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out)
 {
+    *keys_out = keys;
+    *vals_out = vals;
     if (n == 0 || nshifts == 0) return JPK_OK;
     const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
     const size_t table = (size_t)256 * ntiles;
@@ -110,16 +149,70 @@ int jpk_radix_sort_pairs_u64(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint6
     uint64_t *ki = keys, *ko = keys_alt;
     uint32_t *vi = vals, *vo = vals_alt;
     for (int p = 0; p < nshifts; p++) {
-        JPK_LAUNCH(ctx, PROF_RS_HIST, n, k_rs_hist, dim3(ntiles), dim3(RS_THREADS), ki, n, shifts[p], hist, ntiles);
+        const TextSrc none = {nullptr, 0u, 0u};
+        JPK_LAUNCH(ctx, PROF_RS_HIST, n, (k_rs_hist<false>), dim3(ntiles), dim3(RS_THREADS), ki, none, n, shifts[p], hist, ntiles);
         JPK_TRY(jpk_exclusive_sum_u32(ctx, hist, hist, table, scan_scratch, nullptr));
-        JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, k_rs_scatter, dim3(ntiles), dim3(RS_THREADS), ki, vi, ko, vo, n, shifts[p], hist, ntiles);
+        JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter<false>), dim3(ntiles), dim3(RS_THREADS), ki, vi, none, ko, vo, n, shifts[p], hist, ntiles);
         uint64_t *tk = ki; ki = ko; ko = tk;
         uint32_t *tv = vi; vi = vo; vo = tv;
     }
     JPK_HIP(hipGetLastError());
+    *keys_out = ki;
+    *vals_out = vi;
+    return JPK_OK;
+}
+
+int jpk_radix_sort_pairs_u64(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_alt, uint32_t *vals_alt, size_t n,
+                             const int *shifts, int nshifts, uint32_t *scratch)
+{
+    uint64_t *ki;
+    uint32_t *vi;
+    JPK_TRY(jpk_radix_sort_pairs_u64_nocopy(ctx, keys, vals, keys_alt, vals_alt, n, shifts, nshifts, scratch, &ki, &vi));
     if (ki != keys) {
         JPK_HIP(hipMemcpyAsync(keys, ki, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
         JPK_HIP(hipMemcpyAsync(vals, vi, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
+    return JPK_OK;
+}
+
+// Round 0 of the suffix sort (bwt_fwd.hip): all n suffixes of T by their first 7 bytes, 7 LSD passes; the first pass builds the
+// keys from the text on the fly, so no key array is written or read for it.  Result: (keysB, valsB) -- 7 passes, the first one
+// lands in B.
+int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n32, uint64_t *keysA, uint32_t *valsA, uint64_t *keysB, uint32_t *valsB,
+                                uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out)
+{
+    const size_t n = n32;
+    *keys_out = keysB;
+    *vals_out = valsB;
+    if (n == 0) return JPK_OK;
+    const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+    const size_t table = (size_t)256 * ntiles;
+    uint32_t *hist = scratch;
+    uint32_t *scan_scratch = scratch + table;
+    TextSrc txt;
+    txt.off = (uint32_t)((uintptr_t)T & 3u);
+    txt.tb = reinterpret_cast<const uint32_t *>(T - txt.off);
+    txt.n = n32;
+    const TextSrc none = {nullptr, 0u, 0u};
+    uint64_t *ki = keysB, *ko = keysA;        // after pass 0 the pairs are in B
+    uint32_t *vi = valsB, *vo = valsA;
+    for (int p = 0; p < 7; p++) {
+        const int shift = 8 * (p + 1);
+        if (p == 0) {
+            JPK_LAUNCH(ctx, PROF_RS_HIST, n, (k_rs_hist<true>), dim3(ntiles), dim3(RS_THREADS), (const uint64_t *)nullptr, txt, n, shift, hist, ntiles);
+            JPK_TRY(jpk_exclusive_sum_u32(ctx, hist, hist, table, scan_scratch, nullptr));
+            JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter<true>), dim3(ntiles), dim3(RS_THREADS), (const uint64_t *)nullptr, (const uint32_t *)nullptr, txt,
+                       keysB, valsB, n, shift, hist, ntiles);
+            continue;
+        }
+        JPK_LAUNCH(ctx, PROF_RS_HIST, n, (k_rs_hist<false>), dim3(ntiles), dim3(RS_THREADS), ki, none, n, shift, hist, ntiles);
+        JPK_TRY(jpk_exclusive_sum_u32(ctx, hist, hist, table, scan_scratch, nullptr));
+        JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter<false>), dim3(ntiles), dim3(RS_THREADS), ki, vi, none, ko, vo, n, shift, hist, ntiles);
+        uint64_t *tk = ki; ki = ko; ko = tk;
+        uint32_t *tv = vi; vi = vo; vo = tv;
+    }
+    JPK_HIP(hipGetLastError());
+    *keys_out = ki;
+    *vals_out = vi;
     return JPK_OK;
 }

@@ -10,7 +10,7 @@ import torch
 import jampack_amd as jam
 
 n = 64 << 20
-t = jam.corpus.make("text", n, 8)
+t = jam.corpus.make(sys.argv[1] if len(sys.argv) > 1 else "text_survey", n, 8)
 dev = torch.device("cuda", 0)
 ctx = jam.Context(0, None)
 d_in = torch.from_numpy(t).to(dev)

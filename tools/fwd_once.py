@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""two forward BWTs of a 64 MiB text block (for rocprofv3 --kernel-trace timelines)"""
+"""N forward BWTs of a 64 MiB block (for rocprofv3 --kernel-trace --stats):  python tools/fwd_once.py [kind] [reps]"""
 import os
 import sys
 
@@ -9,14 +9,16 @@ import torch
 
 import jampack_amd as jam
 
+kind = sys.argv[1] if len(sys.argv) > 1 else "text_survey"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 n = 64 << 20
-t = jam.corpus.make("text", n, 8)
+t = jam.corpus.make(kind, n, 8)
 dev = torch.device("cuda", 0)
 ctx = jam.Context(0, None)
 d_in = torch.from_numpy(t).to(dev)
 d_bwt = torch.empty(n + 480, dtype=torch.uint8, device=dev)
-for _ in range(2):
+for _ in range(reps):
     ctx.bwt_forward(d_in, n, d_bwt, n + 480)
 torch.cuda.synchronize()
 s = ctx.stats()
-print("rounds", s.sa_rounds)
+print("rounds", s.sa_rounds, list(s.sa_round_active)[: s.sa_rounds])
