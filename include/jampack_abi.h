@@ -65,6 +65,11 @@ typedef struct jpk_stats {
      * suffixes still unresolved when the round starts / of those, members of groups too large for the LDS path */
     int32_t sa_round_active[JPK_SA_MAX_ROUNDS];
     int32_t sa_round_large[JPK_SA_MAX_ROUNDS];
+    /* the rANS chunk whose four state chains ran longest in the last entropy encode (the serial floor of the stage):
+     * shader cycles, nanoseconds (from the 100 MHz real-time counter), encoder steps per chain */
+    int64_t enc_chain_cycles;
+    int64_t enc_chain_ns;
+    int64_t enc_chain_steps;
 } jpk_stats;
 
 /* ---- contexts ------------------------------------------------------------------------------------------ */

@@ -704,7 +704,22 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
 {
     const uint32_t c = chunk_of(d, blockIdx.y);
     const uint32_t t = blockIdx.x * TB + threadIdx.x;
-    if (t >= rlen[c]) return;
+    const uint32_t rl = rlen[c];
+    const size_t lane_stride = rans_lane_stride(rle_stride);
+    uint4 *rc = recs + (size_t)c * 4 * lane_stride;
+    if (t >= rl) {
+        // the chain kernel walks whole batches of 16 steps: steps past a chain's last pair get identity records
+        // (xmax above every state, q * 0 + x + 0), so that it needs no bounds logic
+        const uint32_t u = t - rl;
+        if (u < 64u) {
+            const uint32_t np = 2u * rl, chain = u >> 4;
+            const uint32_t steps16 = np ? (((np - 1u) >> 2) / 16u + 1u) * 16u : 16u;
+            const uint32_t first = (chain < np) ? ((np - 1u - chain) >> 2) + 1u : 0u;
+            const uint32_t k = first + (u & 15u);
+            if (k < steps16) rc[(size_t)chain * lane_stride + k] = make_uint4(0x80000000u, 0u, 0u, 0u);
+        }
+        return;
+    }
     const size_t o = (size_t)c * rle_stride + t;
     const uint32_t s = rle[o];
     const int e = sym_class(s);
@@ -720,8 +735,6 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
         f1 = cdf[m + 1] - l1;
     }
     // lane-major: pairs 2t, 2t+1 -> lanes (2t)&3, (2t+1)&3 at index t >> 1
-    const size_t lane_stride = rans_lane_stride(rle_stride);
-    uint4 *rc = recs + (size_t)c * 4 * lane_stride;
     const uint32_t j0 = 2 * t;
     rc[(size_t)(j0 & 3u) * lane_stride + (j0 >> 2)] = rans_record(l0, h0 - l0);
     rc[(size_t)((j0 + 1) & 3u) * lane_stride + (j0 >> 2)] = rans_record(l1, f1);
@@ -780,16 +793,18 @@ __device__ __forceinline__ uint32_t rans_step_turn2(uint32_t xprev, const uint4 
 
 // One wave per chunk; no LDS.  The four chains of a chunk (pair j -> chain j & 3, ans.cpp:189-208) own one row of
 // 16 lanes each; lane s of a row holds the record of step K - s of the current batch of 16 steps (one coalesced
-// 16-byte global load per lane per batch, the next batch prefetched).  The state travels: every step all lanes run
-// the same eleven instructions on the state handed over by their left neighbour (DPP row rotate, no LDS, no
+// 16-byte global load per lane per batch, eight batches prefetched).  The state travels: every step all lanes run
+// the same twelve instructions on the state handed over by their left neighbour (DPP row rotate, no LDS, no
 // readlane), so after step t lane t holds the chain's true state and the others compute values nobody uses.  A lane
-// keeps the state it was handed on its own turn; after the 16 steps all 64 lanes turn those into emit words and
-// end-relative byte offsets at once (two ballots and per-lane popcounts instead of a scan).
-// Steps outside a chain (before its last pair, after its first) use an identity record.
+// keeps the state it was handed on its own turn; per batch the wave stores those 64 states (one coalesced 4-byte store)
+// and nothing else: the emitted bytes and their stream positions are a pure function of (state before the step, record)
+// and are computed afterwards by wide kernels (k_emit_count / k_emit_prefix / k_put_payload).  This wave is the serial
+// floor of the whole stage -- 13 issue slots per step plus ~1 per step of batch overhead.
+// Steps past a chain's last pair use the identity records k_pairs has written.
 __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ recs, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
-                                                  uint32_t *__restrict__ emit, uint32_t *__restrict__ fstate, uint32_t *__restrict__ eend,
-                                                  uint32_t *__restrict__ csize)
+                                                  uint32_t *__restrict__ xs, uint32_t *__restrict__ fstate, uint64_t *__restrict__ stamp)
 {
+    const uint64_t t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
     // this wave is a long dependent chain: let it win the issue arbitration against the wide kernels of other chunks /
     // blocks that share its SIMD (priority, then age)
     __builtin_amdgcn_s_setprio(3);
@@ -798,106 +813,230 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
     const uint32_t np = 2 * rlen[c];
     if (np == 0) {
         if (t < 4) fstate[(size_t)c * 4 + t] = RANS_L;
-        if (t == 0) csize[c] = 16u;
+        if (t == 0) { stamp[2 * (size_t)c] = 0; stamp[2 * (size_t)c + 1] = 0; }
         return;
     }
     const int chain = t >> 4, s = t & 15;
     const size_t lane_stride = rans_lane_stride(rle_stride);
     const uint4 *rc = recs + ((size_t)c * 4 + chain) * lane_stride;
-    uint32_t *em = emit + ((size_t)c * 4 + chain) * lane_stride;
-    uint32_t *ee = eend + (size_t)c * 2 * rle_stride;
-    const int32_t kmax = ((uint32_t)chain < np) ? (int32_t)((np - 1 - chain) / 4) : -1;    // my chain's last record
+    uint32_t *xo = xs + ((size_t)c * 4 + chain) * lane_stride;
     const int32_t nbatch = (int32_t)((np - 1) / 4) / 16 + 1;
-    // pair order inside a batch, last pair first: p = 4 * s + (3 - chain); before[] = lanes whose pair comes no later
-    const uint32_t myp = 4u * (uint32_t)s + (3u - (uint32_t)chain);
-    uint32_t before_lo = 0, before_hi = 0;
-    for (int q = 0; q < 64; q++) {
-        const uint32_t pq = 4u * (uint32_t)(q & 15) + (3u - (uint32_t)(q >> 4));
-        if (pq <= myp) { if (q < 32) before_lo |= 1u << q; else before_hi |= 1u << (q - 32); }
-    }
-    const uint4 ident = make_uint4(0x80000000u, 0u, 0u, 0u);       // xmax above every state, q * 0 + x + 0
-    int32_t K = 16 * nbatch - 1;                                   // step index of lane 0 in the current batch
-    auto load = [&](int32_t k) -> uint4 {                          // raw: steps outside the chain are replaced at the point of use
-        const int32_t kk = k < 0 ? 0 : (k > kmax ? (kmax < 0 ? 0 : kmax) : k);
-        return rc[kk];
-    };
+    int32_t K = 16 * nbatch - 1 - s;                               // this lane's step index in the current batch
     uint32_t x = RANS_L;                                           // lane 15 of a row hands the start state to lane 0
-    uint32_t carry = 0;                                            // bytes emitted by all earlier batches
-    // one batch = 16 steps of every chain with the records REC (lane s: step KTOP - s), then the batch's emit words and offsets
-#define JPK_BATCH(REC, KTOP)                                                                               \
+    // Record loads are issued from inline asm so that the wait counts are ours: loads and stores share vmcnt and retire in
+    // order, and the compiler (which has to be conservative across the early exits below) waited with vmcnt(6), i.e. for the
+    // kept-state stores of the last three batches as well -- a store acknowledgement on the chain of every batch.  Sixteen
+    // batches (~6 us of steps) are in flight, enough to cover a record load while suffix-sort kernels of another block
+    // saturate the memory system; in steady state 15 loads and 15 stores are younger than the record a batch is about to
+    // use: vmcnt(30).  Fifteen dummy stores in the prologue make the very first batches look like steady state.
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define JPK_LOADREC(R, KK)                                                                                 \
     {                                                                                                      \
+        const int32_t kk_ = (KK) < 0 ? 0 : (KK);              /* prefetches past the last batch re-read record 0 */ \
+        const uint4 *p_ = rc + kk_;                                                                        \
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(R) : "v"(p_) : "memory");                    \
+    }
+    // one batch = wait for its records, 16 steps of every chain (lane s: step KK), one store of the kept states
+#define JPK_BATCH(R, KK)                                                                                   \
+    {                                                                                                      \
+        asm volatile("s_waitcnt vmcnt(30)" : "+v"(R) : : "memory");                                        \
         uint32_t keep = 0;                                                                                 \
-        const int32_t k = (KTOP) - s;                                                                      \
-        const bool live = k >= 0 && k <= kmax;                                                             \
-        const uint4 rr = live ? REC : ident;                                                               \
+        const uint4 rr = make_uint4(R.x, R.y, R.z, R.w);                                                   \
         _Pragma("unroll") for (int st = 0; st < 16; st += 2)                                               \
             x = rans_step_turn2(x, rr, keep, 0x0001000100010001ull << st, 0x0001000100010001ull << (st + 1)); \
-        const uint32_t e = live ? emit_word(keep, rr.x) : 0u;                                              \
-        if (live) em[k] = e;                                                                               \
-        const uint32_t cn = e >> 16;                                                                       \
-        const uint64_t m1 = __ballot(cn != 0), m2 = __ballot(cn == 2);                                     \
-        const uint32_t incl = __popc((uint32_t)m1 & before_lo) + __popc((uint32_t)(m1 >> 32) & before_hi) + \
-                              __popc((uint32_t)m2 & before_lo) + __popc((uint32_t)(m2 >> 32) & before_hi); \
-        /* bytes from the start of pair j's output to the end of the stream (pair j = 4k + chain) */       \
-        if (live) ee[4u * (uint32_t)k + (uint32_t)chain] = carry + incl;                                   \
-        carry += (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2);                                          \
+        xo[KK] = keep;                                                                                     \
+        asm volatile("" : : : "memory");                                                                   \
     }
-    // the records of eight batches are in flight: one batch is ~0.4 us of dependent steps, an HBM load takes longer, and
-    // the compiler's wait counts (loads and the batch's stores share vmcnt) give up part of the distance
-    uint4 r0 = load(K - s), r1 = load(K - 16 - s), r2 = load(K - 32 - s), r3 = load(K - 48 - s);
-    uint4 r4 = load(K - 64 - s), r5 = load(K - 80 - s), r6 = load(K - 96 - s), r7 = load(K - 112 - s);
-    for (int32_t b = 0; b < nbatch; b += 8) {                      // batches past the first pair run on identity records
-        JPK_BATCH(r0, K)
-        r0 = load(K - 128 - s);
+    // (asm, so that the compiler cannot merge them)
+#define JPK_DUMMYST { uint32_t *q_ = xo + K; const uint32_t z_ = 0u; asm volatile("global_store_dword %0, %1, off" : : "v"(q_), "v"(z_) : "memory"); }
+    u32x4 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
+    JPK_LOADREC(r0, K - 0)
+    JPK_DUMMYST
+    JPK_LOADREC(r1, K - 16)
+    JPK_DUMMYST
+    JPK_LOADREC(r2, K - 32)
+    JPK_DUMMYST
+    JPK_LOADREC(r3, K - 48)
+    JPK_DUMMYST
+    JPK_LOADREC(r4, K - 64)
+    JPK_DUMMYST
+    JPK_LOADREC(r5, K - 80)
+    JPK_DUMMYST
+    JPK_LOADREC(r6, K - 96)
+    JPK_DUMMYST
+    JPK_LOADREC(r7, K - 112)
+    JPK_DUMMYST
+    JPK_LOADREC(r8, K - 128)
+    JPK_DUMMYST
+    JPK_LOADREC(r9, K - 144)
+    JPK_DUMMYST
+    JPK_LOADREC(r10, K - 160)
+    JPK_DUMMYST
+    JPK_LOADREC(r11, K - 176)
+    JPK_DUMMYST
+    JPK_LOADREC(r12, K - 192)
+    JPK_DUMMYST
+    JPK_LOADREC(r13, K - 208)
+    JPK_DUMMYST
+    JPK_LOADREC(r14, K - 224)
+    JPK_DUMMYST
+    JPK_LOADREC(r15, K - 240)
+    for (int32_t b = 0; b < nbatch; b += 16) {
+        JPK_BATCH(r0, K - 0)
+        if (b + 1 >= nbatch) break;
+        JPK_LOADREC(r0, K - 256)
         JPK_BATCH(r1, K - 16)
-        r1 = load(K - 144 - s);
+        if (b + 2 >= nbatch) break;
+        JPK_LOADREC(r1, K - 272)
         JPK_BATCH(r2, K - 32)
-        r2 = load(K - 160 - s);
+        if (b + 3 >= nbatch) break;
+        JPK_LOADREC(r2, K - 288)
         JPK_BATCH(r3, K - 48)
-        r3 = load(K - 176 - s);
+        if (b + 4 >= nbatch) break;
+        JPK_LOADREC(r3, K - 304)
         JPK_BATCH(r4, K - 64)
-        r4 = load(K - 192 - s);
+        if (b + 5 >= nbatch) break;
+        JPK_LOADREC(r4, K - 320)
         JPK_BATCH(r5, K - 80)
-        r5 = load(K - 208 - s);
+        if (b + 6 >= nbatch) break;
+        JPK_LOADREC(r5, K - 336)
         JPK_BATCH(r6, K - 96)
-        r6 = load(K - 224 - s);
+        if (b + 7 >= nbatch) break;
+        JPK_LOADREC(r6, K - 352)
         JPK_BATCH(r7, K - 112)
-        r7 = load(K - 240 - s);
-        K -= 128;
+        if (b + 8 >= nbatch) break;
+        JPK_LOADREC(r7, K - 368)
+        JPK_BATCH(r8, K - 128)
+        if (b + 9 >= nbatch) break;
+        JPK_LOADREC(r8, K - 384)
+        JPK_BATCH(r9, K - 144)
+        if (b + 10 >= nbatch) break;
+        JPK_LOADREC(r9, K - 400)
+        JPK_BATCH(r10, K - 160)
+        if (b + 11 >= nbatch) break;
+        JPK_LOADREC(r10, K - 416)
+        JPK_BATCH(r11, K - 176)
+        if (b + 12 >= nbatch) break;
+        JPK_LOADREC(r11, K - 432)
+        JPK_BATCH(r12, K - 192)
+        if (b + 13 >= nbatch) break;
+        JPK_LOADREC(r12, K - 448)
+        JPK_BATCH(r13, K - 208)
+        if (b + 14 >= nbatch) break;
+        JPK_LOADREC(r13, K - 464)
+        JPK_BATCH(r14, K - 224)
+        if (b + 15 >= nbatch) break;
+        JPK_LOADREC(r14, K - 480)
+        JPK_BATCH(r15, K - 240)
+        JPK_LOADREC(r15, K - 496)
+        K -= 256;
     }
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");            // the prefetches of batches that do not exist
+#undef JPK_LOADREC
+#undef JPK_DUMMYST
 #undef JPK_BATCH
-    if (s == 15) fstate[(size_t)c * 4 + chain] = x;               // identity steps carried each chain's state to the end of its row
-    if (t == 0) csize[c] = 16u + carry;
+    if (s == 15) fstate[(size_t)c * 4 + chain] = x;               // the last batch ends at step 0: lane 15 holds each chain's final state
+    if (t == 0) {
+        // diagnostics: shader cycles and 100 MHz ticks this chunk's chains took (jpk_stats.enc_chain_*)
+        stamp[2 * (size_t)c] = __builtin_amdgcn_s_memtime() - t0c;
+        stamp[2 * (size_t)c + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+    }
+}
+
+// ---- emitted bytes and their positions, in parallel over all pairs ---------------------------------------------------------
+// Pair j of a chunk (chain j & 3, step j >> 2) emitted 0..2 bytes; the encoder walks the pairs last to first and the stream grows
+// downwards, so the bytes of pair j start  sum_{j' >= j} count(j')  bytes before the end of the chunk's payload.
+constexpr int ETILE = 4096;                    // pairs per tile
+__device__ __forceinline__ uint32_t pair_emit(const uint32_t *__restrict__ xs, const uint4 *__restrict__ recs, size_t chunk_base, size_t lane_stride, uint32_t j)
+{
+    const size_t o = chunk_base + (size_t)(j & 3u) * lane_stride + (j >> 2);
+    return emit_word(xs[o], recs[o].x);
+}
+
+__global__ __launch_bounds__(TB) void k_emit_count(const uint32_t *__restrict__ xs, const uint4 *__restrict__ recs, size_t rle_stride, EncDims d,
+                                                  const uint32_t *__restrict__ rlen, uint32_t *__restrict__ tsum, uint32_t etpc)
+{
+    const uint32_t c = chunk_of(d, blockIdx.y), tile = blockIdx.x;
+    const uint32_t np = 2 * rlen[c];
+    if (tile * ETILE >= np) return;
+    const size_t lane_stride = rans_lane_stride(rle_stride), cb = (size_t)c * 4 * lane_stride;
+    uint32_t n = 0;
+#pragma unroll 4
+    for (int it = 0; it < ETILE / TB; it++) {
+        const uint32_t j = tile * ETILE + it * TB + threadIdx.x;
+        if (j < np) n += pair_emit(xs, recs, cb, lane_stride, j) >> 16;
+    }
+    __shared__ uint32_t sm[TB / 64 + 1];
+    uint32_t tot;
+    block_incl_scan<OpSum>(n, sm, &tot);
+    if (threadIdx.x == 0) tsum[(size_t)c * etpc + tile] = tot;
+}
+
+// one wave per chunk: tsum -> bytes emitted by all LATER tiles (exclusive suffix sum), csize = 16 state bytes + total
+__global__ __launch_bounds__(64) void k_emit_prefix(EncDims d, const uint32_t *__restrict__ rlen, uint32_t *__restrict__ tsum, uint32_t etpc,
+                                                   uint32_t *__restrict__ csize)
+{
+    const uint32_t c = chunk_of(d, blockIdx.x);
+    const uint32_t np = 2 * rlen[c];
+    const int nt = (int)((np + ETILE - 1) / ETILE), l = lane_id();
+    uint32_t *ts = tsum + (size_t)c * etpc;
+    uint32_t carry = 0;
+    for (int hi = nt; hi > 0; hi -= 64) {                 // windows of 64 tiles, last window first
+        const int tIdx = hi - 1 - l;                      // lane 0 = the last tile of the window
+        const uint32_t v = (tIdx >= 0) ? ts[tIdx] : 0u;
+        const uint32_t inc = wave_incl_sum(v);
+        if (tIdx >= 0) ts[tIdx] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (l == 0) csize[c] = 16u + carry;
 }
 
 constexpr int HDR_MAX = 259 * 5 + 1;   // 1296
 
-// header bytes per chunk (ans.cpp:272-285) and the output offset of every chunk
-__global__ __launch_bounds__(1024) void k_headers(EncDims d, const int32_t *__restrict__ freq, const uint32_t *__restrict__ csize,
-                                                 const uint32_t *__restrict__ rlen, uint8_t *__restrict__ hdr, uint32_t *__restrict__ hsize,
-                                                 uint64_t *__restrict__ outoff, uint32_t *__restrict__ mail)
+// header bytes of one chunk per workgroup (ans.cpp:272-285): thread s encodes Freq[s], the three length fields follow
+__global__ __launch_bounds__(256) void k_headers(EncDims d, const int32_t *__restrict__ freq, const uint32_t *__restrict__ csize,
+                                                const uint32_t *__restrict__ rlen, uint8_t *__restrict__ hdr, uint32_t *__restrict__ hsize)
 {
-    for (uint32_t c = threadIdx.x; c < d.nch; c += blockDim.x) {
-        uint8_t *h = hdr + (size_t)c * HDR_MAX;
-        int p = 0;
-        for (int s = 0; s < 256; s++) p += leb_encode((uint32_t)freq[(size_t)c * 256 + s], h + p);
+    __shared__ uint32_t sm[256 / 64 + 1];
+    const uint32_t c = blockIdx.x;
+    uint8_t *h = hdr + (size_t)c * HDR_MAX;
+    uint8_t tmp[5];
+    const uint32_t n = (uint32_t)leb_encode((uint32_t)freq[(size_t)c * 256 + threadIdx.x], tmp);
+    uint32_t tot;
+    const uint32_t inc = block_incl_scan<OpSum>(n, sm, &tot);
+    uint8_t *o = h + (inc - n);
+    for (uint32_t k = 0; k < n; k++) o[k] = tmp[k];
+    if (threadIdx.x == 0) {
+        int p = (int)tot;
         p += leb_encode(chunk_len(d, c), h + p);
         p += leb_encode(csize[c], h + p);
         p += leb_encode(rlen[c], h + p);
         hsize[c] = (uint32_t)p;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t o = 0;
-        for (uint32_t c = 0; c < d.nch; c++) { outoff[c] = o; o += (uint64_t)hsize[c] + csize[c]; }
-        outoff[d.nch] = o;
-        mail[0] = (uint32_t)o;
-        mail[1] = (uint32_t)(o >> 32);
-        uint64_t rs = 0;
-        for (uint32_t c = 0; c < d.nch; c++) rs += rlen[c];
-        mail[2] = (uint32_t)rs;
-        mail[3] = (uint32_t)(rs >> 32);
+}
+
+// output offset of every chunk, totals and the chain diagnostics -> mailbox
+__global__ __launch_bounds__(64) void k_out_offsets(EncDims d, const uint32_t *__restrict__ csize, const uint32_t *__restrict__ rlen,
+                                                   const uint32_t *__restrict__ hsize, uint64_t *__restrict__ outoff, uint32_t *__restrict__ mail,
+                                                   const uint64_t *__restrict__ stamp)
+{
+    if (threadIdx.x != 0) return;
+    uint64_t o = 0, rs = 0;
+    uint32_t worst = 0;                      // the chunk whose chains ran longest
+    for (uint32_t c = 0; c < d.nch; c++) {
+        outoff[c] = o;
+        o += (uint64_t)hsize[c] + csize[c];
+        rs += rlen[c];
+        if (stamp[2 * (size_t)c] > stamp[2 * (size_t)worst]) worst = c;
     }
+    outoff[d.nch] = o;
+    mail[0] = (uint32_t)o;
+    mail[1] = (uint32_t)(o >> 32);
+    mail[2] = (uint32_t)rs;
+    mail[3] = (uint32_t)(rs >> 32);
+    mail[4] = (uint32_t)stamp[2 * (size_t)worst]; mail[5] = (uint32_t)(stamp[2 * (size_t)worst] >> 32);
+    mail[6] = (uint32_t)stamp[2 * (size_t)worst + 1]; mail[7] = (uint32_t)(stamp[2 * (size_t)worst + 1] >> 32);
+    mail[8] = rlen[worst];
 }
 
 __global__ __launch_bounds__(TB) void k_put_headers(EncDims d, const uint8_t *__restrict__ hdr, const uint32_t *__restrict__ hsize,
@@ -914,20 +1053,41 @@ __global__ __launch_bounds__(TB) void k_put_headers(EncDims d, const uint8_t *__
     }
 }
 
-__global__ __launch_bounds__(TB) void k_put_payload(size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen, const uint32_t *__restrict__ emit,
-                                                   const uint32_t *__restrict__ eend, const uint32_t *__restrict__ csize,
-                                                   const uint32_t *__restrict__ hsize, const uint64_t *__restrict__ outoff, uint8_t *__restrict__ out)
+// payload bytes: every pair places its 0..2 bytes (offset = bytes of all later pairs, from the end of the chunk's payload)
+__global__ __launch_bounds__(TB) void k_put_payload(const uint32_t *__restrict__ xs, const uint4 *__restrict__ recs, size_t rle_stride, EncDims d,
+                                                   const uint32_t *__restrict__ rlen, const uint32_t *__restrict__ tsuf, uint32_t etpc,
+                                                   const uint32_t *__restrict__ csize, const uint32_t *__restrict__ hsize, const uint64_t *__restrict__ outoff,
+                                                   uint8_t *__restrict__ out)
 {
-    const uint32_t c = blockIdx.y;
-    const uint32_t j = blockIdx.x * TB + threadIdx.x;
-    if (j >= 2 * rlen[c]) return;
-    const uint32_t e = emit[(size_t)c * 4 * rans_lane_stride(rle_stride) + (size_t)(j & 3u) * rans_lane_stride(rle_stride) + (j >> 2)];
-    const uint32_t cnt = e >> 16;
-    if (!cnt) return;
-    uint8_t *dst = out + outoff[c] + hsize[c] + csize[c] - eend[(size_t)c * 2 * rle_stride + j];
-    if (cnt == 1) dst[0] = (uint8_t)e;
-    else { dst[0] = (uint8_t)(e >> 8); dst[1] = (uint8_t)e; }   // the later (lower-address) byte of a step comes first in the stream
+    const uint32_t c = blockIdx.y, tile = blockIdx.x;
+    const uint32_t np = 2 * rlen[c];
+    if (tile * ETILE >= np) return;
+    const size_t lane_stride = rans_lane_stride(rle_stride), cb = (size_t)c * 4 * lane_stride;
+    // thread t owns the 16 consecutive pairs [j0, j0 + 16) of the tile; suffix sums run from the tile's last pair backwards
+    const uint32_t j0 = tile * ETILE + threadIdx.x * 16;
+    uint32_t e[16];
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        e[k] = (j0 + k < np) ? pair_emit(xs, recs, cb, lane_stride, j0 + k) : 0u;
+        n += e[k] >> 16;
+    }
+    // bytes emitted by the threads after me = block total - inclusive prefix
+    __shared__ uint32_t sm[TB / 64 + 1];
+    uint32_t tot;
+    const uint32_t inc = block_incl_scan<OpSum>(n, sm, &tot);
+    uint32_t after = tsuf[(size_t)c * etpc + tile] + (tot - inc);       // bytes of all pairs after my 16
+    uint8_t *end = out + outoff[c] + hsize[c] + csize[c];
+#pragma unroll
+    for (int k = 15; k >= 0; k--) {
+        const uint32_t cnt = e[k] >> 16;
+        after += cnt;
+        if (cnt == 1) end[-(int64_t)after] = (uint8_t)e[k];
+        else if (cnt == 2) { uint8_t *p = end - after; p[0] = (uint8_t)(e[k] >> 8); p[1] = (uint8_t)e[k]; }   // the later (lower-address) byte of a step comes first
+    }
 }
+
+inline uint32_t emit_tiles_per_chunk(size_t stride) { return (uint32_t)((2 * stride + ETILE - 1) / ETILE); }
 
 struct EncBufs {
     uint32_t *tilecnt; int32_t *lastpos; int32_t *freq; uint32_t *bstart; uint8_t *ranks;
@@ -937,7 +1097,8 @@ struct EncBufs {
     uint8_t *cls8; uint32_t *clist;
     uint32_t *seg_flag; int32_t *seg_lo, *seg_end, *seg_start; uint16_t *seg_tab;
     uint16_t *explo, *exphi; uint32_t *mantad, *pairs; uint4 *recs;
-    uint32_t *emit, *epos, *fstate, *csize;
+    uint32_t *xs, *etsum, *fstate, *csize;
+    uint64_t *stamp;
     uint8_t *hdr; uint32_t *hsize; uint64_t *outoff;
 };
 
@@ -986,10 +1147,11 @@ void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what)
         b.pairs = (what & LAY_PLAIN) ? a.get<uint32_t>((size_t)d.nch * stride * 2) : nullptr;
     }
     if (what & LAY_RANS) {
-        b.emit = a.get<uint32_t>((size_t)d.nch * 4 * rans_lane_stride(stride));
-        b.epos = a.get<uint32_t>((size_t)d.nch * stride * 2);
+        b.xs = a.get<uint32_t>((size_t)d.nch * 4 * rans_lane_stride(stride));      // state before every step, lane-major like recs
+        b.etsum = a.get<uint32_t>((size_t)d.nch * emit_tiles_per_chunk(stride));
         b.fstate = a.get<uint32_t>((size_t)d.nch * 4);
         b.csize = a.get<uint32_t>(d.nch);
+        b.stamp = a.get<uint64_t>(2 * (size_t)d.nch);
         b.hdr = a.get<uint8_t>((size_t)d.nch * HDR_MAX);
         b.hsize = a.get<uint32_t>(d.nch);
         b.outoff = a.get<uint64_t>(d.nch + 1);
@@ -1011,18 +1173,32 @@ EncDims make_dims(uint32_t len, uint32_t chunk)
 // symbol changes per chunk: a cheap proxy for the length of its rANS chain (used to launch the densest chunks first)
 __global__ __launch_bounds__(TB) void k_density(const uint8_t *__restrict__ in, EncDims d, uint32_t *__restrict__ dens)
 {
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = blockIdx.y, ts = blockIdx.x * ATILE * 4;
     const uint32_t clen = chunk_len(d, c);
+    if (ts >= clen) return;
+    const uint32_t te = (ts + ATILE * 4 < clen) ? ts + ATILE * 4 : clen;
     const uint8_t *src = in + (size_t)c * d.chunk;
     uint32_t n = 0;
-    for (uint32_t i = threadIdx.x * 16; i < clen; i += TB * 16) {
+    for (uint32_t i = ts + threadIdx.x * 16; i < te; i += TB * 16) {
         uint8_t prev = i ? src[i - 1] : 0;
-        for (uint32_t k = 0; k < 16 && i + k < clen; k++) { uint8_t v = src[i + k]; n += (v != prev); prev = v; }
+        for (uint32_t k = 0; k < 16 && i + k < te; k++) { uint8_t v = src[i + k]; n += (v != prev); prev = v; }
     }
-    __shared__ uint32_t sm[TB / 64 + 1];
-    uint32_t tot;
-    block_incl_scan<OpSum>(n, sm, &tot);
-    if (threadIdx.x == 0) dens[c] = tot;
+    n = wave_sum(n);
+    if (lane_id() == 0 && n) atomicAdd(&dens[c], n);
+}
+
+// launch order of the chunks: densest first, ties by chunk number (rank by counting; one workgroup, nch <= a few thousand)
+__global__ __launch_bounds__(256) void k_order(EncDims d, const uint32_t *__restrict__ dens, uint32_t *__restrict__ cmap)
+{
+    for (uint32_t c = threadIdx.x; c < d.nch; c += blockDim.x) {
+        const uint32_t v = dens[c];
+        uint32_t r = 0;
+        for (uint32_t k = 0; k < d.nch; k++) {
+            const uint32_t w = dens[k];
+            r += (w > v || (w == v && k < c)) ? 1u : 0u;
+        }
+        cmap[r] = c;
+    }
 }
 
 int run_rank(jpk_ctx *ctx, const uint8_t *d_in, const EncDims &d, EncBufs &b)
@@ -1060,7 +1236,7 @@ int run_model(jpk_ctx *ctx, const uint16_t *d_rle, const uint32_t *d_rlen, const
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_tab, dim3((d.tpc + 1) / 2, 9, d.ncl), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_b, dim3(jpk_grid((size_t)d.ncl * 16, 64)), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_c, dim3((d.tpc + 3) / 4, d.ncl), dim3(64), d, aa);
-    JPK_LAUNCH(ctx, PROF_ENC_PAIRS, 0, k_pairs, dim3(jpk_grid(stride, TB), d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.explo, b.exphi, b.mantad, b.ord,
+    JPK_LAUNCH(ctx, PROF_ENC_PAIRS, 0, k_pairs, dim3(jpk_grid(stride, TB) + 1, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.explo, b.exphi, b.mantad, b.ord,
                        b.qcdf, b.recs, b.pairs);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
@@ -1096,28 +1272,39 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
         return JPK_OK;
     };
     auto chain = [&](const EncDims &g) -> int {
-        JPK_LAUNCH(ctx, PROF_ENC_RANS, 0, k_rans_lanes, dim3(g.ncl), dim3(64), b.recs, stride, g, b.rlen, b.emit, b.fstate, b.epos, b.csize);
+        JPK_LAUNCH(ctx, PROF_ENC_RANS, 0, k_rans_lanes, dim3(g.ncl), dim3(64), b.recs, stride, g, b.rlen, b.xs, b.fstate, b.stamp);
+        const uint32_t etpc = emit_tiles_per_chunk(stride);
+        JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_emit_count, dim3(etpc, g.ncl), dim3(TB), b.xs, b.recs, stride, g, b.rlen, b.etsum, etpc);
+        JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_emit_prefix, dim3(g.ncl), dim3(64), g, b.rlen, b.etsum, etpc, b.csize);
         return JPK_OK;
     };
     int ngroups = (int)(d.nch / 8u);
     if (ngroups > jpk_ctx::ENC_GROUPS) ngroups = jpk_ctx::ENC_GROUPS;
     if (const char *e = getenv("JPK_ENC_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= jpk_ctx::ENC_GROUPS && (uint32_t)v <= d.nch) ngroups = v; }
     if (ngroups >= 2) {
-        JPK_LAUNCH(ctx, PROF_ENC_HIST, d.len, k_density, dim3(d.nch), dim3(TB), d_in, d, b.dens);
-        JPK_HIP(hipMemcpyAsync(ctx->h_map, b.dens, (size_t)d.nch * 4, hipMemcpyDeviceToHost, st));
-        JPK_HIP(hipStreamSynchronize(st));
-        std::vector<uint32_t> order(d.nch);
-        for (uint32_t c = 0; c < d.nch; c++) order[c] = c;
-        const uint32_t *dn = ctx->h_map;
-        std::vector<uint32_t> dcopy(dn, dn + d.nch);
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return dcopy[x] > dcopy[y]; });
-        for (uint32_t c = 0; c < d.nch; c++) ctx->h_map[c] = order[c];
-        JPK_HIP(hipMemcpyAsync(b.cmap, ctx->h_map, (size_t)d.nch * 4, hipMemcpyHostToDevice, st));
+        // launch order on the device (no host round trip): density per chunk, rank by counting
+        JPK_HIP(hipMemsetAsync(b.dens, 0, (size_t)d.nch * 4, st));
+        JPK_LAUNCH(ctx, PROF_ENC_HIST, d.len, k_density, dim3((d.chunk + ATILE * 4 - 1) / (ATILE * 4), d.nch), dim3(TB), d_in, d, b.dens);
+        JPK_LAUNCH(ctx, PROF_ENC_HIST, 0, k_order, dim3(1), dim3(256), d, b.dens, b.cmap);
         JPK_HIP(hipEventRecord(ctx->ev_pre[0], st));           // histogram memset + chunk order are in place
+        // graded groups, densest first: the first group is small so that the longest chains -- the serial floor of the whole
+        // stage -- start after a sixteenth of the parallel work; with four groups: 1/16, 1/8, 1/4 of the chunks and the rest
+        uint32_t gsz[jpk_ctx::ENC_GROUPS];
+        {
+            uint32_t left = d.nch;
+            for (int g = 0; g < ngroups; g++) {
+                uint32_t n = (g + 1 == ngroups) ? left : d.nch >> (ngroups - g);
+                if (n < 2) n = 2;
+                if (n > left) n = left;
+                gsz[g] = n;
+                left -= n;
+            }
+        }
         uint32_t off = 0;
         int rc = JPK_OK;
         for (int g = 0; g < ngroups && rc == JPK_OK; g++) {
-            const uint32_t n = (d.nch - off + (uint32_t)(ngroups - g) - 1) / (uint32_t)(ngroups - g);
+            const uint32_t n = gsz[g];
+            if (n == 0) continue;
             EncDims gd = d;
             gd.ncl = n; gd.cmap = b.cmap + off;
             off += n;
@@ -1126,10 +1313,12 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
             if (gs != st && hipStreamWaitEvent(gs, ctx->ev_pre[0], 0) != hipSuccess) { rc = JPK_E_DEVICE; break; }
             ctx->stream = gs;
             rc = pre_chain(gd);
+            if (rc == JPK_OK) rc = jpk_gate_mark(ctx, gs);        // the wide kernels of this group end here; the chains run beside the next block
             if (rc == JPK_OK) rc = chain(gd);
             ctx->stream = st;
             if (rc == JPK_OK && gs != st && hipEventRecord(ctx->ev_done[g], gs) != hipSuccess) rc = JPK_E_DEVICE;
         }
+        jpk_gate_leave(ctx);                                       // everything GPU-saturating of this block is enqueued
         for (int g = 0; g + 1 < ngroups && rc == JPK_OK; g++)
             if (hipStreamWaitEvent(st, ctx->ev_done[g], 0) != hipSuccess) rc = JPK_E_DEVICE;
         if (rc != JPK_OK) {
@@ -1139,13 +1328,20 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
             return rc;
         }
     } else {
-        JPK_TRY(pre_chain(d));
+        int rc = pre_chain(d);
+        if (rc == JPK_OK) rc = jpk_gate_mark(ctx, st);
+        jpk_gate_leave(ctx);
+        JPK_TRY(rc);
         JPK_TRY(chain(d));
     }
-    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_headers, dim3(1), dim3(1024), d, b.freq, b.csize, b.rlen, b.hdr, b.hsize, b.outoff, ctx->d_mail);
+    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_headers, dim3(d.nch), dim3(256), d, b.freq, b.csize, b.rlen, b.hdr, b.hsize);
+    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_out_offsets, dim3(1), dim3(64), d, b.csize, b.rlen, b.hsize, b.outoff, ctx->d_mail, b.stamp);
     JPK_HIP(hipGetLastError());
-    uint32_t mail[4];
-    JPK_TRY(jpk_read_mail(ctx, mail, 4));
+    uint32_t mail[9];
+    JPK_TRY(jpk_read_mail(ctx, mail, 9));
+    ctx->stats.enc_chain_cycles = (int64_t)(((uint64_t)mail[5] << 32) | mail[4]);
+    ctx->stats.enc_chain_ns = (int64_t)(((uint64_t)mail[7] << 32) | mail[6]) * 10;     // s_memrealtime ticks at 100 MHz
+    ctx->stats.enc_chain_steps = ((int64_t)mail[8] * 2 + 3) / 4;
     const uint64_t total = ((uint64_t)mail[1] << 32) | mail[0];
     ctx->stats.ans_chunks = d.nch;
     ctx->stats.ans_rle_symbols = (int64_t)(((uint64_t)mail[3] << 32) | mail[2]);
@@ -1159,8 +1355,8 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     }
     if (total > (uint64_t)out_cap) return JPK_E_CAPACITY;
     JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_headers, dim3(d.nch), dim3(TB), d, b.hdr, b.hsize, b.outoff, b.fstate, d_out);
-    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_payload, dim3(jpk_grid(2 * stride, TB), d.nch), dim3(TB), stride, d, b.rlen, b.emit, b.epos, b.csize, b.hsize,
-                       b.outoff, d_out);
+    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_payload, dim3(emit_tiles_per_chunk(stride), d.nch), dim3(TB), b.xs, b.recs, stride, d, b.rlen, b.etsum,
+               emit_tiles_per_chunk(stride), b.csize, b.hsize, b.outoff, d_out);
     JPK_HIP(hipGetLastError());
     JPK_HIP(hipStreamSynchronize(st));
     *out_len = (int32_t)total;

@@ -1208,7 +1208,14 @@ int jpk_fwd_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *
     JPK_TRY(jpk_arena_ensure(ctx, plan.need));
     Arena real(ctx, false);
     sa_layout(real, (size_t)nlen, b);
-    JPK_TRY(build_sa(ctx, d_in, (uint32_t)nlen, b));
+    // heavy-phase gate: a caller that goes on to the entropy stage (jpk_dev_block_compress) already holds it and releases it
+    // there; a stand-alone forward BWT holds it for the sort only
+    const bool outer = ctx->gate_held;
+    JPK_TRY(jpk_gate_enter(ctx));
+    int rc = build_sa(ctx, d_in, (uint32_t)nlen, b);
+    if (rc == JPK_OK) rc = jpk_gate_mark(ctx, ctx->stream);
+    if (!outer) jpk_gate_leave(ctx);
+    JPK_TRY(rc);
     JPK_LAUNCH(ctx, PROF_BWT_GATHER, nlen, k_bwt_image, dim3(cap_grid((size_t)nlen, TB * 16, 4096)), dim3(TB), d_in, b.bwt, b.ISA, (uint32_t)nlen, d_out);
     hipLaunchKernelGGL(k_bwt_trailer, dim3(1), dim3(128), 0, ctx->stream, d_in, b.ISA, (uint32_t)nlen, (uint32_t)len, d_out);
     JPK_HIP(hipGetLastError());

@@ -46,6 +46,12 @@ struct jpk_ctx {
     static constexpr int ENC_GROUPS = 4;
     hipStream_t aux[ENC_GROUPS - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_pre[ENC_GROUPS] = {nullptr, nullptr, nullptr, nullptr}, ev_done[ENC_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+    // heavy-phase gate (abi.hip): events that mark the end of this context's GPU-saturating work -- [0] the suffix sort, [1..] the
+    // wide entropy kernels of each chunk group -- and whether this context currently holds the device's gate
+    static constexpr int GATE_EVENTS = 5;
+    hipEvent_t ev_gate[GATE_EVENTS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int gate_nev = 0;
+    bool gate_held = false;
     hipEvent_t ev_sa[2] = {nullptr, nullptr};      // suffix sort: "the count round r left behind has reached the host"
     bool sa_stats_pending = false;   // per-round statistics of the last suffix sort are still in the pinned mailbox
     uint32_t *h_map = nullptr;       // pinned, 4096 words
@@ -125,6 +131,17 @@ int jpk_radix_sort_pairs_u64_nocopy(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals
                                     const int *shifts, int nshifts, uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out);
 int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n, uint64_t *keysA, uint32_t *valsA, uint64_t *keysB, uint32_t *valsB,
                                 uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out);
+// Heavy-phase gate (experiment, off by default -- see gate_on() in abi.hip for the numbers): the GPU-saturating phases of the
+// blocks in flight on one device -- the suffix sort and the wide kernels of the entropy stage in front of the rANS chains --
+// run one block after the other on the GPU, in the order the blocks arrive here, while the chains (a few waves that run for
+// milliseconds) of earlier blocks run beside them.  A stream-level dependency, no host blocking on GPU
+// work: enter() makes ctx->stream wait for the previous holder's events; jpk_gate_mark() records one of this context's
+// events on a stream; leave() publishes them and releases the gate.  The gate is held while the heavy phases are being
+// ENQUEUED.
+int jpk_gate_enter(jpk_ctx *ctx);
+int jpk_gate_mark(jpk_ctx *ctx, hipStream_t stream);
+void jpk_gate_leave(jpk_ctx *ctx);
+void jpk_gate_forget(jpk_ctx *ctx);
 // moves the per-round statistics of the last suffix sort from the pinned mailbox into ctx->stats (call after a stream sync)
 void jpk_sa_stats_sync(jpk_ctx *ctx);
 
