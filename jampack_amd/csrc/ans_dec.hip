@@ -23,47 +23,92 @@ struct ChunkInfo {          // one per chunk, written by the header walk
 };
 
 // mail: [0]=status, [1]=nch, [2..3]=total out, [4..5]=total rle
-__global__ void k_dec_headers(const uint8_t *__restrict__ in, uint32_t len, uint64_t out_cap, uint32_t max_chunks, ChunkInfo *__restrict__ info,
-                              int32_t *__restrict__ freq, uint32_t *__restrict__ mail)
+// One wave.  The chunk chain is serial by format (chunk c+1 starts behind chunk c's payload, ans.cpp:254-261), but a header is
+// not: it is 259 LEB128 values (256 frequencies, olen, clen, rlen; ReadHeader ans.cpp:287-302) and every value ENDS in the one
+// byte with bit 7 set (utils.cpp:70-90).  The wave walks a header 64 bytes at a time: one ballot marks the terminators, their
+// running count numbers the values, and the lane that holds a terminator decodes that value from the up to four bytes in
+// front of it.
+__global__ __launch_bounds__(64) void k_dec_headers(const uint8_t *__restrict__ in, uint32_t len, uint64_t out_cap, uint32_t max_chunks,
+                                                   ChunkInfo *__restrict__ info, int32_t *__restrict__ freq, uint32_t *__restrict__ mail)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int l = lane_id();
+    const uint32_t C[4] = {127u, 16510u, 2113661u, 270549116u};
     uint64_t ip = 0, op = 0, rp = 0;
     uint32_t nch = 0;
     int status = 0;
-    while (ip < len) {
+    while (ip < len && status == 0) {
         if (nch >= max_chunks) { status = JPK_E_CORRUPT; break; }
-        uint32_t v = 0;
-        int64_t total = 0;
-        bool bad = false;
-        for (int s = 0; s < 256; s++) {
-            int n = leb_decode(&v, in + ip, (int64_t)len - (int64_t)ip);
-            if (n < 0) { bad = true; break; }
-            ip += n;
-            if (v > (uint32_t)ANS_CHUNK) { bad = true; break; }
-            freq[(size_t)nch * 256 + s] = (int32_t)v;
-            total += v;
-        }
+        uint32_t nval = 0;                       // values decoded so far (wave-uniform)
+        uint64_t pos = ip;                       // first byte of the current 64-byte window
         uint32_t olen = 0, clen = 0, rlen = 0;
-        int n = 0;
-        if (!bad) { n = leb_decode(&olen, in + ip, (int64_t)len - (int64_t)ip); if (n < 0) bad = true; else ip += n; }
-        if (!bad) { n = leb_decode(&clen, in + ip, (int64_t)len - (int64_t)ip); if (n < 0) bad = true; else ip += n; }
-        if (!bad) { n = leb_decode(&rlen, in + ip, (int64_t)len - (int64_t)ip); if (n < 0) bad = true; else ip += n; }
-        if (bad || olen > (uint32_t)ANS_CHUNK || rlen > (uint32_t)ANS_CHUNK || (uint64_t)clen > len - ip || clen < 16 ||
-            total != (int64_t)olen) {                                       // ans.cpp:297-298, rank.cpp:104-108
+        uint32_t fsum = 0;                       // per-lane partial sum of the frequencies
+        bool bad = false;
+        uint32_t since = 0;                      // bytes since the last terminator at the start of the window (a value has <= 5 bytes)
+        while (nval < 259u) {
+            if (pos >= len) { bad = true; break; }
+            const uint64_t p = pos + (uint64_t)l;
+            const uint32_t byte = (p < len) ? in[p] : 0u;
+            const uint64_t term = __ballot(p < len && (byte & 0x80u));
+            const uint32_t before = (uint32_t)__popcll(term & ((1ull << l) - 1ull));
+            const uint32_t vidx = nval + before;                         // index of the value that ends at my byte
+            if (((term >> l) & 1ull) && vidx < 259u) {
+                // bytes of my value: from the byte after the previous terminator to me (at most 5)
+                const uint64_t prevmask = term & ((1ull << l) - 1ull);
+                const uint32_t nlead = prevmask ? (uint32_t)l - (63u - (uint32_t)__clzll((long long)prevmask)) - 1u : (uint32_t)l + since;
+                if (nlead > 4u) bad = true;
+                else {
+                    uint32_t x = 0;
+                    for (uint32_t k = nlead; k > 0; k--) x = (x << 7) | in[p - k];
+                    x = (x << 7) | (byte & 0x7fu);
+                    if (nlead > 0) x += C[nlead - 1];
+                    if (vidx < 256u) {
+                        if (x > (uint32_t)ANS_CHUNK) bad = true;
+                        freq[(size_t)nch * 256 + vidx] = (int32_t)x;
+                        fsum += x;
+                    } else if (vidx == 256u) olen = x;
+                    else if (vidx == 257u) clen = x;
+                    else rlen = x;
+                }
+            }
+            const uint32_t nt = (uint32_t)__popcll(term);
+            if (nval + nt >= 259u) {
+                // the header ends at the terminator of value 258: position of the (259 - nval)-th terminator of this window
+                uint64_t t = term;
+                for (uint32_t k = 259u - nval - 1u; k > 0; k--) t &= t - 1ull;
+                pos += (uint64_t)__builtin_ctzll(t) + 1ull;
+                nval = 259u;
+            } else {
+                since = nt ? (uint32_t)__clzll((long long)term) : since + 64u;      // continuation bytes behind the window's last terminator
+                if (since > 4u) { bad = true; break; }            // a value has at most four of them
+                nval += nt;
+                pos += 64;
+            }
+        }
+        bad = __ballot(bad) != 0ull;
+        // the three length fields were decoded by whichever lanes held their terminators
+        olen = wave_sum(olen); clen = wave_sum(clen); rlen = wave_sum(rlen);
+        const uint64_t total = (uint64_t)wave_sum(fsum);
+        ip = pos;
+        if (bad || olen > (uint32_t)ANS_CHUNK || rlen > (uint32_t)ANS_CHUNK || ip > len || (uint64_t)clen > len - ip || clen < 16 ||
+            total != (uint64_t)olen) {                                       // ans.cpp:297-298, rank.cpp:104-108
             status = JPK_E_CORRUPT;
             break;
         }
         if (op + olen > out_cap) { status = JPK_E_CAPACITY; break; }
-        ChunkInfo ci;
-        ci.in_off = ip; ci.clen = clen; ci.olen = olen; ci.rlen = rlen; ci.pad = 0; ci.out_off = op; ci.rle_off = rp;
-        info[nch] = ci;
+        if (l == 0) {
+            ChunkInfo ci;
+            ci.in_off = ip; ci.clen = clen; ci.olen = olen; ci.rlen = rlen; ci.pad = 0; ci.out_off = op; ci.rle_off = rp;
+            info[nch] = ci;
+        }
         ip += clen; op += olen; rp += rlen;
         nch++;
     }
-    mail[0] = (uint32_t)status;
-    mail[1] = nch;
-    mail[2] = (uint32_t)op; mail[3] = (uint32_t)(op >> 32);
-    mail[4] = (uint32_t)rp; mail[5] = (uint32_t)(rp >> 32);
+    if (l == 0) {
+        mail[0] = (uint32_t)status;
+        mail[1] = nch;
+        mail[2] = (uint32_t)op; mail[3] = (uint32_t)(op >> 32);
+        mail[4] = (uint32_t)rp; mail[5] = (uint32_t)(rp >> 32);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -493,7 +538,8 @@ __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, con
     if (len == 0) return;
     const uint8_t *R = data + ci.out_off;        // rank array
     uint8_t *T = tmp + ci.out_off;               // decoded symbols (copied back by the caller)
-    __shared__ uint32_t rows[256][64];
+    __shared__ uint8_t rows[256][64];             // one byte per rank: 16 KiB, so that six chunks fit a CU (24 KiB each)
+    __shared__ uint32_t stage[64];                // landing zone of the top-up in flight (LDS-DMA writes one dword per lane)
     __shared__ RankMeta meta[256];
     __shared__ RankSpan span[256];
     __shared__ uint32_t sf[256];
@@ -531,12 +577,13 @@ __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, con
     for (int k = 0; k < 4; k++)
         for (int j = 0; j < 64; j++) {
             const uint32_t g = (uint32_t)__builtin_amdgcn_readlane((int)g4[k], j), ge = (uint32_t)__builtin_amdgcn_readlane((int)e4[k], j);
-            rows[j + 64 * k][l] = (g + l < ge) ? (uint32_t)R[g + l] : 0xFFu;
+            rows[j + 64 * k][l] = (g + l < ge) ? R[g + l] : (uint8_t)0xFF;
         }
     __syncthreads();
     uint32_t v = lst[l];
     uint32_t sym = rfl(v) & 0xffu;
     uint32_t psym = 256;                                         // row with a top-up in flight (256 = none); it is blocked (fast = 0)
+    uint32_t poff = 0, pcnt = 0;                                 // ... its entries land at rows[psym][poff .. poff + pcnt)
     uint32_t i = 0;
     // The row and metadata of the NEXT symbol are read one iteration ahead: a run that ends in a non-zero rank (or in
     // the end of its bucket) always brings the second list entry to the front, whatever the rank is, so the only
@@ -568,6 +615,7 @@ __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, con
         // ---- general path ----
         if (psym < 256u) {                                       // land the top-up in flight and unblock its row
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((uint32_t)l < pcnt) rows[psym][poff + l] = (uint8_t)stage[l];
             const RankMeta pm = meta[psym];
             const RankSpan ps = span[psym];
             if (l == 0) { meta[psym].nv = 64u; meta[psym].fast = rank_fast_limit(64u, pm.left, ps.gpos >= ps.gend); }
@@ -611,14 +659,17 @@ __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, con
                 sym = rfl(v) & 0xffu;
             }
         }
-        rows[cur][l] = shifted;
+        rows[cur][l] = (uint8_t)shifted;
         RankMeta w;
         w.used = 0; w.nv = nv2; w.left = left2;
         if (!all_loaded && nv2 < RANK_LOW + 8u) {                            // top the row up behind the shifted entries
             const uint32_t want = 64u - nv2;
             __builtin_amdgcn_s_waitcnt(0xc07f);                              // lgkmcnt(0): the shifted row is in LDS before the load may land
-            if ((uint32_t)l < want && gpos + l < gend)
-                __builtin_amdgcn_global_load_lds((jpk_gptr)(R + gpos + l), (jpk_lptr)(&rows[cur][nv2]), 1, 0, 0);
+            const uint32_t avail = gend - gpos;                              // gpos < gend here
+            pcnt = want < avail ? want : avail;
+            poff = nv2;
+            if ((uint32_t)l < pcnt)
+                __builtin_amdgcn_global_load_lds((jpk_gptr)(R + gpos + l), (jpk_lptr)(&stage[0]), 1, 0, 0);
             psym = cur;
             w.fast = 0;                                                      // blocked until the top-up has landed
             if (l == 0) span[cur].gpos = gpos + want;
