@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # blocks in flight live on separate HIP streams; the ROCm default of 4 hardware queues serialises them beyond two
 # (tools/dec_scaling.py).  Must be set before the HIP runtime initialises (torch initialises it before our library loads).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
 

@@ -173,6 +173,17 @@ JPK_API int jpk_dev_checksum(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, 
 JPK_API int jpk_dev_jam_block_write(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, int32_t block_size, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
 JPK_API int jpk_dev_jam_block_read(jpk_ctx *ctx, const uint8_t *d_in, int32_t in_len, uint8_t *d_out, int32_t out_cap, int32_t *out_len, int32_t *consumed);
 
+/* ---- batches of independent blocks (device buffers) ------------------------------------------------------------ */
+/* Jampack::Decompress's multi-block mode (jampack.cpp:286-317: Threads blocks read, Decomp() in an OpenMP loop, written in
+ * order) for blocks that already sit in HBM: Ans::Decode (+ InverseBwt) of nblocks independent blocks in ONE pass -- every
+ * serial entropy kernel runs a single grid over the 1 MiB chunks of all blocks, which is what fills the GPU (one block is 65
+ * chains on 1024 SIMDs).  Arrays of nblocks device pointers / sizes (the arrays themselves are host memory).  status may be
+ * NULL; otherwise status[b] receives block b's jpk_status and a corrupt block does not stop the others. */
+JPK_API int jpk_dev_blocks_ans_decode(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out,
+                              const int32_t *out_cap, int32_t *out_len, int32_t *status);
+JPK_API int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out,
+                              const int32_t *out_cap, int32_t *out_len, int32_t *status);
+
 /* ---- kernel-level probes used by tests/ and bench.py (device buffers) ------------------------------------ */
 /* Comparator for BASELINE config 3 ("120-way parallel LF-map"): the reference's own GPU kernel shape -- 120 threads, one per
  * stored index, p = Map[p-1] (CUDAInverse<<<40,3>>>, bwt.cpp:8-19, 176-183, 226-229) -- on the same Map.  Same bytes as

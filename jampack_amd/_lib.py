@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # see abi.hip: more than two blocks in flight need more HW queues
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # see abi.hip: more than two blocks in flight need more HW queues
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libjampack_amd.so")
@@ -82,6 +82,8 @@ _SIGS = {
     "jpk_dev_rank_decode": (C.c_int, [_vp, _vp, _vp, C.c_int32]),
     "jpk_dev_block_compress": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_dev_block_decompress": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
+    "jpk_dev_blocks_ans_decode": (C.c_int, [_vp, C.c_int32, C.POINTER(_vp), _i32p, C.POINTER(_vp), _i32p, _i32p, _i32p]),
+    "jpk_dev_blocks_decompress": (C.c_int, [_vp, C.c_int32, C.POINTER(_vp), _i32p, C.POINTER(_vp), _i32p, _i32p, _i32p]),
     "jpk_dev_checksum": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(C.c_uint32)]),
     "jpk_dev_jam_block_write": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_dev_jam_block_read": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p, _i32p]),

@@ -337,6 +337,21 @@ class Context:
     def block_decompress(self, d_in, in_len, d_out, out_cap) -> int:
         return self._io(lib().jpk_dev_block_decompress, "jpk_dev_block_decompress", d_in, in_len, d_out, out_cap)
 
+    def _batch(self, fn, what, d_ins, in_lens, d_outs, out_caps):
+        """(out_len list, status list) of a jpk_dev_blocks_* call: one pass over all blocks"""
+        n = len(d_ins)
+        P, I = C.c_void_p * n, C.c_int32 * n
+        ins, outs = P(*[_dptr(x) for x in d_ins]), P(*[_dptr(x) for x in d_outs])
+        il, oc, ol, st = I(*in_lens), I(*out_caps), I(), I()
+        _chk(fn(self._h, n, ins, il, outs, oc, ol, st), what)
+        return list(ol), list(st)
+
+    def blocks_ans_decode(self, d_ins, in_lens, d_outs, out_caps):
+        return self._batch(lib().jpk_dev_blocks_ans_decode, "jpk_dev_blocks_ans_decode", d_ins, in_lens, d_outs, out_caps)
+
+    def blocks_decompress(self, d_ins, in_lens, d_outs, out_caps):
+        return self._batch(lib().jpk_dev_blocks_decompress, "jpk_dev_blocks_decompress", d_ins, in_lens, d_outs, out_caps)
+
     def checksum(self, d_in, in_len) -> int:
         crc = C.c_uint32(0)
         _chk(lib().jpk_dev_checksum(self._h, _dptr(d_in), in_len, C.byref(crc)), "jpk_dev_checksum")

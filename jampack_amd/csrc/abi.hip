@@ -7,10 +7,12 @@
 #include "common.hpp"
 
 // Independent blocks run on separate contexts (= HIP streams).  ROCm multiplexes streams onto GPU_MAX_HW_QUEUES
-// hardware queues (default 4, of which two carried kernels concurrently in our measurements): with the default, more
-// than two blocks in flight serialise.  Ask for 16 queues unless the user has chosen a value; this runs when the library
-// is loaded, i.e. before the first HIP call of a program that links it.
-__attribute__((constructor)) static void jpk_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// hardware queues, round robin in creation order (default 4: tools/conctest.hip shows exactly four kernels at a time whatever
+// the number of streams; with 32 queues sixteen single-wave kernels ran fully concurrently).  Two streams that share a queue
+// serialise -- with four streams per context (main + three encoder group streams) and 16 queues the main streams of contexts
+// 0 and 4 collided, which capped round 1's blocks in flight at eight.  Ask for 32 queues unless the user has chosen a
+// value; this runs when the library is loaded, i.e. before the first HIP call of a program that links it.
+__attribute__((constructor)) static void jpk_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "32", 0); }
 
 // ---- arena / staging ---------------------------------------------------------------------------------------
 int jpk_arena_ensure(jpk_ctx *ctx, size_t bytes)
@@ -213,8 +215,9 @@ extern "C" int jpk_ctx_create(jpk_ctx **out, int device, void *hip_stream)
     for (int k = 0; k < jpk_ctx::GATE_EVENTS; k++)
         if (hipEventCreateWithFlags(&c->ev_gate[k], hipEventDisableTiming) != hipSuccess) { jpk_ctx_destroy(c); return JPK_E_ALLOC; }
     for (int g = 0; g < jpk_ctx::ENC_GROUPS; g++) {
-        if ((g + 1 < jpk_ctx::ENC_GROUPS && hipStreamCreateWithFlags(&c->aux[g], hipStreamNonBlocking) != hipSuccess) ||
-            hipEventCreateWithFlags(&c->ev_pre[g], hipEventDisableTiming) != hipSuccess ||
+        // (the encoder's group streams c->aux[] are created on first use: a context that only decodes owns one stream, and
+        // streams are dealt round robin onto the hardware queues when they are created)
+        if (hipEventCreateWithFlags(&c->ev_pre[g], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_done[g], hipEventDisableTiming) != hipSuccess) {
             jpk_ctx_destroy(c);
             return JPK_E_ALLOC;
@@ -389,6 +392,71 @@ extern "C" int jpk_dev_block_decompress(jpk_ctx *ctx, const uint8_t *d_in, int32
     JPK_TRY(jpk_inv_bwt_device(ctx, ctx->stage_out, mid, d_out));
     JPK_HIP(hipStreamSynchronize(ctx->stream));
     *out_len = mid - JPK_TRAILER_BYTES;
+    return JPK_OK;
+}
+
+// ---- batches of independent blocks -------------------------------------------------------------------------------------------
+// The serial entropy-decode kernels run one wave per 1 MiB chunk; a 64 MiB block keeps 65 of the chip's 1024 SIMDs busy.  A
+// batch runs ONE grid per stage over the chunks of all its blocks, so sixteen blocks fill the chip whatever the hardware
+// queues do with concurrent kernels (tools/conctest.hip).
+extern "C" int jpk_dev_blocks_ans_decode(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out,
+                                         const int32_t *out_cap, int32_t *out_len, int32_t *status)
+{
+    JPK_ENTER(ctx);
+    if (nblocks < 0 || (nblocks > 0 && (!d_in || !in_len || !d_out || !out_cap || !out_len))) return JPK_E_ARG;
+    if (nblocks == 0) return JPK_OK;
+    std::vector<int32_t> st_local((size_t)nblocks);
+    int32_t *stp = status ? status : st_local.data();
+    for (int b = 0; b < nblocks; b++)
+        if (in_len[b] < 0 || out_cap[b] < 0 || !d_out[b] || (in_len[b] > 0 && !d_in[b])) return JPK_E_ARG;
+    JPK_TRY(jpk_ans_decode_batch(ctx, nblocks, d_in, in_len, d_out, out_cap, out_len, stp, 0));
+    if (!status)
+        for (int b = 0; b < nblocks; b++) if (stp[b] != JPK_OK) return stp[b];
+    return JPK_OK;
+}
+
+extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out,
+                                         const int32_t *out_cap, int32_t *out_len, int32_t *status)
+{
+    JPK_ENTER(ctx);
+    if (nblocks < 0 || (nblocks > 0 && (!d_in || !in_len || !d_out || !out_cap || !out_len))) return JPK_E_ARG;
+    if (nblocks == 0) return JPK_OK;
+    std::vector<int32_t> st_local((size_t)nblocks), mid_cap((size_t)nblocks), mid_len((size_t)nblocks);
+    int32_t *stp = status ? status : st_local.data();
+    size_t mid_total = 0, bound = 0;
+    uint32_t nmax = 1;
+    for (int b = 0; b < nblocks; b++) {
+        if (in_len[b] < 0 || out_cap[b] < 0 || !d_out[b] || (in_len[b] > 0 && !d_in[b])) return JPK_E_ARG;
+        const int64_t mc = (int64_t)out_cap[b] + JPK_TRAILER_BYTES;
+        if (mc > 0x7fffffffLL) return JPK_E_ARG;
+        mid_cap[b] = (int32_t)mc;
+        mid_total += jpk_align((size_t)mc + 64);
+        if ((uint32_t)out_cap[b] > nmax) nmax = (uint32_t)out_cap[b];
+        // what the batch decoder can need for this block at most: rank array + 2-byte RLE0 symbols + chunk tables
+        bound += (size_t)mc * 3 + ((size_t)in_len[b] / 275 + 2) * 1100 + 4096;
+    }
+    // arena: [inverse-BWT scratch of the largest block][BWT images of all blocks][the batch decoder's buffers]; sized once so that
+    // it cannot move while the images sit in it
+    const size_t inv_bytes = jpk_align(jpk_inv_bwt_arena_bytes(nmax), 4096);
+    JPK_TRY(jpk_arena_ensure(ctx, inv_bytes + mid_total + bound + (1u << 20)));
+    std::vector<uint8_t *> mid((size_t)nblocks);
+    {
+        size_t off = inv_bytes;
+        for (int b = 0; b < nblocks; b++) { mid[b] = ctx->arena + off; off += jpk_align((size_t)mid_cap[b] + 64); }
+    }
+    JPK_TRY(jpk_ans_decode_batch(ctx, nblocks, d_in, in_len, mid.data(), mid_cap.data(), mid_len.data(), stp, inv_bytes + mid_total));
+    for (int b = 0; b < nblocks; b++) {
+        out_len[b] = 0;
+        if (stp[b] != JPK_OK) continue;
+        if (mid_len[b] < JPK_TRAILER_BYTES) { stp[b] = JPK_E_CORRUPT; continue; }
+        if (mid_len[b] - JPK_TRAILER_BYTES > out_cap[b]) { stp[b] = JPK_E_CAPACITY; continue; }
+        const int rc = jpk_inv_bwt_device(ctx, mid[b], mid_len[b], d_out[b]);
+        if (rc != JPK_OK) { stp[b] = rc; continue; }
+        out_len[b] = mid_len[b] - JPK_TRAILER_BYTES;
+    }
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    if (!status)
+        for (int b = 0; b < nblocks; b++) if (stp[b] != JPK_OK) return stp[b];
     return JPK_OK;
 }
 

@@ -6,6 +6,8 @@
 //                                                                 byte-vector register (4 positions per lane)
 // The entropy decoder is sequential inside a chunk by construction of the format (shared byte pointer of the
 // four rANS states, adaptive models, bucket hopping of the rank decoder); parallelism comes from the chunks.
+#include <vector>
+
 #include "ans_common.hpp"
 #include "common.hpp"
 
@@ -15,11 +17,24 @@ namespace {
 
 
 struct ChunkInfo {          // one per chunk, written by the header walk
-    uint64_t in_off;        // payload offset in the input
+    uint64_t in_off;        // payload offset in the block's input
     uint32_t clen, olen, rlen;
-    uint32_t pad;
-    uint64_t out_off;       // offset in the decoded output
-    uint64_t rle_off;       // offset in the packed rle buffer
+    uint32_t blk;           // block of the batch this chunk belongs to
+    uint64_t out_off;       // offset in the block's decoded output
+    uint64_t rle_off;       // offset in the block's packed rle buffer
+};
+
+// one block of a batch (jpk_dev_blocks_*): every serial kernel runs ONE grid over the chunks of all blocks, so the number of
+// chains in flight does not depend on how many kernels the hardware queues run side by side
+struct DecBlock {
+    const uint8_t *in;      // Ans stream
+    int64_t in_len;
+    uint64_t out_cap;
+    uint8_t *ranks;         // RLE0 decode writes the rank array here, the rank decoder reads it
+    uint8_t *out;           // decoded bytes (the rank decoder's output)
+    uint16_t *rle;          // packed RLE0 symbols
+    uint32_t cbase;         // first global chunk index of the block
+    uint32_t max_chunks;
 };
 
 // mail: [0]=status, [1]=nch, [2..3]=total out, [4..5]=total rle
@@ -28,9 +43,19 @@ struct ChunkInfo {          // one per chunk, written by the header walk
 // byte with bit 7 set (utils.cpp:70-90).  The wave walks a header 64 bytes at a time: one ballot marks the terminators, their
 // running count numbers the values, and the lane that holds a terminator decodes that value from the up to four bytes in
 // front of it.
-__global__ __launch_bounds__(64) void k_dec_headers(const uint8_t *__restrict__ in, uint32_t len, uint64_t out_cap, uint32_t max_chunks,
-                                                   ChunkInfo *__restrict__ info, int32_t *__restrict__ freq, uint32_t *__restrict__ mail)
+// One wave per block.  WRITE = false: count the chunks and total the sizes only (mail); WRITE = true: also fill info / freq at
+// the block's global chunk base.  mail of block b: mail[8 b + ...].
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_dec_headers(const DecBlock *__restrict__ blocks, ChunkInfo *__restrict__ info_all, int32_t *__restrict__ freq_all,
+                                                   uint32_t *__restrict__ mail_all)
 {
+    const DecBlock B = blocks[blockIdx.x];
+    const uint8_t *__restrict__ in = B.in;
+    const uint32_t len = (uint32_t)B.in_len, max_chunks = B.max_chunks;
+    const uint64_t out_cap = B.out_cap;
+    ChunkInfo *info = WRITE ? info_all + B.cbase : nullptr;
+    int32_t *freq = WRITE ? freq_all + (size_t)B.cbase * 256 : nullptr;
+    uint32_t *mail = mail_all + 8 * blockIdx.x;
     const int l = lane_id();
     const uint32_t C[4] = {127u, 16510u, 2113661u, 270549116u};
     uint64_t ip = 0, op = 0, rp = 0;
@@ -63,7 +88,7 @@ __global__ __launch_bounds__(64) void k_dec_headers(const uint8_t *__restrict__ 
                     if (nlead > 0) x += C[nlead - 1];
                     if (vidx < 256u) {
                         if (x > (uint32_t)ANS_CHUNK) bad = true;
-                        freq[(size_t)nch * 256 + vidx] = (int32_t)x;
+                        if (WRITE) freq[(size_t)nch * 256 + vidx] = (int32_t)x;
                         fsum += x;
                     } else if (vidx == 256u) olen = x;
                     else if (vidx == 257u) clen = x;
@@ -95,9 +120,9 @@ __global__ __launch_bounds__(64) void k_dec_headers(const uint8_t *__restrict__ 
             break;
         }
         if (op + olen > out_cap) { status = JPK_E_CAPACITY; break; }
-        if (l == 0) {
+        if (WRITE && l == 0) {
             ChunkInfo ci;
-            ci.in_off = ip; ci.clen = clen; ci.olen = olen; ci.rlen = rlen; ci.pad = 0; ci.out_off = op; ci.rle_off = rp;
+            ci.in_off = ip; ci.clen = clen; ci.olen = olen; ci.rlen = rlen; ci.blk = blockIdx.x; ci.out_off = op; ci.rle_off = rp;
             info[nch] = ci;
         }
         ip += clen; op += olen; rp += rlen;
@@ -344,13 +369,17 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
         }                                                                                                 \
     }
 
-__global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in, int64_t in_len, const ChunkInfo *__restrict__ info,
-                                                uint16_t *__restrict__ rle, uint32_t *__restrict__ status)
+__global__ __launch_bounds__(64) void k_dec_rans(const DecBlock *__restrict__ blocks, const ChunkInfo *__restrict__ info, uint32_t *__restrict__ status_all)
 {
     __builtin_amdgcn_s_setprio(3);         // serial chain: win the issue arbitration on a shared SIMD
     const uint32_t c = blockIdx.x;
     const int l = lane_id();
     const ChunkInfo ci = info[c];
+    const DecBlock B = blocks[ci.blk];
+    const uint8_t *__restrict__ in = B.in;
+    const int64_t in_len = B.in_len;
+    uint16_t *__restrict__ rle = B.rle;
+    uint32_t *status = status_all + ci.blk;
     const uint8_t *p = in + ci.in_off;
     const uint32_t clen = ci.clen, rlen = ci.rlen;
     uint16_t *out = rle + ci.rle_off;
@@ -423,11 +452,14 @@ __global__ __launch_bounds__(64) void k_dec_rans(const uint8_t *__restrict__ in,
 // RLE0 decode: one workgroup per chunk.  Output is pre-zeroed, so only symbols > 1 are written; a digit group
 // contributes value-1 zeros at the position of its last digit (rle.cpp:52-74).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_dec_rle(const uint16_t *__restrict__ rle, const ChunkInfo *__restrict__ info, uint8_t *__restrict__ out,
-                                                 uint32_t *__restrict__ status)
+__global__ __launch_bounds__(1024) void k_dec_rle(const DecBlock *__restrict__ blocks, const ChunkInfo *__restrict__ info, uint32_t *__restrict__ status_all)
 {
     const uint32_t c = blockIdx.x;
     const ChunkInfo ci = info[c];
+    const DecBlock B = blocks[ci.blk];
+    const uint16_t *__restrict__ rle = B.rle;
+    uint8_t *__restrict__ out = B.ranks;
+    uint32_t *status = status_all + ci.blk;
     const uint16_t *src = rle + ci.rle_off;
     uint8_t *dst = out + ci.out_off;
     const uint32_t rlen = ci.rlen, olen = ci.olen;
@@ -527,8 +559,8 @@ __device__ __forceinline__ uint32_t rank_fast_limit(uint32_t nv, uint32_t left, 
     return a < slack ? a : slack;
 }
 
-__global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, const ChunkInfo *__restrict__ info, const int32_t *__restrict__ freq,
-                                                uint8_t *__restrict__ tmp, uint32_t *__restrict__ status)
+__global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ blocks, const ChunkInfo *__restrict__ info, const int32_t *__restrict__ freq,
+                                                uint32_t *__restrict__ status_all)
 {
     __builtin_amdgcn_s_setprio(3);         // serial chain: win the issue arbitration on a shared SIMD
     const uint32_t c = blockIdx.x;
@@ -536,8 +568,9 @@ __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, con
     const ChunkInfo ci = info[c];
     const uint32_t len = ci.olen;
     if (len == 0) return;
-    const uint8_t *R = data + ci.out_off;        // rank array
-    uint8_t *T = tmp + ci.out_off;               // decoded symbols (copied back by the caller)
+    const DecBlock B = blocks[ci.blk];
+    const uint8_t *R = B.ranks + ci.out_off;     // rank array
+    uint8_t *T = B.out + ci.out_off;             // decoded symbols
     __shared__ uint8_t rows[256][64];             // one byte per rank: 16 KiB, so that six chunks fit a CU (24 KiB each)
     __shared__ uint32_t stage[64];                // landing zone of the top-up in flight (LDS-DMA writes one dword per lane)
     __shared__ RankMeta meta[256];
@@ -685,65 +718,104 @@ __global__ __launch_bounds__(64) void k_dec_rank(uint8_t *__restrict__ data, con
 
 }  // namespace
 
+// Ans::Decode of `nblk` independent blocks in one pass: header walk (count), buffers, header walk (fill), then ONE grid per
+// serial kernel over the chunks of all blocks.  status[b] = JPK_OK / JPK_E_CORRUPT / JPK_E_CAPACITY per block; a corrupt block
+// does not stop the others.  arena_skip: bytes at the start of the arena the caller keeps for itself.
+int jpk_ans_decode_batch(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out, const int32_t *out_cap,
+                         int32_t *out_len, int32_t *status, size_t arena_skip)
+{
+    hipStream_t st = ctx->stream;
+    std::vector<DecBlock> hb((size_t)nblk);
+    for (int b = 0; b < nblk; b++) {
+        out_len[b] = 0;
+        status[b] = JPK_OK;
+        memset(&hb[b], 0, sizeof(DecBlock));
+        hb[b].in = d_in[b];
+        hb[b].in_len = in_len[b];
+        hb[b].out_cap = (uint64_t)out_cap[b];
+        hb[b].max_chunks = (uint32_t)in_len[b] / 275u + 2u;      // a chunk is >= 259 header bytes + 16 state bytes
+    }
+    // ---- pass 1: count the chunks, total the sizes ----
+    const size_t tab_bytes = jpk_align((size_t)nblk * sizeof(DecBlock) + 64), mail_bytes = jpk_align((size_t)nblk * 8 * 4 + 64);
+    JPK_TRY(jpk_arena_ensure(ctx, arena_skip + tab_bytes + mail_bytes + 4096));
+    DecBlock *d_tab = reinterpret_cast<DecBlock *>(ctx->arena + arena_skip);
+    uint32_t *d_mail = reinterpret_cast<uint32_t *>(ctx->arena + arena_skip + tab_bytes);
+    JPK_HIP(hipMemcpyAsync(d_tab, hb.data(), (size_t)nblk * sizeof(DecBlock), hipMemcpyHostToDevice, st));
+    JPK_LAUNCH(ctx, PROF_DEC_HEADERS, 0, (k_dec_headers<false>), dim3(nblk), dim3(64), d_tab, (ChunkInfo *)nullptr, (int32_t *)nullptr, d_mail);
+    JPK_HIP(hipGetLastError());
+    std::vector<uint32_t> mail((size_t)nblk * 8);
+    JPK_HIP(hipMemcpyAsync(mail.data(), d_mail, mail.size() * 4, hipMemcpyDeviceToHost, st));
+    JPK_HIP(hipStreamSynchronize(st));
+    if (ctx->prof_on) jpk_prof_resolve(ctx);
+    uint64_t nch_total = 0, rle_total = 0, out_total = 0;
+    std::vector<uint64_t> tot_out((size_t)nblk), tot_rle((size_t)nblk);
+    std::vector<uint32_t> nchb((size_t)nblk);
+    for (int b = 0; b < nblk; b++) {
+        const uint32_t *m = &mail[(size_t)b * 8];
+        if ((int32_t)m[0] != 0) { status[b] = (int32_t)m[0]; hb[b].in_len = 0; nchb[b] = 0; tot_out[b] = tot_rle[b] = 0; hb[b].cbase = (uint32_t)nch_total; continue; }
+        nchb[b] = m[1];
+        tot_out[b] = ((uint64_t)m[3] << 32) | m[2];
+        tot_rle[b] = ((uint64_t)m[5] << 32) | m[4];
+        hb[b].cbase = (uint32_t)nch_total;
+        hb[b].max_chunks = nchb[b] + 1u;
+        nch_total += nchb[b];
+        rle_total += tot_rle[b];
+        out_total += tot_out[b];
+    }
+    ctx->stats.ans_chunks = (int64_t)nch_total;
+    ctx->stats.ans_rle_symbols = (int64_t)rle_total;
+    if (nch_total == 0) return JPK_OK;
+
+    // ---- buffers: block table, mail, status, chunk table, frequencies; per block the packed RLE0 symbols and the rank array ----
+    size_t off = arena_skip + tab_bytes + mail_bytes;
+    auto take = [&](size_t bytes) { size_t o = off; off += jpk_align(bytes + 64); return o; };
+    const size_t o_status = take((size_t)nblk * 4), o_info = take((size_t)nch_total * sizeof(ChunkInfo)), o_freq = take((size_t)nch_total * 256 * 4);
+    std::vector<size_t> o_rle((size_t)nblk), o_ranks((size_t)nblk);
+    for (int b = 0; b < nblk; b++) { o_rle[b] = take(tot_rle[b] * 2); o_ranks[b] = take(tot_out[b]); }
+    JPK_TRY(jpk_arena_ensure(ctx, off + 4096));            // may move the arena: every pointer is formed below
+    d_tab = reinterpret_cast<DecBlock *>(ctx->arena + arena_skip);
+    d_mail = reinterpret_cast<uint32_t *>(ctx->arena + arena_skip + tab_bytes);
+    uint32_t *d_status = reinterpret_cast<uint32_t *>(ctx->arena + o_status);
+    ChunkInfo *info = reinterpret_cast<ChunkInfo *>(ctx->arena + o_info);
+    int32_t *freq = reinterpret_cast<int32_t *>(ctx->arena + o_freq);
+    for (int b = 0; b < nblk; b++) {
+        hb[b].rle = reinterpret_cast<uint16_t *>(ctx->arena + o_rle[b]);
+        hb[b].ranks = ctx->arena + o_ranks[b];
+        hb[b].out = d_out[b];
+    }
+    JPK_HIP(hipMemcpyAsync(d_tab, hb.data(), (size_t)nblk * sizeof(DecBlock), hipMemcpyHostToDevice, st));
+    JPK_HIP(hipMemsetAsync(d_status, 0, (size_t)nblk * 4, st));
+    // the rank arrays start as zeros: RLE0 decode writes only the non-zero ranks (k_dec_rle); they are contiguous in the arena
+    JPK_HIP(hipMemsetAsync(ctx->arena + o_ranks[0], 0, off - o_ranks[0], st));
+    // ---- pass 2: fill the chunk table, then one grid per stage over all chunks ----
+    JPK_LAUNCH(ctx, PROF_DEC_HEADERS, 0, (k_dec_headers<true>), dim3(nblk), dim3(64), d_tab, info, freq, d_mail);
+    // The two serial kernels are one wave per chunk.  A 40 KB LDS reservation keeps them to four workgroups per CU, one chain
+    // per SIMD, while fewer than 1024 chains are in flight.
+    const size_t lds_cap = (size_t)(getenv("JPK_DEC_LDS") ? atoi(getenv("JPK_DEC_LDS")) : 40960);
+    const unsigned g = (unsigned)nch_total;
+    JPK_LAUNCH_LDS(ctx, PROF_DEC_RANS, 2 * rle_total, lds_cap, k_dec_rans, dim3(g), dim3(64), d_tab, info, d_status);
+    JPK_LAUNCH(ctx, PROF_DEC_RLE, rle_total, k_dec_rle, dim3(g), dim3(1024), d_tab, info, d_status);
+    JPK_LAUNCH_LDS(ctx, PROF_DEC_RANK, out_total, (lds_cap > 24576 ? lds_cap - 24576 : 0), k_dec_rank, dim3(g), dim3(64), d_tab, info, freq, d_status);
+    JPK_HIP(hipGetLastError());
+    std::vector<uint32_t> hs((size_t)nblk);
+    JPK_HIP(hipMemcpyAsync(hs.data(), d_status, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
+    JPK_HIP(hipStreamSynchronize(st));
+    if (ctx->prof_on) jpk_prof_resolve(ctx);
+    for (int b = 0; b < nblk; b++) {
+        if (status[b] != JPK_OK) continue;
+        if (hs[b]) { status[b] = JPK_E_CORRUPT; continue; }
+        out_len[b] = (int32_t)tot_out[b];
+    }
+    return JPK_OK;
+}
+
 int jpk_ans_decode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
 {
     *out_len = 0;
     if (len == 0) return JPK_OK;
-    hipStream_t st = ctx->stream;
-    const uint32_t max_chunks = (uint32_t)len / 275u + 2u;   // a chunk is >= 259 header bytes + 16 state bytes
-    // pass 1: headers
-    ChunkInfo *info;
-    int32_t *freq;
-    {
-        Arena plan(ctx, true);
-        plan.get<ChunkInfo>(max_chunks);
-        plan.get<int32_t>((size_t)max_chunks * 256);
-        JPK_TRY(jpk_arena_ensure(ctx, plan.need));
-    }
-    size_t head_bytes;
-    {
-        Arena real(ctx, false);
-        info = real.get<ChunkInfo>(max_chunks);
-        freq = real.get<int32_t>((size_t)max_chunks * 256);
-        head_bytes = ctx->arena_off;
-    }
-    JPK_LAUNCH(ctx, PROF_DEC_HEADERS, 0, k_dec_headers, dim3(1), dim3(64), d_in, (uint32_t)len, (uint64_t)out_cap, max_chunks, info, freq, ctx->d_mail);
-    JPK_HIP(hipGetLastError());
-    uint32_t mail[6];
-    JPK_TRY(jpk_read_mail(ctx, mail, 6));
-    if ((int32_t)mail[0] != 0) return (int32_t)mail[0];
-    const uint32_t nch = mail[1];
-    const uint64_t total_out = ((uint64_t)mail[3] << 32) | mail[2];
-    const uint64_t total_rle = ((uint64_t)mail[5] << 32) | mail[4];
-    ctx->stats.ans_chunks = nch;
-    ctx->stats.ans_rle_symbols = (int64_t)total_rle;
-    if (nch == 0) return JPK_OK;
-
-    // pass 2 buffers: the arena may move when it grows, so the header tables are re-created if it does
-    const size_t need = head_bytes + jpk_align(total_rle * 2 + 64) + jpk_align(total_out + 64) + 4096;
-    if (need > ctx->arena_cap) {
-        JPK_TRY(jpk_arena_ensure(ctx, need));
-        Arena real(ctx, false);
-        info = real.get<ChunkInfo>(max_chunks);
-        freq = real.get<int32_t>((size_t)max_chunks * 256);
-        JPK_LAUNCH(ctx, PROF_DEC_HEADERS, 0, k_dec_headers, dim3(1), dim3(64), d_in, (uint32_t)len, (uint64_t)out_cap, max_chunks, info, freq, ctx->d_mail);
-    }
-    uint16_t *rle = (uint16_t *)(ctx->arena + head_bytes);
-    uint8_t *tmp = ctx->arena + head_bytes + jpk_align(total_rle * 2 + 64);
-    uint32_t *status = ctx->d_mail + 8;
-    JPK_HIP(hipMemsetAsync(status, 0, 4, st));
-    JPK_HIP(hipMemsetAsync(d_out, 0, total_out, st));
-    JPK_LAUNCH(ctx, PROF_DEC_RANS, 2 * total_rle, k_dec_rans, dim3(nch), dim3(64), d_in, (int64_t)len, info, rle, status);
-    JPK_LAUNCH(ctx, PROF_DEC_RLE, total_rle, k_dec_rle, dim3(nch), dim3(1024), rle, info, d_out, status);
-    JPK_LAUNCH(ctx, PROF_DEC_RANK, total_out, k_dec_rank, dim3(nch), dim3(64), d_out, info, freq, tmp, status);
-    JPK_HIP(hipGetLastError());
-    JPK_HIP(hipMemcpyAsync(d_out, tmp, total_out, hipMemcpyDeviceToDevice, st));
-    JPK_HIP(hipMemcpyAsync(ctx->d_mail, status, 4, hipMemcpyDeviceToDevice, st));
-    uint32_t stw = 0;
-    JPK_TRY(jpk_read_mail(ctx, &stw, 1));
-    if (stw) return JPK_E_CORRUPT;
-    *out_len = (int32_t)total_out;
-    return JPK_OK;
+    int32_t status = JPK_OK;
+    JPK_TRY(jpk_ans_decode_batch(ctx, 1, &d_in, &len, &d_out, &out_cap, out_len, &status, 0));
+    return status;
 }
 
 // Postcoder::Decode (rank.cpp:96-151) for one buffer (len <= 2^31), in place
@@ -753,11 +825,13 @@ int jpk_rank_decode_device(jpk_ctx *ctx, uint8_t *d_r, const int32_t *d_freq, in
     hipStream_t st = ctx->stream;
     Arena plan(ctx, true);
     plan.get<ChunkInfo>(1);
+    plan.get<DecBlock>(1);
     plan.get<uint8_t>((size_t)len + 64);
     plan.get<int32_t>(256);
     JPK_TRY(jpk_arena_ensure(ctx, plan.need));
     Arena real(ctx, false);
     ChunkInfo *info = real.get<ChunkInfo>(1);
+    DecBlock *tab = real.get<DecBlock>(1);
     uint8_t *tmp = real.get<uint8_t>((size_t)len + 64);
     int32_t *hf = real.get<int32_t>(256);
     // validate sum(freq) == len on the host (rank.cpp:104-108)
@@ -771,10 +845,15 @@ int jpk_rank_decode_device(jpk_ctx *ctx, uint8_t *d_r, const int32_t *d_freq, in
     ChunkInfo ci;
     memset(&ci, 0, sizeof ci);
     ci.olen = (uint32_t)len;
+    DecBlock hb;
+    memset(&hb, 0, sizeof hb);
+    hb.ranks = d_r;
+    hb.out = tmp;
     JPK_HIP(hipMemcpyAsync(info, &ci, sizeof ci, hipMemcpyHostToDevice, st));
+    JPK_HIP(hipMemcpyAsync(tab, &hb, sizeof hb, hipMemcpyHostToDevice, st));
     JPK_HIP(hipStreamSynchronize(st));
     uint32_t *status = ctx->d_mail + 8;
-    JPK_LAUNCH(ctx, PROF_DEC_RANK, 0, k_dec_rank, dim3(1), dim3(64), d_r, info, hf, tmp, status);
+    JPK_LAUNCH(ctx, PROF_DEC_RANK, 0, k_dec_rank, dim3(1), dim3(64), tab, info, hf, status);
     JPK_HIP(hipGetLastError());
     JPK_HIP(hipMemcpyAsync(d_r, tmp, (size_t)len, hipMemcpyDeviceToDevice, st));
     JPK_HIP(hipStreamSynchronize(st));

@@ -1281,6 +1281,8 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     int ngroups = (int)(d.nch / 8u);
     if (ngroups > jpk_ctx::ENC_GROUPS) ngroups = jpk_ctx::ENC_GROUPS;
     if (const char *e = getenv("JPK_ENC_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= jpk_ctx::ENC_GROUPS && (uint32_t)v <= d.nch) ngroups = v; }
+    for (int g = 0; g + 1 < ngroups; g++)         // group streams are created when a block first needs them
+        if (!ctx->aux[g] && hipStreamCreateWithFlags(&ctx->aux[g], hipStreamNonBlocking) != hipSuccess) { ctx->aux[g] = nullptr; ngroups = g + 1; break; }
     if (ngroups >= 2) {
         // launch order on the device (no host round trip): density per chunk, rank by counting
         JPK_HIP(hipMemsetAsync(b.dens, 0, (size_t)d.nch * 4, st));
@@ -1323,7 +1325,7 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
             if (hipStreamWaitEvent(st, ctx->ev_done[g], 0) != hipSuccess) rc = JPK_E_DEVICE;
         if (rc != JPK_OK) {
             // groups already launched keep reading and writing the arena: join them before the caller may reuse it
-            for (int g = 0; g + 1 < jpk_ctx::ENC_GROUPS; g++) (void)hipStreamSynchronize(ctx->aux[g]);
+            for (int g = 0; g + 1 < jpk_ctx::ENC_GROUPS; g++) if (ctx->aux[g]) (void)hipStreamSynchronize(ctx->aux[g]);
             (void)hipStreamSynchronize(st);
             return rc;
         }

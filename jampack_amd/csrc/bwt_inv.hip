@@ -275,6 +275,17 @@ void inv_layout(Arena &a, size_t n, InvBufs &b, size_t &ntiles, size_t &nsplit, 
 
 }  // namespace
 
+// arena bytes one inverse BWT of n sorted bytes takes from the start of the arena (the batch decoder parks its own buffers behind)
+size_t jpk_inv_bwt_arena_bytes(uint32_t n)
+{
+    InvBufs b;
+    size_t ntiles, nsplit, max_slots;
+    jpk_ctx dummy;
+    Arena plan(&dummy, true);
+    inv_layout(plan, n ? n : 1, b, ntiles, nsplit, max_slots);
+    return plan.need + (1u << 20);
+}
+
 int jpk_inv_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trailer, uint8_t *d_out)
 {
     hipStream_t st = ctx->stream;

@@ -86,6 +86,14 @@ void jpk_prof_resolve(jpk_ctx *ctx);   // call after a stream synchronisation
         if ((ctx)->prof_on) jpk_prof_end((ctx));                                               \
     } while (0)
 
+// the same with a dynamic LDS reservation (bytes): used to cap the number of resident workgroups of a kernel per CU
+#define JPK_LAUNCH_LDS(ctx, id, units, lds, kernel, grid, block, ...)                          \
+    do {                                                                                       \
+        if ((ctx)->prof_on) jpk_prof_begin((ctx), (id), (uint64_t)(units));                    \
+        hipLaunchKernelGGL(kernel, grid, block, (lds), (ctx)->stream, __VA_ARGS__);            \
+        if ((ctx)->prof_on) jpk_prof_end((ctx));                                               \
+    } while (0)
+
 static inline size_t jpk_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 struct Arena {
@@ -152,6 +160,9 @@ int jpk_inv_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trail
 int jpk_inv_bwt_chains120_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trailer, uint8_t *d_out, float *chase_ms);
 int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
 int jpk_ans_decode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
+int jpk_ans_decode_batch(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out, const int32_t *out_cap,
+                         int32_t *out_len, int32_t *status, size_t arena_skip);
+size_t jpk_inv_bwt_arena_bytes(uint32_t n);
 int jpk_rank_encode_device(jpk_ctx *ctx, uint8_t *d_t, int32_t *d_freq, int32_t len);
 int jpk_rank_decode_device(jpk_ctx *ctx, uint8_t *d_r, const int32_t *d_freq, int32_t len);
 int jpk_rle_encode_device(jpk_ctx *ctx, const uint8_t *d_ranks, int32_t len, uint16_t *d_rle, int32_t *rlen);

@@ -21,7 +21,7 @@ _ensure_built()
 
 # torch bundles its own HIP runtime: let it initialise first so that libjampack_amd.so (linked against the system
 # ROCm) and torch share one runtime instance in the GPU tests that use both (torch tensors as device buffers)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 try:
     import torch
     torch.cuda.is_available()

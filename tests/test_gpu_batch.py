@@ -1,0 +1,75 @@
+"""Batches of independent blocks (jpk_dev_blocks_ans_decode / jpk_dev_blocks_decompress): Jampack::Decompress's multi-block mode
+(jampack.cpp:286-317) for HBM-resident blocks.  One pass must give, block by block, exactly what the single-block entry
+points give -- for ragged block sizes, empty blocks, mixed corpora -- and a corrupt block must be reported in its own status
+slot without disturbing its neighbours.  -m gpu"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import jampack_amd as jam
+    assert torch.cuda.is_available()
+    ctx = jam.Context(0, torch.cuda.current_stream().cuda_stream)
+    yield torch, jam, ctx
+    ctx.close()
+
+
+def _blocks(jam):
+    spec = [("text_survey", 3_000_000), ("random", 70_001), ("zero", 2_100_000), ("geometric", 1_048_576 - 480), ("text", 5),
+            ("runs", 1_300_000), ("dna", 119), ("silesia", 4_000_000), ("two", 120), ("text_survey", 1_048_577)]
+    return [jam.corpus.make(k, n, 11 + i) for i, (k, n) in enumerate(spec)]
+
+
+def test_batch_equals_single_block_calls(gpu, oracle):
+    torch, jam, ctx = gpu
+    dev = torch.device("cuda", 0)
+    blocks = _blocks(jam)
+    comp, bwts = [], []
+    for t in blocks:
+        bw = oracle.bwt_forward(t)                     # defined trailer bytes for the < 120-byte blocks too
+        bwts.append(bw)
+        comp.append(oracle.ans_encode(bw))
+    d_in = [torch.from_numpy(c).to(dev) for c in comp]
+    # Ans::Decode of the whole batch
+    d_mid = [torch.empty(len(b) + 16, dtype=torch.uint8, device=dev) for b in bwts]
+    n, st = ctx.blocks_ans_decode(d_in, [len(c) for c in comp], d_mid, [m.numel() for m in d_mid])
+    assert st == [0] * len(blocks)
+    for i, b in enumerate(bwts):
+        assert n[i] == len(b) and np.array_equal(d_mid[i][: n[i]].cpu().numpy(), b), i
+    # fused: Ans::Decode + InverseBwt of the whole batch
+    d_out = [torch.empty(max(len(t), 1), dtype=torch.uint8, device=dev) for t in blocks]
+    n, st = ctx.blocks_decompress(d_in, [len(c) for c in comp], d_out, [len(t) for t in blocks])
+    assert st == [0] * len(blocks)
+    for i, t in enumerate(blocks):
+        assert n[i] == len(t) and np.array_equal(d_out[i][: n[i]].cpu().numpy(), t), i
+        one = torch.empty(max(len(t), 1), dtype=torch.uint8, device=dev)
+        assert ctx.block_decompress(d_in[i], len(comp[i]), one, len(t)) == len(t) and torch.equal(one[: len(t)], d_out[i][: len(t)])
+
+
+def test_corrupt_block_is_isolated(gpu, oracle):
+    torch, jam, ctx = gpu
+    dev = torch.device("cuda", 0)
+    blocks = _blocks(jam)[:6]
+    comp = [oracle.ans_encode(oracle.bwt_forward(t)) for t in blocks]
+    bad = [c.copy() for c in comp]
+    bad[1][300] ^= 0x40                               # a frequency byte of block 1: header sum no longer matches
+    bad[3] = bad[3][: len(bad[3]) // 2]               # block 3 truncated
+    bad[4][-5] ^= 0xFF                                # payload of block 4: final rANS states wrong
+    d_in = [torch.from_numpy(c).to(dev) for c in bad]
+    d_out = [torch.empty(max(len(t), 1), dtype=torch.uint8, device=dev) for t in blocks]
+    n, st = ctx.blocks_decompress(d_in, [len(c) for c in bad], d_out, [len(t) for t in blocks])
+    assert st[0] == 0 and st[2] == 0 and st[5] == 0
+    assert st[1] in (-3, -2) and st[3] in (-3, -2) and st[4] in (-3, -2)
+    for i in (0, 2, 5):
+        assert n[i] == len(blocks[i]) and np.array_equal(d_out[i][: n[i]].cpu().numpy(), blocks[i])
+    # too small an output buffer is a capacity error of that block only
+    n, st = ctx.blocks_decompress(d_in[:1] + d_in[2:3], [len(bad[0]), len(bad[2])], [d_out[0][:1000], d_out[2]], [1000, len(blocks[2])])
+    assert st[0] == -2 and st[1] == 0 and n[1] == len(blocks[2])
+    # and the context still decodes exact bytes afterwards
+    ok = torch.empty(len(blocks[0]), dtype=torch.uint8, device=dev)
+    good = torch.from_numpy(comp[0]).to(dev)
+    assert ctx.block_decompress(good, len(comp[0]), ok, len(blocks[0])) == len(blocks[0]) and np.array_equal(ok.cpu().numpy(), blocks[0])
