@@ -42,16 +42,17 @@ import numpy as np  # noqa: E402
 PROFILE_ROUND = "r02"
 
 # algorithmic HBM bytes per processed unit of every timed kernel class, and what the class is
-# actually limited by ("hbm": streaming traffic; "hbm-random": 4-byte gathers/scatters, priced per 64-byte line in
-# DESIGN.md; "issue": instruction issue of single waves walking serial chains)
+# actually limited by ("hbm": streaming traffic; "hbm-random": 4-byte gathers/scatters, ~55 G accesses/s whatever the bytes;
+# "lds": barrier-separated LDS sort passes; "issue": instruction issue of single waves walking serial chains)
 ALG_BYTES_PER_UNIT = {
     "k_rs_hist": (8, "sorted (key,value) pair", "hbm"),
     "k_rs_scatter": (24, "sorted (key,value) pair", "hbm"),
-    "k_scan_*": (12, "u32 element", "hbm"),
-    "k_init_keys/k_make_keys/k_win_heads": (12, "suffix", "hbm"),
-    "k_seg_round": (28, "active suffix", "hbm-random"),
-    "sa rerank kernels": (16, "suffix", "hbm-random"),
-    "k_bwt_gather": (6, "block byte", "hbm-random"),
+    "k_lg_hist": (4, "member of a large group x pass", "hbm"),
+    "k_lg_scatter": (16, "member of a large group x pass", "hbm"),
+    "k_gather_win": (16, "active suffix", "hbm-random"),
+    "k_seg_round": (24, "active suffix in a group <= 1024", "lds"),
+    "k_r0_*/k_lg_finish/k_cmp_*": (20, "suffix", "hbm-random"),
+    "k_bwt_image": (2, "block byte", "hbm"),
     "k_enc_hist/k_enc_prep": (1, "block byte", "hbm"),
     "k_enc_mtf": (2, "block byte", "issue"),
     "k_rle_*": (2, "block byte", "hbm"),
@@ -59,7 +60,7 @@ ALG_BYTES_PER_UNIT = {
     "k_adaptive": (15, "RLE0 symbol", "issue"),
     "k_pairs": (44, "RLE0 symbol", "hbm"),
     "k_rans_lanes": (20, "rANS pair", "issue"),
-    "k_emit_scan/k_put_*": (13, "rANS pair", "hbm"),
+    "k_emit_*/k_put_*": (25, "rANS pair", "hbm"),
 }
 # algorithmic bytes per block byte of the four stages (c = compressed size / block size)
 STAGE_ALG = {"forward_bwt": lambda c: 10.0, "ans_encode": lambda c: 4.0 + c, "ans_decode": lambda c: 4.0 + c, "inverse_bwt": lambda c: 12.0}
@@ -355,10 +356,23 @@ def main():
             for i in lanes[k]:
                 dsz[i] = ctxs[k].block_decompress(d_cmp[i], sizes[i], d_dcm[i], len(blocks[i]))
 
-        def decompress_step():
+        def decompress_step_ctx():
             for f in [pool.submit(dlane, k) for k in range(nctx)]:
                 f.result()
 
+        def decompress_step():
+            # all blocks of the batch in ONE call: every serial decode kernel runs a single grid over the chunks of all blocks
+            n_, st_ = ctxs[0].blocks_decompress(d_cmp, sizes, d_dcm, [len(b) for b in blocks])
+            for i in range(len(blocks)):
+                dsz[i] = n_[i] if st_[i] == 0 else -1
+
+        decompress_step_ctx()
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        for _ in range(reps):
+            decompress_step_ctx()
+        torch.cuda.synchronize()
+        tdc = (time.perf_counter() - tc0) / reps
         decompress_step()
         torch.cuda.synchronize()
         td0 = time.perf_counter()
@@ -368,6 +382,8 @@ def main():
         td = (time.perf_counter() - td0) / reps
         ok = ok and all(dsz[i] == len(blocks[i]) and bool(torch.equal(d_dcm[i][: len(blocks[i])], d_in[i])) for i in range(len(blocks)))
         extra["decompress"] = {"value": round(mb / td, 1), "unit": "MB/s", "ms_per_step": round(td * 1e3, 3), "steps": reps,
+                               "how": "jpk_dev_blocks_decompress: all blocks of the batch in one call",
+                               "one_context_per_block_MBps": round(mb / tdc, 1),
                                "one_block_at_a_time_MBps": round(mb / ((stage_ms["ans_decode"] + stage_ms["inverse_bwt"]) / 1e3), 1),
                                "inverse_bwt_MBps": round(mb / (stage_ms["inverse_bwt"] / 1e3), 1)}
         extra["round_trip_ok"] = ok
@@ -378,6 +394,8 @@ def main():
         import threading
         for mode, fn, args_of in (("compress", "block_compress", lambda i: (d_in[i], len(blocks[i]), d_out[i], caps[i])),
                                   ("decompress", "block_decompress", lambda i: (d_cmp[i], sizes[i], d_dcm[i], len(blocks[i])))):
+            if mode == "decompress" and len(blocks) * 4 > 64:
+                continue
             passes = 4
             tasks = queue.Queue()
             for _ in range(passes):

@@ -1,6 +1,7 @@
 // abi.hip -- C ABI of libjampack_amd.so (include/jampack_abi.h): contexts, HBM arena, PCIe staging for the
 // host-buffer (drop-in) entry points, and the fused block pipeline.  No CPU fallback: without a gfx950 device
 // every entry point returns JPK_E_NODEVICE.
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -147,10 +148,10 @@ void jpk_prof_resolve(jpk_ctx *ctx)
     ctx->prof_pending.clear();
 }
 static const char *const PROF_NAMES[PROF_COUNT] = {
-    "k_rs_hist", "k_rs_scatter", "k_scan_*", "k_init_keys/k_make_keys/k_win_heads", "k_seg_round", "sa rerank kernels", "k_bwt_gather",
+    "k_rs_hist", "k_rs_scatter", "k_scan_*/k_tab_*/k_win_*", "k_gather_win", "k_seg_round", "k_r0_*/k_lg_finish/k_cmp_*", "k_bwt_image",
     "k_hist", "k_build_nxt", "k_walk", "k_rank_jump", "k_copy_out",
-    "k_enc_hist/k_enc_prep", "k_enc_mtf", "k_rle_*", "k_cls_*/k_quasi_build", "k_adaptive", "k_pairs", "k_rans_lanes", "k_emit_scan/k_put_*",
-    "k_dec_headers", "k_dec_rans", "k_dec_rle", "k_dec_rank", "k_chk_*"};
+    "k_enc_hist/k_enc_prep", "k_enc_mtf", "k_rle_*", "k_cls_*/k_quasi_build", "k_adaptive", "k_pairs", "k_rans_lanes", "k_emit_*/k_put_*",
+    "k_dec_headers", "k_dec_rans", "k_dec_rle", "k_dec_rank", "k_chk_*", "k_lg_hist", "k_lg_scatter"};
 
 extern "C" int jpk_ctx_profile(jpk_ctx *ctx, int enable)
 {
@@ -711,12 +712,20 @@ int staged(dev_fn fn, const uint8_t *in, int32_t in_len, uint8_t *out, int32_t o
     // the fused entry points use stage_out as their intermediate, so the host-visible result gets its own buffer
     JPK_TRY(buf_ensure(ctx, &ctx->stage_res, &ctx->stage_res_cap, (size_t)out_cap + 64));
     uint8_t *d_res = ctx->stage_res;
+    static const bool timing = getenv("JPK_TIME_HOST") != nullptr;      // JPK_TIME_HOST=1: where a host-buffer call spends its time
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = timing ? now() : 0;
     if (in_len) JPK_HIP(hipMemcpyAsync(ctx->stage_in, in, (size_t)in_len, hipMemcpyHostToDevice, ctx->stream));
     if (prefill_out && out_cap) JPK_HIP(hipMemcpyAsync(d_res, out, (size_t)out_cap, hipMemcpyHostToDevice, ctx->stream));
+    if (timing) (void)hipStreamSynchronize(ctx->stream);
+    const double t1 = timing ? now() : 0;
     int32_t n = 0;
     JPK_TRY(fn(ctx, ctx->stage_in, in_len, d_res, out_cap, &n));
+    if (timing) (void)hipStreamSynchronize(ctx->stream);
+    const double t2 = timing ? now() : 0;
     if (n > 0) JPK_HIP(hipMemcpyAsync(out, d_res, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     JPK_HIP(hipStreamSynchronize(ctx->stream));
+    if (timing) fprintf(stderr, "[jampack_amd] host call: in %d B, out %d B: H2D %.2f ms, device %.2f ms, D2H %.2f ms\n", in_len, n, t1 - t0, t2 - t1, now() - t2);
     *out_len = n;
     return JPK_OK;
 }
@@ -897,8 +906,9 @@ extern "C" int jpk_jam_cli_block_read(const uint8_t *in, int32_t in_len, uint8_t
     const int64_t cap64 = (int64_t)((double)block_size * 1.05) + 4096;             // the reference's stage buffers, jampack.cpp:156
     if (cap64 > 0x7fffffff) return JPK_E_ARG;
     const int32_t cap = (int32_t)cap64;
-    std::vector<uint8_t> a, b;
-    try { a.resize((size_t)cap); b.resize((size_t)cap); } catch (...) { return JPK_E_ALLOC; }
+    // the two 1.05 x BlockSize stage buffers of the reference (jampack.cpp:156-159), kept per thread across frames
+    static thread_local std::vector<uint8_t> a, b;
+    try { if (a.size() < (size_t)cap) a.resize((size_t)cap); if (b.size() < (size_t)cap) b.resize((size_t)cap); } catch (...) { return JPK_E_ALLOC; }
     int32_t n = 0;
     JPK_TRY(jpk_block_decompress(in + JPK_JAM_HEADER_BYTES, csize, a.data(), cap, &n));     // Ans::Decode + InverseBwt
     int32_t m = 0;

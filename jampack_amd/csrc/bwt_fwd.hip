@@ -406,18 +406,23 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
                                                  const uint8_t *__restrict__ T, uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
                                                  uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp)
 {
-    __shared__ uint32_t g[SEG_SPAN];          // group rank (abs SA position of the group head) per loaded element
-    __shared__ uint32_t sv[SEG_SPAN];         // suffix index of the owned elements
+    // LDS diet (30 KB, five workgroups per CU instead of three): the group ranks g[] are only needed while the group boundaries
+    // are worked out and share their 8 KB with the two index permutations of the sort; the suffix numbers and the group rank of
+    // the final positions are re-read from the (L2-resident) window instead of being kept; the scratch of the boundary scans
+    // shares the digit counters' space.
+    __shared__ uint32_t u_g_idx[SEG_SPAN];    // phase 1: g[] = group rank per loaded element; afterwards: idxA | idxB (uint16 each)
     __shared__ uint32_t k2[SEG_SPAN];         // sort key of the owned elements
     __shared__ uint16_t gsl[SEG_SPAN];        // group start (local position) per loaded element, 0xFFFF = spill-in
     __shared__ uint16_t lgid[SEG_SPAN];       // local group id of the owned elements
-    __shared__ uint16_t idxA[SEG_SPAN], idxB[SEG_SPAN];
-    __shared__ uint32_t cnt[TB / 64][SEG_DIGITS];
-    __shared__ uint32_t dbase[SEG_DIGITS];
+    __shared__ uint16_t cnt[TB / 64][SEG_DIGITS];
+    __shared__ uint32_t dbase[SEG_DIGITS];    // also fz | rz of the boundary scans (2 x TB words)
     __shared__ uint32_t sm[TB / 64 + 1];
     __shared__ uint32_t s_fo, s_oe;
-    __shared__ uint32_t fz[TB], rz[TB];
     __shared__ uint8_t firstflag[TB + 1];
+    uint32_t *const g = u_g_idx;
+    uint16_t *const idxA = reinterpret_cast<uint16_t *>(u_g_idx), *const idxB = idxA + SEG_SPAN;
+    uint32_t *const fz = dbase, *const rz = dbase + TB;
+    static_assert(SEG_DIGITS >= 2 * TB, "fz | rz live in dbase");
 
     const uint32_t m = st->m[par];
     const uint32_t nwin = (m + SEG_TILE - 1) / SEG_TILE;
@@ -529,9 +534,8 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
             }
         }
         for (uint32_t q = tid; q < no; q += TB) {
-            sv[q] = a_sa[base + fo + q];
             k2[q] = k2g[base + fo + q];
-            idxA[q] = (uint16_t)q;
+            idxA[q] = (uint16_t)q;            // g[] is dead from here on (last read: the classification above)
         }
         __syncthreads();
         const uint32_t ngroups = (uint32_t)lgid[no - 1] + 1u;
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
         for (int pass = 0; pass < npass; pass++) {
             const int shift = SEG_DBITS * pass;
             const int part = (shift + SEG_DBITS <= key_bits) ? 0 : (shift >= key_bits ? 2 : 1);   // digit from key2 / both / group id
-            for (int i = tid; i < (TB / 64) * SEG_DIGITS; i += TB) (&cnt[0][0])[i] = 0;
+            for (int i = tid; i < (TB / 64) * SEG_DIGITS / 2; i += TB) reinterpret_cast<uint32_t *>(&cnt[0][0])[i] = 0;
             __syncthreads();
             uint32_t rk[SEG_ITEMS], dg[SEG_ITEMS];
 #pragma unroll
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
                 const uint32_t below = (uint32_t)__popcll(mm & lt);
                 const uint32_t c = valid ? cnt[w][d] : 0u;
                 rk[it] = c + below;
-                if (valid && below == 0) cnt[w][d] = c + (uint32_t)__popcll(mm);
+                if (valid && below == 0) cnt[w][d] = (uint16_t)(c + (uint32_t)__popcll(mm));
             }
             __syncthreads();
             {   // per digit: exclusive over waves, then exclusive over digits (two digits per thread, in digit order)
@@ -577,7 +581,7 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
                     const int d = 2 * tid + e;
                     uint32_t s = 0;
 #pragma unroll
-                    for (int k = 0; k < TB / 64; k++) { uint32_t t = cnt[k][d]; cnt[k][d] = s; s += t; }
+                    for (int k = 0; k < TB / 64; k++) { uint32_t t = cnt[k][d]; cnt[k][d] = (uint16_t)s; s += t; }
                     s2[e] = s;
                 }
                 const uint32_t inc = block_incl_scan<OpSum>(s2[0] + s2[1], sm, nullptr);
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
             if (q < no) {
                 const uint32_t id = src[q];
                 const uint32_t pos = fo + q;                        // groups keep their positions through the sort
-                ap[k] = g[pos] + (pos - (uint32_t)gsl[pos]);
+                ap[k] = a_grp[base + pos] + (pos - (uint32_t)gsl[pos]);
                 bool head = (q == 0);
                 if (!head) {
                     const uint32_t pid = src[q - 1];
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
                 if (nh[k]) run = ap[k];
                 const bool next_head = (q + 1 >= no) ? true : (k + 1 < SEG_ITEMS ? (nh[k + 1] != 0) : (firstflag[tid + 1] != 0));
                 const bool single = nh[k] && next_head;
-                const uint32_t s = sv[src[q]];
+                const uint32_t s = a_sa[base + fo + src[q]];
                 ISA[s] = run;
                 if (single) {
                     bwt[ap[k]] = s ? T[s - 1] : (uint8_t)0;
@@ -1055,11 +1059,11 @@ template <int DB>
 void launch_lg_pass(jpk_ctx *ctx, SaBufs &b, const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int shift, unsigned gp, unsigned gt)
 {
     constexpr uint32_t NB = 1u << DB;
-    JPK_LAUNCH(ctx, PROF_RS_HIST, 0, (k_lg_hist<DB>), dim3(gp), dim3(TB), kin, b.pieces, b.state, shift, b.table);
+    JPK_LAUNCH(ctx, PROF_LG_HIST, 0, (k_lg_hist<DB>), dim3(gp), dim3(TB), kin, b.pieces, b.state, shift, b.table);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_tab_reduce, dim3(gt), dim3(TB), b.table, b.state, NB, b.partial);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_tab_partials, dim3(1), dim3(WG1), b.partial, b.state, NB);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_tab_down, dim3(gt), dim3(TB), b.table, b.table, b.state, NB, b.partial);
-    JPK_LAUNCH(ctx, PROF_RS_SCATTER, 0, (k_lg_scatter<DB>), dim3(gp), dim3(TB), kin, vin, kout, vout, b.pieces, b.state, shift, b.table);
+    JPK_LAUNCH(ctx, PROF_LG_SCATTER, 0, (k_lg_scatter<DB>), dim3(gp), dim3(TB), kin, vin, kout, vout, b.pieces, b.state, shift, b.table);
 }
 
 // builds the BWT-in-SA-order bytes (b.bwt), the complete inverse suffix array (b.ISA) and, if b.SA is set, the suffix array
@@ -1118,13 +1122,13 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         const unsigned g_pc = cap_grid(pc_bound, 1, CAP);
         const unsigned g_tab = cap_grid(pc_bound << lg_db, SC_TILE, CAP);
         const uint32_t hh = (h < n) ? (uint32_t)h : n;
-        JPK_LAUNCH(ctx, PROF_SA_KEYS, bound, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, hh, b.ISA, b.k2, b.FH, b.LH);
+        JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, hh, b.ISA, b.k2, b.FH, b.LH);
         const unsigned g_wm = cap_grid((size_t)bound / SEG_TILE + 1, TB, 256);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan1, dim3(1), dim3(WG1), b.FH, b.LH, b.PH, b.NH, b.state, par);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_count, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.state, par);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan2, dim3(1), dim3(WG1), b.PC, b.state, par, round);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_pieces, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.pieces, b.state, par);
-        JPK_LAUNCH(ctx, PROF_SA_SEG, bound, k_seg_round, dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, kbits, b.PH, T, b.ISA, b.bwt, b.SA,
+        JPK_LAUNCH(ctx, PROF_SA_SEG, 0, k_seg_round, dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, kbits, b.PH, T, b.ISA, b.bwt, b.SA,
                    b.b_sa, b.b_grp);
         {   // large groups: lg_pass LSD passes over (key2, sa), ping-pong between (k2, a_sa) and (k2alt, sa_alt)
             uint32_t *kin = b.k2, *vin = b.a_sa, *kout = b.k2alt, *vout = b.sa_alt;
@@ -1145,9 +1149,9 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_lg_finish, dim3(g_pc), dim3(TB), kin, vin, b.a_grp, b.pieces, b.state, b.pLast, T, b.ISA, b.bwt, b.SA, b.b_sa,
                        b.b_grp);
         }
-        JPK_LAUNCH(ctx, PROF_SA_RERANK, bound, k_cmp_count, dim3(g_cmp), dim3(TB), b.b_grp, b.state, par, b.tA);
+        JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_cmp_count, dim3(g_cmp), dim3(TB), b.b_grp, b.state, par, b.tA);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_cmp_scan, dim3(1), dim3(WG1), b.tA, b.state, par, round);
-        JPK_LAUNCH(ctx, PROF_SA_RERANK, bound, k_cmp_scatter, dim3(g_cmp), dim3(TB), b.b_sa, b.b_grp, b.state, par, b.tA, b.a_sa, b.a_grp);
+        JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_cmp_scatter, dim3(g_cmp), dim3(TB), b.b_sa, b.b_grp, b.state, par, b.tA, b.a_sa, b.a_grp);
         JPK_HIP(hipGetLastError());
         JPK_HIP(hipMemcpyAsync(&h_m[par], &b.state->m[par ^ 1], 4, hipMemcpyDeviceToHost, st));
         JPK_HIP(hipEventRecord(ctx->ev_sa[par], st));
@@ -1178,6 +1182,13 @@ void jpk_sa_stats_sync(jpk_ctx *ctx)
         ctx->stats.sa_round_active[r] = live ? (int32_t)rm[r] : 0;
         ctx->stats.sa_round_large[r] = live ? (int32_t)rl[r] : 0;
         if (r >= 1 && live) ctx->stats.sa_sorted_elems += rm[r];
+        if (r >= 1 && live && ctx->prof_on) {     // units of the round kernels are only known now
+            ctx->prof_units[PROF_SA_KEYS] += rm[r];
+            ctx->prof_units[PROF_SA_SEG] += rm[r] - rl[r];
+            ctx->prof_units[PROF_SA_RERANK] += rm[r];
+            ctx->prof_units[PROF_LG_HIST] += (uint64_t)rl[r] * 4;
+            ctx->prof_units[PROF_LG_SCATTER] += (uint64_t)rl[r] * 4;
+        }
     }
 }
 

@@ -34,7 +34,7 @@ enum JpkProfId {
     PROF_RS_HIST = 0, PROF_RS_SCATTER, PROF_SCAN, PROF_SA_KEYS, PROF_SA_SEG, PROF_SA_RERANK, PROF_BWT_GATHER,
     PROF_INV_HIST, PROF_INV_BUILD, PROF_INV_WALK, PROF_INV_RANK, PROF_INV_COPY,
     PROF_ENC_HIST, PROF_ENC_MTF, PROF_ENC_RLE, PROF_ENC_CLASS, PROF_ENC_ADAPTIVE, PROF_ENC_PAIRS, PROF_ENC_RANS, PROF_ENC_EMIT,
-    PROF_DEC_HEADERS, PROF_DEC_RANS, PROF_DEC_RLE, PROF_DEC_RANK, PROF_CHECKSUM, PROF_COUNT
+    PROF_DEC_HEADERS, PROF_DEC_RANS, PROF_DEC_RLE, PROF_DEC_RANK, PROF_CHECKSUM, PROF_LG_HIST, PROF_LG_SCATTER, PROF_COUNT
 };
 struct JpkProfPending { hipEvent_t a, b; int id; uint64_t units; };
 
