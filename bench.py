@@ -422,6 +422,25 @@ def main():
             extra.setdefault("streamed", {})[mode] = {"value": round(passes * mb / tsd, 1), "unit": "MB/s", "passes": passes,
                                                       "ms_per_pass": round(tsd / passes * 1e3, 3)}
         del d_cmp, d_dcm
+        # BASELINE config 3's "120-way parallel LF-map": the reference's own GPU kernel shape (CUDAInverse<<<40,3>>>, bwt.cpp:8-19) as
+        # a measured comparator beside the list-ranking inverse, on block 0
+        try:
+            n0 = len(blocks[0])
+            d_b0 = torch.empty(n0 + jam.TRAILER, dtype=torch.uint8, device=dev)
+            d_t0 = torch.empty(max(n0, 1), dtype=torch.uint8, device=dev)
+            ctx.bwt_forward(d_in[0], n0, d_b0, n0 + jam.TRAILER)
+            m0, chase_ms = ctx.bwt_inverse_chains120(d_b0, n0 + jam.TRAILER, d_t0, n0)
+            e0, e1 = ev(), ev()
+            e0.record(stream)
+            ctx.bwt_inverse(d_b0, n0 + jam.TRAILER, d_t0, n0)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            extra["inverse_bwt_120_chains"] = {"block_bytes": n0, "chase_kernel_ms": round(chase_ms, 3), "MBps": round(n0 / 1e6 / (chase_ms / 1e3), 1),
+                                               "list_ranking_inverse_ms": round(e0.elapsed_time(e1), 3), "same_bytes": bool(m0 == n0),
+                                               "note": "120 threads, p = Map[p-1] (the reference's CUDAInverse shape) on the same Map; comparator only"}
+            del d_b0, d_t0
+        except Exception as ex:
+            extra["inverse_bwt_120_chains"] = {"error": repr(ex)}
         extra["compressed_bytes"] = int(sum(comp_sizes))
         extra["compressed_ratio"] = round(sum(comp_sizes) / batch_bytes, 4)
         extra["workspace_bytes"] = int(ctx.stats().workspace_bytes)

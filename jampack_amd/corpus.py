@@ -268,9 +268,18 @@ def load_or_make(name: str, limit: int | None = None, seed_offset: int = 0, star
         p = os.path.join(d, fname)
         if os.path.isfile(p):
             return np.fromfile(p, dtype=np.uint8, count=count, offset=start), f"file:{p}"
+    cache = os.environ.get("JAMPACK_CORPUS_CACHE")      # directory: generated ranges are kept as raw files (repeated bench runs)
+    cpath = os.path.join(cache, f"{name}_{seed + seed_offset}_{nbytes}_{start}_{count}.bin") if cache else None
+    if cpath and os.path.isfile(cpath):
+        return np.fromfile(cpath, dtype=np.uint8), "synthetic"
     if kind == "text_survey":
-        return text_survey(count, seed + seed_offset, start), "synthetic"
-    return make(kind, nbytes, seed + seed_offset)[start:start + count], "synthetic"
+        out = text_survey(count, seed + seed_offset, start)
+    else:
+        out = make(kind, nbytes, seed + seed_offset)[start:start + count]
+    if cpath:
+        os.makedirs(cache, exist_ok=True)
+        out.tofile(cpath)
+    return out, "synthetic"
 
 
 def block_ranges(total: int, block_size: int):

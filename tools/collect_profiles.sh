@@ -1,29 +1,39 @@
 #!/bin/bash
 # Run on the MI355X box from the repo root:  bash tools/collect_profiles.sh <tag>
-# Produces gpurun_out/<tag>/: PMC passes + summary, rocprofv3 kernel stats, bench lines.
+# Produces gpurun_out/<tag>/: PMC passes + summary, rocprofv3 kernel stats of the bench command, bench lines, worst cases.
+# (counters and traces in separate runs; the program itself after `--`)
 set -u
-TAG=${1:-r01_f}
-OUT=$PWD/gpurun_out/$TAG
+TAG=${1:-r02}
+REPO=$PWD
+OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-REPO=$PWD
+export JAMPACK_CORPUS_CACHE=/tmp/jpk_corpus
 cd /tmp
-# 1. PMC passes (separate, counters only) of one compress+decompress pass
+# 1. PMC passes (separate, counters only) of one compress step of the default workload
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
-  rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_$C -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /tmp/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_$C -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-extras > /tmp/pmc_$C.log 2>&1
   cp /tmp/pmc_$C/*/*counter_collection.csv "$OUT/$(echo $C | tr A-Z a-z)_counter_collection.csv" 2>/dev/null
 done
-python3 $REPO/tools/pmc_summary.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $REPO/profiles/r01_pmc_traffic.json > "$OUT/pmc_summary.txt" 2>&1
-cp $REPO/profiles/r01_pmc_traffic.json "$OUT/r01_pmc_traffic.json"
+python3 $REPO/tools/pmc_summary.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "$OUT/pmc_traffic.json" > "$OUT/pmc_summary.txt" 2>&1
 # 2. kernel trace + stats of the bench command
 rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2>/tmp/kt.log
-cp /tmp/kt/*/*kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null
-# 3. the bench lines (traffic now comes from the fresh PMC summary)
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2>/tmp/kt.log
+python3 $REPO/tools/rocpd_stats.py /tmp/kt/kt_results.db > "$OUT/kernel_stats.txt" 2>&1
+# 3. stage-level traces of one 64 MiB block (per-rep numbers)
+rm -rf /tmp/kf /tmp/ke
+rocprofv3 --kernel-trace -d /tmp/kf -o f -- python3 $REPO/tools/fwd_once.py text_survey 3 > /dev/null 2>&1
+python3 $REPO/tools/rocpd_stats.py /tmp/kf/f_results.db 3 > "$OUT/kernel_stats_forward_bwt_64mib.txt" 2>&1
+rocprofv3 --kernel-trace -d /tmp/ke -o e -- python3 $REPO/tools/enc_once.py text_survey > /dev/null 2>&1
+python3 $REPO/tools/rocpd_stats.py /tmp/ke/e_results.db 3 > "$OUT/kernel_stats_ans_encode_64mib.txt" 2>&1
+python3 $REPO/tools/rocpd_timeline.py /tmp/ke/e_results.db k_density > "$OUT/timeline_ans_encode_64mib.txt" 2>&1
+# 4. the bench lines
 cd $REPO
-python3 bench.py --steps 5 --warmup 2 2>/dev/null | tail -1 > "$OUT/bench.json"
-python3 bench.py --workload enwik9 --contexts 8 --steps 1 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_enwik9like_8ctx.json"
+cp "$OUT/pmc_traffic.json" profiles/${TAG}_pmc_traffic.json 2>/dev/null     # bench.py reads the traffic of the dominant kernel from here
+python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/bench.json"
+python3 bench.py --workload enwik9 --contexts 4 --steps 2 --warmup 1 --no-extras 2>/dev/null | tail -1 > "$OUT/bench_enwik9like_4ctx.json"
 python3 bench.py --workload silesia --block-mib 256 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_silesialike_256mib.json"
 python3 tools/worst_cases.py > "$OUT/worst_cases.txt" 2>/dev/null
+python3 tools/dec_scaling.py batch > "$OUT/decode_batch_scaling.txt" 2>/dev/null
 ls -la "$OUT"
