@@ -87,6 +87,7 @@ def pmc_traffic(kernel_class: str):
     return (round((fetch + write) / launches) if launches else None), os.path.basename(path)
 
 
+ONE_GPU_RANKS = bool(int(os.environ.get("JPK_BENCH_ONE_GPU", "0")))   # test hook: all ranks on cuda:0 over gloo (a 1-GPU box can then run the N>1 code path)
 FORCE_GATHER = bool(int(os.environ.get("JPK_FORCE_GATHER", "0")))      # exercise the RCCL gather with WORLD_SIZE=1 (test hook)
 
 
@@ -100,7 +101,7 @@ def parse():
     ap.add_argument("--limit-bytes", type=int, default=0, help="truncate the workload (debug only; marks the line invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (multi-GPU children print this anyway)")
-    ap.add_argument("--contexts", type=int, default=2, help="blocks in flight per GPU (one context + HIP stream each)")
+    ap.add_argument("--contexts", type=int, default=4, help="blocks in flight per GPU (one context + HIP stream each)")
     ap.add_argument("--cpu-sample-mib", type=int, default=64, help="bytes of block 0 the CPU reference is timed on")
     ap.add_argument("--master-port", type=int, default=29511)
     return ap.parse_args()
@@ -205,7 +206,7 @@ def main():
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if ONE_GPU_RANKS else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -214,7 +215,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(args.master_port))
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if ONE_GPU_RANKS:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import jampack_amd as jam
     from jampack_amd import corpus, shard
@@ -247,40 +251,98 @@ def main():
     # blocks are independent (jampack.cpp:215: one Jampack instance per OpenMP thread): keep `--contexts` of them in
     # flight, each on its own context = own HBM arena + own HIP stream, driven by one host thread each
     import concurrent.futures as cf
-    nctx = max(1, min(args.contexts, max(len(blocks), 1)))
+    import queue
+    import threading
+    nctx = max(1, args.contexts)          # blocks in flight; with fewer blocks than contexts in a pass, consecutive passes overlap
     ctxs = [jam.Context(local_rank, None) for _ in range(nctx)]
     for c in [ctx] + ctxs:
         c.reserve(max([len(b) for b in blocks] + [1]))          # HBM arenas sized before anything is timed
     pool = cf.ThreadPoolExecutor(max_workers=nctx)
     order = sorted(range(len(blocks)), key=lambda i: -len(blocks[i]))          # largest first
     lanes = [order[k::nctx] for k in range(nctx)]
+    nblk = len(blocks)
+    # every context owns its output buffers (two per block: the RCCL gather of step s reads while step s+1 is being written)
+    out_bufs = [[[torch.empty(caps[i], dtype=torch.uint8, device=dev) for i in range(nblk)] for _ in (0, 1)] for _ in range(nctx)]
 
-    sizes = [0] * len(blocks)
+    sizes = [0] * nblk
     gathered = [None]
+
+    def run_steps(nsteps):
+        """`nsteps` passes over the batch.  The (step, block) tasks go through one queue to the contexts -- a free context takes the
+        next block, as the reference's OpenMP block loop over a long file does (jampack.cpp:205-224) -- so the passes follow each
+        other without a host-side join; `--contexts` blocks are in flight at any time.  With more than one rank the compressed
+        blocks of step s are gathered on rank 0 (the path's only exchange: all_gather of the sizes, one gather of a buffer padded
+        to the largest rank total, RCCL over xGMI; jampack_amd/shard.py) while step s+1 is being compressed."""
+        if nsteps <= 0 or nblk == 0:
+            return
+        q = queue.Queue()
+        cond = threading.Condition()
+        remaining = [nblk] * nsteps
+        res = [[None] * nblk for _ in range(nsteps)]
+        err = []
+
+        def enqueue(s_):
+            for i in order:
+                q.put((s_, i))
+
+        def worker(k):
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                s_, i = item
+                try:
+                    n = ctxs[k].block_compress(d_in[i], len(blocks[i]), out_bufs[k][s_ & 1][i], caps[i])
+                except Exception as ex:       # noqa: BLE001 -- reported by the main thread
+                    err.append(ex)
+                    n = -1
+                with cond:
+                    res[s_][i] = (k, n)
+                    remaining[s_] -= 1
+                    cond.notify_all()
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(nctx)]
+        for t_ in th:
+            t_.start()
+        depth = 2 if use_dist else nsteps          # steps ahead of the one whose gather is pending
+        for s_ in range(min(depth, nsteps)):
+            enqueue(s_)
+        for s_ in range(nsteps):
+            with cond:
+                cond.wait_for(lambda: remaining[s_] == 0)
+            if use_dist:
+                gathered[0] = shard.gather_blocks([out_bufs[res[s_][i][0]][s_ & 1][i][: max(res[s_][i][1], 0)] for i in range(nblk)], dst=0, device=dev)
+                torch.cuda.current_stream().synchronize()      # the gather has read this parity's buffers before step s+2 may write them
+            if s_ + depth < nsteps:
+                enqueue(s_ + depth)
+        for _ in th:
+            q.put(None)
+        for t_ in th:
+            t_.join()
+        if err:
+            raise err[0]
+        last = res[nsteps - 1]
+        for i in range(nblk):
+            sizes[i] = last[i][1]
+            d_out[i] = out_bufs[last[i][0]][(nsteps - 1) & 1][i]
 
     def lane_work(k):
         for i in lanes[k]:
             sizes[i] = ctxs[k].block_compress(d_in[i], len(blocks[i]), d_out[i], caps[i])
 
-    def compress_step():
+    def compress_step():               # one pass with a host-side join at its end (round 1's timed loop; kept as an extra)
         for f in [pool.submit(lane_work, k) for k in range(nctx)]:
             f.result()
-        if use_dist:
-            # the only exchange of the path: the compressed blocks of every rank -> rank 0 (all_gather of the sizes, one
-            # gather of a buffer padded to the largest rank total), RCCL over xGMI; jampack_amd/shard.py
-            gathered[0] = shard.gather_blocks([d_out[i][: sizes[i]] for i in range(len(blocks))], dst=0, device=dev)
 
     def sync_all():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        compress_step()
+    run_steps(args.warmup)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        compress_step()
+    run_steps(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -441,6 +503,16 @@ def main():
             del d_b0, d_t0
         except Exception as ex:
             extra["inverse_bwt_120_chains"] = {"error": repr(ex)}
+        # round 1's timed loop for comparison: every pass ends with a host-side join of the contexts
+        compress_step()
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        for _ in range(reps):
+            compress_step()
+        torch.cuda.synchronize()
+        tb = (time.perf_counter() - tb0) / reps
+        extra["join_per_step"] = {"value": round(mb / tb, 1), "unit": "MB/s", "ms_per_step": round(tb * 1e3, 3), "steps": reps,
+                                  "note": "the same passes with all contexts joined after every pass (the timed loop of round 1)"}
         extra["compressed_bytes"] = int(sum(comp_sizes))
         extra["compressed_ratio"] = round(sum(comp_sizes) / batch_bytes, 4)
         extra["workspace_bytes"] = int(ctx.stats().workspace_bytes)
@@ -529,7 +601,7 @@ def main():
             "dtype": "u8/int32", "data": "synthetic" if source == "synthetic" else source,
             "config": {"workload": wl + ("" if not args.limit_bytes else " [TRUNCATED: not a valid headline]"),
                        "block_bytes": [len(b) for b in blocks] if not stream_mode else [r[1] for r in ranges],
-                       "parallelism": par + f", {nctx} blocks in flight per GPU"},
+                       "parallelism": par + f", {nctx} blocks in flight per GPU, passes enqueued back to back through a work queue (no host join between steps)"},
         }
         line.update(extra)
         print(json.dumps(line), flush=True)
