@@ -789,10 +789,11 @@ int jpk_ans_decode_batch(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in, con
     JPK_HIP(hipMemsetAsync(ctx->arena + o_ranks[0], 0, off - o_ranks[0], st));
     // ---- pass 2: fill the chunk table, then one grid per stage over all chunks ----
     JPK_LAUNCH(ctx, PROF_DEC_HEADERS, 0, (k_dec_headers<true>), dim3(nblk), dim3(64), d_tab, info, freq, d_mail);
-    // The two serial kernels are one wave per chunk.  A 40 KB LDS reservation keeps them to four workgroups per CU, one chain
-    // per SIMD, while fewer than 1024 chains are in flight.
-    const size_t lds_cap = (size_t)(getenv("JPK_DEC_LDS") ? atoi(getenv("JPK_DEC_LDS")) : 40960);
+    // The two serial kernels are one wave per chunk.  While the chains fit one per SIMD (<= 1024) a 40 KB LDS reservation keeps
+    // them to four workgroups per CU; larger batches run without it, because two chains on a SIMD fill each other's issue
+    // bubbles and a second round of workgroups would wait for the first (64 blocks: 3.5 -> 4.8 GB/s, tools/dec_scaling.py).
     const unsigned g = (unsigned)nch_total;
+    const size_t lds_cap = (size_t)(getenv("JPK_DEC_LDS") ? atoi(getenv("JPK_DEC_LDS")) : (g <= 1024u ? 40960 : 0));
     JPK_LAUNCH_LDS(ctx, PROF_DEC_RANS, 2 * rle_total, lds_cap, k_dec_rans, dim3(g), dim3(64), d_tab, info, d_status);
     JPK_LAUNCH(ctx, PROF_DEC_RLE, rle_total, k_dec_rle, dim3(g), dim3(1024), d_tab, info, d_status);
     JPK_LAUNCH_LDS(ctx, PROF_DEC_RANK, out_total, (lds_cap > 24576 ? lds_cap - 24576 : 0), k_dec_rank, dim3(g), dim3(64), d_tab, info, freq, d_status);

@@ -19,7 +19,7 @@ d_bwt = torch.empty(n + 480, dtype=torch.uint8, device=dev)
 ctx0.bwt_forward(d_in, n, d_bwt, n + 480)
 mode = sys.argv[1] if len(sys.argv) > 1 else "ans"
 if mode == "batch":
-    for N in (1, 4, 8, 16, 24, 32):
+    for N in [int(x) for x in os.environ.get("NLIST", "1,4,8,16,24,32").split(",")]:
         outs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(N)]
         encs = [d_enc[:clen].clone() for _ in range(N)]
         for rep in range(2):
