@@ -105,60 +105,73 @@ __global__ __launch_bounds__(256) void k_enc_prep(EncDims d, uint32_t *__restric
 
 // one wave per tile: wave-sequential MTF by time stamps + bucket scatter (rank.cpp:69-87).
 // The 256 time stamps live in 4 registers per lane for the rank (4 x v_cmp -> popcount); a per-wave LDS mirror
-// gives the previous occurrence of the current symbol, the bucket write positions and the (dest, rank) staging of a
-// 64-byte group with wave-uniform LDS accesses instead of register selects.
+// gives the previous occurrence of the current symbol and the bucket write positions with wave-uniform LDS accesses.
+// Only run HEADS are walked serially (a repeat has rank 0, leaves the recency order unchanged and lands right behind its
+// head in the same bucket): a ballot marks them in each 64-byte group, the loop visits the set bits, and every lane then
+// derives its own (destination, rank) from the record of the head at or before it.  All loop control is wave-uniform
+// (scalar branches, no exec-mask loops): the wave index is read with readfirstlane.
 __global__ __launch_bounds__(TB) void k_enc_mtf(const uint8_t *__restrict__ in, EncDims d, const uint32_t *__restrict__ tilebase,
                                                const int32_t *__restrict__ prevlast, const uint32_t *__restrict__ bstart,
                                                uint8_t *__restrict__ ranks)
 {
-    __shared__ int32_t s_last[TB / 64][256];
-    __shared__ uint32_t s_pos[TB / 64][256];
-    __shared__ uint32_t s_dst[TB / 64][64];
-    __shared__ uint32_t s_rk[TB / 64][64];
+    struct WaveLds {                       // one per wave; neighbours in one struct so that pairs of accesses share an address register
+        int32_t last[256];                 // time stamp of the last occurrence of every symbol (mirror of the registers)
+        uint32_t pos[256];                 // next write position of every symbol's bucket
+        uint32_t dst[64], rk[64];          // (bucket position, rank) of the heads of the group in flight
+    };
+    __shared__ WaveLds s_w[TB / 64];
     const uint32_t c = chunk_of(d, blockIdx.y);
-    const int w = threadIdx.x >> 6;
-    const uint32_t t = blockIdx.x * (TB / 64) + w;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t t = blockIdx.x * (TB / 64) + (uint32_t)w;
     const uint32_t clen = chunk_len(d, c), ts = t * ATILE;
     if (ts >= clen) return;
     const int l = lane_id();
     const size_t o = ((size_t)c * d.tpc + t) * 256;
     int32_t last0 = prevlast[o + l], last1 = prevlast[o + 64 + l], last2 = prevlast[o + 128 + l], last3 = prevlast[o + 192 + l];
     const uint32_t *bs = bstart + (size_t)c * 256;
-    int32_t *ll = s_last[w];
-    uint32_t *lp = s_pos[w], *ld = s_dst[w], *lr = s_rk[w];
-    ll[l] = last0; ll[64 + l] = last1; ll[128 + l] = last2; ll[192 + l] = last3;
+    WaveLds &L = s_w[w];
+    L.last[l] = last0; L.last[64 + l] = last1; L.last[128 + l] = last2; L.last[192 + l] = last3;
 #pragma unroll
-    for (int qq = 0; qq < 4; qq++) lp[qq * 64 + l] = bs[qq * 64 + l] + tilebase[o + qq * 64 + l];
+    for (int qq = 0; qq < 4; qq++) L.pos[qq * 64 + l] = bs[qq * 64 + l] + tilebase[o + qq * 64 + l];
     const uint8_t *src = in + (size_t)c * d.chunk;
     uint8_t *dst = ranks + (size_t)c * d.chunk;
-    uint32_t prevc = 256;
     const uint32_t te = (ts + ATILE < clen) ? ts + ATILE : clen;
+    const uint32_t sym0 = (uint32_t)l, sym1 = (uint32_t)l + 64u, sym2 = (uint32_t)l + 128u, sym3 = (uint32_t)l + 192u;     // my four symbols
+    uint32_t prevc = 256;                                                     // no byte before the tile: its first byte is a head
+    uint32_t bn = ((uint32_t)l < te - ts) ? src[ts + l] : 0x100u;             // group in flight
     for (uint32_t i0 = ts; i0 < te; i0 += 64) {
         const uint32_t nvalid = (te - i0 < 64u) ? te - i0 : 64u;
-        const uint32_t b = ((uint32_t)l < nvalid) ? src[i0 + l] : 0u;
-        for (uint32_t k = 0; k < nvalid; k++) {
-            const uint32_t cc = __builtin_amdgcn_readlane(b, k);
-            uint32_t rank = 0;
-            if (cc != prevc) {                         // a repeat has rank 0 and leaves the recency order unchanged
-                const int32_t own = ll[cc];
-                rank = (uint32_t)__popcll(__ballot(last0 > own)) + (uint32_t)__popcll(__ballot(last1 > own)) +
-                       (uint32_t)__popcll(__ballot(last2 > own)) + (uint32_t)__popcll(__ballot(last3 > own));
-                const int32_t nv = (int32_t)(i0 + k);
-                const uint32_t q = cc >> 6;
-                const bool mine = (uint32_t)l == (cc & 63u);
-                if (q == 0) last0 = mine ? nv : last0;
-                else if (q == 1) last1 = mine ? nv : last1;
-                else if (q == 2) last2 = mine ? nv : last2;
-                else last3 = mine ? nv : last3;
-                ll[cc] = nv;                           // every lane stores the same value
-                prevc = cc;
-            }
-            const uint32_t dpos = lp[cc];
-            lp[cc] = dpos + 1;
-            ld[k] = dpos;
-            lr[k] = rank;
+        const uint32_t b = bn;
+        if (i0 + 64 < te) bn = (i0 + 64 + (uint32_t)l < te) ? src[i0 + 64 + l] : 0x100u;      // next group, loaded under this one's walk
+        // byte before mine (lane 0: the last byte of the previous group)
+        uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp((int)prevc, (int)b, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        uint64_t rem = __ballot((uint32_t)l < nvalid && (b != pb || l == 0));     // lane 0 is always walked: a repeat gets rank 0 there
+        const uint64_t heads = rem;
+        while (rem) {
+            const uint32_t k = (uint32_t)__builtin_ctzll(rem);
+            rem &= rem - 1;
+            const uint32_t nk = rem ? (uint32_t)__builtin_ctzll(rem) : nvalid;
+            const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)k);
+            const int32_t own = L.last[cc];
+            const uint32_t dpos = L.pos[cc];
+            const uint32_t rank = (uint32_t)__popcll(__ballot(last0 > own)) + (uint32_t)__popcll(__ballot(last1 > own)) +
+                                  (uint32_t)__popcll(__ballot(last2 > own)) + (uint32_t)__popcll(__ballot(last3 > own));
+            const int32_t nv = (int32_t)(i0 + k);
+            last0 = (sym0 == cc) ? nv : last0;         // branch-free: one of the four compares hits in one lane
+            last1 = (sym1 == cc) ? nv : last1;
+            last2 = (sym2 == cc) ? nv : last2;
+            last3 = (sym3 == cc) ? nv : last3;
+            L.last[cc] = nv;                           // every lane stores the same value
+            L.pos[cc] = dpos + (nk - k);
+            L.dst[k] = dpos;
+            L.rk[k] = rank;
         }
-        if ((uint32_t)l < nvalid) dst[ld[l]] = (uint8_t)lr[l];
+        prevc = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)(nvalid - 1u));
+        if ((uint32_t)l < nvalid) {
+            const uint32_t hl = 63u - (uint32_t)__builtin_clzll(heads & ((2ull << l) - 1ull));     // my head (bit 0 is always set)
+            const uint32_t dp = L.dst[hl] + ((uint32_t)l - hl);
+            dst[dp] = ((uint32_t)l == hl) ? (uint8_t)L.rk[hl] : (uint8_t)0;
+        }
     }
 }
 
