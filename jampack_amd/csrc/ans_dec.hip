@@ -252,31 +252,41 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
 
 #define JPK_ICMP_ULT 36     // llvm::CmpInst::ICMP_ULT
 
-// refills inside the rare path keep >= 4 bytes queued, so the common path never looks at the queue
-#define JPK_RENORM(X)                                             \
-    if (__builtin_expect((X) < RANS_L, 0)) {                      \
-        (X) = ((X) << 8) | bq.take();                             \
-        if ((X) < RANS_L) (X) = ((X) << 8) | bq.take();           \
+// Both states of a symbol are renormalised in the slow block: up to four bytes leave the queue, in stream order (exponent
+// state first, ans.cpp:50-86), and one refill restores the >= 4 queued bytes the next symbol relies on.
+#define JPK_RENORM2(X, X2)                                        \
+    {                                                             \
+        if ((X) < RANS_L) {                                       \
+            (X) = ((X) << 8) | bq.take();                         \
+            if ((X) < RANS_L) (X) = ((X) << 8) | bq.take();       \
+        }                                                         \
+        if ((X2) < RANS_L) {                                      \
+            (X2) = ((X2) << 8) | bq.take();                       \
+            if ((X2) < RANS_L) (X2) = ((X2) << 8) | bq.take();    \
+        }                                                         \
         bq.top_up();                                              \
     }
 
-// one RLE0 symbol: exponent from state RA, mantissa from state RB (the states rotate, ans.cpp:50-86).
-// Instruction order matters on a single wave: the vector work that does not need the exponent (the mantissa
-// compare and candidates) and the model updates sit where the scalar unit would otherwise wait for a mask or a
-// v_readlane result; sched_barrier keeps the compiler from undoing that.
-#define JPK_DEC_SYMBOL(RA, RB)                                                                            \
+// one RLE0 symbol: exponent from state RA, mantissa from state RB (the states rotate, ans.cpp:50-86); LANEI = its lane in
+// the 64-symbol output tile.
+// Instruction order matters on a single wave: the exponent compare goes first so that the vector work that does not need
+// the exponent (candidates, mantissa compare) covers the wait of the scalar unit for its mask; the model updates sit where
+// the scalar unit would otherwise wait for a v_readlane result; sched_barrier keeps the compiler from undoing that.
+// A symbol pays one branch plus a quarter of the loop's: the slow block is entered when a model rebuild is due, when the
+// class is 6/7 (their lanes of `rem` hold 1 permanently) or when min(x, x2) says that a state needs bytes.
+#define JPK_DEC_SYMBOL(RA, RB, LANEI)                                                                     \
     {                                                                                                     \
         const uint32_t range = (RA) & 0xffffu, xs = (RA) >> 16;                                           \
         const uint32_t range2 = (RB) & 0xffffu, xs2 = (RB) >> 16;                                         \
         const uint64_t eabove = __builtin_amdgcn_uicmp(range, ehi, JPK_ICMP_ULT);                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
         const uint32_t ecand = __umul24(efr, xs) + (range - elo);                                         \
         const uint64_t qabove = __builtin_amdgcn_uicmp(range2, qhi, JPK_ICMP_ULT);                        \
         const uint32_t qcand = __umul24(qfr, xs2) + (range2 - qlo);                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                \
         const uint32_t e = (uint32_t)__builtin_ctz((uint32_t)eabove);                                     \
         uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)ecand, (int)e);                             \
-        /* symbol s = lane s; class e owns the lanes whose class is e.  For e >= 6 no lane matches: the guard bit      \
-           sends the (discarded) result to lane 0, whose count is never used, and the LDS block below takes over */    \
+        /* symbol s = lane s; class e owns the lanes whose class is e (none for e >= 6: the event block takes over) */ \
         const bool mine = lane_cls == e;                                                                  \
         const uint64_t minemask = __ballot(mine);                                                         \
         {   /* AdaptiveModel update (model.cpp:60-77): entry i = j + 1 lives in lane j */                 \
@@ -285,16 +295,16 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
             elo = dpp_row_shr1_zero(ehi);                                                                 \
             efr = ehi - elo;                                                                              \
         }                                                                                                 \
-        /* countdowns: lane e - 2 for a register class, lane 8 for the output tile */                     \
-        rem -= (cls_of_lane == e) ? 1u : tile_dec;                                                        \
-        const bool event = __builtin_amdgcn_uicmp(rem, 0u, 32 /* ICMP_EQ */) != 0;                        \
+        /* countdowns: lane e - 2 counts the symbols of class e until its rebuild (classes 6, 7: always due) */ \
+        rem -= (cls_of_lane == e) ? 1u : 0u;                                                              \
+        const uint64_t due = __builtin_amdgcn_uicmp(rem, 0u, 32 /* ICMP_EQ */);                           \
         __builtin_amdgcn_sched_barrier(0);                                                                \
-        uint32_t sym = (uint32_t)__builtin_ctzll((qabove & minemask) | (uint64_t)((e + 2u) >> 3));        \
+        /* for e >= 6 the mask is empty: s_ff1 returns -1, v_readlane takes lane 63 and no lane counts; the event block redoes both */ \
+        uint32_t sym;                                                                                     \
+        asm("s_ff1_i32_b64 %0, %1" : "=s"(sym) : "s"(qabove & minemask));                                 \
         uint32_t x2 = (uint32_t)__builtin_amdgcn_readlane((int)qcand, (int)sym);                          \
-        JPK_RENORM(x)                                                                                     \
-        (RA) = x;                                                                                         \
         {                                                                                                 \
-            qf += ((uint32_t)l == sym) ? 16u : 0u;                                         /* QuasiModel count */ \
+            qf += ((uint32_t)l == sym) ? 1u : 0u;                                /* QuasiModel count, in units of 16 */ \
             /* AdaptiveModel update of the alphabet-2 pair (lanes 2e, 2e+1) when e < 2: both lanes carry a = cdf[1] */ \
             const int32_t tgt = (sym & 1u) ? 1 : 65535;                                                   \
             const int32_t d = mine ? (tgt - (int32_t)qa) >> 5 : 0;                                        \
@@ -304,17 +314,22 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
             qfr = (uint32_t)(__mul24(d, sign_lane) + (int32_t)qfr);                                       \
         }                                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                \
-        const uint32_t range_m = range2, xs_m = xs2;                                                      \
-        if (__builtin_expect(e >= 6u, 0)) {                                                               \
-            /* classes 6 (64 symbols) and 7 (129): same lane-per-symbol search over one / three registers */ \
+        /* ONE test sends a symbol to the slow block: an event is due, or one of the two states needs bytes */ \
+        uint32_t gate;                                       /* 0 when an event is due, else min(x, x2) */ \
+        asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 0, %2" : "=s"(gate) : "s"(due), "s"(x < x2 ? x : x2) : "scc"); \
+        if (__builtin_expect(gate < RANS_L, 0)) {                                                         \
+          if (due != 0ull) {                                                                              \
+            const uint32_t range_m = range2, xs_m = xs2;                                                  \
             if (e == 6u) {                                                                                \
+                /* classes 6 (64 symbols) and 7 (129): same lane-per-symbol search over one / three registers */ \
                 const uint32_t cand = __umul24(fr6[0], xs_m) + (range_m - lo6[0]);                        \
                 const uint32_t m = (uint32_t)__builtin_ctzll(__builtin_amdgcn_uicmp(range_m, hi6[0], JPK_ICMP_ULT)); \
                 x2 = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)m);                              \
                 f6[0] += ((uint32_t)l == m) ? 16u : 0u;                                                   \
                 sym = 64u + m;                                                                            \
                 if (++seen6 > expn6) { quasi_rebuild_regs<1>(64, l, hi6, lo6, fr6, f6, expn6); seen6 = 0; } \
-            } else {                                                                                      \
+                rem = (l == 4) ? 1u : rem;                                                                \
+            } else if (e == 7u) {                                                                         \
                 const uint64_t a0 = __builtin_amdgcn_uicmp(range_m, hi7[0], JPK_ICMP_ULT);                \
                 const uint64_t a1 = __builtin_amdgcn_uicmp(range_m, hi7[1], JPK_ICMP_ULT);                \
                 uint32_t m;                                                                               \
@@ -334,23 +349,13 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
                 }                                                                                         \
                 sym = 128u + m;                                                                           \
                 if (++seen7 > expn7) { quasi_rebuild_regs<3>(129, l, hi7, lo7, fr7, f7, expn7); seen7 = 0; } \
-            }                                                                                             \
-        }                                                                                                 \
-        JPK_RENORM(x2)                                                                                    \
-        (RB) = x2;                                                                                        \
-        mysym = ((t & 63u) == (uint32_t)l) ? sym : mysym;                                                 \
-        t++;                                                                                              \
-        if (__builtin_expect(event, 0)) {                                                                 \
-            if (__builtin_amdgcn_readlane((int)rem, 8) == 0) {          /* 64 symbols collected */        \
-                out[t - 64 + l] = (uint16_t)mysym;                                                        \
-                rem = (l == 8) ? 64u : rem;                                                               \
-            }                                                                                             \
-            const uint32_t kl = e - 2u;                                                                   \
-            if (kl < 4u && __builtin_amdgcn_readlane((int)rem, (int)(kl & 3u)) == 0) {                    \
-                /* QuasiModel rebuild (model.cpp:160-204) of class e in its lanes [2^e, 2^(e+1)) */       \
+                rem = (l == 5) ? 1u : rem;                                                                \
+            } else {                                                                                      \
+                /* QuasiModel rebuild (model.cpp:160-204) of class e (2..5) in its lanes [2^e, 2^(e+1)) */ \
+                const uint32_t kl = e - 2u;                                                               \
                 const uint32_t A = 1u << e;                                                               \
-                const bool mine = ((uint32_t)l >> e) == 1u;                                               \
-                uint32_t F = mine ? qf : 0u;                                                              \
+                const bool mine = ((uint32_t)l >> e) == 1u;      /* shadows the symbol's flag: same lanes */ \
+                uint32_t F = mine ? qf << 4 : 0u;                                                         \
                 const uint32_t tot = wave_sum(F);                                                         \
                 int lg = 0;                                                                               \
                 while ((tot >> lg) + A > 65536u) lg++;                                                    \
@@ -366,7 +371,13 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
                 qexpn = ((uint32_t)l == kl) ? ex1 : qexpn;                                                \
                 rem = ((uint32_t)l == kl) ? ex1 + 1u : rem;                                               \
             }                                                                                             \
+          }                                                                                               \
+          JPK_RENORM2(x, x2)                                                                              \
         }                                                                                                 \
+        (RA) = x;                                                                                         \
+        (RB) = x2;                                                                                        \
+        /* value and lane select are both scalar: the lane select goes through M0 (one SGPR per VALU instruction on gfx9) */ \
+        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(mysym) : "s"(sym), "s"((uint32_t)(LANEI)) : "m0"); \
     }
 
 __global__ __launch_bounds__(64) void k_dec_rans(const DecBlock *__restrict__ blocks, const ChunkInfo *__restrict__ info, uint32_t *__restrict__ status_all)
@@ -397,8 +408,10 @@ __global__ __launch_bounds__(64) void k_dec_rans(const DecBlock *__restrict__ bl
     // symbols 0,1; class 1 = symbols 2,3; cdf[1] = 32768), lanes 4..63 the QuasiModels of classes 2..5 (uniform start).
     uint32_t qlo, qhi, qfr, qf = 0;
     const uint32_t lane_cls = (l < 2) ? 0u : (uint32_t)(31 - __clz(l));
-    const int32_t even_lane = (l < 4 && !(l & 1)) ? 1 : 0, odd_lane = (l < 4 && (l & 1)) ? 1 : 0;
-    const int32_t sign_lane = even_lane - odd_lane;
+    int32_t even_lane = (l < 4 && !(l & 1)) ? 1 : 0, odd_lane = (l < 4 && (l & 1)) ? 1 : 0;
+    int32_t sign_lane = even_lane - odd_lane;
+    // opaque to the optimiser: three v_mad_i32_i24 per symbol instead of select + add pairs
+    asm volatile("" : "+v"(even_lane), "+v"(odd_lane), "+v"(sign_lane));
     uint32_t qa = (l < 4) ? 32768u : 0u;                          // lanes 0..3: cdf[1] of the pair's AdaptiveModel
     {
         const int A = (l < 4) ? 2 : 1 << lane_cls, i = (l < 4) ? (l & 1) : l - A;
@@ -418,9 +431,9 @@ __global__ __launch_bounds__(64) void k_dec_rans(const DecBlock *__restrict__ bl
         fr7[j] = hi7[j] - lo7[j];
     }
     uint32_t qexpn = 8;                                          // lane k: EXP of class k + 2 (model.cpp:160-204)
-    uint32_t rem = (l < 4) ? 9u : (l == 8 ? 64u : 0x40000000u);  // lane k: symbols until the rebuild of class k + 2; lane 8: until the tile store
-    const uint32_t tile_dec = (l == 8) ? 1u : 0u;
-    const uint32_t cls_of_lane = (l < 4) ? (uint32_t)l + 2u : 99u;   // lane k counts down for class k + 2
+    // lane k < 4: symbols until the rebuild of class k + 2; lanes 4, 5: classes 6, 7 (always due: they decode in the event block)
+    uint32_t rem = (l < 4) ? 9u : ((l < 6) ? 1u : 0x40000000u);
+    const uint32_t cls_of_lane = (l < 6) ? (uint32_t)l + 2u : 99u;   // lane k counts down for class k + 2
     uint32_t R0, R1, R2, R3;
     {
         uint32_t b[16];
@@ -432,21 +445,35 @@ __global__ __launch_bounds__(64) void k_dec_rans(const DecBlock *__restrict__ bl
     }
     uint32_t mysym = 0;
     uint32_t t = 0;
-    while (t + 2 <= rlen) {
-        JPK_DEC_SYMBOL(R0, R1)
-        JPK_DEC_SYMBOL(R2, R3)
+    // whole tiles of 64 symbols: the tile is collected with v_writelane and stored once
+    for (; t + 64 <= rlen; t += 64) {
+        uint32_t j = 0;
+        do {
+            JPK_DEC_SYMBOL(R0, R1, j)
+            JPK_DEC_SYMBOL(R2, R3, j + 1)
+            JPK_DEC_SYMBOL(R0, R1, j + 2)
+            JPK_DEC_SYMBOL(R2, R3, j + 3)
+            j += 4;
+        } while (j < 64);
+        out[t + l] = (uint16_t)mysym;
     }
-    if (t < rlen) JPK_DEC_SYMBOL(R0, R1)
-    if (rlen & 63u) {
-        const uint32_t base = rlen & ~63u;
-        if (base + l < rlen) out[base + l] = (uint16_t)mysym;
+    {
+        // the last, partial tile one symbol at a time; the state pairs swap instead of a second copy of the symbol code (the
+        // final check below looks at all four states, whichever names they ended up under)
+        const uint32_t left = rlen - t;
+        for (uint32_t j = 0; j < left; j++) {
+            JPK_DEC_SYMBOL(R0, R1, j)
+            uint32_t sw = R0; R0 = R2; R2 = sw;
+            sw = R1; R1 = R3; R3 = sw;
+        }
+        if ((uint32_t)l < left) out[t + l] = (uint16_t)mysym;
     }
     // ans.cpp:91-92 (all four states back at the lower bound) and no byte taken from beyond the chunk's payload
     const bool bad = (R0 != RANS_L || R1 != RANS_L || R2 != RANS_L || R3 != RANS_L) || bq.taken > clen;
     if (bad && l == 0) atomicOr(status, 1u);
 }
 #undef JPK_DEC_SYMBOL
-#undef JPK_RENORM
+#undef JPK_RENORM2
 
 // ---------------------------------------------------------------------------------------------------------------
 // RLE0 decode: one workgroup per chunk.  Output is pre-zeroed, so only symbols > 1 are written; a digit group
