@@ -276,13 +276,19 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
 // class is 6/7 (their lanes of `rem` hold 1 permanently) or when min(x, x2) says that a state needs bytes.
 #define JPK_DEC_SYMBOL(RA, RB, LANEI)                                                                     \
     {                                                                                                     \
-        const uint32_t range = (RA) & 0xffffu, xs = (RA) >> 16;                                           \
-        const uint32_t range2 = (RB) & 0xffffu, xs2 = (RB) >> 16;                                         \
-        const uint64_t eabove = __builtin_amdgcn_uicmp(range, ehi, JPK_ICMP_ULT);                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-        const uint32_t ecand = __umul24(efr, xs) + (range - elo);                                         \
-        const uint64_t qabove = __builtin_amdgcn_uicmp(range2, qhi, JPK_ICMP_ULT);                        \
-        const uint32_t qcand = __umul24(qfr, xs2) + (range2 - qlo);                                       \
+        /* range = state & 0xffff and state >> 16 are taken straight from the scalar state by SDWA / op_sel operands:  \
+           v_cmp(range < HI), range - LO, FR * (state >> 16) + (range - LO) for the exponent and the mantissa model.   \
+           One block fixes the order (the SDWA results are consumed two instructions later; FR < 65536 fits u16) */  \
+        uint64_t eabove, qabove;                                                                          \
+        uint32_t et_, qt_, ecand, qcand;                                                                  \
+        asm("v_cmp_lt_u32_sdwa %0, %6, %7 src0_sel:WORD_0 src1_sel:DWORD\n\t"                            \
+            "v_sub_u32_sdwa %2, %6, %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t" \
+            "v_cmp_lt_u32_sdwa %1, %9, %10 src0_sel:WORD_0 src1_sel:DWORD\n\t"                           \
+            "v_sub_u32_sdwa %3, %9, %11 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t" \
+            "v_mad_u32_u16 %4, %12, %6, %2 op_sel:[0,1,0,0]\n\t"                                          \
+            "v_mad_u32_u16 %5, %13, %9, %3 op_sel:[0,1,0,0]"                                              \
+            : "=&s"(eabove), "=&s"(qabove), "=&v"(et_), "=&v"(qt_), "=&v"(ecand), "=&v"(qcand)            \
+            : "s"(RA), "v"(ehi), "v"(elo), "s"(RB), "v"(qhi), "v"(qlo), "v"(efr), "v"(qfr));              \
         __builtin_amdgcn_sched_barrier(0);                                                                \
         const uint32_t e = (uint32_t)__builtin_ctz((uint32_t)eabove);                                     \
         uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)ecand, (int)e);                             \
@@ -319,7 +325,7 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
         asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 0, %2" : "=s"(gate) : "s"(due), "s"(x < x2 ? x : x2) : "scc"); \
         if (__builtin_expect(gate < RANS_L, 0)) {                                                         \
           if (due != 0ull) {                                                                              \
-            const uint32_t range_m = range2, xs_m = xs2;                                                  \
+            const uint32_t range_m = (RB) & 0xffffu, xs_m = (RB) >> 16;                                   \
             if (e == 6u) {                                                                                \
                 /* classes 6 (64 symbols) and 7 (129): same lane-per-symbol search over one / three registers */ \
                 const uint32_t cand = __umul24(fr6[0], xs_m) + (range_m - lo6[0]);                        \
