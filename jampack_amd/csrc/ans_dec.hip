@@ -540,38 +540,67 @@ __global__ __launch_bounds__(1024) void k_dec_rle(const DecBlock *__restrict__ b
 
 // ---------------------------------------------------------------------------------------------------------------
 // sorted-rank decode (rank.cpp:96-151): one wave per chunk.
-// list: 256 byte positions held as one dword per lane (lane l = positions 4l..4l+3, little endian).
+// list: positions 0..63 are one symbol per lane of register L0, so that the common update -- insert at a rank below 64 --
+// is one DPP move, one select and one v_writelane.  Positions 64..255 are packed four to a lane in register P (lane l =
+// positions 64 + 4l .. 67 + 4l, little endian; lanes 48.. unused): ranks >= 64 (incompressible data) pay a full shift of L0
+// plus one branch-free byte shift-insert of P.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_shl1(uint32_t v)        // lane i <- lane i+1 (lane 63 keeps its value): one DPP move
 {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
 }
 
-__device__ __forceinline__ uint32_t list_shift_insert(uint32_t v, int l, uint32_t r, uint32_t sym)
+__device__ __forceinline__ uint32_t lane_write(uint32_t v, uint32_t value, uint32_t lane)      // v with lane `lane` = value (both wave-uniform)
 {
-    // positions < r take the value of position+1, position r takes sym, positions > r unchanged.  Branch-free:
-    // keep = bytes of this lane at or above position r (two half shifts, so that 4 bytes below r give 0).
+    // value and lane select are both scalar: the lane select goes through M0 (one SGPR per VALU instruction on gfx9)
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(value), "s"(lane) : "m0");
+    return v;
+}
+
+// packed register: byte positions < r take the value of position + 1; INSERT: position r takes sym.  Branch-free:
+// keep = bytes of this lane at or above position r (two half shifts, so that 4 bytes below r give 0).
+template <bool INSERT>
+__device__ __forceinline__ uint32_t packed_shift(uint32_t v, int l, uint32_t r, uint32_t sym)
+{
     const uint32_t nextv = wave_shl1(v);
     const uint32_t shifted = __builtin_amdgcn_alignbyte(nextv, v, 1);      // (v >> 8) | (nextv << 24)
     const int nb = (int)r - 4 * l;                                          // bytes of this lane below position r
     const uint32_t h = 4u * (uint32_t)(nb < 0 ? 0 : (nb > 4 ? 4 : nb));
     const uint32_t keep = (0xFFFFFFFFu << h) << h;
     uint32_t res = (v & keep) | (shifted & ~keep);
-    const uint32_t ins = ((uint32_t)nb < 4u) ? 0xFFu << (8u * ((uint32_t)nb & 3u)) : 0u;
-    return (res & ~ins) | ((sym * 0x01010101u) & ins);
+    if (INSERT) {
+        const uint32_t ins = ((uint32_t)nb < 4u) ? 0xFFu << (8u * ((uint32_t)nb & 3u)) : 0u;
+        res = (res & ~ins) | ((sym * 0x01010101u) & ins);
+    }
+    return res;
 }
 
-// Every symbol keeps the next 64 ranks of its bucket in an LDS row, one rank per dword (row[0] = the rank its next
+// positions < r take the value of position + 1; INSERT: position r takes sym (rank.cpp:131-134), else it keeps its value
+// (the front drop of an exhausted bucket, rank.cpp:140-147).  r <= 255.
+template <bool INSERT>
+__device__ __forceinline__ void list_shift(uint32_t &L0, uint32_t &P, int l, uint32_t r, uint32_t sym)
+{
+    const uint32_t nxt = wave_shl1(L0);
+    if (r < 64u) {
+        const uint32_t res = ((uint32_t)l < r) ? nxt : L0;
+        L0 = INSERT ? lane_write(res, sym, r) : res;
+    } else {
+        L0 = lane_write(nxt, rfl(P) & 0xffu, 63u);          // position 63 takes position 64 = byte 0 of P's lane 0
+        P = packed_shift<INSERT>(P, l, r - 64u, sym);
+    }
+}
+
+// Every symbol keeps the next 64 ranks of its bucket in an LDS row, one rank per byte (row[used] = the rank its next
 // occurrence reads), so the serial chain never waits for HBM: a run costs one LDS round trip, one ballot and one list
-// update.  Rows are consumed by shifting; a row that runs low is topped up by a direct-to-LDS load
-// (global_load_lds_ubyte: lane j's byte lands zero-extended in dword j behind the M0 base, no VGPR and therefore no
-// compiler-inserted wait).  Entries past the end of a bucket are 0xFF (non-zero: they end the zero run).
+// update.  A row that runs low is topped up by a direct-to-LDS load (global_load_lds_ubyte: lane j's byte lands
+// zero-extended in dword j behind the M0 base, no VGPR and therefore no compiler-inserted wait).  Entries past the end of
+// a bucket are 0xFF (non-zero: they end the zero run).
 //
-// The loop has a fast path for the common iteration -- a non-zero rank found inside the safe part of the row -- that
-// touches one counter of the row's metadata; everything else (end of a bucket, empty or low rows, landing a top-up,
-// the end of the chunk) goes through the general path, which also re-normalises the metadata.
+// The inner loop is the common iteration -- a non-zero rank found inside the safe part of the row, at least 64 bytes of
+// output left -- and touches one counter of the row's metadata; everything else (end of a bucket, empty or low rows,
+// landing a top-up, the last bytes of the chunk) goes through the general path, which also re-normalises the metadata.
 struct RankMeta {
-    uint32_t used;      // entries consumed by fast iterations since the last normalisation
+    uint32_t used;      // entries consumed by fast iterations since the last normalisation (the row is read from here on)
     uint32_t fast;      // fast iterations may consume this many entries (as of the last normalisation); 0 = row blocked
     uint32_t nv;        // known entries in the row (as of the last normalisation)
     uint32_t left;      // ranks of the bucket not yet consumed (as of the last normalisation)
@@ -584,6 +613,7 @@ constexpr uint32_t RANK_LOW = 24;          // top a row up when fewer known entr
 
 typedef const __attribute__((address_space(1))) void *jpk_gptr;
 typedef __attribute__((address_space(3))) void *jpk_lptr;
+typedef __attribute__((address_space(1))) uint8_t *jpk_gbytes;
 
 __device__ __forceinline__ uint32_t rank_fast_limit(uint32_t nv, uint32_t left, bool all_loaded)
 {
@@ -599,20 +629,20 @@ __global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ bl
     const uint32_t c = blockIdx.x;
     const int l = lane_id();
     const ChunkInfo ci = info[c];
-    const uint32_t len = ci.olen;
+    const uint32_t len = rfl(ci.olen);
     if (len == 0) return;
     const DecBlock B = blocks[ci.blk];
     const uint8_t *R = B.ranks + ci.out_off;     // rank array
     uint8_t *T = B.out + ci.out_off;             // decoded symbols
+    const jpk_gbytes Tg = (jpk_gbytes)T;
     __shared__ uint8_t rows[256][64];             // one byte per rank: 16 KiB, so that six chunks fit a CU (24 KiB each)
     __shared__ uint32_t stage[64];                // landing zone of the top-up in flight (LDS-DMA writes one dword per lane)
     __shared__ RankMeta meta[256];
     __shared__ RankSpan span[256];
     __shared__ uint32_t sf[256];
-    __shared__ uint32_t lst[64];
+    __shared__ uint32_t lst[256];
     const int32_t *fq = freq + (size_t)c * 256;
-    for (int s = l; s < 256; s += 64) sf[s] = (uint32_t)fq[s];
-    lst[l] = 0;
+    for (int s = l; s < 256; s += 64) { sf[s] = (uint32_t)fq[s]; lst[s] = 0; }
     __syncthreads();
     uint32_t uniq = 0;
     // bucket layout in GenerateSortedMap order; list[R[bucket start]] = symbol (rank.cpp:114-123)
@@ -631,10 +661,7 @@ __global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ bl
         sp.gpos = b + 1 + 64; sp.gend = b + f;
         span[s] = sp;
         g4[k] = b + 1; e4[k] = b + f;
-        if (f > 0) {
-            const uint32_t r0 = R[b];
-            atomicOr(&lst[r0 >> 2], (uint32_t)s << (8 * (r0 & 3u)));
-        }
+        if (f > 0) lst[R[b]] = (uint32_t)s;           // a corrupt stream may name a position twice: the last writer wins, as in rank.cpp
         uniq += (f > 0);
     }
     uniq = rfl(wave_sum(uniq));
@@ -646,38 +673,48 @@ __global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ bl
             rows[j + 64 * k][l] = (g + l < ge) ? R[g + l] : (uint8_t)0xFF;
         }
     __syncthreads();
-    uint32_t v = lst[l];
-    uint32_t sym = rfl(v) & 0xffu;
+    uint32_t L0 = lst[l];
+    uint32_t P = (l < 48) ? (lst[64 + 4 * l] | (lst[65 + 4 * l] << 8) | (lst[66 + 4 * l] << 16) | (lst[67 + 4 * l] << 24)) : 0u;
+    uint32_t sym = (uint32_t)__builtin_amdgcn_readlane((int)L0, 0);
     uint32_t psym = 256;                                         // row with a top-up in flight (256 = none); it is blocked (fast = 0)
     uint32_t poff = 0, pcnt = 0;                                 // ... its entries land at rows[psym][poff .. poff + pcnt)
     uint32_t i = 0;
-    // The row and metadata of the NEXT symbol are read one iteration ahead: a run that ends in a non-zero rank (or in
-    // the end of its bucket) always brings the second list entry to the front, whatever the rank is, so the only
-    // dependent chain from one fast iteration to the next is the list update itself.
-    uint32_t rl = rows[sym][l];                                  // physical order: entry (used + j) & 63 is the j-th unread rank
+    const uint32_t fast_end = rfl(len >= 64u ? len - 63u : 0u);  // the inner loop stores 64 bytes at i: it runs while i < fast_end
+    uint32_t rl = rows[sym][l];                                  // entry `used` is the next unread rank (no wrap between normalisations)
     RankMeta m = meta[sym];
-    while (i < len) {
-        const uint32_t nsym = (rfl(v) >> 8) & 0xffu;
-        const uint32_t nrl = rows[nsym][l];
-        const RankMeta nm = meta[nsym];
-        const uint32_t used = rfl(m.used), room = rfl(m.fast) - used;
-        const uint64_t nzp = __ballot(rl != 0);
-        const uint32_t rot = used & 63u;
-        const uint64_t nz = (nzp >> rot) | (nzp << ((64u - rot) & 63u));
-        const uint32_t z = nz ? (uint32_t)__builtin_ctzll(nz) : 64u;
-        const uint32_t rest = len - i;
-        if (__builtin_expect(z < (room < rest ? room : rest), 1)) {
-            // ---- fast path: z zero ranks, then the real non-zero rank; z + 1 outputs.  The row itself is not touched:
-            // fast iterations only advance `used` (they never look past the entries known at the last normalisation)
+    for (;;) {
+        // ---- inner loop: z zero ranks, then the real non-zero rank; z + 1 outputs.  The row itself is not touched: these
+        // iterations only advance `used` (they never look past the entries known at the last normalisation).  The row and
+        // metadata of the NEXT symbol are read before the list update: a run that ends in a non-zero rank always brings the
+        // second list entry to the front, whatever the rank is.
+        uint32_t big_r = 0, big_sym = 0;                        // a rank >= 64 leaves the loop for its insert (L0 and P), so that
+        for (;;) {                                               // the loop itself carries L0 only
+            const uint32_t used = rfl(m.used), room = rfl(m.fast) - used;
+            const uint64_t nz = __ballot(rl != 0) >> (used & 63u);
+            uint32_t z;
+            asm("s_ff1_i32_b64 %0, %1" : "=s"(z) : "s"(nz));    // no non-zero entry: -1, which fails the test below
+            uint32_t lim;                                        // room, or 0 behind fast_end (select on the scalar unit, no mask logic)
+            asm("s_cmp_lt_u32 %1, %2\n\ts_cselect_b32 %0, %3, 0" : "=s"(lim) : "s"(i), "s"(fast_end), "s"(room) : "scc");
+            if (!(z < lim)) break;
+            const uint32_t nsym = (uint32_t)__builtin_amdgcn_readlane((int)L0, 1);
+            const uint32_t nrl = rows[nsym][l];
+            const RankMeta nm = meta[nsym];
+            // all 64 lanes store: the bytes behind the run are rewritten by the runs that own them (same wave, program order)
+            // (issued as asm: the store is never waited for -- nothing in this kernel reads T -- and the compiler's wait-count
+            // bookkeeping for the LDS-DMA top-ups would otherwise put a vmcnt(0) in front of the next LDS read)
+            asm volatile("global_store_byte %0, %1, %2" : : "v"(i + (uint32_t)l), "v"(sym), "s"(Tg));
             const uint32_t cnt = z + 1u;
-            if ((uint32_t)l < cnt) T[i + l] = (uint8_t)sym;
             i += cnt;
-            const uint32_t r = __builtin_amdgcn_readlane(rl, (rot + z) & 63u);
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rl, (int)(used + z));
             meta[sym].used = used + cnt;                         // every lane stores the same word: cheaper than masking to one lane
-            v = list_shift_insert(v, l, r, sym);
+            const uint32_t cur = sym;
             sym = nsym; rl = nrl; m = nm;
-            continue;
+            if (__builtin_expect(r >= 64u, 0)) { big_r = r; big_sym = cur; break; }
+            const uint32_t nxt = wave_shl1(L0);
+            L0 = lane_write(((uint32_t)l < r) ? nxt : L0, cur, r);
         }
+        if (big_r) { list_shift<true>(L0, P, l, big_r, big_sym); continue; }
+        if (i >= len) break;
         // ---- general path ----
         if (psym < 256u) {                                       // land the top-up in flight and unblock its row
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -691,6 +728,8 @@ __global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ bl
             m = meta[sym];
             continue;
         }
+        const uint32_t used = rfl(m.used);
+        const uint32_t rest = len - i;
         const RankSpan sp = span[sym];
         const uint32_t gpos = rfl(sp.gpos), gend = rfl(sp.gend);
         const uint32_t nv = rfl(m.nv) - used, left = rfl(m.left) - used;
@@ -712,17 +751,13 @@ __global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ bl
         if (stop) {
             if (zk < left) {
                 const uint32_t r = __builtin_amdgcn_readlane(rlk, zk);       // the non-zero rank that ends the run
-                v = list_shift_insert(v, l, r, sym);
-                sym = rfl(v) & 0xffu;
+                list_shift<true>(L0, P, l, r, sym);
+                sym = (uint32_t)__builtin_amdgcn_readlane((int)L0, 0);
             } else if (uniq > 0) {                                           // bucket exhausted: drop the front
                 uniq--;
                 const uint32_t lim = uniq > 0 ? uniq : 1u;                  // rank.cpp:140-147; executes at least once
-                const uint32_t nextv = wave_shl1(v);
-                const uint32_t sh = (v >> 8) | (nextv << 24);
-                const int nb = (int)lim - 4 * l;
-                const uint32_t mask = nb <= 0 ? 0u : (nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u));
-                v = (sh & mask) | (v & ~mask);
-                sym = rfl(v) & 0xffu;
+                list_shift<false>(L0, P, l, lim, 0u);
+                sym = (uint32_t)__builtin_amdgcn_readlane((int)L0, 0);
             }
         }
         rows[cur][l] = (uint8_t)shifted;
