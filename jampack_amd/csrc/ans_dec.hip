@@ -136,6 +136,22 @@ __global__ __launch_bounds__(64) void k_dec_headers(const DecBlock *__restrict__
     }
 }
 
+// Launch order of the chains of a large batch: longest first (by RLE0 symbols, what both serial kernels' time follows), so that
+// the chains that set the length of the stage are not the ones that had to wait for a free slot.  n is a few thousand: every
+// chunk counts the chunks ahead of it.
+__global__ __launch_bounds__(256) void k_dec_order(const ChunkInfo *__restrict__ info, uint32_t n, uint32_t *__restrict__ order)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t key = info[t].rlen;
+    uint32_t before = 0;
+    for (uint32_t j = 0; j < n; j++) {
+        const uint32_t kj = info[j].rlen;
+        before += (kj > key || (kj == key && j < t)) ? 1u : 0u;
+    }
+    order[before] = t;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // rANS + model decode: one wave per chunk (ans.cpp:30-92).
 //
@@ -386,10 +402,11 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
         asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(mysym) : "s"(sym), "s"((uint32_t)(LANEI)) : "m0"); \
     }
 
-__global__ __launch_bounds__(64) void k_dec_rans(const DecBlock *__restrict__ blocks, const ChunkInfo *__restrict__ info, uint32_t *__restrict__ status_all)
+__global__ __launch_bounds__(64) void k_dec_rans(const DecBlock *__restrict__ blocks, const ChunkInfo *__restrict__ info, const uint32_t *__restrict__ order,
+                                                uint32_t *__restrict__ status_all)
 {
     __builtin_amdgcn_s_setprio(3);         // serial chain: win the issue arbitration on a shared SIMD
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = order ? order[blockIdx.x] : blockIdx.x;
     const int l = lane_id();
     const ChunkInfo ci = info[c];
     const DecBlock B = blocks[ci.blk];
@@ -622,11 +639,11 @@ __device__ __forceinline__ uint32_t rank_fast_limit(uint32_t nv, uint32_t left, 
     return a < slack ? a : slack;
 }
 
-__global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ blocks, const ChunkInfo *__restrict__ info, const int32_t *__restrict__ freq,
-                                                uint32_t *__restrict__ status_all)
+__global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ blocks, const ChunkInfo *__restrict__ info, const uint32_t *__restrict__ order,
+                                                const int32_t *__restrict__ freq, uint32_t *__restrict__ status_all)
 {
     __builtin_amdgcn_s_setprio(3);         // serial chain: win the issue arbitration on a shared SIMD
-    const uint32_t c = blockIdx.x;
+    const uint32_t c = order ? order[blockIdx.x] : blockIdx.x;
     const int l = lane_id();
     const ChunkInfo ci = info[c];
     const uint32_t len = rfl(ci.olen);
@@ -838,6 +855,7 @@ int jpk_ans_decode_batch(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in, con
     size_t off = arena_skip + tab_bytes + mail_bytes;
     auto take = [&](size_t bytes) { size_t o = off; off += jpk_align(bytes + 64); return o; };
     const size_t o_status = take((size_t)nblk * 4), o_info = take((size_t)nch_total * sizeof(ChunkInfo)), o_freq = take((size_t)nch_total * 256 * 4);
+    const size_t o_order = take((size_t)nch_total * 4);
     std::vector<size_t> o_rle((size_t)nblk), o_ranks((size_t)nblk);
     for (int b = 0; b < nblk; b++) { o_rle[b] = take(tot_rle[b] * 2); o_ranks[b] = take(tot_out[b]); }
     JPK_TRY(jpk_arena_ensure(ctx, off + 4096));            // may move the arena: every pointer is formed below
@@ -862,9 +880,15 @@ int jpk_ans_decode_batch(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in, con
     // bubbles and a second round of workgroups would wait for the first (64 blocks: 3.5 -> 4.8 GB/s, tools/dec_scaling.py).
     const unsigned g = (unsigned)nch_total;
     const size_t lds_cap = (size_t)(getenv("JPK_DEC_LDS") ? atoi(getenv("JPK_DEC_LDS")) : (g <= 1024u ? 40960 : 0));
-    JPK_LAUNCH_LDS(ctx, PROF_DEC_RANS, 2 * rle_total, lds_cap, k_dec_rans, dim3(g), dim3(64), d_tab, info, d_status);
+    // more chains than run at once: longest first (a few thousand chunks; beyond that the quadratic count is not worth it)
+    uint32_t *order = nullptr;
+    if (g > 1024u && g <= 16384u) {
+        order = reinterpret_cast<uint32_t *>(ctx->arena + o_order);
+        JPK_LAUNCH(ctx, PROF_DEC_HEADERS, 0, k_dec_order, dim3(jpk_grid(g, 256)), dim3(256), info, g, order);
+    }
+    JPK_LAUNCH_LDS(ctx, PROF_DEC_RANS, 2 * rle_total, lds_cap, k_dec_rans, dim3(g), dim3(64), d_tab, info, order, d_status);
     JPK_LAUNCH(ctx, PROF_DEC_RLE, rle_total, k_dec_rle, dim3(g), dim3(1024), d_tab, info, d_status);
-    JPK_LAUNCH_LDS(ctx, PROF_DEC_RANK, out_total, (lds_cap > 24576 ? lds_cap - 24576 : 0), k_dec_rank, dim3(g), dim3(64), d_tab, info, freq, d_status);
+    JPK_LAUNCH_LDS(ctx, PROF_DEC_RANK, out_total, (lds_cap > 24576 ? lds_cap - 24576 : 0), k_dec_rank, dim3(g), dim3(64), d_tab, info, order, freq, d_status);
     JPK_HIP(hipGetLastError());
     std::vector<uint32_t> hs((size_t)nblk);
     JPK_HIP(hipMemcpyAsync(hs.data(), d_status, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));
@@ -922,7 +946,7 @@ int jpk_rank_decode_device(jpk_ctx *ctx, uint8_t *d_r, const int32_t *d_freq, in
     JPK_HIP(hipMemcpyAsync(tab, &hb, sizeof hb, hipMemcpyHostToDevice, st));
     JPK_HIP(hipStreamSynchronize(st));
     uint32_t *status = ctx->d_mail + 8;
-    JPK_LAUNCH(ctx, PROF_DEC_RANK, 0, k_dec_rank, dim3(1), dim3(64), tab, info, hf, status);
+    JPK_LAUNCH(ctx, PROF_DEC_RANK, 0, k_dec_rank, dim3(1), dim3(64), tab, info, (const uint32_t *)nullptr, hf, status);
     JPK_HIP(hipGetLastError());
     JPK_HIP(hipMemcpyAsync(d_r, tmp, (size_t)len, hipMemcpyDeviceToDevice, st));
     JPK_HIP(hipStreamSynchronize(st));
