@@ -35,5 +35,7 @@ python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/bench.json"
 python3 bench.py --workload enwik9 --contexts 4 --steps 2 --warmup 1 --no-extras 2>/dev/null | tail -1 > "$OUT/bench_enwik9like_4ctx.json"
 python3 bench.py --workload silesia --block-mib 256 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_silesialike_256mib.json"
 python3 tools/worst_cases.py > "$OUT/worst_cases.txt" 2>/dev/null
-python3 tools/dec_scaling.py batch > "$OUT/decode_batch_scaling.txt" 2>/dev/null
+NLIST=1,4,8,16,24,32,48,64 python3 tools/dec_scaling.py batch > "$OUT/decode_batch_scaling.txt" 2>/dev/null
+python3 tools/stage_scaling.py 2>/dev/null | grep contexts > "$OUT/stage_scaling.txt"
+python3 tools/chunk_lens.py 2>/dev/null | grep -E "chunks|k_dec_" > "$OUT/decode_chain_lengths.txt"
 ls -la "$OUT"
