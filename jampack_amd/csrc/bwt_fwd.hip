@@ -658,24 +658,28 @@ __global__ __launch_bounds__(TB) void k_lg_hist(const uint32_t *__restrict__ key
                                                uint32_t *__restrict__ table)
 {
     constexpr int NB = 1 << DB;
-    __shared__ uint32_t h[WAVES][NB];
+    // the members of one group share the upper digits of their keys (ranks inside one old group), and LDS atomics on one
+    // address serialise: HC copies of the table per wave (lane l adds to copy l % HC), NB + 1 words apart (different banks)
+    constexpr int HC = 8, HS = NB + 1;
+    __shared__ uint32_t h[WAVES * HC * HS];
     const uint32_t np = st->npieces;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    uint32_t *mine = h + (w * HC + (l & (HC - 1))) * HS;
     for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
         const Piece q = pieces[p];
         __syncthreads();
-        for (int i = threadIdx.x; i < WAVES * NB; i += TB) (&h[0][0])[i] = 0;
+        for (int i = threadIdx.x; i < WAVES * HC * HS; i += TB) h[i] = 0;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < WIN_ITEMS; k++) {
             const uint32_t e = w * (64 * WIN_ITEMS) + k * 64 + l;
-            if (e < q.count) atomicAdd(&h[w][(key[q.begin + e] >> shift) & (uint32_t)(NB - 1)], 1u);
+            if (e < q.count) atomicAdd(&mine[(key[q.begin + e] >> shift) & (uint32_t)(NB - 1)], 1u);
         }
         __syncthreads();
         for (int d = threadIdx.x; d < NB; d += TB) {
             uint32_t s = 0;
 #pragma unroll
-            for (int k = 0; k < WAVES; k++) s += h[k][d];
+            for (int k = 0; k < WAVES * HC; k++) s += h[k * HS + d];
             table[(size_t)q.fp * NB + (size_t)d * q.nt + q.tl] = s;
         }
     }
