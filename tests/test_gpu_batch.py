@@ -73,3 +73,39 @@ def test_corrupt_block_is_isolated(gpu, oracle):
     ok = torch.empty(len(blocks[0]), dtype=torch.uint8, device=dev)
     good = torch.from_numpy(comp[0]).to(dev)
     assert ctx.block_decompress(good, len(comp[0]), ok, len(blocks[0])) == len(blocks[0]) and np.array_equal(ok.cpu().numpy(), blocks[0])
+
+
+def test_more_than_1024_chains_longest_first(gpu, oracle):
+    """A batch with more chunk chains than one launch wave of the GPU (> 1024) takes the longest-first launch order (k_dec_order)
+    and drops the one-chain-per-SIMD LDS reservation: 1104 blocks (138 distinct ones of ragged sizes and mixed content, eight
+    output buffers each) in ONE call, every block exact, two corrupted ones reported in their own slots."""
+    torch, jam, ctx = gpu
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(2024)
+    kinds = ["text_survey", "random", "runs", "geometric", "dna", "text"]
+    sizes = [int(x) for x in rng.integers(100, 40_000, size=134)] + [2_200_000, 1_048_576 - 480, 1_048_577 - 480, 3_000_000]
+    distinct = [jam.corpus.make(kinds[i % len(kinds)], n, 500 + i) for i, n in enumerate(sizes)]
+    dcomp = []
+    for i, t in enumerate(distinct):
+        d_t = torch.from_numpy(t).to(dev)
+        cap = jam.ans_capacity(len(t) + jam.TRAILER)
+        d_c = torch.empty(cap, dtype=torch.uint8, device=dev)
+        n = ctx.block_compress(d_t, len(t), d_c, cap)
+        dcomp.append(d_c[:n].clone())
+        if i % 23 == 0 or i >= 134:                      # the inputs of the batch are what the reference would have written
+            assert np.array_equal(dcomp[-1].cpu().numpy(), oracle.ans_encode(oracle.bwt_forward(t))), i
+    order = [int(x) for x in rng.permutation(np.repeat(np.arange(len(distinct)), 8))]
+    blocks = [distinct[k] for k in order]
+    comp = [dcomp[k] for k in order]
+    bad = {333, order.index(135)}
+    comp[333] = comp[333].clone(); comp[333][270] ^= 0x21          # rlen / payload of one block
+    j = order.index(135)
+    comp[j] = comp[j][: comp[j].numel() - 9]                        # one copy of the 1 MiB-chunk block loses its tail
+    d_out = [torch.empty(max(len(t), 1), dtype=torch.uint8, device=dev) for t in blocks]
+    n, st = ctx.blocks_decompress(comp, [int(c.numel()) for c in comp], d_out, [len(t) for t in blocks])
+    assert ctx.stats().ans_chunks > 1024
+    for i, t in enumerate(blocks):
+        if i in bad:
+            assert st[i] in (-3, -2), (i, st[i])
+        else:
+            assert st[i] == 0 and n[i] == len(t) and np.array_equal(d_out[i][: n[i]].cpu().numpy(), t), i
