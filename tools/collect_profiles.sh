@@ -39,3 +39,4 @@ NLIST=1,4,8,16,24,32,48,64 python3 tools/dec_scaling.py batch > "$OUT/decode_bat
 python3 tools/stage_scaling.py 2>/dev/null | grep contexts > "$OUT/stage_scaling.txt"
 python3 tools/chunk_lens.py 2>/dev/null | grep -E "chunks|k_dec_" > "$OUT/decode_chain_lengths.txt"
 ls -la "$OUT"
+python3 tools/block_sizes.py 2>/dev/null > "$OUT/block_sizes.txt"
