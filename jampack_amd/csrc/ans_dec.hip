@@ -562,9 +562,9 @@ __global__ __launch_bounds__(1024) void k_dec_rle(const DecBlock *__restrict__ b
 // positions 64 + 4l .. 67 + 4l, little endian; lanes 48.. unused): ranks >= 64 (incompressible data) pay a full shift of L0
 // plus one branch-free byte shift-insert of P.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_shl1(uint32_t v)        // lane i <- lane i+1 (lane 63 keeps its value): one DPP move
+__device__ __forceinline__ uint32_t wave_shl1(uint32_t v)        // lane i <- lane i+1, lane 63 <- 0 (no user reads it): one DPP move
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);      // bound_ctrl: no tied old value, no copy
 }
 
 __device__ __forceinline__ uint32_t lane_write(uint32_t v, uint32_t value, uint32_t lane)      // v with lane `lane` = value (both wave-uniform)
