@@ -1,9 +1,10 @@
 // ans_dec.hip -- Ans::Decode (ans.cpp:236-270) on gfx950.
-//   header walk (ans.cpp:254-261, ReadHeader :287-302)           one lane, chunk chain is serial by format
+//   header walk (ans.cpp:254-261, ReadHeader :287-302)           one wave per block (terminator ballot), chunk chain serial by format
 //   rANS + model decode (Threaded_Decode, ans.cpp:30-92)          one wave per chunk; lanes = CDF entries
 //   RLE0 decode (rle.cpp:52-74)                                   one workgroup per chunk, scan based
-//   sorted-rank decode (rank.cpp:96-151)                          one wave per chunk; the 256-entry list is one
-//                                                                 byte-vector register (4 positions per lane)
+//   sorted-rank decode (rank.cpp:96-151)                          one wave per chunk; list positions 0..63 one per lane,
+//                                                                 64..255 packed four to a lane
+// Batches of blocks run ONE grid per serial kernel over the chunks of all blocks (longest chains first beyond 1024).
 // The entropy decoder is sequential inside a chunk by construction of the format (shared byte pointer of the
 // four rANS states, adaptive models, bucket hopping of the rank decoder); parallelism comes from the chunks.
 #include <vector>

@@ -5,15 +5,14 @@
 // Parallel restructuring (bytes identical to the reference):
 //   rank coding   MTF rank of byte i = #symbols whose last occurrence is later than the previous occurrence of
 //                 T[i]; last-occurrence tables are carried across 4 KiB tiles by a per-symbol max-scan, so every
-//                 tile is an independent wave-sequential pass (lanes hold the 256 time stamps, v_cmp -> popcount);
-//                 the bucket scatter uses per-tile per-symbol prefix counts.
+//                 tile is an independent wave-sequential pass over its run heads (lanes hold the 256 time stamps,
+//                 v_cmp -> popcount); the bucket scatter uses per-tile per-symbol prefix counts.
 //   RLE0          run heads found per tile, run lengths through a per-chunk "zeros that follow the tile" table,
 //                 output offsets by scans.
 //   models        QuasiModel tables only change at fixed per-class symbol counts -> built in parallel from
 //                 per-interval histograms; the AdaptiveModel CDF entries are independent scalar recurrences.
 //   rANS          pair j lives in state lane j mod 4 -> four independent sequential chains per chunk that record
 //                 (bytes, count) per step; byte positions are a prefix sum; payload scattered afterwards.
-#include <algorithm>
 #include <vector>
 
 #include "ans_common.hpp"
