@@ -14,6 +14,10 @@
 
 using namespace jpk;
 
+// v_writelane with a scalar value AND a scalar lane select needs the lane select in M0 (one SGPR per VALU instruction on gfx9);
+// the asm statements that do so name M0 as clobbered, which is what keeps the compiler's own M0 users (the LDS-DMA top-ups) correct
+#pragma clang diagnostic ignored "-Winline-asm"
+
 namespace {
 
 
