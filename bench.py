@@ -263,8 +263,9 @@ def main():
     order = sorted(range(len(blocks)), key=lambda i: -len(blocks[i]))          # largest first
     lanes = [order[k::nctx] for k in range(nctx)]
     nblk = len(blocks)
-    # every context owns its output buffers (two per block: the RCCL gather of step s reads while step s+1 is being written)
-    out_bufs = [[[torch.empty(caps[i], dtype=torch.uint8, device=dev) for i in range(nblk)] for _ in (0, 1)] for _ in range(nctx)]
+    # every context owns its output buffers (NSETS per block: the RCCL gather of step s reads while steps s+1 .. s+NSETS-1 are being written)
+    NSETS = 4
+    out_bufs = [[[torch.empty(caps[i], dtype=torch.uint8, device=dev) for i in range(nblk)] for _ in range(NSETS)] for _ in range(nctx)]
 
     sizes = [0] * nblk
     gathered = [None]
@@ -295,7 +296,7 @@ def main():
                     return
                 s_, i = item
                 try:
-                    n = ctxs[k].block_compress(inputs[i], len(blocks[i]), out_bufs[k][s_ & 1][i], caps[i])
+                    n = ctxs[k].block_compress(inputs[i], len(blocks[i]), out_bufs[k][s_ % NSETS][i], caps[i])
                 except Exception as ex:       # noqa: BLE001 -- reported by the main thread
                     err.append(ex)
                     n = -1
@@ -308,15 +309,15 @@ def main():
         for t_ in th:
             t_.start()
         gather = gather and use_dist
-        depth = 2 if gather else nsteps            # steps ahead of the one whose gather is pending
+        depth = NSETS if gather else nsteps        # steps in flight, the one whose gather is pending included
         for s_ in range(min(depth, nsteps)):
             enqueue(s_)
         for s_ in range(nsteps):
             with cond:
                 cond.wait_for(lambda: remaining[s_] == 0)
             if gather:
-                gathered[0] = shard.gather_blocks([out_bufs[res[s_][i][0]][s_ & 1][i][: max(res[s_][i][1], 0)] for i in range(nblk)], dst=0, device=dev)
-                torch.cuda.current_stream().synchronize()      # the gather has read this parity's buffers before step s+2 may write them
+                gathered[0] = shard.gather_blocks([out_bufs[res[s_][i][0]][s_ % NSETS][i][: max(res[s_][i][1], 0)] for i in range(nblk)], dst=0, device=dev)
+                torch.cuda.current_stream().synchronize()      # the gather has read this buffer set before step s+NSETS may write it
             if s_ + depth < nsteps:
                 enqueue(s_ + depth)
         for _ in th:
@@ -331,7 +332,7 @@ def main():
                 result[i] = last[i][1]
             else:
                 sizes[i] = last[i][1]
-                d_out[i] = out_bufs[last[i][0]][(nsteps - 1) & 1][i]
+                d_out[i] = out_bufs[last[i][0]][(nsteps - 1) % NSETS][i]
 
     def lane_work(k):
         for i in lanes[k]:
@@ -642,6 +643,13 @@ def main():
                        "parallelism": par + f", {nctx} blocks in flight per GPU, passes enqueued back to back through a work queue (no host join between steps)"},
         }
         line.update(extra)
+        # RCCL prints its version banner through C stdio, which sits in a buffer until exit when stdout is a pipe: push it out
+        # first so that the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:       # noqa: BLE001
+            pass
         print(json.dumps(line), flush=True)
     pool.shutdown()
     for c in ctxs:
