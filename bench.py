@@ -276,7 +276,12 @@ def main():
         other without a host-side join; `--contexts` blocks are in flight at any time.  With more than one rank the compressed
         blocks of step s are gathered on rank 0 (the path's only exchange: all_gather of the sizes, one gather of a buffer padded
         to the largest rank total, RCCL over xGMI; jampack_amd/shard.py) while step s+1 is being compressed."""
-        if nsteps <= 0 or nblk == 0:
+        if nsteps <= 0:
+            return
+        if nblk == 0:                    # more ranks than blocks: this rank still takes part in every gather
+            if gather and use_dist:
+                for _ in range(nsteps):
+                    shard.gather_blocks([], dst=0, device=dev)
             return
         inputs = d_in if inputs is None else inputs
         q = queue.Queue()
