@@ -279,11 +279,11 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
     {                                                             \
         if ((X) < RANS_L) {                                       \
             (X) = ((X) << 8) | bq.take();                         \
-            if ((X) < RANS_L) (X) = ((X) << 8) | bq.take();       \
+            if (__builtin_expect((X) < RANS_L, 0)) (X) = ((X) << 8) | bq.take();       \
         }                                                         \
         if ((X2) < RANS_L) {                                      \
             (X2) = ((X2) << 8) | bq.take();                       \
-            if ((X2) < RANS_L) (X2) = ((X2) << 8) | bq.take();    \
+            if (__builtin_expect((X2) < RANS_L, 0)) (X2) = ((X2) << 8) | bq.take();    \
         }                                                         \
         bq.top_up();                                              \
     }
@@ -345,7 +345,7 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
         uint32_t gate;                                       /* 0 when an event is due, else min(x, x2) */ \
         asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 0, %2" : "=s"(gate) : "s"(due), "s"(x < x2 ? x : x2) : "scc"); \
         if (__builtin_expect(gate < RANS_L, 0)) {                                                         \
-          if (due != 0ull) {                                                                              \
+          if (__builtin_expect(due != 0ull, 0)) {        /* most visits are renormalisations */           \
             const uint32_t range_m = (RB) & 0xffffu, xs_m = (RB) >> 16;                                   \
             if (e == 6u) {                                                                                \
                 /* classes 6 (64 symbols) and 7 (129): same lane-per-symbol search over one / three registers */ \
