@@ -222,7 +222,7 @@ struct ByteQueue {
     uint32_t di;              // next dword of the stream to enter the queue
     uint64_t buf;             // queued bytes, next one in bits 7:0
     uint32_t nb;              // bytes in the queue
-    uint32_t taken;           // payload bytes consumed so far
+    uint32_t skip;            // bytes in front of the payload in the first dword (alignment)
     int l;
     __device__ __forceinline__ uint32_t load(uint32_t w) const
     {
@@ -249,19 +249,20 @@ struct ByteQueue {
         gbase = (p - a) - input;
         cur = load(0);
         nxt = load(1);
-        di = 0; buf = 0; nb = 0; taken = 0;
+        di = 0; buf = 0; nb = 0; skip = a;
         refill();
         buf >>= 8u * a;
         nb -= a;
         refill();
     }
     __device__ __forceinline__ void top_up() { if (__builtin_expect(nb < 4u, 0)) refill(); }      // leaves nb >= 4
+    // payload bytes consumed so far: what entered the queue minus what is still queued (not counted per byte)
+    __device__ __forceinline__ uint32_t taken() const { return 4u * di - skip - nb; }
     __device__ __forceinline__ uint32_t take()
     {
         const uint32_t b = (uint32_t)buf & 0xffu;
         buf >>= 8;
         nb--;
-        taken++;
         return b;
     }
 };
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(64) void k_dec_rans(const DecBlock *__restrict__ bl
         if ((uint32_t)l < left) out[t + l] = (uint16_t)mysym;
     }
     // ans.cpp:91-92 (all four states back at the lower bound) and no byte taken from beyond the chunk's payload
-    const bool bad = (R0 != RANS_L || R1 != RANS_L || R2 != RANS_L || R3 != RANS_L) || bq.taken > clen;
+    const bool bad = (R0 != RANS_L || R1 != RANS_L || R2 != RANS_L || R3 != RANS_L) || bq.taken() > clen;
     if (bad && l == 0) atomicOr(status, 1u);
 }
 #undef JPK_DEC_SYMBOL
