@@ -624,7 +624,7 @@ __device__ __forceinline__ void list_shift(uint32_t &L0, uint32_t &P, int l, uin
 // landing a top-up, the last bytes of the chunk) goes through the general path, which also re-normalises the metadata.
 struct RankMeta {
     uint32_t used;      // entries consumed by fast iterations since the last normalisation (the row is read from here on)
-    uint32_t fast;      // fast iterations may consume this many entries (as of the last normalisation); 0 = row blocked
+    uint32_t fast;      // fast iterations may consume this many entries (as of the last normalisation)
     uint32_t nv;        // known entries in the row (as of the last normalisation)
     uint32_t left;      // ranks of the bucket not yet consumed (as of the last normalisation)
 };
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ bl
     uint32_t L0 = lst[l];
     uint32_t P = (l < 48) ? (lst[64 + 4 * l] | (lst[65 + 4 * l] << 8) | (lst[66 + 4 * l] << 16) | (lst[67 + 4 * l] << 24)) : 0u;
     uint32_t sym = (uint32_t)__builtin_amdgcn_readlane((int)L0, 0);
-    uint32_t psym = 256;                                         // row with a top-up in flight (256 = none); it is blocked (fast = 0)
+    uint32_t psym = 256;                                         // row with a top-up in flight (256 = none)
     uint32_t poff = 0, pcnt = 0;                                 // ... its entries land at rows[psym][poff .. poff + pcnt)
     uint32_t i = 0;
     const uint32_t fast_end = rfl(len >= 64u ? len - 63u : 0u);  // the inner loop stores 64 bytes at i: it runs while i < fast_end
@@ -795,7 +795,9 @@ __global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ bl
             if ((uint32_t)l < pcnt)
                 __builtin_amdgcn_global_load_lds((jpk_gptr)(R + gpos + l), (jpk_lptr)(&stage[0]), 1, 0, 0);
             psym = cur;
-            w.fast = 0;                                                      // blocked until the top-up has landed
+            // the known entries stay readable while the top-up is in flight (it lands behind them): the row only stops the
+            // inner loop when they run out, and by then the load has had the time of ~24 of this symbol's runs
+            w.fast = rank_fast_limit(nv2, left2, true);
             if (l == 0) span[cur].gpos = gpos + want;
         } else {
             w.fast = rank_fast_limit(nv2, left2, all_loaded);
