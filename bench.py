@@ -422,6 +422,34 @@ def main():
         extra["stages_ms"] = {k: round(v, 3) for k, v in stage_ms.items()}
         extra["stages_MBps"] = {k: round(mb / (v / 1e3), 1) for k, v in stage_ms.items() if v > 0}
         extra["stages_reps"] = reps
+        # roofline: one profiled compress pass, one block at a time (HIP events around every kernel on its launch stream).  It runs
+        # BEFORE the extras that create more contexts: streams are dealt onto the hardware queues round robin at creation, and a chain
+        # kernel whose stream shares a queue with another group's stream is timed from its event, i.e. including its wait in the queue
+        # (seen as 13-17 ms per launch instead of the 9.8 ms the kernel trace shows)
+        ctx.profile_enable(2)
+        for i, b in enumerate(blocks):
+            ctx.block_compress(d_in[i], len(b), d_out[i], caps[i])
+        tab = ctx.profile_table()
+        ctx.profile_enable(0)
+        rows = []
+        for r in tab:
+            bpu = ALG_BYTES_PER_UNIT.get(r["name"])
+            if not bpu or not r["units"] or r["ms"] <= 0:
+                continue
+            ach = bpu[0] * r["units"] / 1e9 / (r["ms"] / 1e3)
+            rows.append({"kernel": r["name"], "ms_total": round(r["ms"], 3), "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
+                         "alg_bytes_per_unit": bpu[0], "unit_is": bpu[1], "units": r["units"], "achieved": round(ach, 2), "frac": round(ach / 8000.0, 5),
+                         "limited_by": bpu[2]})
+        rows.sort(key=lambda r: -r["ms_total"])
+        if rows:
+            d0 = rows[0]
+            traffic, pmc_file = pmc_traffic(d0["kernel"])
+            extra["roofline"] = {"bound": "hbm" if d0["limited_by"].startswith("hbm") else d0["limited_by"], "achieved": d0["achieved"], "peak": 8000.0, "unit": "GB/s",
+                                 "frac": d0["frac"], "traffic": traffic,
+                                 "kernel": d0["kernel"], "limited_by": d0["limited_by"], "avg_launch_us": d0["avg_launch_us"], "launches": d0["launches"],
+                                 "alg_bytes_per_launch": round(d0["alg_bytes_per_unit"] * d0["units"] / d0["launches"]),
+                                 "note": f"dominant kernel class of the compress pass by total time; achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream); traffic = PMC bytes per launch from profiles/{pmc_file}; peak = HBM spec; limited_by says what the class is really bound by (DESIGN.md section 4)"}
+            extra["roofline_kernels"] = rows[:8]
         # decompress leg (rANS decode -> inverse BWT, jampack.cpp:49-50) over the same batch, blocks in flight like compress
         d_cmp = [d_out[i][: sizes[i]].clone() for i in range(len(blocks))]
         d_dcm = [torch.empty(max(len(b), 1), dtype=torch.uint8, device=dev) for b in blocks]
@@ -577,30 +605,6 @@ def main():
         extra["compress_alg"] = {"bytes_per_byte": round(14.0 + c, 2), "achieved_GBps": round((14.0 + c) * batch_bytes / 1e9 / (ms_per_step / 1e3), 2),
                                  "frac": round((14.0 + c) * batch_bytes / 1e9 / (ms_per_step / 1e3) / 8000.0, 5), "one_block_at_a_time_ms": round(comp_ms, 3)}
         # per-kernel HIP-event timing (events recorded by the library on the launch stream) of one more compress pass
-        ctx.profile_enable(2)
-        for i, b in enumerate(blocks):
-            ctx.block_compress(d_in[i], len(b), d_out[i], caps[i])
-        tab = ctx.profile_table()
-        ctx.profile_enable(0)
-        rows = []
-        for r in tab:
-            bpu = ALG_BYTES_PER_UNIT.get(r["name"])
-            if not bpu or not r["units"] or r["ms"] <= 0:
-                continue
-            ach = bpu[0] * r["units"] / 1e9 / (r["ms"] / 1e3)
-            rows.append({"kernel": r["name"], "ms_total": round(r["ms"], 3), "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
-                         "alg_bytes_per_unit": bpu[0], "unit_is": bpu[1], "units": r["units"], "achieved": round(ach, 2), "frac": round(ach / 8000.0, 5),
-                         "limited_by": bpu[2]})
-        rows.sort(key=lambda r: -r["ms_total"])
-        if rows:
-            d0 = rows[0]
-            traffic, pmc_file = pmc_traffic(d0["kernel"])
-            extra["roofline"] = {"bound": "hbm" if d0["limited_by"].startswith("hbm") else d0["limited_by"], "achieved": d0["achieved"], "peak": 8000.0, "unit": "GB/s",
-                                 "frac": d0["frac"], "traffic": traffic,
-                                 "kernel": d0["kernel"], "limited_by": d0["limited_by"], "avg_launch_us": d0["avg_launch_us"], "launches": d0["launches"],
-                                 "alg_bytes_per_launch": round(d0["alg_bytes_per_unit"] * d0["units"] / d0["launches"]),
-                                 "note": f"dominant kernel class of the compress pass by total time; achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream); traffic = PMC bytes per launch from profiles/{pmc_file}; peak = HBM spec; limited_by says what the class is really bound by (DESIGN.md section 4)"}
-            extra["roofline_kernels"] = rows[:8]
         if args.workload == "enwik8" and not args.limit_bytes:
             # the same step on the phrase-book text (deeper repeats, ratio ~10 %): round 1's headline corpus, kept for comparison
             pdata, _ = corpus.load_or_make("enwik8-phrase")
