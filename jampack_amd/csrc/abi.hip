@@ -2,6 +2,7 @@
 // host-buffer (drop-in) entry points, and the fused block pipeline.  No CPU fallback: without a gfx950 device
 // every entry point returns JPK_E_NODEVICE.
 #include <chrono>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -292,6 +293,10 @@ extern "C" const char *jpk_strerror(int s)
 extern "C" const char *jpk_version(void) { return "jampack_amd 0.1 (gfx950)"; }
 
 // ---- device-buffer entry points ----------------------------------------------------------------------------
+namespace { std::atomic<int> g_compress_inflight{0}; }
+int jpk_compress_inflight_enter() { return g_compress_inflight.fetch_add(1, std::memory_order_relaxed) + 1; }
+void jpk_compress_inflight_leave() { g_compress_inflight.fetch_sub(1, std::memory_order_relaxed); }
+
 #define JPK_ENTER(ctx)                         \
     if (!(ctx)) return JPK_E_ARG;              \
     JPK_HIP(hipSetDevice((ctx)->device))

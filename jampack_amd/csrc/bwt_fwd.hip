@@ -1211,6 +1211,7 @@ int jpk_suffix_array_device(jpk_ctx *ctx, const uint8_t *d_t, int32_t n, int32_t
 
 int jpk_fwd_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out)
 {
+    const JpkCompressInflight inflight;      // counted while this block is in its suffix sort
     const int32_t rem = len % JPK_BWT_UNITS, nlen = len - rem;
     if (nlen <= 0) {
         // bwt.cpp:29-35: only the raw tail is produced; the 480 trailer bytes are left untouched

@@ -146,6 +146,17 @@ int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n, uint
 // work: enter() makes ctx->stream wait for the previous holder's events; jpk_gate_mark() records one of this context's
 // events on a stream; leave() publishes them and releases the gate.  The gate is held while the heavy phases are being
 // ENQUEUED.
+// compress-side calls (forward BWT, rANS encode) of all contexts of the process that are running right now: the encoder cuts its
+// chains into fewer launch groups when other blocks are in flight (abi.hip)
+int jpk_compress_inflight_enter();        // returns the count including the caller
+void jpk_compress_inflight_leave();
+struct JpkCompressInflight {
+    int n;
+    JpkCompressInflight() : n(jpk_compress_inflight_enter()) {}
+    ~JpkCompressInflight() { jpk_compress_inflight_leave(); }
+    JpkCompressInflight(const JpkCompressInflight &) = delete;
+    JpkCompressInflight &operator=(const JpkCompressInflight &) = delete;
+};
 int jpk_gate_enter(jpk_ctx *ctx);
 int jpk_gate_mark(jpk_ctx *ctx, hipStream_t stream);
 void jpk_gate_leave(jpk_ctx *ctx);
