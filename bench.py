@@ -486,12 +486,13 @@ def main():
         ok = ok and all(dsz[i] == len(blocks[i]) and bool(torch.equal(d_dcm[i][: len(blocks[i])], d_in[i])) for i in range(len(blocks)))
         # the same passes in flight, as the compress loop runs them: `ndec` contexts each take whole passes (one batched call per
         # pass) from a queue; a block is 65 serial chains, so a pass alone leaves most of the 1024 SIMDs without a chain
-        ndec = 8
-        dctxs = [jam.Context(local_rank, None) for _ in range(ndec)]
-        dbufs = [[torch.empty(max(len(b), 1), dtype=torch.uint8, device=dev) for b in blocks] for _ in range(ndec)]
-        dok = [True] * ndec
+        ndec = int(os.environ.get("JPK_BENCH_DEC_PASSES", "8"))
+        ndec_max = max(16, ndec)
+        dctxs = [jam.Context(local_rank, None) for _ in range(ndec_max)]
+        dbufs = [[torch.empty(max(len(b), 1), dtype=torch.uint8, device=dev) for b in blocks] for _ in range(ndec_max)]
+        dok = [True] * ndec_max
 
-        def dec_passes(npass):
+        def dec_passes(npass, nthreads):
             q_ = queue.Queue()
             for _ in range(npass):
                 q_.put(1)
@@ -505,26 +506,30 @@ def main():
                     n_, st_ = dctxs[k].blocks_decompress(d_cmp, sizes, dbufs[k], [len(b) for b in blocks])
                     dok[k] = dok[k] and all(st_[i] == 0 and n_[i] == len(blocks[i]) for i in range(len(blocks)))
 
-            th_ = [threading.Thread(target=w_, args=(k,)) for k in range(ndec)]
+            th_ = [threading.Thread(target=w_, args=(k,)) for k in range(nthreads)]
             for t_ in th_:
                 t_.start()
             for t_ in th_:
                 t_.join()
 
-        dec_passes(ndec)
+        dec_passes(ndec_max, ndec_max)             # every context has decoded once (arenas sized)
         torch.cuda.synchronize()
-        npass = max(2 * ndec, reps)
-        tp0 = time.perf_counter()
-        dec_passes(npass)
-        torch.cuda.synchronize()
-        tdp = (time.perf_counter() - tp0) / npass
-        ok = ok and all(dok) and all(bool(torch.equal(dbufs[k][i][: len(blocks[i])], d_in[i])) for k in range(ndec) for i in range(len(blocks)))
+        in_flight = {}
+        for nfl in sorted({4, ndec, 16}):
+            npass = max(2 * nfl, reps)
+            tp0 = time.perf_counter()
+            dec_passes(npass, nfl)
+            torch.cuda.synchronize()
+            in_flight[nfl] = ((time.perf_counter() - tp0) / npass, npass)
+        tdp, npass = in_flight[ndec]
+        ok = ok and all(dok) and all(bool(torch.equal(dbufs[k][i][: len(blocks[i])], d_in[i])) for k in range(ndec_max) for i in range(len(blocks)))
         for c_ in dctxs:
             c_.close()
         del dbufs
         extra["decompress"] = {"value": round(mb / tdp, 1), "unit": "MB/s", "ms_per_step": round(tdp * 1e3, 3), "steps": npass,
                                "how": f"passes over the batch fed through a queue to {ndec} contexts, one jpk_dev_blocks_decompress call (all blocks of "
                                       "the batch, one grid per serial kernel) per pass; every pass verified against the input",
+                               "MBps_by_passes_in_flight": {str(k): round(mb / v[0], 1) for k, v in in_flight.items()},
                                "one_pass_at_a_time_MBps": round(mb / td, 1), "one_pass_at_a_time_ms": round(td * 1e3, 3),
                                "one_context_per_block_MBps": round(mb / tdc, 1),
                                "one_block_at_a_time_MBps": round(mb / ((stage_ms["ans_decode"] + stage_ms["inverse_bwt"]) / 1e3), 1),
@@ -533,8 +538,6 @@ def main():
         # the same passes as a continuous stream: 4 passes over the batch through the same contexts WITHOUT a barrier
         # between passes (a free context takes the next block, as the reference's OpenMP block loop over a long file
         # does, jampack.cpp:215).  Informational: `value` above stays the barrier-per-step number.
-        import queue
-        import threading
         for mode, fn, args_of in (("compress", "block_compress", lambda i: (d_in[i], len(blocks[i]), d_out[i], caps[i])),
                                   ("decompress", "block_decompress", lambda i: (d_cmp[i], sizes[i], d_dcm[i], len(blocks[i])))):
             if mode == "decompress" and len(blocks) * 4 > 64:
