@@ -109,3 +109,42 @@ def test_more_than_1024_chains_longest_first(gpu, oracle):
             assert st[i] in (-3, -2), (i, st[i])
         else:
             assert st[i] == 0 and n[i] == len(t) and np.array_equal(d_out[i][: n[i]].cpu().numpy(), t), i
+
+
+def test_blocks_in_flight_change_the_schedule_not_the_bytes(gpu, oracle):
+    """The encoder cuts its chains into 4 / 2 / 1 launch groups depending on how many blocks of the process are being compressed
+    at that moment (jpk_compress_inflight): four contexts compressing at once must write exactly what one context alone writes,
+    which is what the reference writes."""
+    import threading
+    torch, jam, ctx = gpu
+    dev = torch.device("cuda", 0)
+    blocks = [jam.corpus.make(k, n, 900 + i) for i, (k, n) in enumerate([("text_survey", 9_000_000), ("random", 3_000_001), ("runs", 5_000_000),
+                                                                         ("text", 12_000_000), ("dna", 4_200_000), ("silesia", 6_000_000)])]
+    want = [oracle.ans_encode(oracle.bwt_forward(t)) for t in blocks[:2]]
+    d_in = [torch.from_numpy(t).to(dev) for t in blocks]
+    caps = [jam.ans_capacity(len(t) + jam.TRAILER) for t in blocks]
+    alone = []
+    for i, t in enumerate(blocks):
+        o = torch.empty(caps[i], dtype=torch.uint8, device=dev)
+        n = ctx.block_compress(d_in[i], len(t), o, caps[i])
+        alone.append(o[:n].clone())
+    for i in range(2):
+        assert np.array_equal(alone[i].cpu().numpy(), want[i]), i
+    ctxs = [jam.Context(0, None) for _ in range(4)]
+    outs = [[torch.empty(caps[i], dtype=torch.uint8, device=dev) for i in range(len(blocks))] for _ in range(4)]
+    got = [[0] * len(blocks) for _ in range(4)]
+
+    def work(k):
+        for rep in range(3):
+            for i in range(len(blocks)):
+                j = (i + k) % len(blocks)                 # the threads walk the blocks out of phase: 1..4 blocks in flight at any time
+                got[k][j] = ctxs[k].block_compress(d_in[j], len(blocks[j]), outs[k][j], caps[j])
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for k in range(4):
+        for i in range(len(blocks)):
+            assert got[k][i] == alone[i].numel() and torch.equal(outs[k][i][: got[k][i]], alone[i]), (k, i)
+    for c in ctxs:
+        c.close()
