@@ -450,6 +450,27 @@ def main():
                                  "alg_bytes_per_launch": round(d0["alg_bytes_per_unit"] * d0["units"] / d0["launches"]),
                                  "note": f"dominant kernel class of the compress pass by total time; achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream); traffic = PMC bytes per launch from profiles/{pmc_file}; peak = HBM spec; limited_by says what the class is really bound by (DESIGN.md section 4)"}
             extra["roofline_kernels"] = rows[:8]
+        # the library's own blocks-in-flight loop: ONE jpk_dev_blocks_compress call over 16 passes' worth of blocks (what a
+        # drop-in caller without threads of its own gets)
+        npl = 16
+        l_in = [d_in[i] for _ in range(npl) for i in range(nblk)]
+        l_len = [len(blocks[i]) for _ in range(npl) for i in range(nblk)]
+        l_cap = [caps[i] for _ in range(npl) for i in range(nblk)]
+        l_out = [torch.empty(c, dtype=torch.uint8, device=dev) for c in l_cap]
+        lctx = jam.Context(local_rank, None)
+        lctx.blocks_compress(l_in, l_len, l_out, l_cap, nctx)            # the workers' contexts exist and their arenas are sized
+        torch.cuda.synchronize()
+        tl0 = time.perf_counter()
+        ln_, ls_ = lctx.blocks_compress(l_in, l_len, l_out, l_cap, nctx)
+        torch.cuda.synchronize()
+        tl = (time.perf_counter() - tl0) / npl
+        lctx.close()
+        jam.shutdown()          # the workers' contexts (and their streams) go back: the extras below create contexts of their own, and
+                                # streams beyond the 32 hardware queues share them (a chain kernel then blocks its neighbour)
+        lib_ok = ls_ == [0] * len(l_in) and all(ln_[j] == sizes[j % nblk] and bool(torch.equal(l_out[j][: ln_[j]], d_out[j % nblk][: ln_[j]])) for j in range(len(l_in)))
+        extra["blocks_compress_call"] = {"value": round(mb / tl, 1), "unit": "MB/s", "ms_per_pass": round(tl * 1e3, 3), "passes": npl, "in_flight": nctx,
+                                         "same_bytes": bool(lib_ok), "how": "one jpk_dev_blocks_compress call (C ABI) over all the blocks of 16 passes"}
+        del l_out
         # decompress leg (rANS decode -> inverse BWT, jampack.cpp:49-50) over the same batch, blocks in flight like compress
         d_cmp = [d_out[i][: sizes[i]].clone() for i in range(len(blocks))]
         d_dcm = [torch.empty(max(len(b), 1), dtype=torch.uint8, device=dev) for b in blocks]

@@ -184,6 +184,16 @@ JPK_API int jpk_dev_blocks_ans_decode(jpk_ctx *ctx, int32_t nblocks, const uint8
 JPK_API int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out,
                               const int32_t *out_cap, int32_t *out_len, int32_t *status);
 
+/* The compress direction of the same loop (jampack.cpp:205-224: Threads blocks read, Comp() in an OpenMP loop, written in order)
+ * for blocks that sit in HBM: ForwardBwt + Ans::Encode of nblocks independent blocks in ONE call.  Compression wants several
+ * blocks IN FLIGHT rather than one wide grid (the suffix sort fills the GPU by itself; the entropy stage of the other blocks
+ * hides in its latency), so the library runs `in_flight` worker threads (<= 0: 4, the measured optimum on one MI355X), each with
+ * a context of its own on ctx's device (kept by the library between calls, released by jpk_shutdown), that take the blocks in
+ * array order.  The calling thread works too (with ctx) and returns when every block is done.  status may be NULL; otherwise
+ * status[b] receives block b's jpk_status (JPK_E_CAPACITY when out_cap[b] is too small, ...) and the other blocks still complete. */
+JPK_API int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out,
+                            const int32_t *out_cap, int32_t *out_len, int32_t *status, int32_t in_flight);
+
 /* ---- kernel-level probes used by tests/ and bench.py (device buffers) ------------------------------------ */
 /* Comparator for BASELINE config 3 ("120-way parallel LF-map"): the reference's own GPU kernel shape -- 120 threads, one per
  * stored index, p = Map[p-1] (CUDAInverse<<<40,3>>>, bwt.cpp:8-19, 176-183, 226-229) -- on the same Map.  Same bytes as

@@ -84,6 +84,7 @@ _SIGS = {
     "jpk_dev_block_decompress": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_dev_blocks_ans_decode": (C.c_int, [_vp, C.c_int32, C.POINTER(_vp), _i32p, C.POINTER(_vp), _i32p, _i32p, _i32p]),
     "jpk_dev_blocks_decompress": (C.c_int, [_vp, C.c_int32, C.POINTER(_vp), _i32p, C.POINTER(_vp), _i32p, _i32p, _i32p]),
+    "jpk_dev_blocks_compress": (C.c_int, [_vp, C.c_int32, C.POINTER(_vp), _i32p, C.POINTER(_vp), _i32p, _i32p, _i32p, C.c_int32]),
     "jpk_dev_checksum": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(C.c_uint32)]),
     "jpk_dev_jam_block_write": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp, C.c_int32, _i32p]),
     "jpk_dev_jam_block_read": (C.c_int, [_vp, _vp, C.c_int32, _vp, C.c_int32, _i32p, _i32p]),

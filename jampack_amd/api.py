@@ -352,6 +352,16 @@ class Context:
     def blocks_decompress(self, d_ins, in_lens, d_outs, out_caps):
         return self._batch(lib().jpk_dev_blocks_decompress, "jpk_dev_blocks_decompress", d_ins, in_lens, d_outs, out_caps)
 
+    def blocks_compress(self, d_ins, in_lens, d_outs, out_caps, in_flight: int = 0):
+        """ForwardBwt + Ans::Encode of independent blocks in one call; the library keeps `in_flight` (0: 4) of them in flight on
+        contexts of its own (jampack.cpp:205-224's OpenMP block loop).  Returns (out_len list, status list)."""
+        n = len(d_ins)
+        P, I = C.c_void_p * n, C.c_int32 * n
+        ins, outs = P(*[_dptr(x) for x in d_ins]), P(*[_dptr(x) for x in d_outs])
+        il, oc, ol, st = I(*in_lens), I(*out_caps), I(), I()
+        _chk(lib().jpk_dev_blocks_compress(self._h, n, ins, il, outs, oc, ol, st, int(in_flight)), "jpk_dev_blocks_compress")
+        return list(ol), list(st)
+
     def checksum(self, d_in, in_len) -> int:
         crc = C.c_uint32(0)
         _chk(lib().jpk_dev_checksum(self._h, _dptr(d_in), in_len, C.byref(crc)), "jpk_dev_checksum")

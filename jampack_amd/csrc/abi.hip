@@ -4,6 +4,7 @@
 #include <chrono>
 #include <atomic>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -664,6 +665,73 @@ int tls_ctx(jpk_ctx **out)
 }
 }  // namespace
 
+// ---- jpk_dev_blocks_compress: blocks in flight inside the library ---------------------------------------------------------
+namespace {
+// worker contexts of the batch compress call, per device; owned by the pool (p.all) so that jpk_shutdown destroys them
+std::vector<std::vector<jpk_ctx *>> &batch_idle() { static std::vector<std::vector<jpk_ctx *>> v(64); return v; }
+
+int batch_ctx_acquire(int device, jpk_ctx **out)
+{
+    CtxPool &p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    auto &idle = batch_idle()[(size_t)device];
+    if (!idle.empty()) { *out = idle.back(); idle.pop_back(); return JPK_OK; }
+    jpk_ctx *c = nullptr;
+    JPK_TRY(jpk_ctx_create(&c, device, nullptr));
+    p.all.push_back(c);
+    *out = c;
+    return JPK_OK;
+}
+void batch_ctx_release(int device, jpk_ctx *c, uint64_t generation)
+{
+    CtxPool &p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    if (generation == p.generation) batch_idle()[(size_t)device].push_back(c);      // else jpk_shutdown already destroyed it
+}
+}  // namespace
+
+extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out,
+                                       const int32_t *out_cap, int32_t *out_len, int32_t *status, int32_t in_flight)
+{
+    JPK_ENTER(ctx);
+    if (nblocks < 0 || (nblocks > 0 && (!d_in || !in_len || !d_out || !out_cap || !out_len))) return JPK_E_ARG;
+    if (nblocks == 0) return JPK_OK;
+    if (ctx->device < 0 || ctx->device >= 64) return JPK_E_ARG;
+    for (int b = 0; b < nblocks; b++)
+        if (in_len[b] < 0 || out_cap[b] < 0 || !d_out[b] || (in_len[b] > 0 && !d_in[b])) return JPK_E_ARG;
+    std::vector<int32_t> st_local((size_t)nblocks);
+    int32_t *stp = status ? status : st_local.data();
+    int nw = in_flight > 0 ? in_flight : 4;
+    if (nw > nblocks) nw = nblocks;
+    if (nw > 16) nw = 16;
+    uint64_t generation;
+    { CtxPool &p = pool(); std::lock_guard<std::mutex> g(p.mu); generation = p.generation; }
+    std::atomic<int> next{0};
+    auto work = [&](jpk_ctx *c) {
+        for (;;) {
+            const int b = next.fetch_add(1, std::memory_order_relaxed);
+            if (b >= nblocks) return;
+            out_len[b] = 0;
+            stp[b] = jpk_dev_block_compress(c, d_in[b], in_len[b], d_out[b], out_cap[b], &out_len[b]);
+        }
+    };
+    // workers 1 .. nw-1 on contexts of their own; a worker that cannot get one leaves its share to the others
+    std::vector<std::thread> threads;
+    std::vector<jpk_ctx *> held;
+    for (int k = 1; k < nw; k++) {
+        jpk_ctx *c = nullptr;
+        if (batch_ctx_acquire(ctx->device, &c) != JPK_OK) break;
+        held.push_back(c);
+        threads.emplace_back(work, c);
+    }
+    work(ctx);
+    for (auto &t : threads) t.join();
+    for (jpk_ctx *c : held) batch_ctx_release(ctx->device, c, generation);
+    if (!status)
+        for (int b = 0; b < nblocks; b++) if (stp[b] != JPK_OK) return stp[b];
+    return JPK_OK;
+}
+
 extern "C" int jpk_init(uint64_t device_mask)
 {
     CtxPool &p = pool();
@@ -697,6 +765,7 @@ extern "C" void jpk_shutdown(void)
     for (jpk_ctx *c : p.all) jpk_ctx_destroy(c);    // synchronises each context's streams first
     p.all.clear();
     p.idle.clear();
+    for (auto &v : batch_idle()) v.clear();         // the batch-compress workers' contexts were in p.all
     p.devices.clear();
     p.generation++;
     p.next_thread = 0;

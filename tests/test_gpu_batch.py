@@ -148,3 +148,36 @@ def test_blocks_in_flight_change_the_schedule_not_the_bytes(gpu, oracle):
             assert got[k][i] == alone[i].numel() and torch.equal(outs[k][i][: got[k][i]], alone[i]), (k, i)
     for c in ctxs:
         c.close()
+
+
+def test_blocks_compress_equals_single_calls(gpu, oracle):
+    """jpk_dev_blocks_compress: the library's own blocks-in-flight loop (jampack.cpp:205-224) gives, block by block, the bytes of
+    jpk_dev_block_compress = the reference's; a block whose output buffer is too small reports JPK_E_CAPACITY in its own slot."""
+    torch, jam, ctx = gpu
+    dev = torch.device("cuda", 0)
+    blocks = _blocks(jam) + [jam.corpus.make("text_survey", 9_000_000, 77), jam.corpus.make("silesia", 7_000_000, 78)]
+    d_in = [torch.from_numpy(t).to(dev) for t in blocks]
+    caps = [jam.ans_capacity(len(t) + jam.TRAILER) for t in blocks]
+    want = []
+    for i, t in enumerate(blocks):
+        o = torch.empty(caps[i], dtype=torch.uint8, device=dev)
+        n = ctx.block_compress(d_in[i], len(t), o, caps[i])
+        want.append(o[:n].clone())
+        if len(t) < 200_000 or i == 0:
+            bw = oracle.bwt_forward(t)
+            assert np.array_equal(want[-1].cpu().numpy(), oracle.ans_encode(bw)), i
+    for in_flight in (0, 1, 3, 7):
+        d_out = [torch.empty(c, dtype=torch.uint8, device=dev) for c in caps]
+        n, st = ctx.blocks_compress(d_in, [len(t) for t in blocks], d_out, caps, in_flight)
+        assert st == [0] * len(blocks)
+        for i in range(len(blocks)):
+            assert n[i] == want[i].numel() and torch.equal(d_out[i][: n[i]], want[i]), (in_flight, i)
+    # capacity error of one block only
+    small = list(caps)
+    small[0] = 1000
+    d_out = [torch.empty(c, dtype=torch.uint8, device=dev) for c in small]
+    n, st = ctx.blocks_compress(d_in, [len(t) for t in blocks], d_out, small, 4)
+    assert st[0] == -2 and st[1:] == [0] * (len(blocks) - 1)
+    assert all(n[i] == want[i].numel() and torch.equal(d_out[i][: n[i]], want[i]) for i in range(1, len(blocks)))
+    # an empty batch is fine
+    assert ctx.blocks_compress([], [], [], [], 4) == ([], [])
