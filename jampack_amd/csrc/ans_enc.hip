@@ -1299,6 +1299,11 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     if (ngroups > gmax) ngroups = gmax;
     if (ngroups < 1) ngroups = 1;
     if (const char *e = getenv("JPK_ENC_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= jpk_ctx::ENC_GROUPS && (uint32_t)v <= d.nch) ngroups = v; }
+    // group streams a busy process no longer uses go back: streams beyond the hardware queues share them, and a chain kernel on a
+    // shared queue blocks its neighbour
+    if (ngroups == 1 && inflight.n >= 3)
+        for (int g = 0; g + 1 < jpk_ctx::ENC_GROUPS; g++)
+            if (ctx->aux[g]) { (void)hipStreamSynchronize(ctx->aux[g]); (void)hipStreamDestroy(ctx->aux[g]); ctx->aux[g] = nullptr; }
     for (int g = 0; g + 1 < ngroups; g++)         // group streams are created when a block first needs them
         if (!ctx->aux[g] && hipStreamCreateWithFlags(&ctx->aux[g], hipStreamNonBlocking) != hipSuccess) { ctx->aux[g] = nullptr; ngroups = g + 1; break; }
     if (ngroups >= 2) {
