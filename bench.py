@@ -68,10 +68,12 @@ ALG_BYTES_PER_UNIT = {
 STAGE_ALG = {"forward_bwt": lambda c: 10.0, "ans_encode": lambda c: 4.0 + c, "ans_decode": lambda c: 4.0 + c, "inverse_bwt": lambda c: 12.0}
 
 
-def pmc_traffic(kernel_class: str):
+def pmc_traffic(kernel_class: str, passes: float, launches: int):
     """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (profiles/<round>_pmc_traffic.json:
     separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; KiB counters; reads x2 for the gfx950
-    half-count of wide coalesced loads, MI355X_MICROARCH.md section HBM).  None if no PMC summary is committed."""
+    half-count of wide coalesced loads, MI355X_MICROARCH.md section HBM).  The encoder's launch shape follows the blocks in
+    flight, so the file's bytes per PASS over the workload are scaled to the `launches` that `passes` passes took here.
+    None if no PMC summary is committed."""
     for rnd in (PROFILE_ROUND, "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if os.path.exists(path):
@@ -80,13 +82,18 @@ def pmc_traffic(kernel_class: str):
         return None, None
     tab = json.load(open(path))
     names = [n.strip().rstrip("*") for n in kernel_class.split("/")]
-    fetch = write = launches = 0.0
+    fetch = write = nl = 0.0
     for k, v in tab.items():
-        if any(k.startswith(n) for n in names if n.startswith("k_")):
+        if k != "_meta" and any(k.startswith(n) for n in names if n.startswith("k_")):
             fetch += 2.0 * v["fetch_KiB_raw"] * 1024
             write += v["write_KiB"] * 1024
-            launches += v["launches"]
-    return (round((fetch + write) / launches) if launches else None), os.path.basename(path)
+            nl += v["launches"]
+    if not nl:
+        return None, os.path.basename(path)
+    file_passes = tab.get("_meta", {}).get("passes")
+    if file_passes and launches:
+        return round((fetch + write) / file_passes * passes / launches), os.path.basename(path)
+    return round((fetch + write) / nl), os.path.basename(path)
 
 
 ONE_GPU_RANKS = bool(int(os.environ.get("JPK_BENCH_ONE_GPU", "0")))   # test hook: all ranks on cuda:0 over gloo (a 1-GPU box can then run the N>1 code path)
@@ -422,34 +429,56 @@ def main():
         extra["stages_ms"] = {k: round(v, 3) for k, v in stage_ms.items()}
         extra["stages_MBps"] = {k: round(mb / (v / 1e3), 1) for k, v in stage_ms.items() if v > 0}
         extra["stages_reps"] = reps
-        # roofline: one profiled compress pass, one block at a time (HIP events around every kernel on its launch stream).  It runs
-        # BEFORE the extras that create more contexts: streams are dealt onto the hardware queues round robin at creation, and a chain
-        # kernel whose stream shares a queue with another group's stream is timed from its event, i.e. including its wait in the queue
-        # (seen as 13-17 ms per launch instead of the 9.8 ms the kernel trace shows)
+        # roofline: HIP events around every kernel on its launch stream (the library's profiler), (a) over passes of the timed loop
+        # itself -- the same contexts, the same blocks in flight, so the launch shape and the contention are those of `value` -- and
+        # (b) over one pass with one block at a time.  Both run BEFORE the extras that create more contexts: streams are dealt onto
+        # the hardware queues round robin at creation, and a chain kernel whose stream shares a queue with another stream is timed
+        # from its event, i.e. including its wait in the queue.
+        def prof_rows(tabs):
+            acc = {}
+            for tab in tabs:
+                for r in tab:
+                    a_ = acc.setdefault(r["name"], {"ms": 0.0, "launches": 0, "units": 0})
+                    a_["ms"] += r["ms"]; a_["launches"] += r["launches"]; a_["units"] += r["units"]
+            rows = []
+            for name, r in acc.items():
+                bpu = ALG_BYTES_PER_UNIT.get(name)
+                if not bpu or not r["units"] or r["ms"] <= 0:
+                    continue
+                ach = bpu[0] * r["units"] / 1e9 / (r["ms"] / 1e3)
+                rows.append({"kernel": name, "ms_total": round(r["ms"], 3), "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
+                             "alg_bytes_per_unit": bpu[0], "unit_is": bpu[1], "units": r["units"], "achieved": round(ach, 2), "frac": round(ach / 8000.0, 5),
+                             "limited_by": bpu[2]})
+            rows.sort(key=lambda r: -r["ms_total"])
+            return rows
+
+        for c_ in ctxs:
+            c_.profile_enable(2)
+        run_steps(4, gather=False)
+        torch.cuda.synchronize()
+        rows = prof_rows([c_.profile_table() for c_ in ctxs])
+        for c_ in ctxs:
+            c_.profile_enable(0)
         ctx.profile_enable(2)
         for i, b in enumerate(blocks):
             ctx.block_compress(d_in[i], len(b), d_out[i], caps[i])
-        tab = ctx.profile_table()
+        rows1 = prof_rows([ctx.profile_table()])
         ctx.profile_enable(0)
-        rows = []
-        for r in tab:
-            bpu = ALG_BYTES_PER_UNIT.get(r["name"])
-            if not bpu or not r["units"] or r["ms"] <= 0:
-                continue
-            ach = bpu[0] * r["units"] / 1e9 / (r["ms"] / 1e3)
-            rows.append({"kernel": r["name"], "ms_total": round(r["ms"], 3), "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
-                         "alg_bytes_per_unit": bpu[0], "unit_is": bpu[1], "units": r["units"], "achieved": round(ach, 2), "frac": round(ach / 8000.0, 5),
-                         "limited_by": bpu[2]})
-        rows.sort(key=lambda r: -r["ms_total"])
         if rows:
             d0 = rows[0]
-            traffic, pmc_file = pmc_traffic(d0["kernel"])
+            traffic, pmc_file = pmc_traffic(d0["kernel"], 4, d0["launches"])
             extra["roofline"] = {"bound": "hbm" if d0["limited_by"].startswith("hbm") else d0["limited_by"], "achieved": d0["achieved"], "peak": 8000.0, "unit": "GB/s",
                                  "frac": d0["frac"], "traffic": traffic,
                                  "kernel": d0["kernel"], "limited_by": d0["limited_by"], "avg_launch_us": d0["avg_launch_us"], "launches": d0["launches"],
                                  "alg_bytes_per_launch": round(d0["alg_bytes_per_unit"] * d0["units"] / d0["launches"]),
-                                 "note": f"dominant kernel class of the compress pass by total time; achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream); traffic = PMC bytes per launch from profiles/{pmc_file}; peak = HBM spec; limited_by says what the class is really bound by (DESIGN.md section 4)"}
+                                 "note": f"dominant kernel class by total time over 4 passes of the timed loop ({nctx} blocks in flight: one chain launch per block, stretched by the other blocks' kernels); achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream); traffic = PMC bytes per launch of the same command from profiles/{pmc_file}; peak = HBM spec; limited_by says what the class is really bound by (DESIGN.md section 4)"}
             extra["roofline_kernels"] = rows[:8]
+            one = next((r for r in rows1 if r["kernel"] == d0["kernel"]), None)
+            if one:
+                extra["roofline"]["one_block_at_a_time"] = {"avg_launch_us": one["avg_launch_us"], "launches": one["launches"], "achieved": one["achieved"], "frac": one["frac"],
+                                                            "traffic": pmc_traffic(d0["kernel"], 1, one["launches"])[0],
+                                                            "alg_bytes_per_launch": round(one["alg_bytes_per_unit"] * one["units"] / one["launches"]),
+                                                            "note": "a block alone cuts its chains into four graded launches"}
         # the library's own blocks-in-flight loop: ONE jpk_dev_blocks_compress call over 16 passes' worth of blocks (what a
         # drop-in caller without threads of its own gets)
         npl = 16

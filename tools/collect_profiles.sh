@@ -40,3 +40,4 @@ python3 tools/stage_scaling.py 2>/dev/null | grep contexts > "$OUT/stage_scaling
 python3 tools/chunk_lens.py 2>/dev/null | grep -E "chunks|k_dec_" > "$OUT/decode_chain_lengths.txt"
 ls -la "$OUT"
 python3 tools/block_sizes.py 2>/dev/null > "$OUT/block_sizes.txt"
+python3 tools/batch_compress.py 2>/dev/null | grep "in flight" > "$OUT/blocks_compress_call.txt"
