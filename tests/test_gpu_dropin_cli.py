@@ -112,6 +112,9 @@ def test_block_pipeline_program_runs(gpu, tmp_path):
     _mixed(3_000_000, 5).tofile(src)
     out = _run([PIPELINE, str(src), "1"])
     assert "round trip ok" in out and "3000000 ->" in out, out
+    # multi-block mode: three threads, each with a Pipeline of its own, take the three blocks in turn (jampack.cpp:205-224)
+    out = _run([PIPELINE, str(src), "1", "3"])
+    assert "3 threads (blocks in flight), 3 blocks" in out and out.count("round trip ok") == 2, out
 
 
 def test_host_buffer_path_keeps_most_of_the_hbm_resident_rate(gpu, tmp_path):
