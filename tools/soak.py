@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""soak: N random blocks (mixed generators, ragged sizes) through compress -> batch decompress; small ones also against the oracle.
+   python tools/soak.py [N=300] [seed=1]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import jampack_amd as jam
+from oracle.pyoracle import Oracle
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+o = Oracle()
+dev = torch.device("cuda", 0)
+ctx = jam.Context(0, None)
+kinds = ["text_survey", "text", "random", "runs", "geometric", "dna", "silesia", "zero", "two", "samples16", "repeat"]
+kinds = [k for k in kinds if k in jam.corpus.KINDS] if hasattr(jam.corpus, "KINDS") else kinds
+t0 = time.time()
+blocks, comp = [], []
+checked = 0
+for i in range(N):
+    k = kinds[int(rng.integers(len(kinds)))]
+    r = rng.random()
+    n = int(rng.integers(1, 3000)) if r < 0.15 else (int(rng.integers(3000, 1_300_000)) if r < 0.7 else int(rng.integers(1_300_000, 9_000_000)))
+    try:
+        t = jam.corpus.make(k, n, 10_000 * seed + i)
+    except Exception:
+        t = jam.corpus.make("text_survey", n, 10_000 * seed + i)
+    d_t = torch.from_numpy(t).to(dev)
+    cap = jam.ans_capacity(len(t) + jam.TRAILER)
+    d_c = torch.empty(cap, dtype=torch.uint8, device=dev)
+    m = ctx.block_compress(d_t, len(t), d_c, cap)
+    c = d_c[:m].clone()
+    if n < 400_000:
+        want = o.ans_encode(o.bwt_forward(t))
+        assert np.array_equal(c.cpu().numpy(), want), (i, k, n)
+        checked += 1
+    blocks.append(t); comp.append(c)
+outs = [torch.empty(max(len(t), 1), dtype=torch.uint8, device=dev) for t in blocks]
+for lo in range(0, N, 64):
+    hi = min(N, lo + 64)
+    n_, st = ctx.blocks_decompress(comp[lo:hi], [int(c.numel()) for c in comp[lo:hi]], outs[lo:hi], [len(t) for t in blocks[lo:hi]])
+    for j in range(lo, hi):
+        assert st[j - lo] == 0 and n_[j - lo] == len(blocks[j]) and np.array_equal(outs[j][: len(blocks[j])].cpu().numpy(), blocks[j]), (j, st[j - lo])
+# and one at a time for a sample
+for j in range(0, N, 7):
+    one = torch.empty(max(len(blocks[j]), 1), dtype=torch.uint8, device=dev)
+    assert ctx.block_decompress(comp[j], int(comp[j].numel()), one, len(blocks[j])) == len(blocks[j]) and np.array_equal(one[: len(blocks[j])].cpu().numpy(), blocks[j]), j
+# the library's blocks-in-flight loop over everything, twice (launch groups and their streams come and go with the load)
+for rep, nfl in enumerate((6, 3)):
+    caps = [jam.ans_capacity(len(t) + jam.TRAILER) for t in blocks]
+    d_ins = [torch.from_numpy(t).to(dev) for t in blocks]
+    d_outs = [torch.empty(c, dtype=torch.uint8, device=dev) for c in caps]
+    n_, st = ctx.blocks_compress(d_ins, [len(t) for t in blocks], d_outs, caps, nfl)
+    for j in range(N):
+        assert st[j] == 0 and n_[j] == comp[j].numel() and torch.equal(d_outs[j][: n_[j]], comp[j]), (rep, j)
+    del d_ins, d_outs
+print(f"soak ok: {N} blocks, {sum(len(b) for b in blocks) / 1e6:.0f} MB, {checked} compared with the oracle byte for byte, {time.time() - t0:.0f} s")
