@@ -161,20 +161,22 @@ __global__ __launch_bounds__(256) void k_dec_order(const ChunkInfo *__restrict__
 // rANS + model decode: one wave per chunk (ans.cpp:30-92).
 //
 // The loop is one long dependent chain, so it is written for the issue costs of a single gfx950 wave (measured with
-// tools/issuetest.hip): every VALU or SALU instruction costs 4 cycles, a SALU instruction that reads an SGPR a VALU
-// instruction has just written stalls ~16 cycles more, an LDS round trip is 50-60 cycles, a branch 13 (not taken)
-// to 26 (taken) cycles, and every value that is live across diverging arms costs a copy at the join.  Hence:
+// tools/issuetest.hip): a VALU or SALU instruction issues every ~5 cycles (4.4 ns-ticks at 2.4 GHz: 5.1 independent, 5-6
+// in a dependent chain), a SALU instruction that reads an SGPR a VALU instruction has just written stalls ~17 cycles
+// more, an LDS round trip is 52-68 cycles, a branch ~14 (not taken) to ~24 (taken) cycles, and every value that is live
+// across diverging arms costs a copy at the join.  Hence:
 //   * the four rANS states, the byte queue and the two alphabet-2 models are wave-uniform and live in SGPRs;
 //   * the 8-symbol exponent model and the mantissa models of classes 2..5 are register resident with "lane = symbol":
 //     lane j holds LO_j = cdf[j], HI_j = cdf[j+1], FR_j = HI_j - LO_j of its symbol (class e owns lanes
 //     [2^e, 2^(e+1)), which is exactly the RLE0 symbol numbering, tables.hpp:10).  All lanes form their candidate
 //     next state FR_j * (x >> 16) + (x & 0xffff) - LO_j at once; one v_cmp (HI_j > x & 0xffff), one s_ff1 and one
 //     v_readlane pick the coded symbol and its next state: no LDS, no search loop;
-//   * the rebuild countdowns of classes 2..5 and the 64-symbol output tile share one VGPR (lanes 0..3 and 8), so a
-//     symbol pays a single rarely-taken branch for all of them;
+//   * the rebuild countdowns of classes 2..5 live in lanes 0..3 of one VGPR (lanes 4, 5 hold a permanent 1 for classes 6
+//     and 7), the output tile is collected with v_writelane and stored every 64 symbols, and ONE scalar test per symbol
+//     covers "an event is due" and "a state needs bytes";
 //   * payload bytes come from a 64-bit SGPR queue refilled one dword at a time from a 256-byte window held across
 //     the wave (lane l = dword l, next window prefetched).
-// Classes 6 and 7 (64 and 129 symbols, rare outside incompressible data) keep their CDFs in LDS.
+// Classes 6 and 7 (64 and 129 symbols, rare outside incompressible data) keep their CDFs in one / three more registers.
 // ---------------------------------------------------------------------------------------------------------------
 // QuasiModel rebuild (model.cpp:160-204) of a register-resident model of A <= 64 * NR symbols: symbol i = lane l of
 // register j (i = l + 64 j).  hi/lo/fr become the bounds and width of every symbol, the counts are cleared.

@@ -770,7 +770,7 @@ __device__ __forceinline__ uint32_t emit_word(uint32_t x, uint32_t xmax)
 
 // One encoder step on every lane at once (see k_rans_lanes): the state comes from the lane on the left (DPP row
 // rotate), keep = the state this lane had to start from once its turn came (captured when `turn` selects the lane).
-// Cost on one wave (tools/issuetest.hip): every VALU instruction is 4 cycles whatever it does, so the step is kept to
+// Cost on one wave (tools/issuetest.hip): a VALU instruction issues every ~4.4-5 cycles whatever it does, so the step is kept to
 // twelve of them, written as one block (two steps per asm statement) because the order carries the wait states gfx940+ needs and the compiler
 // cannot see into asm: two between a VALU write of an SGPR mask and the VALU reading it (cmp b2 .. select u,
 // cmp b1 .. select xr) and two between the write of the new state and the next step's DPP read (capture + s_nop).
