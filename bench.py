@@ -384,6 +384,63 @@ def main():
             extra["gathered_payload_bytes"] = int(sum(t.numel() for t in ordered))
         extra["gather_ok"] = bool(ok)
 
+    def roofline_extra():
+        """`roofline` (+ `roofline_kernels`) of the JSON line, measured on this rank"""
+        extra_ = {}
+        # roofline: HIP events around every kernel on its launch stream (the library's profiler), (a) over passes of the timed loop
+        # itself -- the same contexts, the same blocks in flight, so the launch shape and the contention are those of `value` -- and
+        # (b) over one pass with one block at a time.  Both run BEFORE the extras that create more contexts: streams are dealt onto
+        # the hardware queues round robin at creation, and a chain kernel whose stream shares a queue with another stream is timed
+        # from its event, i.e. including its wait in the queue.
+        def prof_rows(tabs):
+            acc = {}
+            for tab in tabs:
+                for r in tab:
+                    a_ = acc.setdefault(r["name"], {"ms": 0.0, "launches": 0, "units": 0})
+                    a_["ms"] += r["ms"]; a_["launches"] += r["launches"]; a_["units"] += r["units"]
+            rows = []
+            for name, r in acc.items():
+                bpu = ALG_BYTES_PER_UNIT.get(name)
+                if not bpu or not r["units"] or r["ms"] <= 0:
+                    continue
+                ach = bpu[0] * r["units"] / 1e9 / (r["ms"] / 1e3)
+                rows.append({"kernel": name, "ms_total": round(r["ms"], 3), "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
+                             "alg_bytes_per_unit": bpu[0], "unit_is": bpu[1], "units": r["units"], "achieved": round(ach, 2), "frac": round(ach / 8000.0, 5),
+                             "limited_by": bpu[2]})
+            rows.sort(key=lambda r: -r["ms_total"])
+            return rows
+
+        for c_ in ctxs:
+            c_.profile_enable(2)
+        run_steps(4, gather=False)
+        torch.cuda.synchronize()
+        rows = prof_rows([c_.profile_table() for c_ in ctxs])
+        for c_ in ctxs:
+            c_.profile_enable(0)
+        ctx.profile_enable(2)
+        for i, b in enumerate(blocks):
+            ctx.block_compress(d_in[i], len(b), d_out[i], caps[i])
+        rows1 = prof_rows([ctx.profile_table()])
+        ctx.profile_enable(0)
+        if rows:
+            d0 = rows[0]
+            traffic, pmc_file = pmc_traffic(d0["kernel"], 4, d0["launches"])
+            extra_["roofline"] = {"bound": "hbm" if d0["limited_by"].startswith("hbm") else d0["limited_by"], "achieved": d0["achieved"], "peak": 8000.0, "unit": "GB/s",
+                                 "frac": d0["frac"], "traffic": traffic,
+                                 "kernel": d0["kernel"], "limited_by": d0["limited_by"], "avg_launch_us": d0["avg_launch_us"], "launches": d0["launches"],
+                                 "alg_bytes_per_launch": round(d0["alg_bytes_per_unit"] * d0["units"] / d0["launches"]),
+                                 "note": f"dominant kernel class by total time over 4 passes of the timed loop ({nctx} blocks in flight: one chain launch per block, stretched by the other blocks' kernels); achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream); traffic = PMC bytes per launch of the same command from profiles/{pmc_file}; peak = HBM spec; limited_by says what the class is really bound by (DESIGN.md section 4)"}
+            extra_["roofline_kernels"] = rows[:8]
+            one = next((r for r in rows1 if r["kernel"] == d0["kernel"]), None)
+            if one:
+                extra_["roofline"]["one_block_at_a_time"] = {"avg_launch_us": one["avg_launch_us"], "launches": one["launches"], "achieved": one["achieved"], "frac": one["frac"],
+                                                            "traffic": pmc_traffic(d0["kernel"], 1, one["launches"])[0],
+                                                            "alg_bytes_per_launch": round(one["alg_bytes_per_unit"] * one["units"] / one["launches"]),
+                                                            "note": "a block alone cuts its chains into four graded launches"}
+        return extra_
+
+    if rank == 0 and world > 1 and not args.no_extras and blocks:
+        extra.update(roofline_extra())          # the other ranks wait at the final barrier meanwhile
     # ---- un-timed extras on rank 0 of a 1-GPU run: stage breakdown, decompress leg, parity flags, roofline, CPU baseline ----
     if rank == 0 and world == 1 and not args.no_extras and blocks:
         reps = max(3, min(args.steps, 10))
@@ -429,56 +486,7 @@ def main():
         extra["stages_ms"] = {k: round(v, 3) for k, v in stage_ms.items()}
         extra["stages_MBps"] = {k: round(mb / (v / 1e3), 1) for k, v in stage_ms.items() if v > 0}
         extra["stages_reps"] = reps
-        # roofline: HIP events around every kernel on its launch stream (the library's profiler), (a) over passes of the timed loop
-        # itself -- the same contexts, the same blocks in flight, so the launch shape and the contention are those of `value` -- and
-        # (b) over one pass with one block at a time.  Both run BEFORE the extras that create more contexts: streams are dealt onto
-        # the hardware queues round robin at creation, and a chain kernel whose stream shares a queue with another stream is timed
-        # from its event, i.e. including its wait in the queue.
-        def prof_rows(tabs):
-            acc = {}
-            for tab in tabs:
-                for r in tab:
-                    a_ = acc.setdefault(r["name"], {"ms": 0.0, "launches": 0, "units": 0})
-                    a_["ms"] += r["ms"]; a_["launches"] += r["launches"]; a_["units"] += r["units"]
-            rows = []
-            for name, r in acc.items():
-                bpu = ALG_BYTES_PER_UNIT.get(name)
-                if not bpu or not r["units"] or r["ms"] <= 0:
-                    continue
-                ach = bpu[0] * r["units"] / 1e9 / (r["ms"] / 1e3)
-                rows.append({"kernel": name, "ms_total": round(r["ms"], 3), "launches": r["launches"], "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
-                             "alg_bytes_per_unit": bpu[0], "unit_is": bpu[1], "units": r["units"], "achieved": round(ach, 2), "frac": round(ach / 8000.0, 5),
-                             "limited_by": bpu[2]})
-            rows.sort(key=lambda r: -r["ms_total"])
-            return rows
-
-        for c_ in ctxs:
-            c_.profile_enable(2)
-        run_steps(4, gather=False)
-        torch.cuda.synchronize()
-        rows = prof_rows([c_.profile_table() for c_ in ctxs])
-        for c_ in ctxs:
-            c_.profile_enable(0)
-        ctx.profile_enable(2)
-        for i, b in enumerate(blocks):
-            ctx.block_compress(d_in[i], len(b), d_out[i], caps[i])
-        rows1 = prof_rows([ctx.profile_table()])
-        ctx.profile_enable(0)
-        if rows:
-            d0 = rows[0]
-            traffic, pmc_file = pmc_traffic(d0["kernel"], 4, d0["launches"])
-            extra["roofline"] = {"bound": "hbm" if d0["limited_by"].startswith("hbm") else d0["limited_by"], "achieved": d0["achieved"], "peak": 8000.0, "unit": "GB/s",
-                                 "frac": d0["frac"], "traffic": traffic,
-                                 "kernel": d0["kernel"], "limited_by": d0["limited_by"], "avg_launch_us": d0["avg_launch_us"], "launches": d0["launches"],
-                                 "alg_bytes_per_launch": round(d0["alg_bytes_per_unit"] * d0["units"] / d0["launches"]),
-                                 "note": f"dominant kernel class by total time over 4 passes of the timed loop ({nctx} blocks in flight: one chain launch per block, stretched by the other blocks' kernels); achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream); traffic = PMC bytes per launch of the same command from profiles/{pmc_file}; peak = HBM spec; limited_by says what the class is really bound by (DESIGN.md section 4)"}
-            extra["roofline_kernels"] = rows[:8]
-            one = next((r for r in rows1 if r["kernel"] == d0["kernel"]), None)
-            if one:
-                extra["roofline"]["one_block_at_a_time"] = {"avg_launch_us": one["avg_launch_us"], "launches": one["launches"], "achieved": one["achieved"], "frac": one["frac"],
-                                                            "traffic": pmc_traffic(d0["kernel"], 1, one["launches"])[0],
-                                                            "alg_bytes_per_launch": round(one["alg_bytes_per_unit"] * one["units"] / one["launches"]),
-                                                            "note": "a block alone cuts its chains into four graded launches"}
+        extra.update(roofline_extra())
         # the library's own blocks-in-flight loop: ONE jpk_dev_blocks_compress call over 16 passes' worth of blocks (what a
         # drop-in caller without threads of its own gets)
         npl = 16
