@@ -722,6 +722,9 @@ __global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ bl
             asm("s_cmp_lt_u32 %1, %2\n\ts_cselect_b32 %0, %3, 0" : "=s"(lim) : "s"(i), "s"(fast_end), "s"(room) : "scc");
             if (!(z < lim)) break;
             const uint32_t nsym = (uint32_t)__builtin_amdgcn_readlane((int)L0, 1);
+            // the rank that ends the run is taken out of the row BEFORE the next row is loaded: the old row's register is dead by
+            // then and the load can land in it (no copy per iteration)
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rl, (int)(used + z));
             const uint32_t nrl = rows[nsym][l];
             const RankMeta nm = meta[nsym];
             // all 64 lanes store: the bytes behind the run are rewritten by the runs that own them (same wave, program order)
@@ -730,7 +733,6 @@ __global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ bl
             asm volatile("global_store_byte %0, %1, %2" : : "v"(i + (uint32_t)l), "v"(sym), "s"(Tg));
             const uint32_t cnt = z + 1u;
             i += cnt;
-            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rl, (int)(used + z));
             meta[sym].used = used + cnt;                         // every lane stores the same word: cheaper than masking to one lane
             const uint32_t cur = sym;
             sym = nsym; rl = nrl; m = nm;
