@@ -315,28 +315,37 @@ __device__ __forceinline__ uint32_t dpp_row_shr1_zero(uint32_t v)     // lane j 
             : "s"(RA), "v"(ehi), "v"(elo), "s"(RB), "v"(qhi), "v"(qlo), "v"(efr), "v"(qfr));              \
         __builtin_amdgcn_sched_barrier(0);                                                                \
         const uint32_t e = (uint32_t)__builtin_ctz((uint32_t)eabove);                                     \
+        /* symbol s = lane s; class e owns the lanes whose class is e (none for e >= 6: the event block takes over).           \
+           The three lane masks that depend on e are formed first: their users below then sit far enough behind them that no  \
+           wait state is needed between a vector compare and the vector instruction that takes its mask */            \
+        const bool below = (uint32_t)l < e;                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
         uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)ecand, (int)e);                             \
-        /* symbol s = lane s; class e owns the lanes whose class is e (none for e >= 6: the event block takes over) */ \
+        const bool counts = cls_of_lane == e;                                                             \
         const bool mine = lane_cls == e;                                                                  \
         const uint64_t minemask = __ballot(mine);                                                         \
-        {   /* AdaptiveModel update (model.cpp:60-77): entry i = j + 1 lives in lane j */                 \
-            const int32_t mix = ((uint32_t)l < e) ? emix_lo : emix_hi;                                    \
-            ehi = (uint32_t)((int32_t)ehi + ((mix - (int32_t)ehi) >> 5));                                 \
-            elo = dpp_row_shr1_zero(ehi);                                                                 \
-            efr = ehi - elo;                                                                              \
-        }                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        /* AdaptiveModel update (model.cpp:60-77): entry i = j + 1 lives in lane j */                     \
+        const int32_t mix = below ? emix_lo : emix_hi;                                                    \
+        ehi = (uint32_t)((int32_t)ehi + ((mix - (int32_t)ehi) >> 5));                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
         /* countdowns: lane e - 2 counts the symbols of class e until its rebuild (classes 6, 7: always due) */ \
-        rem -= (cls_of_lane == e) ? 1u : 0u;                                                              \
+        rem -= counts ? 1u : 0u;                                                                          \
         const uint64_t due = __builtin_amdgcn_uicmp(rem, 0u, 32 /* ICMP_EQ */);                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        elo = dpp_row_shr1_zero(ehi);                                                                     \
+        efr = ehi - elo;                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                \
         /* for e >= 6 the mask is empty: s_ff1 returns -1, v_readlane takes lane 63 and no lane counts; the event block redoes both */ \
         uint32_t sym;                                                                                     \
         asm("s_ff1_i32_b64 %0, %1" : "=s"(sym) : "s"(qabove & minemask));                                 \
+        const bool hit = (uint32_t)l == sym;                                                              \
         uint32_t x2 = (uint32_t)__builtin_amdgcn_readlane((int)qcand, (int)sym);                          \
+        const int32_t tgt = (sym & 1u) ? 1 : 65535;                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
         {                                                                                                 \
-            qf += ((uint32_t)l == sym) ? 1u : 0u;                                /* QuasiModel count, in units of 16 */ \
+            qf += hit ? 1u : 0u;                                                 /* QuasiModel count, in units of 16 */ \
             /* AdaptiveModel update of the alphabet-2 pair (lanes 2e, 2e+1) when e < 2: both lanes carry a = cdf[1] */ \
-            const int32_t tgt = (sym & 1u) ? 1 : 65535;                                                   \
             const int32_t d = mine ? (tgt - (int32_t)qa) >> 5 : 0;                                        \
             qa += (uint32_t)d;                                                                            \
             qhi = (uint32_t)(__mul24(d, even_lane) + (int32_t)qhi);                                       \
