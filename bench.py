@@ -103,8 +103,8 @@ FORCE_GATHER = bool(int(os.environ.get("JPK_FORCE_GATHER", "0")))      # exercis
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="enwik8", choices=["enwik6", "enwik8", "enwik8-phrase", "enwik9", "silesia"])
     ap.add_argument("--block-mib", type=int, default=64)
     ap.add_argument("--limit-bytes", type=int, default=0, help="truncate the workload (debug only; marks the line invalid)")
