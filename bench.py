@@ -13,16 +13,19 @@ over one batch of 64 MiB blocks, inputs already resident in HBM.
       b mod N (jampack_amd/shard.py), compressed blocks gathered on rank 0 in block order = the .jam payload order of
       jampack.cpp:220-224: strong scaling.
 
-value = uncompressed bytes of the whole job / max-over-ranks time, in MB/s (1e6 B/s).
+value = uncompressed bytes of the whole job / max-over-ranks time, in MB/s (1e6 B/s).  The K timed steps are K passes over the
+batch fed through one queue to `--contexts` contexts (a free context takes the next block, jampack.cpp:205-224), so consecutive
+passes overlap; barrier + torch.cuda.synchronize() bracket the K steps.
 
 N > 1 without a launcher: `python bench.py --gpus N` starts N child processes itself (one per GPU, before anything touches
 the GPU in the parent); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it uses the ranks it
 is given.  A --gpus that disagrees with WORLD_SIZE is an error, never a silent 1-GPU run.
 
-Extra keys on the same JSON line: `decompress` (rANS decode -> inverse BWT over the same batch), per-stage timings over
-warmed repetitions, `roofline` for the dominant kernel (HIP-event timed inside the library on the launch stream),
-`sa_rounds` (active suffixes per doubling round), `phrase_book_variant`, and `cpu_baseline` (the real reference,
-oracle/_ref, on this box's host cores; rank 0, N = 1 only).
+Extra keys on the same JSON line: `decompress` (rANS decode -> inverse BWT over the same batch, passes in flight), per-stage
+timings over warmed repetitions, `roofline` for the dominant kernel (HIP-event timed inside the library on the launch stream,
+over passes of the timed loop's own shape), `blocks_compress_call` (the same work through ONE jpk_dev_blocks_compress call),
+`join_per_step` (round 1's loop), `sa_rounds` (active suffixes per doubling round), `phrase_book_variant`, and `cpu_baseline`
+(the real reference, oracle/_ref, on this box's host cores; rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -593,38 +596,6 @@ def main():
                                "one_block_at_a_time_MBps": round(mb / ((stage_ms["ans_decode"] + stage_ms["inverse_bwt"]) / 1e3), 1),
                                "inverse_bwt_MBps": round(mb / (stage_ms["inverse_bwt"] / 1e3), 1)}
         extra["round_trip_ok"] = ok
-        # the same passes as a continuous stream: 4 passes over the batch through the same contexts WITHOUT a barrier
-        # between passes (a free context takes the next block, as the reference's OpenMP block loop over a long file
-        # does, jampack.cpp:215).  Informational: `value` above stays the barrier-per-step number.
-        for mode, fn, args_of in (("compress", "block_compress", lambda i: (d_in[i], len(blocks[i]), d_out[i], caps[i])),
-                                  ("decompress", "block_decompress", lambda i: (d_cmp[i], sizes[i], d_dcm[i], len(blocks[i])))):
-            if mode == "decompress" and len(blocks) * 4 > 64:
-                continue
-            passes = 4
-            tasks = queue.Queue()
-            for _ in range(passes):
-                for i in order:
-                    tasks.put(i)
-
-            def drain(k):
-                while True:
-                    try:
-                        i = tasks.get_nowait()
-                    except queue.Empty:
-                        return
-                    getattr(ctxs[k], fn)(*args_of(i))
-
-            torch.cuda.synchronize()
-            ts0 = time.perf_counter()
-            th = [threading.Thread(target=drain, args=(k,)) for k in range(nctx)]
-            for t_ in th:
-                t_.start()
-            for t_ in th:
-                t_.join()
-            torch.cuda.synchronize()
-            tsd = time.perf_counter() - ts0
-            extra.setdefault("streamed", {})[mode] = {"value": round(passes * mb / tsd, 1), "unit": "MB/s", "passes": passes,
-                                                      "ms_per_pass": round(tsd / passes * 1e3, 3)}
         del d_cmp, d_dcm
         # BASELINE config 3's "120-way parallel LF-map": the reference's own GPU kernel shape (CUDAInverse<<<40,3>>>, bwt.cpp:8-19) as
         # a measured comparator beside the list-ranking inverse, on block 0
