@@ -60,6 +60,10 @@ def test_argument_validation():
     assert lib().jpk_bwt_forward(buf, 8, buf, 16, ctypes.byref(n)) == -2     # capacity: needs len + 480
     assert lib().jpk_ctx_create(None, 0, None) == -1
     assert lib().jpk_strerror(-3).decode().startswith("corrupt")
+    # the batch entries refuse a missing context before anything else (no GPU call is made)
+    for name in ("jpk_dev_blocks_ans_decode", "jpk_dev_blocks_decompress"):
+        assert getattr(lib(), name)(None, 0, None, None, None, None, None, None) == -1
+    assert lib().jpk_dev_blocks_compress(None, 0, None, None, None, None, None, None, 4) == -1
 
 
 def test_shim_headers_compile_against_reference_call_pattern(tmp_path):
