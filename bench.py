@@ -44,7 +44,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
 
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 # algorithmic HBM bytes per processed unit of every timed kernel class, and what the class is
 # actually limited by ("hbm": streaming traffic; "hbm-random": 4-byte gathers/scatters, ~55 G accesses/s whatever the bytes;
@@ -77,7 +77,7 @@ def pmc_traffic(kernel_class: str, passes: float, launches: int):
     half-count of wide coalesced loads, MI355X_MICROARCH.md section HBM).  The encoder's launch shape follows the blocks in
     flight, so the file's bytes per PASS over the workload are scaled to the `launches` that `passes` passes took here.
     None if no PMC summary is committed."""
-    for rnd in (PROFILE_ROUND, "r01"):
+    for rnd in (PROFILE_ROUND, "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if os.path.exists(path):
             break
@@ -115,6 +115,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (multi-GPU children print this anyway)")
     ap.add_argument("--contexts", type=int, default=4, help="blocks in flight per GPU (one context + HIP stream each)")
     ap.add_argument("--cpu-sample-mib", type=int, default=64, help="bytes of block 0 the CPU reference is timed on")
+    ap.add_argument("--no-block-sizes", action="store_true", help="skip the per_block_size extra (1 / 64 / 256 MiB blocks)")
     ap.add_argument("--master-port", type=int, default=29511)
     return ap.parse_args()
 
@@ -205,6 +206,75 @@ def cpu_baseline(blocks, sample_mib: int):
     return res, enc, n
 
 
+def per_block_size(jam, corpus, torch, dev, device_index: int, in_flight: int):
+    """BASELINE.json's metric is "per block size"; Options.BlockSize is a first-class option of the reference (format.hpp:20-22,
+    main.cpp:78) and SURVEY 8d names {1, 64, 256 MiB}.  For each size, on the first 256 MiB of the enwik9-like text stream:
+      one_at_a_time   one block per call (jpk_dev_block_compress / _decompress), the next call starts when the last one returned;
+      streamed        the blocks of a 64 / 256 / 512 MiB stream through ONE jpk_dev_blocks_compress call (`in_flight` blocks in
+                      flight) and ONE jpk_dev_blocks_decompress call (one grid per serial kernel over all blocks);
+      same_bytes      streamed output == one-at-a-time output for every block, and every round trip == the input.
+    Inputs and outputs resident in HBM; wall clock around synchronised calls; each leg warmed once."""
+    MiB = 1 << 20
+    data, _ = corpus.load_or_make("enwik9", start=0, count=256 * MiB)
+    d_all = torch.from_numpy(np.ascontiguousarray(data)).to(dev)
+    out = {}
+    ctx = jam.Context(device_index, None)
+    try:
+        # (block MiB, blocks of the stream, blocks timed one at a time)
+        for bm, nstream, nsingle in ((1, 64, 8), (64, 4, 2), (256, 2, 1)):
+            bs = bm * MiB
+            nuniq = min(nstream, (256 * MiB) // bs)
+            srcs = [d_all[(k % nuniq) * bs: (k % nuniq) * bs + bs] for k in range(nstream)]
+            cap = jam.ans_capacity(bs + jam.TRAILER)
+            ctx.reserve(bs)
+            outs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(nstream)]
+            backs = [torch.empty(bs, dtype=torch.uint8, device=dev) for _ in range(nstream)]
+            single = torch.empty(cap, dtype=torch.uint8, device=dev)
+            # one at a time
+            ctx.block_compress(srcs[0], bs, single, cap)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sz1 = [ctx.block_compress(srcs[k], bs, outs[k], cap) for k in range(nsingle)]
+            torch.cuda.synchronize()
+            tc1 = (time.perf_counter() - t0) / nsingle
+            ctx.block_decompress(outs[0], sz1[0], backs[0], bs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            bk1 = [ctx.block_decompress(outs[k], sz1[k], backs[k], bs) for k in range(nsingle)]
+            torch.cuda.synchronize()
+            td1 = (time.perf_counter() - t0) / nsingle
+            ok = all(bk1[k] == bs and bool(torch.equal(backs[k], srcs[k])) for k in range(nsingle))
+            ref = [outs[k][: sz1[k]].clone() for k in range(nsingle)]
+            # streamed
+            ctx.blocks_compress(srcs, [bs] * nstream, outs, [cap] * nstream, in_flight)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            szs, st = ctx.blocks_compress(srcs, [bs] * nstream, outs, [cap] * nstream, in_flight)
+            torch.cuda.synchronize()
+            tcs = (time.perf_counter() - t0) / nstream
+            ok = ok and st == [0] * nstream and all(szs[k] == sz1[k] and bool(torch.equal(outs[k][: szs[k]], ref[k])) for k in range(nsingle))
+            ctx.blocks_decompress(outs, szs, backs, [bs] * nstream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            bks, st = ctx.blocks_decompress(outs, szs, backs, [bs] * nstream)
+            torch.cuda.synchronize()
+            tds = (time.perf_counter() - t0) / nstream
+            ok = ok and st == [0] * nstream and all(bks[k] == bs and bool(torch.equal(backs[k], srcs[k])) for k in range(nstream))
+            mb = bs / 1e6
+            out[f"{bm}MiB"] = {"block_bytes": bs, "stream_blocks": nstream, "in_flight": min(in_flight, nstream),
+                               "compress_MBps": {"one_at_a_time": round(mb / tc1, 1), "streamed": round(mb / tcs, 1)},
+                               "decompress_MBps": {"one_at_a_time": round(mb / td1, 1), "streamed": round(mb / tds, 1)},
+                               "compressed_ratio": round(sum(szs) / (bs * nstream), 4), "same_bytes": bool(ok)}
+            del outs, backs, single, ref, srcs
+            torch.cuda.empty_cache()
+    finally:
+        ctx.close()
+        jam.shutdown()                 # the batch call's worker contexts (a 256 MiB block's arena is ~17 GB each)
+    out["note"] = ("enwik9-like text; one_at_a_time = one block per call; streamed = all blocks of the stream through one jpk_dev_blocks_compress / "
+                   "jpk_dev_blocks_decompress call; HBM resident; MB/s of uncompressed bytes")
+    return out
+
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -279,19 +349,22 @@ def main():
 
     sizes = [0] * nblk
     gathered = [None]
+    # the largest number of blocks one rank owns: sizes the one fixed-size all_gather of (count, sizes) in shard.gather_blocks
+    max_local = (nblocks_job + world - 1) // world if stream_mode else nblk
+    gather_s = [0.0, 0]                  # host time this rank spent inside the gather (+ its stream sync), gathers
 
     def run_steps(nsteps, inputs=None, result=None, gather=True):
         """`nsteps` passes over the batch.  The (step, block) tasks go through one queue to the contexts -- a free context takes the
         next block, as the reference's OpenMP block loop over a long file does (jampack.cpp:205-224) -- so the passes follow each
         other without a host-side join; `--contexts` blocks are in flight at any time.  With more than one rank the compressed
-        blocks of step s are gathered on rank 0 (the path's only exchange: all_gather of the sizes, one gather of a buffer padded
-        to the largest rank total, RCCL over xGMI; jampack_amd/shard.py) while step s+1 is being compressed."""
+        blocks of step s are gathered on rank 0 (the path's only exchange: one fixed-size all_gather of the sizes, then one send per
+        rank of exactly its bytes, RCCL over xGMI; jampack_amd/shard.py) while step s+1 is being compressed."""
         if nsteps <= 0:
             return
         if nblk == 0:                    # more ranks than blocks: this rank still takes part in every gather
             if gather and use_dist:
                 for _ in range(nsteps):
-                    shard.gather_blocks([], dst=0, device=dev)
+                    shard.gather_blocks([], dst=0, device=dev, max_local=max_local)
             return
         inputs = d_in if inputs is None else inputs
         q = queue.Queue()
@@ -331,8 +404,12 @@ def main():
             with cond:
                 cond.wait_for(lambda: remaining[s_] == 0)
             if gather:
-                gathered[0] = shard.gather_blocks([out_bufs[res[s_][i][0]][s_ % NSETS][i][: max(res[s_][i][1], 0)] for i in range(nblk)], dst=0, device=dev)
+                tg0 = time.perf_counter()
+                gathered[0] = shard.gather_blocks([out_bufs[res[s_][i][0]][s_ % NSETS][i][: max(res[s_][i][1], 0)] for i in range(nblk)], dst=0, device=dev,
+                                                  max_local=max_local)
                 torch.cuda.current_stream().synchronize()      # the gather has read this buffer set before step s+NSETS may write it
+                gather_s[0] += time.perf_counter() - tg0
+                gather_s[1] += 1
             if s_ + depth < nsteps:
                 enqueue(s_ + depth)
         for _ in th:
@@ -364,6 +441,7 @@ def main():
 
     run_steps(args.warmup)
     sync_all()
+    gather_s[0], gather_s[1] = 0.0, 0
     t0 = time.perf_counter()
     run_steps(args.steps)
     sync_all()
@@ -376,6 +454,13 @@ def main():
     value = job_bytes / 1e6 / (dt / args.steps)
 
     extra = {}
+    if use_dist:
+        backend = dist.get_backend()
+        extra["collective"] = {"backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend), "ranks": dist.get_world_size(),
+                               "gathers_timed": gather_s[1],
+                               "gather_ms_per_step": round(gather_s[0] / max(gather_s[1], 1) * 1e3, 3),
+                               "note": "host time rank 0 spends in one gather of a step's compressed blocks (fixed-size all_gather of the sizes + one exact-size "
+                                       "send per rank + stream sync); it overlaps the compression of the following steps"}
     if rank == 0 and gathered[0] is not None:
         # rank 0 holds every rank's compressed blocks; in stream mode they are put back into file order (what the in-order
         # CompWriteBlock loop writes, jampack.cpp:220-224) and rank 0's own blocks are checked against their sources
@@ -654,6 +739,11 @@ def main():
                                             "compressed_ratio": round(sum(psz) / batch_bytes, 4),
                                             "workload": "same shape, text with a 200 000-phrase book (round 1's corpus)"}
             del p_in
+        if not args.no_block_sizes and not args.limit_bytes:
+            try:
+                extra["per_block_size"] = per_block_size(jam, corpus, torch, dev, local_rank, nctx)
+            except Exception as ex:       # noqa: BLE001 -- an extra must never take the headline down
+                extra["per_block_size"] = {"error": repr(ex)}
         if not args.no_cpu_baseline:
             try:
                 cb, ref_enc, n = cpu_baseline(blocks, args.cpu_sample_mib)
@@ -667,13 +757,19 @@ def main():
                 extra["cpu_baseline"] = {"value": None, "unit": "MB/s", "cores": 0, "kind": "error", "sample": repr(ex)}
 
     if rank == 0:
+        # the strings say what was timed: a gather only when one ran, under the name of the backend that carried it
+        coll = ""
+        if use_dist:
+            coll = ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend()) + " gather of the compressed blocks on rank 0"
         if stream_mode:
             wl = (f"{args.workload}-like: ONE {job_bytes} B stream as {args.block_mib} MiB blocks ({nblocks_job} blocks), block b on GPU b mod {world}, "
-                  "forward BWT + rANS encode, inputs resident in HBM, compressed blocks gathered on rank 0 in block order")
-            par = f"{nblocks_job} blocks sharded b mod {world} over {world} GPU(s)" + (", RCCL gather of compressed blocks" if use_dist else "")
+                  "forward BWT + rANS encode, inputs resident in HBM" + (f", {coll} in block order" if use_dist else ", no gather (one rank)"))
+            par = f"{nblocks_job} blocks sharded b mod {world} over {world} GPU(s)" + (f", {coll}" if use_dist else "")
         else:
             wl = (f"{args.workload}-like {batch_bytes} B per GPU as {args.block_mib} MiB blocks ({len(blocks)} blocks), forward BWT + rANS encode, inputs resident in HBM")
-            par = (f"one batch per GPU on {world} GPUs, RCCL gather of compressed blocks" if world > 1 else "1 GPU")
+            par = (f"one batch per GPU on {world} GPUs, {coll}" if world > 1 else ("1 GPU" + (f", {coll} (forced, world 1)" if use_dist else "")))
+        if ONE_GPU_RANKS and world > 1:
+            par += " [test hook JPK_BENCH_ONE_GPU: all ranks share cuda:0 -- exercises the N > 1 code path, not a scaling number]"
         line = {
             "metric": "MB/s compress (forward BWT + rANS encode) on 64 MiB blocks; bit-exact vs CPU ref",
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -190,7 +190,10 @@ JPK_API int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const uint8
  * hides in its latency), so the library runs `in_flight` worker threads (<= 0: 4, the measured optimum on one MI355X), each with
  * a context of its own on ctx's device (kept by the library between calls, released by jpk_shutdown), that take the blocks in
  * array order.  The calling thread works too (with ctx) and returns when every block is done.  status may be NULL; otherwise
- * status[b] receives block b's jpk_status (JPK_E_CAPACITY when out_cap[b] is too small, ...) and the other blocks still complete. */
+ * status[b] receives block b's jpk_status (JPK_E_CAPACITY when out_cap[b] is too small, ...) and the other blocks still complete.
+ * Stream order: as for every jpk_dev_* call, work already queued on ctx's stream (the producers of d_in[], readers of an earlier
+ * d_out[]) is ordered in front of the batch -- the workers' streams wait for an event recorded on ctx's stream at entry -- and
+ * every block is complete when the call returns. */
 JPK_API int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out,
                             const int32_t *out_cap, int32_t *out_len, int32_t *status, int32_t in_flight);
 
@@ -209,6 +212,18 @@ JPK_API int jpk_dev_exclusive_scan_u32(jpk_ctx *ctx, uint32_t *d_data, int32_t n
 /* entropy sub-stages of one chunk: rank array -> RLE0 symbols; symbols -> packed (low | freq<<16) pairs */
 JPK_API int jpk_dev_rle_encode(jpk_ctx *ctx, const uint8_t *d_ranks, int32_t len, uint16_t *d_rle, int32_t *rlen);
 JPK_API int jpk_dev_model_pairs(jpk_ctx *ctx, const uint16_t *d_rle, int32_t rlen, uint32_t *d_pairs);
+
+/* ---- host-logic probes (no device call; tests/test_abi_and_host.py) ----------------------------------------------- */
+/* The encoder cuts one block's chunks into 1..4 graded launch groups by the number of blocks that are in their forward BWT or
+ * entropy encode ON THE SAME DEVICE at that moment (jampack.cpp:215 runs one block per OpenMP thread; with jpk_init over eight
+ * GPUs every block is alone on its device).  jpk_debug_compress_inflight: delta > 0 registers a block on `device` and returns the
+ * count including it, delta < 0 removes one and returns what is left, delta == 0 reads.  jpk_debug_enc_groups: the launch groups
+ * a block of `nch` chunks arriving on `device` now would get. */
+JPK_API int jpk_debug_compress_inflight(int device, int delta);
+/* HBM arena bytes stage 0 (forward BWT) / 1 (rANS encode) / 2 (inverse BWT) / 3 (rANS decode, bound) plans for one block of
+ * block_bytes; jpk_ctx_reserve takes their maximum. */
+JPK_API int64_t jpk_debug_arena_bytes(int64_t block_bytes, int stage);
+JPK_API int jpk_debug_enc_groups(int device, int32_t nch);
 
 #ifdef __cplusplus
 }

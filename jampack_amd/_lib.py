@@ -93,6 +93,9 @@ _SIGS = {
     "jpk_dev_exclusive_scan_u32": (C.c_int, [_vp, _vp, C.c_int32, C.POINTER(C.c_uint32)]),
     "jpk_dev_rle_encode": (C.c_int, [_vp, _vp, C.c_int32, _vp, _i32p]),
     "jpk_dev_model_pairs": (C.c_int, [_vp, _vp, C.c_int32, _vp]),
+    "jpk_debug_compress_inflight": (C.c_int, [C.c_int, C.c_int]),
+    "jpk_debug_enc_groups": (C.c_int, [C.c_int, C.c_int32]),
+    "jpk_debug_arena_bytes": (C.c_int64, [C.c_int64, C.c_int]),
 }
 
 ABI_SYMBOLS = tuple(_SIGS)

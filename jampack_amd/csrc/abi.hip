@@ -18,6 +18,8 @@
 __attribute__((constructor)) static void jpk_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "32", 0); }
 
 // ---- arena / staging ---------------------------------------------------------------------------------------
+bool jpk_arena_fits(const jpk_ctx *ctx, size_t bytes) { return jpk_align(bytes + 4096, 1 << 20) <= ctx->arena_cap; }
+
 int jpk_arena_ensure(jpk_ctx *ctx, size_t bytes)
 {
     bytes = jpk_align(bytes + 4096, 1 << 20);
@@ -215,6 +217,7 @@ extern "C" int jpk_ctx_create(jpk_ctx **out, int device, void *hip_stream)
     }
     for (int k = 0; k < 2; k++)
         if (hipEventCreateWithFlags(&c->ev_sa[k], hipEventDisableTiming) != hipSuccess) { jpk_ctx_destroy(c); return JPK_E_ALLOC; }
+    if (hipEventCreateWithFlags(&c->ev_batch, hipEventDisableTiming) != hipSuccess) { jpk_ctx_destroy(c); return JPK_E_ALLOC; }
     for (int k = 0; k < jpk_ctx::GATE_EVENTS; k++)
         if (hipEventCreateWithFlags(&c->ev_gate[k], hipEventDisableTiming) != hipSuccess) { jpk_ctx_destroy(c); return JPK_E_ALLOC; }
     for (int g = 0; g < jpk_ctx::ENC_GROUPS; g++) {
@@ -252,6 +255,7 @@ extern "C" void jpk_ctx_destroy(jpk_ctx *c)
     }
     for (int k = 0; k < 2; k++)
         if (c->ev_sa[k]) (void)hipEventDestroy(c->ev_sa[k]);
+    if (c->ev_batch) (void)hipEventDestroy(c->ev_batch);
     for (auto &p : c->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -274,7 +278,32 @@ extern "C" int jpk_ctx_reserve(jpk_ctx *ctx, int64_t max_block_bytes)
 {
     if (!ctx || max_block_bytes < 0) return JPK_E_ARG;
     JPK_HIP(hipSetDevice(ctx->device));
-    return jpk_arena_ensure(ctx, (size_t)max_block_bytes * 72 + (64u << 20));
+    if (max_block_bytes > (int64_t)JPK_MAX_BLOCKSIZE) return JPK_E_ARG;
+    // the largest of the four stages' own layouts (their planning passes), not a guess: forward BWT ~39 n, rANS encode ~41 n
+    // worst case, inverse BWT ~10 n, rANS decode 3 n + chunk tables
+    const uint32_t n = (uint32_t)max_block_bytes, mid = n + JPK_TRAILER_BYTES;
+    size_t need = jpk_fwd_bwt_arena_bytes(n);
+    const size_t enc = jpk_ans_encode_arena_bytes(mid), inv = jpk_inv_bwt_arena_bytes(n);
+    const size_t dec = (size_t)mid * 3 + ((size_t)mid / JPK_ANS_CHUNK + 2) * 1100 + (1u << 20);
+    if (enc > need) need = enc;
+    if (inv > need) need = inv;
+    if (dec > need) need = dec;
+    return jpk_arena_ensure(ctx, need);
+}
+
+// host-logic probe: arena bytes stage `stage` (0 forward BWT, 1 rANS encode, 2 inverse BWT, 3 rANS decode bound) plans for one
+// block of block_bytes -- what jpk_ctx_reserve takes the maximum of (DESIGN.md section 3 quotes these)
+extern "C" int64_t jpk_debug_arena_bytes(int64_t block_bytes, int stage)
+{
+    if (block_bytes < 0 || block_bytes > (int64_t)JPK_MAX_BLOCKSIZE) return JPK_E_ARG;
+    const uint32_t n = (uint32_t)block_bytes, mid = n + JPK_TRAILER_BYTES;
+    switch (stage) {
+    case 0: return (int64_t)jpk_fwd_bwt_arena_bytes(n);
+    case 1: return (int64_t)jpk_ans_encode_arena_bytes(mid);
+    case 2: return (int64_t)jpk_inv_bwt_arena_bytes(n);
+    case 3: return (int64_t)((size_t)mid * 3 + ((size_t)mid / JPK_ANS_CHUNK + 2) * 1100 + (1u << 20));
+    default: return JPK_E_ARG;
+    }
 }
 
 extern "C" const char *jpk_strerror(int s)
@@ -294,9 +323,43 @@ extern "C" const char *jpk_strerror(int s)
 extern "C" const char *jpk_version(void) { return "jampack_amd 0.1 (gfx950)"; }
 
 // ---- device-buffer entry points ----------------------------------------------------------------------------
-namespace { std::atomic<int> g_compress_inflight{0}; }
-int jpk_compress_inflight_enter() { return g_compress_inflight.fetch_add(1, std::memory_order_relaxed) + 1; }
-void jpk_compress_inflight_leave() { g_compress_inflight.fetch_sub(1, std::memory_order_relaxed); }
+// Blocks in their forward BWT or entropy encode right now, PER DEVICE: the encoder's launch grouping follows the load of the GPU
+// the block runs on -- with one thread per GPU (jpk_init over eight devices) every block is alone on its device, whatever the
+// other seven are doing.
+namespace { std::atomic<int> g_compress_inflight[64]; }
+int jpk_compress_inflight_enter(int device)
+{
+    if (device < 0 || device >= 64) return 1;
+    return g_compress_inflight[device].fetch_add(1, std::memory_order_relaxed) + 1;
+}
+void jpk_compress_inflight_leave(int device)
+{
+    if (device >= 0 && device < 64) g_compress_inflight[device].fetch_sub(1, std::memory_order_relaxed);
+}
+// launch groups of the entropy encoder for a block of `nch` chunks that is one of `inflight` blocks on its device (ans_enc.hip):
+// graded groups shorten ONE block and cost throughput when other blocks fill the machine anyway
+int jpk_enc_groups_for(int inflight, uint32_t nch)
+{
+    int ngroups = (int)(nch / 8u);
+    const int gmax = inflight <= 1 ? jpk_ctx::ENC_GROUPS : (inflight == 2 ? 2 : 1);
+    if (ngroups > gmax) ngroups = gmax;
+    if (ngroups < 1) ngroups = 1;
+    return ngroups;
+}
+// test hooks (host logic only, no device call): the per-device accounting and the grouping rule
+extern "C" int jpk_debug_compress_inflight(int device, int delta)
+{
+    if (device < 0 || device >= 64) return JPK_E_ARG;
+    if (delta > 0) return jpk_compress_inflight_enter(device);
+    if (delta < 0) { jpk_compress_inflight_leave(device); return g_compress_inflight[device].load(std::memory_order_relaxed); }
+    return g_compress_inflight[device].load(std::memory_order_relaxed);
+}
+extern "C" int jpk_debug_enc_groups(int device, int32_t nch)
+{
+    if (device < 0 || device >= 64 || nch < 0) return JPK_E_ARG;
+    // what a block that arrives on `device` now would choose (it counts itself)
+    return jpk_enc_groups_for(g_compress_inflight[device].load(std::memory_order_relaxed) + 1, (uint32_t)nch);
+}
 
 #define JPK_ENTER(ctx)                         \
     if (!(ctx)) return JPK_E_ARG;              \
@@ -667,8 +730,10 @@ int tls_ctx(jpk_ctx **out)
 
 // ---- jpk_dev_blocks_compress: blocks in flight inside the library ---------------------------------------------------------
 namespace {
-// worker contexts of the batch compress call, per device; owned by the pool (p.all) so that jpk_shutdown destroys them
+// worker contexts of the batch compress call, per device.  They are the library's own (a list apart from the host-buffer pool:
+// a device-API call must not make jpk_init() believe that host-buffer contexts exist); jpk_shutdown destroys them too.
 std::vector<std::vector<jpk_ctx *>> &batch_idle() { static std::vector<std::vector<jpk_ctx *>> v(64); return v; }
+std::vector<jpk_ctx *> &batch_all() { static std::vector<jpk_ctx *> v; return v; }
 
 int batch_ctx_acquire(int device, jpk_ctx **out)
 {
@@ -678,7 +743,7 @@ int batch_ctx_acquire(int device, jpk_ctx **out)
     if (!idle.empty()) { *out = idle.back(); idle.pop_back(); return JPK_OK; }
     jpk_ctx *c = nullptr;
     JPK_TRY(jpk_ctx_create(&c, device, nullptr));
-    p.all.push_back(c);
+    batch_all().push_back(c);
     *out = c;
     return JPK_OK;
 }
@@ -706,8 +771,15 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
     if (nw > 16) nw = 16;
     uint64_t generation;
     { CtxPool &p = pool(); std::lock_guard<std::mutex> g(p.mu); generation = p.generation; }
+    // Stream order: the workers' streams are the library's own.  Whatever the caller has queued on ctx->stream before this call
+    // (the kernels that produce d_in[], the consumers of a previous d_out[]) must be ordered in front of them, as it is for
+    // jpk_dev_block_compress on the caller's context: an event on ctx->stream that every worker stream waits for.  The call
+    // returns when every block is complete (each worker synchronises its stream), so nothing needs ordering at the exit.
+    JPK_HIP(hipEventRecord(ctx->ev_batch, ctx->stream));
     std::atomic<int> next{0};
     auto work = [&](jpk_ctx *c) {
+        if (hipSetDevice(c->device) != hipSuccess) return;                  // a fresh thread starts on device 0
+        if (c != ctx && hipStreamWaitEvent(c->stream, ctx->ev_batch, 0) != hipSuccess) return;   // leaves its share to the others
         for (;;) {
             const int b = next.fetch_add(1, std::memory_order_relaxed);
             if (b >= nblocks) return;
@@ -715,14 +787,15 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
             stp[b] = jpk_dev_block_compress(c, d_in[b], in_len[b], d_out[b], out_cap[b], &out_len[b]);
         }
     };
-    // workers 1 .. nw-1 on contexts of their own; a worker that cannot get one leaves its share to the others
+    // workers 1 .. nw-1 on contexts of their own; a worker that cannot get one (or a thread that cannot be started) leaves its
+    // share to the others
     std::vector<std::thread> threads;
     std::vector<jpk_ctx *> held;
     for (int k = 1; k < nw; k++) {
         jpk_ctx *c = nullptr;
         if (batch_ctx_acquire(ctx->device, &c) != JPK_OK) break;
         held.push_back(c);
-        threads.emplace_back(work, c);
+        try { threads.emplace_back(work, c); } catch (...) { break; }      // std::system_error: the caller's thread does that share
     }
     work(ctx);
     for (auto &t : threads) t.join();
@@ -765,7 +838,9 @@ extern "C" void jpk_shutdown(void)
     for (jpk_ctx *c : p.all) jpk_ctx_destroy(c);    // synchronises each context's streams first
     p.all.clear();
     p.idle.clear();
-    for (auto &v : batch_idle()) v.clear();         // the batch-compress workers' contexts were in p.all
+    for (jpk_ctx *c : batch_all()) jpk_ctx_destroy(c);      // the batch-compress workers' contexts
+    batch_all().clear();
+    for (auto &v : batch_idle()) v.clear();
     p.devices.clear();
     p.generation++;
     p.next_thread = 0;
@@ -857,15 +932,15 @@ extern "C" int jpk_ans_decoded_size(const uint8_t *in, int32_t in_len, int64_t *
     int32_t nch = 0;
     while (ip < in_len) {
         int64_t fsum = 0;
-        uint32_t v = 0;
+        uint32_t v = 0, olen = 0;
         for (int s = 0; s < 259; s++) {                 // 256 frequencies, olen, clen, rlen (ans.cpp:272-302)
             const int n = leb_host(&v, in + ip, (int64_t)in_len - ip);
             if (n < 0) return JPK_E_CORRUPT;
             ip += n;
             if (s < 256) { if (v > (uint32_t)JPK_ANS_CHUNK) return JPK_E_CORRUPT; fsum += v; }
-            else if (s == 256) { if (v > (uint32_t)JPK_ANS_CHUNK || (int64_t)v != fsum) return JPK_E_CORRUPT; total += v; }
+            else if (s == 256) { if (v > (uint32_t)JPK_ANS_CHUNK || (int64_t)v != fsum) return JPK_E_CORRUPT; total += v; olen = v; }
             else if (s == 257) { if (v < 16 || (int64_t)v > (int64_t)in_len - ip) return JPK_E_CORRUPT; fsum = v; }   // clen, payload follows rlen
-            else { if (v > (uint32_t)JPK_ANS_CHUNK) return JPK_E_CORRUPT; }
+            else { if (v > olen) return JPK_E_CORRUPT; }     // RLE0 never has more symbols than bytes ("rle mismatch!", rle.cpp:73)
         }
         if (fsum > (int64_t)in_len - ip) return JPK_E_CORRUPT;
         ip += fsum;                                      // skip the payload

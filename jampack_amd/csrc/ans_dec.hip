@@ -119,7 +119,9 @@ __global__ __launch_bounds__(64) void k_dec_headers(const DecBlock *__restrict__
         olen = wave_sum(olen); clen = wave_sum(clen); rlen = wave_sum(rlen);
         const uint64_t total = (uint64_t)wave_sum(fsum);
         ip = pos;
-        if (bad || olen > (uint32_t)ANS_CHUNK || rlen > (uint32_t)ANS_CHUNK || ip > len || (uint64_t)clen > len - ip || clen < 16 ||
+        // rlen > olen: RLE0 never emits more symbols than bytes (a run of k binary digits stands for >= k zeros, every other symbol
+        // for one byte), so RLE::decode would end in "rle mismatch!" (rle.cpp:73) -- and the buffers below are sized by olen
+        if (bad || olen > (uint32_t)ANS_CHUNK || rlen > olen || ip > len || (uint64_t)clen > len - ip || clen < 16 ||
             total != (uint64_t)olen) {                                       // ans.cpp:297-298, rank.cpp:104-108
             status = JPK_E_CORRUPT;
             break;
@@ -142,19 +144,29 @@ __global__ __launch_bounds__(64) void k_dec_headers(const DecBlock *__restrict__
 }
 
 // Launch order of the chains of a large batch: longest first (by RLE0 symbols, what both serial kernels' time follows), so that
-// the chains that set the length of the stage are not the ones that had to wait for a free slot.  n is a few thousand: every
-// chunk counts the chunks ahead of it.
-__global__ __launch_bounds__(256) void k_dec_order(const ChunkInfo *__restrict__ info, uint32_t n, uint32_t *__restrict__ order)
+// the chains that set the length of the stage are not the ones that had to wait for a free slot.  One pass of counting: 4096
+// buckets of 256 symbols, longest bucket first; the order inside a bucket is arrival order (any order is a valid launch order:
+// it only decides which chain starts first, never a byte).  One workgroup, any number of chunks.
+constexpr int ORD_BUCKETS = 4096, ORD_TB = 1024;
+__global__ __launch_bounds__(ORD_TB) void k_dec_order(const ChunkInfo *__restrict__ info, uint32_t n, uint32_t *__restrict__ order)
 {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
-    const uint32_t key = info[t].rlen;
-    uint32_t before = 0;
-    for (uint32_t j = 0; j < n; j++) {
-        const uint32_t kj = info[j].rlen;
-        before += (kj > key || (kj == key && j < t)) ? 1u : 0u;
-    }
-    order[before] = t;
+    __shared__ uint32_t h[ORD_BUCKETS];
+    __shared__ uint32_t sm[ORD_TB / 64 + 1];
+    for (int i = threadIdx.x; i < ORD_BUCKETS; i += ORD_TB) h[i] = 0;
+    __syncthreads();
+    auto bucket = [](uint32_t rlen) { const uint32_t b = rlen >> 8; return (uint32_t)(ORD_BUCKETS - 1) - (b < (uint32_t)ORD_BUCKETS ? b : (uint32_t)(ORD_BUCKETS - 1)); };
+    for (uint32_t t = threadIdx.x; t < n; t += ORD_TB) atomicAdd(&h[bucket(info[t].rlen)], 1u);
+    __syncthreads();
+    // exclusive scan of the bucket counts, four consecutive buckets per thread
+    uint32_t v[ORD_BUCKETS / ORD_TB], acc = 0;
+#pragma unroll
+    for (int k = 0; k < ORD_BUCKETS / ORD_TB; k++) { v[k] = h[threadIdx.x * (ORD_BUCKETS / ORD_TB) + k]; acc += v[k]; }
+    const uint32_t inc = block_incl_scan<OpSum>(acc, sm, nullptr);
+    uint32_t run = inc - acc;
+#pragma unroll
+    for (int k = 0; k < ORD_BUCKETS / ORD_TB; k++) { h[threadIdx.x * (ORD_BUCKETS / ORD_TB) + k] = run; run += v[k]; }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < n; t += ORD_TB) order[atomicAdd(&h[bucket(info[t].rlen)], 1u)] = t;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -843,6 +855,7 @@ int jpk_ans_decode_batch(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in, con
     }
     // ---- pass 1: count the chunks, total the sizes ----
     const size_t tab_bytes = jpk_align((size_t)nblk * sizeof(DecBlock) + 64), mail_bytes = jpk_align((size_t)nblk * 8 * 4 + 64);
+    if (arena_skip && !jpk_arena_fits(ctx, arena_skip + tab_bytes + mail_bytes + 4096)) return JPK_E_ALLOC;
     JPK_TRY(jpk_arena_ensure(ctx, arena_skip + tab_bytes + mail_bytes + 4096));
     DecBlock *d_tab = reinterpret_cast<DecBlock *>(ctx->arena + arena_skip);
     uint32_t *d_mail = reinterpret_cast<uint32_t *>(ctx->arena + arena_skip + tab_bytes);
@@ -879,6 +892,9 @@ int jpk_ans_decode_batch(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in, con
     const size_t o_order = take((size_t)nch_total * 4);
     std::vector<size_t> o_rle((size_t)nblk), o_ranks((size_t)nblk);
     for (int b = 0; b < nblk; b++) { o_rle[b] = take(tot_rle[b] * 2); o_ranks[b] = take(tot_out[b]); }
+    // A caller that keeps buffers of its own at the start of the arena (arena_skip != 0) has sized it for the worst case of the
+    // streams' declared sizes; an arena that would have to grow -- and therefore move -- under those buffers is refused.
+    if (arena_skip && !jpk_arena_fits(ctx, off + 4096)) return JPK_E_ALLOC;
     JPK_TRY(jpk_arena_ensure(ctx, off + 4096));            // may move the arena: every pointer is formed below
     d_tab = reinterpret_cast<DecBlock *>(ctx->arena + arena_skip);
     d_mail = reinterpret_cast<uint32_t *>(ctx->arena + arena_skip + tab_bytes);
@@ -900,12 +916,13 @@ int jpk_ans_decode_batch(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in, con
     // them to four workgroups per CU; larger batches run without it, because two chains on a SIMD fill each other's issue
     // bubbles and a second round of workgroups would wait for the first (64 blocks: 3.5 -> 4.8 GB/s, tools/dec_scaling.py).
     const unsigned g = (unsigned)nch_total;
-    const size_t lds_cap = (size_t)(getenv("JPK_DEC_LDS") ? atoi(getenv("JPK_DEC_LDS")) : (g <= 1024u ? 40960 : 0));
-    // more chains than run at once: longest first (a few thousand chunks; beyond that the quadratic count is not worth it)
+    static const int lds_env = [] { const char *e = getenv("JPK_DEC_LDS"); if (!e) return -1; const int v = atoi(e); return v < 0 ? 0 : (v > 65536 ? 65536 : v); }();
+    const size_t lds_cap = (size_t)(lds_env >= 0 ? lds_env : (g <= 1024u ? 40960 : 0));
+    // more chains than run at once: longest first
     uint32_t *order = nullptr;
-    if (g > 1024u && g <= 16384u) {
+    if (g > 1024u) {
         order = reinterpret_cast<uint32_t *>(ctx->arena + o_order);
-        JPK_LAUNCH(ctx, PROF_DEC_HEADERS, 0, k_dec_order, dim3(jpk_grid(g, 256)), dim3(256), info, g, order);
+        JPK_LAUNCH(ctx, PROF_DEC_HEADERS, 0, k_dec_order, dim3(1), dim3(ORD_TB), info, g, order);
     }
     JPK_LAUNCH_LDS(ctx, PROF_DEC_RANS, 2 * rle_total, lds_cap, k_dec_rans, dim3(g), dim3(64), d_tab, info, order, d_status);
     JPK_LAUNCH(ctx, PROF_DEC_RLE, rle_total, k_dec_rle, dim3(g), dim3(1024), d_tab, info, d_status);

@@ -712,13 +712,14 @@ __device__ __forceinline__ uint4 rans_record(uint32_t lo, uint32_t fr)
 __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
                                              const uint16_t *__restrict__ explo, const uint16_t *__restrict__ exphi, const uint32_t *__restrict__ mantad,
                                              const uint32_t *__restrict__ ord, const uint32_t *__restrict__ qcdf, uint4 *__restrict__ recs,
-                                             uint32_t *__restrict__ pairs_plain)
+                                             uint16_t *__restrict__ fr16, uint32_t *__restrict__ pairs_plain)
 {
     const uint32_t c = chunk_of(d, blockIdx.y);
     const uint32_t t = blockIdx.x * TB + threadIdx.x;
     const uint32_t rl = rlen[c];
     const size_t lane_stride = rans_lane_stride(rle_stride);
     uint4 *rc = recs + (size_t)c * 4 * lane_stride;
+    uint16_t *fq = fr16 + (size_t)c * 4 * lane_stride;     // frequency sidecar: what the emit kernels need of a record (2 of its 16 bytes)
     if (t >= rl) {
         // the chain kernel walks whole batches of 16 steps: steps past a chain's last pair get identity records
         // (xmax above every state, q * 0 + x + 0), so that it needs no bounds logic
@@ -750,6 +751,8 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
     const uint32_t j0 = 2 * t;
     rc[(size_t)(j0 & 3u) * lane_stride + (j0 >> 2)] = rans_record(l0, h0 - l0);
     rc[(size_t)((j0 + 1) & 3u) * lane_stride + (j0 >> 2)] = rans_record(l1, f1);
+    fq[(size_t)(j0 & 3u) * lane_stride + (j0 >> 2)] = (uint16_t)(h0 - l0);          // every model keeps each symbol >= 1: freq <= 65535
+    fq[(size_t)((j0 + 1) & 3u) * lane_stride + (j0 >> 2)] = (uint16_t)f1;
     if (pairs_plain) {
         uint32_t *out = pairs_plain + (size_t)c * 2 * rle_stride + 2 * (size_t)t;
         out[0] = l0 | ((h0 - l0) << 16);
@@ -959,13 +962,15 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
 // Pair j of a chunk (chain j & 3, step j >> 2) emitted 0..2 bytes; the encoder walks the pairs last to first and the stream grows
 // downwards, so the bytes of pair j start  sum_{j' >= j} count(j')  bytes before the end of the chunk's payload.
 constexpr int ETILE = 4096;                    // pairs per tile
-__device__ __forceinline__ uint32_t pair_emit(const uint32_t *__restrict__ xs, const uint4 *__restrict__ recs, size_t chunk_base, size_t lane_stride, uint32_t j)
+// (state before the step, frequency): 6 bytes per pair -- the 16-byte step records are read once, by the chain
+__device__ __forceinline__ uint32_t pair_emit(const uint32_t *__restrict__ xs, const uint16_t *__restrict__ fr16, size_t chunk_base, size_t lane_stride, uint32_t j)
 {
     const size_t o = chunk_base + (size_t)(j & 3u) * lane_stride + (j >> 2);
-    return emit_word(xs[o], recs[o].x);
+    const uint32_t f = fr16[o];
+    return emit_word(xs[o], f ? f << 15 : 0x80000000u);       // a frequency of 65536 wraps to 0 in the sidecar (cannot occur: every symbol keeps >= 1)
 }
 
-__global__ __launch_bounds__(TB) void k_emit_count(const uint32_t *__restrict__ xs, const uint4 *__restrict__ recs, size_t rle_stride, EncDims d,
+__global__ __launch_bounds__(TB) void k_emit_count(const uint32_t *__restrict__ xs, const uint16_t *__restrict__ recs, size_t rle_stride, EncDims d,
                                                   const uint32_t *__restrict__ rlen, uint32_t *__restrict__ tsum, uint32_t etpc)
 {
     const uint32_t c = chunk_of(d, blockIdx.y), tile = blockIdx.x;
@@ -1066,7 +1071,7 @@ __global__ __launch_bounds__(TB) void k_put_headers(EncDims d, const uint8_t *__
 }
 
 // payload bytes: every pair places its 0..2 bytes (offset = bytes of all later pairs, from the end of the chunk's payload)
-__global__ __launch_bounds__(TB) void k_put_payload(const uint32_t *__restrict__ xs, const uint4 *__restrict__ recs, size_t rle_stride, EncDims d,
+__global__ __launch_bounds__(TB) void k_put_payload(const uint32_t *__restrict__ xs, const uint16_t *__restrict__ recs, size_t rle_stride, EncDims d,
                                                    const uint32_t *__restrict__ rlen, const uint32_t *__restrict__ tsuf, uint32_t etpc,
                                                    const uint32_t *__restrict__ csize, const uint32_t *__restrict__ hsize, const uint64_t *__restrict__ outoff,
                                                    uint8_t *__restrict__ out)
@@ -1108,7 +1113,7 @@ struct EncBufs {
     uint32_t *clscnt, *clstotal, *ord, *qhist, *qcdf, *dens, *cmap;
     uint8_t *cls8; uint32_t *clist;
     uint32_t *seg_flag; int32_t *seg_lo, *seg_end, *seg_start; uint16_t *seg_tab;
-    uint16_t *explo, *exphi; uint32_t *mantad, *pairs; uint4 *recs;
+    uint16_t *explo, *exphi; uint32_t *mantad, *pairs; uint4 *recs; uint16_t *fr16;
     uint32_t *xs, *etsum, *fstate, *csize;
     uint64_t *stamp;
     uint8_t *hdr; uint32_t *hsize; uint64_t *outoff;
@@ -1156,6 +1161,7 @@ void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what)
         b.seg_start = a.get<int32_t>(segs);
         b.seg_tab = a.get<uint16_t>(segs * 32);
         b.recs = a.get<uint4>((size_t)d.nch * 4 * rans_lane_stride(stride));
+        b.fr16 = a.get<uint16_t>((size_t)d.nch * 4 * rans_lane_stride(stride));
         b.pairs = (what & LAY_PLAIN) ? a.get<uint32_t>((size_t)d.nch * stride * 2) : nullptr;
     }
     if (what & LAY_RANS) {
@@ -1249,16 +1255,28 @@ int run_model(jpk_ctx *ctx, const uint16_t *d_rle, const uint32_t *d_rlen, const
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_b, dim3(jpk_grid((size_t)d.ncl * 16, 64)), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_c, dim3((d.tpc + 3) / 4, d.ncl), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_PAIRS, 0, k_pairs, dim3(jpk_grid(stride, TB) + 1, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.explo, b.exphi, b.mantad, b.ord,
-                       b.qcdf, b.recs, b.pairs);
+                       b.qcdf, b.recs, b.fr16, b.pairs);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
 }
 
 }  // namespace
 
+// arena bytes of one Ans::Encode of len bytes (jpk_ctx_reserve)
+size_t jpk_ans_encode_arena_bytes(uint32_t len)
+{
+    if (len == 0) return 0;
+    const EncDims d = make_dims(len, ANS_CHUNK);
+    EncBufs b;
+    jpk_ctx dummy;
+    Arena plan(&dummy, true);
+    enc_layout(plan, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
+    return plan.need;
+}
+
 int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
 {
-    const JpkCompressInflight inflight;      // blocks of the process in their forward BWT or entropy encode right now, this one included
+    const JpkCompressInflight inflight(ctx->device);      // blocks of this device in their forward BWT or entropy encode right now, this one included
     *out_len = 0;
     ctx->stats.ans_chunks = 0;
     ctx->stats.ans_rle_symbols = 0;
@@ -1287,24 +1305,19 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     auto chain = [&](const EncDims &g) -> int {
         JPK_LAUNCH(ctx, PROF_ENC_RANS, 0, k_rans_lanes, dim3(g.ncl), dim3(64), b.recs, stride, g, b.rlen, b.xs, b.fstate, b.stamp);
         const uint32_t etpc = emit_tiles_per_chunk(stride);
-        JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_emit_count, dim3(etpc, g.ncl), dim3(TB), b.xs, b.recs, stride, g, b.rlen, b.etsum, etpc);
+        JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_emit_count, dim3(etpc, g.ncl), dim3(TB), b.xs, b.fr16, stride, g, b.rlen, b.etsum, etpc);
         JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_emit_prefix, dim3(g.ncl), dim3(64), g, b.rlen, b.etsum, etpc, b.csize);
         return JPK_OK;
     };
     // Graded launch groups shorten ONE block (its longest chains start after a sixteenth of the parallel work) but cost throughput
     // when other blocks fill the machine anyway (more kernels, more streams on the hardware queues): 4 groups alone, 2 beside one
     // other block, 1 beside two or more (default bench, 4 blocks in flight: 3.23 / 3.32 / 3.46 GB/s with 4 / 2 / 1 groups)
-    int ngroups = (int)(d.nch / 8u);
-    const int gmax = inflight.n <= 1 ? jpk_ctx::ENC_GROUPS : (inflight.n == 2 ? 2 : 1);
-    if (ngroups > gmax) ngroups = gmax;
-    if (ngroups < 1) ngroups = 1;
-    if (const char *e = getenv("JPK_ENC_GROUPS")) { int v = atoi(e); if (v >= 1 && v <= jpk_ctx::ENC_GROUPS && (uint32_t)v <= d.nch) ngroups = v; }
-    // group streams a busy process no longer uses go back: streams beyond the hardware queues share them, and a chain kernel on a
-    // shared queue blocks its neighbour
-    if (ngroups == 1 && inflight.n >= 3)
-        for (int g = 0; g + 1 < jpk_ctx::ENC_GROUPS; g++)
-            if (ctx->aux[g]) { (void)hipStreamSynchronize(ctx->aux[g]); (void)hipStreamDestroy(ctx->aux[g]); ctx->aux[g] = nullptr; }
-    for (int g = 0; g + 1 < ngroups; g++)         // group streams are created when a block first needs them
+    int ngroups = jpk_enc_groups_for(inflight.n, d.nch);
+    static const int groups_env = [] { const char *e = getenv("JPK_ENC_GROUPS"); return e ? atoi(e) : 0; }();
+    if (groups_env >= 1 && groups_env <= jpk_ctx::ENC_GROUPS && (uint32_t)groups_env <= d.nch) ngroups = groups_env;
+    // group streams are created when a block first needs them and then stay with the context (parked while the device is busy
+    // with other blocks: an idle stream costs nothing, destroying and re-creating it under fluctuating load costs a synchronise)
+    for (int g = 0; g + 1 < ngroups; g++)
         if (!ctx->aux[g] && hipStreamCreateWithFlags(&ctx->aux[g], hipStreamNonBlocking) != hipSuccess) { ctx->aux[g] = nullptr; ngroups = g + 1; break; }
     if (ngroups >= 2) {
         // launch order on the device (no host round trip): density per chunk, rank by counting
@@ -1380,7 +1393,7 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     }
     if (total > (uint64_t)out_cap) return JPK_E_CAPACITY;
     JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_headers, dim3(d.nch), dim3(TB), d, b.hdr, b.hsize, b.outoff, b.fstate, d_out);
-    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_payload, dim3(emit_tiles_per_chunk(stride), d.nch), dim3(TB), b.xs, b.recs, stride, d, b.rlen, b.etsum,
+    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_payload, dim3(emit_tiles_per_chunk(stride), d.nch), dim3(TB), b.xs, b.fr16, stride, d, b.rlen, b.etsum,
                emit_tiles_per_chunk(stride), b.csize, b.hsize, b.outoff, d_out);
     JPK_HIP(hipGetLastError());
     JPK_HIP(hipStreamSynchronize(st));

@@ -1196,6 +1196,16 @@ void jpk_sa_stats_sync(jpk_ctx *ctx)
     }
 }
 
+// arena bytes of one forward BWT of n sorted bytes (jpk_ctx_reserve)
+size_t jpk_fwd_bwt_arena_bytes(uint32_t n)
+{
+    SaBufs b;
+    jpk_ctx dummy;
+    Arena plan(&dummy, true);
+    sa_layout(plan, n ? n : 1, b);
+    return plan.need;
+}
+
 int jpk_suffix_array_device(jpk_ctx *ctx, const uint8_t *d_t, int32_t n, int32_t *d_sa)
 {
     if (n <= 0) return JPK_OK;
@@ -1211,7 +1221,7 @@ int jpk_suffix_array_device(jpk_ctx *ctx, const uint8_t *d_t, int32_t n, int32_t
 
 int jpk_fwd_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out)
 {
-    const JpkCompressInflight inflight;      // counted while this block is in its suffix sort
+    const JpkCompressInflight inflight(ctx->device);      // counted while this block is in its suffix sort
     const int32_t rem = len % JPK_BWT_UNITS, nlen = len - rem;
     if (nlen <= 0) {
         // bwt.cpp:29-35: only the raw tail is produced; the 480 trailer bytes are left untouched

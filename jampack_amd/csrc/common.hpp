@@ -52,6 +52,7 @@ struct jpk_ctx {
     hipEvent_t ev_gate[GATE_EVENTS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     int gate_nev = 0;
     bool gate_held = false;
+    hipEvent_t ev_batch = nullptr;                 // jpk_dev_blocks_*: "the caller's stream has reached the batch call"
     hipEvent_t ev_sa[2] = {nullptr, nullptr};      // suffix sort: "the count round r left behind has reached the host"
     bool sa_stats_pending = false;   // per-round statistics of the last suffix sort are still in the pinned mailbox
     uint32_t *h_map = nullptr;       // pinned, 4096 words
@@ -112,6 +113,7 @@ struct Arena {
 };
 
 int jpk_arena_ensure(jpk_ctx *ctx, size_t bytes);
+bool jpk_arena_fits(const jpk_ctx *ctx, size_t bytes);      // jpk_arena_ensure(bytes) would keep the arena where it is
 int jpk_stage_ensure(jpk_ctx *ctx, size_t in_bytes, size_t out_bytes);
 // copy `words` u32 from device mailbox offset to host (synchronises the stream)
 int jpk_read_mail(jpk_ctx *ctx, uint32_t *dst, int words);
@@ -146,14 +148,15 @@ int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n, uint
 // work: enter() makes ctx->stream wait for the previous holder's events; jpk_gate_mark() records one of this context's
 // events on a stream; leave() publishes them and releases the gate.  The gate is held while the heavy phases are being
 // ENQUEUED.
-// compress-side calls (forward BWT, rANS encode) of all contexts of the process that are running right now: the encoder cuts its
-// chains into fewer launch groups when other blocks are in flight (abi.hip)
-int jpk_compress_inflight_enter();        // returns the count including the caller
-void jpk_compress_inflight_leave();
+// compress-side calls (forward BWT, rANS encode) of the contexts of ONE DEVICE that are running right now: the encoder cuts its
+// chains into fewer launch groups when other blocks are in flight on the same GPU (abi.hip)
+int jpk_compress_inflight_enter(int device);        // returns the count on that device including the caller
+void jpk_compress_inflight_leave(int device);
+int jpk_enc_groups_for(int inflight, uint32_t nch);
 struct JpkCompressInflight {
-    int n;
-    JpkCompressInflight() : n(jpk_compress_inflight_enter()) {}
-    ~JpkCompressInflight() { jpk_compress_inflight_leave(); }
+    int n, device;
+    explicit JpkCompressInflight(int dev) : n(jpk_compress_inflight_enter(dev)), device(dev) {}
+    ~JpkCompressInflight() { jpk_compress_inflight_leave(device); }
     JpkCompressInflight(const JpkCompressInflight &) = delete;
     JpkCompressInflight &operator=(const JpkCompressInflight &) = delete;
 };
@@ -174,6 +177,8 @@ int jpk_ans_decode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
 int jpk_ans_decode_batch(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out, const int32_t *out_cap,
                          int32_t *out_len, int32_t *status, size_t arena_skip);
 size_t jpk_inv_bwt_arena_bytes(uint32_t n);
+size_t jpk_fwd_bwt_arena_bytes(uint32_t n);
+size_t jpk_ans_encode_arena_bytes(uint32_t len);
 int jpk_rank_encode_device(jpk_ctx *ctx, uint8_t *d_t, int32_t *d_freq, int32_t len);
 int jpk_rank_decode_device(jpk_ctx *ctx, uint8_t *d_r, const int32_t *d_freq, int32_t len);
 int jpk_rle_encode_device(jpk_ctx *ctx, const uint8_t *d_ranks, int32_t len, uint16_t *d_rle, int32_t *rlen);

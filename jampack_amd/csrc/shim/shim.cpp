@@ -1,7 +1,12 @@
 // shim.cpp -- forwards the reference's stage classes to the C ABI (include/jampack_abi.h) and maps a non-zero
 // status back to Error(), which is how every reference stage reports failure (format.cpp:6-10).
+#include <malloc.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <vector>
 
 #include "../../../include/jampack_abi.h"
 #include "ans.hpp"
@@ -15,6 +20,9 @@ static void fail(const char *where, int rc)
 	Error(msg);
 }
 
+// Diagnostics for a maintainer who diffs a patched build against the stock one, compiled in with -DJPK_SHIM_DIAG only
+// (tools/cli_dump.sh, tools/cli_guard.sh build such a shim); the product shim has none of it on its call path.
+#ifdef JPK_SHIM_DIAG
 // JPK_SHIM_TRACE=1: one line per stage call with the block checksum (checksum.cpp:12-36) of its input and output -- lets a
 // maintainer diff a run of the patched program against the stock one stage by stage
 static void trace(const char *stage, const unsigned char *in, int in_len, const unsigned char *out, int out_len)
@@ -32,9 +40,6 @@ static void trace(const char *stage, const unsigned char *in, int in_len, const 
 
 // JPK_SHIM_GUARD=<capacity bytes>: verifies that a stage call changes nothing but Output[0, n): the rest of Output up to the
 // capacity and all of Input keep their bytes, and Output[0, n) does not change after the call has returned
-#include <string.h>
-#include <unistd.h>
-#include <vector>
 struct Guard {
 	long cap;
 	std::vector<unsigned char> in0, out0;
@@ -60,6 +65,14 @@ struct Guard {
 		if (jpk_checksum_host(out, n) != c0) fprintf(stderr, "[guard] %s: output changed AFTER the call returned\n", stage);
 	}
 };
+
+#else
+static inline void trace(const char *, const unsigned char *, int, const unsigned char *, int) {}
+struct Guard {
+	Guard(const char *, const unsigned char *, int, const unsigned char *) {}
+	void check(int, bool) {}
+};
+#endif
 
 // stage buffers are allocated as int(BlockSize * 1.05) by the caller (jampack.cpp:74-76, 157-159)
 static int stage_capacity(const Options &Opt) { return (int)((double)Opt.BlockSize * 1.05); }
@@ -96,15 +109,32 @@ void Ans::Encode(Buffer Input, Buffer Output, Options Opt)
 	trace("AnsEncode", Input.block, *Input.size, Output.block, n);
 }
 
+// Capacity of a stage buffer of the caller.  Ans::Decode has no capacity argument and Options.BlockSize is not it on the
+// decompress path (the CLI default, main.cpp:60, while the buffers follow the frame header, jampack.cpp:146-159).  Every stage
+// buffer of the reference's call sites is the start of a heap block (calloc / realloc in jampack.cpp:74-76, 157-159), so the
+// allocator itself knows the real capacity; -DJPK_SHIM_NO_HEAP_QUERY (callers with buffers that are not heap blocks) falls back
+// to what the stream declares.
+static long buffer_capacity(const unsigned char *block)
+{
+#if defined(__GLIBC__) && !defined(JPK_SHIM_NO_HEAP_QUERY)
+	return block ? (long)malloc_usable_size((void *)block) : 0;
+#else
+	(void)block;
+	return -1;
+#endif
+}
+
 void Ans::Decode(Buffer Input, Buffer Output, Options Opt)
 {
-	// Not stage_capacity(Opt): on the decompress path Options.BlockSize is the CLI option (default 8 MiB, main.cpp:60),
-	// while the buffers were sized from the frame header (Jampack::BlockSize, jampack.cpp:146-159).  Like the reference
-	// the shim trusts that the caller's buffer holds what the stream declares; the declared size itself is validated.
+	// Not stage_capacity(Opt), see buffer_capacity().  The stream's own chunk headers declare the decoded size (validated by
+	// the header walk); a stream that declares more than the caller's buffer holds is refused instead of overflowing it in the
+	// final device-to-host copy (the reference would write past the buffer chunk by chunk).
 	int64_t need = 0;
 	int rc = jpk_ans_decoded_size(Input.block, *Input.size, &need, 0);
 	if (rc) fail("Ans", rc);
 	if (need > (int64_t)((double)JPK_MAX_BLOCKSIZE * 1.05)) fail("Ans", JPK_E_CORRUPT);
+	const long cap = buffer_capacity(Output.block);
+	if (cap >= 0 && need > (int64_t)cap) fail("Ans", JPK_E_CAPACITY);
 	int n = 0;
 	rc = jpk_ans_decode(Input.block, *Input.size, Output.block, (int)need, &n, (int)Opt.Threads);
 	if (rc) fail("Ans", rc);

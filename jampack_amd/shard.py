@@ -4,6 +4,10 @@ over xGMI on the GPU box, "gloo" in the CPU tests).
 Blocks are independent units (jampack.cpp:215-219, 313-317: one Jampack instance per OpenMP thread and block), so
 the data path has no collective.  The only exchange is the final gather of the per-block outputs on one rank, which
 the reference does implicitly by writing blocks to the file in order (jampack.cpp:220-224).
+
+The exchange lives on the Python side by choice: bench.py and the tests own the process group (torch.distributed), and the
+C++ multi-block host (jampack.cpp:205-224 through the shim) is a file writer -- each block returns through its own D2H copy
+to the thread that writes it, which needs no device-side gather at all.
 """
 from __future__ import annotations
 
@@ -32,44 +36,66 @@ def _collective_device(local, device, group) -> torch.device:
     return torch.device("cpu")
 
 
-def gather_blocks(local: list[torch.Tensor], dst: int = 0, group=None, device=None):
+def gather_blocks(local: list[torch.Tensor], dst: int = 0, group=None, device=None, max_local: int | None = None):
     """Variable-size gather of 1-D uint8 tensors (one per local block) onto rank `dst`.
 
-    Returns on dst a list (per rank) of lists of tensors in local block order, elsewhere None.
-    Two collectives: all_gather of the size vectors, then one gather of a flat buffer padded to the largest rank
-    total (compressed blocks are ~0.15-0.25 x the input, so the padding is noise next to the compute).
+    Returns on dst a list (per rank) of lists of tensors in local block order, elsewhere None.  The tensors are VIEWS: of the
+    receive buffers for the other ranks' blocks, the local tensors themselves for dst's own (nothing is copied on dst).
+
+    Exchange (size all-gather, then grouped send/recv of exactly the bytes):
+      1. ONE fixed-size all_gather of an int64 vector [count, size_0 .. size_{max_local-1}] per rank, read back with one
+         device-to-host copy -- the only host synchronisation.  `max_local` = the largest number of blocks any rank can own
+         (ceil(nblocks / world) for the b mod world ownership); without it one extra all_reduce(MAX) finds it.
+      2. every other rank with bytes sends ONE flat buffer to dst, dst posts one receive of exactly that size per such rank
+         (batch_isend_irecv = grouped ncclSend/ncclRecv over each GPU's direct xGMI link with RCCL; plain send/recv with gloo).
+         No padding, no zero fill, no clone.
+    With a stream-ordered backend (nccl) the receives are ordered on the current stream: synchronise it before the host reads.
     """
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    dev = _collective_device(local, device, group)
-    nloc = torch.tensor([len(local)], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(nloc) for _ in range(world)]
-    dist.all_gather(counts, nloc, group=group)
-    maxn = int(max(int(c.item()) for c in counts))
-    sizes = torch.zeros(max(maxn, 1), dtype=torch.int64, device=dev)
-    for i, t in enumerate(local):
-        sizes[i] = t.numel()
-    allsizes = [torch.zeros_like(sizes) for _ in range(world)]
-    dist.all_gather(allsizes, sizes, group=group)
-    totals = [int(s.sum().item()) for s in allsizes]
-    pad = max(max(totals), 1)
-    flat = torch.zeros(pad, dtype=torch.uint8, device=dev)
-    off = 0
-    for t in local:
-        flat[off:off + t.numel()] = t
-        off += t.numel()
-    bufs = [torch.empty(pad, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
-    dist.gather(flat, bufs, dst=dst, group=group)
+    out_dev = _collective_device(local, device, group)
+    # gloo moves host memory: device tensors (bench.py's one-GPU test hook) are staged through the host for the exchange
+    dev = torch.device("cpu") if dist.get_backend(group) == "gloo" else out_dev
+    if max_local is None:
+        n = torch.tensor([len(local)], dtype=torch.int64, device=dev)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
+        max_local = int(n.item())
+    if len(local) > max_local:
+        raise ValueError(f"gather_blocks: {len(local)} local blocks but max_local={max_local}")
+    width = max_local + 1
+    meta = torch.tensor([len(local)] + [int(t.numel()) for t in local] + [0] * (max_local - len(local)), dtype=torch.int64).to(dev)
+    allmeta = torch.empty(world * width, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allmeta, meta, group=group)
+    table = allmeta.cpu().view(world, width).tolist()          # the one host synchronisation
+    totals = [sum(row[1:1 + row[0]]) for row in table]
+
+    def peer(r):                                               # P2POp takes global ranks
+        return dist.get_global_rank(group, r) if group is not None else r
+
+    ops, bufs = [], {}
+    if rank == dst:
+        for r in range(world):
+            if r != dst and totals[r] > 0:
+                bufs[r] = torch.empty(totals[r], dtype=torch.uint8, device=dev)
+                ops.append(dist.P2POp(dist.irecv, bufs[r], peer(r), group))
+    elif totals[rank] > 0:
+        flat = local[0] if len(local) == 1 else torch.cat(local)
+        ops.append(dist.P2POp(dist.isend, flat.contiguous().to(dev), peer(dst), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     if rank != dst:
         return None
+    if dev != out_dev:
+        bufs = {r: b.to(out_dev) for r, b in bufs.items()}
     out = []
     for r in range(world):
-        n = int(counts[r].item())
-        o = 0
-        blocks = []
-        for i in range(n):
-            sz = int(allsizes[r][i].item())
-            blocks.append(bufs[r][o:o + sz].clone())
+        if r == dst:
+            out.append(list(local))
+            continue
+        o, blocks = 0, []
+        for sz in table[r][1:1 + table[r][0]]:
+            blocks.append(bufs[r][o:o + sz] if sz else torch.empty(0, dtype=torch.uint8, device=out_dev))
             o += sz
         out.append(blocks)
     return out

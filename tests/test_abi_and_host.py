@@ -140,3 +140,64 @@ def test_corpus_is_deterministic():
     assert not np.array_equal(a, corpus.make("text", 100000, 9))
     blocks = corpus.split_blocks(np.zeros(100_000_000, dtype=np.uint8), 64 << 20)
     assert [len(x) for x in blocks] == [67108864, 32891136]
+
+
+def test_encoder_launch_grouping_follows_the_load_of_its_own_device():
+    """the blocks-in-flight count that drives the encoder's launch grouping is per DEVICE.  Faked two-device
+    load through the host-logic probes (no device call): three blocks on device 0 leave a block on device 1 alone."""
+    from jampack_amd import lib
+    l = lib()
+    nch = 65                                   # a 64 MiB block: 64 full chunks + the trailer chunk
+    assert l.jpk_debug_compress_inflight(0, 0) == 0 and l.jpk_debug_compress_inflight(1, 0) == 0
+    assert l.jpk_debug_enc_groups(0, nch) == 4 and l.jpk_debug_enc_groups(1, nch) == 4        # alone: four graded groups
+    try:
+        assert [l.jpk_debug_compress_inflight(0, 1) for _ in range(3)] == [1, 2, 3]
+        assert l.jpk_debug_enc_groups(0, nch) == 1           # a fourth block on device 0: the machine is full, one group
+        assert l.jpk_debug_enc_groups(1, nch) == 4           # ... while a block on device 1 is still alone on ITS GPU
+        assert l.jpk_debug_compress_inflight(1, 1) == 1
+        assert l.jpk_debug_enc_groups(1, nch) == 2           # beside one other block: two groups
+        assert l.jpk_debug_compress_inflight(1, -1) == 0
+    finally:
+        while l.jpk_debug_compress_inflight(0, 0) > 0:
+            l.jpk_debug_compress_inflight(0, -1)
+    assert l.jpk_debug_enc_groups(0, 7) == 1                 # fewer than 8 chunks: never split
+    assert l.jpk_debug_compress_inflight(64, 1) == -1 and l.jpk_debug_enc_groups(-1, nch) == -1
+
+
+def test_reserve_follows_the_stage_layouts():
+    """jpk_ctx_reserve takes the maximum of the four stages' own planning passes (DESIGN.md section 3 quotes these factors)"""
+    from jampack_amd import lib
+    n = 64 << 20
+    per_byte = [lib().jpk_debug_arena_bytes(n, st) / n for st in range(4)]
+    assert 38 < per_byte[0] < 41          # forward BWT: radix ping-pong 24 n + ISA 4 n + active list 8 n + BWT bytes + tables
+    assert 60 < per_byte[1] < 70          # rANS encode, worst case (every byte a symbol)
+    assert 9 < per_byte[2] < 11           # inverse BWT
+    assert 3 <= per_byte[3] < 3.2         # rANS decode bound
+    assert lib().jpk_debug_arena_bytes(n, 4) == -1 and lib().jpk_debug_arena_bytes(-1, 0) == -1
+
+
+def test_decoded_size_rejects_more_rle_symbols_than_bytes():
+    """RLE0 never has more symbols than bytes; a header that claims so is refused before any buffer is sized
+    by it (the reference ends such a chunk in "rle mismatch!", rle.cpp:73)."""
+    import jampack_amd
+    from jampack_amd.api import ans_decoded_size
+
+    def leb(v):
+        for nb, c in ((1, 0), (2, 127), (3, 16510), (4, 2113661)):
+            if v < (127, 16510, 2113661, 270549116)[nb - 1]:
+                v -= c
+                b = [(v >> (7 * (nb - 1 - k))) & 0x7F for k in range(nb)]
+                b[-1] |= 0x80
+                return bytes(b)
+        raise ValueError(v)
+
+    def chunk(olen, clen, rlen):
+        freq = [olen] + [0] * 255
+        return b"".join(leb(f) for f in freq) + leb(olen) + leb(clen) + leb(rlen) + bytes(clen)
+
+    ok = np.frombuffer(chunk(1, 16, 1), dtype=np.uint8)
+    assert ans_decoded_size(ok) == (1, 1)
+    bad = np.frombuffer(chunk(1, 16, 1 << 20), dtype=np.uint8)
+    with pytest.raises(jampack_amd.JampackError) as e:
+        ans_decoded_size(bad)
+    assert e.value.status == -3

