@@ -223,6 +223,11 @@ JPK_API int jpk_debug_compress_inflight(int device, int delta);
 /* HBM arena bytes stage 0 (forward BWT) / 1 (rANS encode) / 2 (inverse BWT) / 3 (rANS decode, bound) plans for one block of
  * block_bytes; jpk_ctx_reserve takes their maximum. */
 JPK_API int64_t jpk_debug_arena_bytes(int64_t block_bytes, int stage);
+/* jpk_ans_decode calls that arrive from different threads at about the same time are merged into one batched pass on their
+ * device (ans.cpp:254-264 decodes Threads chunks at a time; jampack.cpp:313 calls Decomp() from Threads OpenMP threads): the
+ * number of requests the most recent pass on `device` carried (1: a lone caller, single-block path).  JPK_COMBINE_US=<grace
+ * in microseconds, default 300; negative: never merge> in the environment. */
+JPK_API int jpk_debug_combiner_last_batch(int device);
 JPK_API int jpk_debug_enc_groups(int device, int32_t nch);
 
 #ifdef __cplusplus

@@ -507,24 +507,36 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
     }
     // arena: [inverse-BWT scratch of the largest block][BWT images of all blocks][the batch decoder's buffers]; sized once so that
     // it cannot move while the images sit in it
-    const size_t inv_bytes = jpk_align(jpk_inv_bwt_arena_bytes(nmax), 4096);
+    // [inverse-BWT scratch][one verdict per block][BWT images][the batch decoder's buffers]
+    const size_t inv_bytes = jpk_align(jpk_inv_bwt_arena_bytes(nmax), 4096) + jpk_align((size_t)nblocks * 16 + 64, 4096);
     JPK_TRY(jpk_arena_ensure(ctx, inv_bytes + mid_total + bound + (1u << 20)));
+    uint32_t *d_verdict = reinterpret_cast<uint32_t *>(ctx->arena + inv_bytes - jpk_align((size_t)nblocks * 16 + 64, 4096));
     std::vector<uint8_t *> mid((size_t)nblocks);
     {
         size_t off = inv_bytes;
         for (int b = 0; b < nblocks; b++) { mid[b] = ctx->arena + off; off += jpk_align((size_t)mid_cap[b] + 64); }
     }
     JPK_TRY(jpk_ans_decode_batch(ctx, nblocks, d_in, in_len, mid.data(), mid_cap.data(), mid_len.data(), stp, inv_bytes + mid_total));
+    // the inverse BWTs are enqueued back to back, without a host round trip between them (trailer index, slot count and the
+    // head check stay on the device); their verdicts come back in one copy
+    std::vector<int> ran;
     for (int b = 0; b < nblocks; b++) {
         out_len[b] = 0;
         if (stp[b] != JPK_OK) continue;
         if (mid_len[b] < JPK_TRAILER_BYTES) { stp[b] = JPK_E_CORRUPT; continue; }
         if (mid_len[b] - JPK_TRAILER_BYTES > out_cap[b]) { stp[b] = JPK_E_CAPACITY; continue; }
-        const int rc = jpk_inv_bwt_device(ctx, mid[b], mid_len[b], d_out[b]);
+        const int rc = jpk_inv_bwt_enqueue(ctx, mid[b], mid_len[b], d_out[b], d_verdict + 4 * (size_t)b);
         if (rc != JPK_OK) { stp[b] = rc; continue; }
+        ran.push_back(b);
+    }
+    std::vector<uint32_t> verdict((size_t)nblocks * 4);
+    if (!ran.empty()) JPK_HIP(hipMemcpyAsync(verdict.data(), d_verdict, (size_t)nblocks * 16, hipMemcpyDeviceToHost, ctx->stream));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof_on) jpk_prof_resolve(ctx);
+    for (int b : ran) {
+        if (verdict[4 * (size_t)b]) { stp[b] = JPK_E_CORRUPT; continue; }
         out_len[b] = mid_len[b] - JPK_TRAILER_BYTES;
     }
-    JPK_HIP(hipStreamSynchronize(ctx->stream));
     if (!status)
         for (int b = 0; b < nblocks; b++) if (stp[b] != JPK_OK) return stp[b];
     return JPK_OK;
@@ -900,10 +912,131 @@ extern "C" int jpk_ans_encode(uint8_t *in_clobbered, int32_t in_len, uint8_t *ou
     return staged(jpk_dev_ans_encode, in_clobbered, in_len, out, out_cap, out_len, false);
 }
 
+// ---- decode combiner: concurrent host-buffer Ans::Decode calls share one batched grid ---------------------------------------
+// The reference decodes `Threads` chunks at a time inside one Ans::Decode call (ans.cpp:254-264) and its multi-block loop calls
+// Decomp() from `Threads` OpenMP threads at once (jampack.cpp:313).  On the GPU one block is 65 single-wave chains on 1024
+// SIMDs, so the rate lives in the batch (jpk_ans_decode_batch: ONE grid per serial kernel over the chunks of all blocks).  A
+// plain drop-in caller never sees the batch ABI; instead, calls that arrive from different threads within a short window are
+// merged here: every thread stages its own input (its context, its stream), the first one to arrive leads -- it waits until
+// nobody is on the way in any more (threads between entry and submission are counted) plus a grace period that applies only
+// when the process has shown concurrency before, decodes all requests in one pass on a combiner context of the device, and
+// wakes the others, which copy their own results back.  A lone caller runs exactly the single-block path at once; a thread
+// that arrives while a batch is already on the GPU leads a new batch immediately (nobody ever waits for a running batch).
+#include <condition_variable>
+namespace {
+struct DecReq {
+    const uint8_t *d_in; int32_t in_len; uint8_t *d_out; int32_t out_cap;
+    hipEvent_t staged;              // the request's input has reached the device
+    int32_t out_len = 0, status = JPK_OK;
+    bool done = false;
+};
+struct Combiner {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<DecReq *> pending;
+    bool collecting = false;        // a leader is gathering `pending`
+    std::atomic<int> arriving{0};   // threads between entry and submission
+    int last_batch = 1;             // requests of the most recent batch (> 1: the process decodes concurrently)
+};
+Combiner &combiner(int device) { static Combiner c[64]; return c[device & 63]; }
+// grace in microseconds the leader grants late arrivals once the process has shown concurrent decode calls; < 0 = combiner off
+int combine_grace_us()
+{
+    static const int v = [] { const char *e = getenv("JPK_COMBINE_US"); return e ? atoi(e) : 300; }();
+    return v;
+}
+}  // namespace
+
+// test hook: requests the most recent combined decode on `device` carried (1 = a lone caller took the single-block path)
+extern "C" int jpk_debug_combiner_last_batch(int device)
+{
+    if (device < 0 || device >= 64) return JPK_E_ARG;
+    Combiner &cb = combiner(device);
+    std::lock_guard<std::mutex> lk(cb.mu);
+    return cb.last_batch;
+}
+
 extern "C" int jpk_ans_decode(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len, int32_t threads)
 {
     (void)threads;
-    return staged(jpk_dev_ans_decode, in, in_len, out, out_cap, out_len, false);
+    if (combine_grace_us() < 0) return staged(jpk_dev_ans_decode, in, in_len, out, out_cap, out_len, false);
+    if (!out || !out_len || in_len < 0 || out_cap < 0 || (in_len > 0 && !in)) return JPK_E_ARG;
+    jpk_ctx *ctx;
+    JPK_TRY(tls_ctx(&ctx));
+    JPK_HIP(hipSetDevice(ctx->device));
+    if (ctx->device < 0 || ctx->device >= 64 || in_len == 0) return staged(jpk_dev_ans_decode, in, in_len, out, out_cap, out_len, false);
+    Combiner &cb = combiner(ctx->device);
+    cb.arriving.fetch_add(1);
+    struct Arrived { Combiner &c; bool in = true; ~Arrived() { if (in) c.arriving.fetch_sub(1); } void submitted() { if (in) { c.arriving.fetch_sub(1); in = false; } } } arrived{cb};
+    JPK_TRY(buf_ensure(ctx, &ctx->stage_in, &ctx->stage_in_cap, (size_t)in_len + 64));
+    JPK_TRY(buf_ensure(ctx, &ctx->stage_res, &ctx->stage_res_cap, (size_t)out_cap + 64));
+    JPK_HIP(hipMemcpyAsync(ctx->stage_in, in, (size_t)in_len, hipMemcpyHostToDevice, ctx->stream));
+    JPK_HIP(hipEventRecord(ctx->ev_batch, ctx->stream));
+    DecReq req;
+    req.d_in = ctx->stage_in; req.in_len = in_len; req.d_out = ctx->stage_res; req.out_cap = out_cap; req.staged = ctx->ev_batch;
+    bool leader;
+    {
+        std::unique_lock<std::mutex> lk(cb.mu);
+        cb.pending.push_back(&req);
+        arrived.submitted();
+        leader = !cb.collecting;
+        if (leader) cb.collecting = true;
+        else cb.cv.wait(lk, [&] { return req.done; });
+    }
+    if (leader) {
+        // gather: until nobody is on the way in; once the process has decoded concurrently before, a grace period on top
+        const auto t0 = std::chrono::steady_clock::now();
+        int grace;
+        { std::lock_guard<std::mutex> lk(cb.mu); grace = cb.last_batch > 1 ? combine_grace_us() : 0; }
+        for (;;) {
+            const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (cb.arriving.load() == 0 && waited >= grace) break;
+            if (waited > 20000) break;                              // a thread stuck in its staging must not hold the others
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        std::vector<DecReq *> batch;
+        {
+            std::lock_guard<std::mutex> lk(cb.mu);
+            batch.swap(cb.pending);
+            cb.collecting = false;                                   // the next arrival leads a batch of its own, beside this one
+        }
+        const int nb = (int)batch.size();
+        int rc = JPK_OK;
+        if (nb == 1) {
+            rc = jpk_dev_ans_decode(ctx, req.d_in, req.in_len, req.d_out, req.out_cap, &req.out_len);       // the single-block path, as ever
+            req.status = rc;
+        } else {
+            jpk_ctx *cc = nullptr;
+            rc = batch_ctx_acquire(ctx->device, &cc);
+            uint64_t generation;
+            { CtxPool &p = pool(); std::lock_guard<std::mutex> g(p.mu); generation = p.generation; }
+            if (rc == JPK_OK) {
+                std::vector<const uint8_t *> ins((size_t)nb);
+                std::vector<uint8_t *> outs((size_t)nb);
+                std::vector<int32_t> il((size_t)nb), oc((size_t)nb), ol((size_t)nb), st((size_t)nb);
+                for (int b = 0; b < nb && rc == JPK_OK; b++) {
+                    ins[b] = batch[b]->d_in; il[b] = batch[b]->in_len; outs[b] = batch[b]->d_out; oc[b] = batch[b]->out_cap;
+                    if (hipStreamWaitEvent(cc->stream, batch[b]->staged, 0) != hipSuccess) rc = JPK_E_DEVICE;
+                }
+                if (rc == JPK_OK) rc = jpk_ans_decode_batch(cc, nb, ins.data(), il.data(), outs.data(), oc.data(), ol.data(), st.data(), 0);   // synchronises cc->stream
+                for (int b = 0; b < nb; b++) { batch[b]->out_len = rc == JPK_OK ? ol[b] : 0; batch[b]->status = rc == JPK_OK ? st[b] : rc; }
+                batch_ctx_release(ctx->device, cc, generation);
+            } else {
+                for (int b = 0; b < nb; b++) batch[b]->status = rc;
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(cb.mu);
+            cb.last_batch = nb;
+            for (DecReq *r : batch) r->done = true;
+        }
+        cb.cv.notify_all();
+    }
+    if (req.status != JPK_OK) return req.status;
+    if (req.out_len > 0) JPK_HIP(hipMemcpyAsync(out, ctx->stage_res, (size_t)req.out_len, hipMemcpyDeviceToHost, ctx->stream));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    *out_len = req.out_len;
+    return JPK_OK;
 }
 
 namespace {

@@ -33,6 +33,26 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 __device__ __forceinline__ uint32_t splitter_of(uint32_t k) { return k * STRIDE + (mix32(k) & (STRIDE - 1)); }
 __device__ __forceinline__ bool is_splitter(uint32_t j) { return (j & (STRIDE - 1)) == (mix32(j / STRIDE) & (STRIDE - 1)); }
 
+// Device-resident bookkeeping of one inverse BWT: nothing of it is needed on the host before the call's last kernel, so the
+// whole transform is enqueued without a host round trip (a batch of blocks: one status read at the very end).
+struct InvState {
+    uint32_t status;        // 0 or JPK_E_CORRUPT (as uint32)
+    uint32_t I;             // trailer[0] = ISA[0] + 1 (bwt.cpp:57-61 / :134); 0 = invalid: every later kernel leaves at once
+    uint32_t novf;          // overflow slots the walk has chained
+    uint32_t head_dist;     // bytes the chain from the head covers (must be n)
+};
+
+__global__ void k_inv_prep(const uint8_t *__restrict__ trailer, uint32_t n, InvState *__restrict__ st)
+{
+    if (threadIdx.x != 0) return;
+    const uint32_t I = (uint32_t)trailer[0] | ((uint32_t)trailer[1] << 8) | ((uint32_t)trailer[2] << 16) | ((uint32_t)trailer[3] << 24);
+    const bool ok = I >= 1u && I <= n;
+    st->status = ok ? 0u : (uint32_t)JPK_E_CORRUPT;
+    st->I = ok ? I : 0u;
+    st->novf = 0;
+    st->head_dist = 0;
+}
+
 // ---- Map build ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TB) void k_hist(const uint8_t *__restrict__ B, uint32_t n, uint32_t *__restrict__ tilehist, uint32_t ntiles)
 {
@@ -60,11 +80,14 @@ __global__ void k_cum(const uint32_t *__restrict__ tileoff, uint32_t ntiles, uin
 }
 
 // nxt[F-position] = (i < I ? i : i + 1) - 1     (bwt.cpp:171-174, minus one so that -1 terminates the chain)
-__global__ __launch_bounds__(TB) void k_build_nxt(const uint8_t *__restrict__ B, uint32_t n, uint32_t I, const uint32_t *__restrict__ tileoff,
-                                                 uint32_t ntiles, int32_t *__restrict__ nxt)
+template <bool DEV>
+__global__ __launch_bounds__(TB) void k_build_nxt(const uint8_t *__restrict__ B, uint32_t n, uint32_t I_host, const InvState *__restrict__ st,
+                                                 const uint32_t *__restrict__ tileoff, uint32_t ntiles, int32_t *__restrict__ nxt)
 {
     __shared__ uint32_t cnt[WAVES][256];
     __shared__ uint32_t gbase[256];
+    const uint32_t I = DEV ? st->I : I_host;
+    if (DEV && I == 0u) return;
     for (int i = threadIdx.x; i < WAVES * 256; i += TB) (&cnt[0][0])[i] = 0;
     for (int d = threadIdx.x; d < 256; d += TB) gbase[d] = tileoff[(size_t)d * ntiles + blockIdx.x];
     __syncthreads();
@@ -111,13 +134,15 @@ __global__ __launch_bounds__(TB) void k_build_nxt(const uint8_t *__restrict__ B,
 // freshly allocated overflow slot, so every slot holds <= CAP bytes.
 constexpr int LUT = 4096;
 
-__global__ __launch_bounds__(TB) void k_walk(const int32_t *__restrict__ nxt, const uint32_t *__restrict__ cum_g, uint32_t n, uint32_t I,
+__global__ __launch_bounds__(TB) void k_walk(const int32_t *__restrict__ nxt, const uint32_t *__restrict__ cum_g, uint32_t n, InvState *__restrict__ st,
                                             uint32_t nsplit, uint32_t lut_shift, uint8_t *__restrict__ scratch,
-                                            uint32_t *__restrict__ slot_len, uint32_t *__restrict__ slot_next, uint32_t *__restrict__ ovf_counter,
-                                            uint32_t max_slots)
+                                            uint32_t *__restrict__ slot_len, uint32_t *__restrict__ slot_next, uint32_t max_slots)
 {
     __shared__ uint32_t cum[257];
     __shared__ uint8_t lut[LUT];
+    const uint32_t I = st->I;
+    if (I == 0u) return;
+    uint32_t *const ovf_counter = &st->novf;
     for (int i = threadIdx.x; i < 257; i += TB) cum[i] = cum_g[i];
     __syncthreads();
     for (int q = threadIdx.x; q < LUT; q += TB) {
@@ -183,17 +208,28 @@ __global__ __launch_bounds__(TB) void k_walk(const int32_t *__restrict__ nxt, co
 
 // ---- list ranking of the slots (Wyllie pointer jumping, ping-pong buffers) ----------------------------
 // dist[s] = bytes from the start of slot s to the end of the text.
-__global__ __launch_bounds__(TB) void k_rank_init(const uint32_t *__restrict__ slot_len, const uint32_t *__restrict__ slot_next, uint32_t nslots,
-                                                 uint32_t *__restrict__ dist, uint32_t *__restrict__ link)
+// slots in use: the splitters, the head and the overflow slots the walk chained (known on the device only; grids are launched
+// for the upper bound max_slots)
+__device__ __forceinline__ uint32_t slots_in_use(const InvState *st, uint32_t nsplit, uint32_t max_slots)
 {
+    if (st->I == 0u) return 0u;
+    const uint32_t ns = nsplit + 1u + st->novf;
+    return ns < max_slots ? ns : max_slots;
+}
+
+__global__ __launch_bounds__(TB) void k_rank_init(const uint32_t *__restrict__ slot_len, const uint32_t *__restrict__ slot_next, const InvState *__restrict__ st,
+                                                 uint32_t nsplit, uint32_t max_slots, uint32_t *__restrict__ dist, uint32_t *__restrict__ link)
+{
+    const uint32_t nslots = slots_in_use(st, nsplit, max_slots);
     uint32_t s = blockIdx.x * TB + threadIdx.x;
     if (s >= nslots) return;
     dist[s] = slot_len[s];
     link[s] = slot_next[s];
 }
-__global__ __launch_bounds__(TB) void k_rank_jump(const uint32_t *__restrict__ dist_in, const uint32_t *__restrict__ link_in, uint32_t nslots,
-                                                 uint32_t *__restrict__ dist_out, uint32_t *__restrict__ link_out)
+__global__ __launch_bounds__(TB) void k_rank_jump(const uint32_t *__restrict__ dist_in, const uint32_t *__restrict__ link_in, const InvState *__restrict__ st,
+                                                 uint32_t nsplit, uint32_t max_slots, uint32_t *__restrict__ dist_out, uint32_t *__restrict__ link_out)
 {
+    const uint32_t nslots = slots_in_use(st, nsplit, max_slots);
     uint32_t s = blockIdx.x * TB + threadIdx.x;
     if (s >= nslots) return;
     uint32_t d = dist_in[s], l = link_in[s];
@@ -204,8 +240,10 @@ __global__ __launch_bounds__(TB) void k_rank_jump(const uint32_t *__restrict__ d
 
 // one wave per 4 slots (16 lanes each): T[n - dist[s] ...] = scratch[s*CAP ... + len)
 __global__ __launch_bounds__(TB) void k_copy_out(const uint8_t *__restrict__ scratch, const uint32_t *__restrict__ slot_len,
-                                                const uint32_t *__restrict__ dist, uint32_t nslots, uint32_t n, uint8_t *__restrict__ T)
+                                                const uint32_t *__restrict__ dist, const InvState *__restrict__ st, uint32_t nsplit, uint32_t max_slots,
+                                                uint32_t n, uint8_t *__restrict__ T)
 {
+    const uint32_t nslots = slots_in_use(st, nsplit, max_slots);
     const uint32_t gid = blockIdx.x * TB + threadIdx.x;
     const uint32_t s = gid >> 4, sub = gid & 15u;
     if (s >= nslots) return;
@@ -224,9 +262,13 @@ __global__ void k_inv_tail(const uint8_t *__restrict__ B, uint32_t n, uint32_t l
     if (t < len - n) T[n + t] = B[n + t];
 }
 
-__global__ void k_head_check(const uint32_t *__restrict__ dist, uint32_t head_slot, uint32_t *__restrict__ mail)
+// the chain from trailer[0] must cover the whole block; more overflow slots than a valid block can need = corrupt as well
+__global__ void k_head_check(const uint32_t *__restrict__ dist, uint32_t head_slot, uint32_t n, uint32_t max_slots, InvState *__restrict__ st)
 {
-    mail[1] = dist[head_slot];
+    if (st->I == 0u) return;
+    const uint32_t d = dist[head_slot];
+    st->head_dist = d;
+    if (d != n || head_slot + 1u + st->novf > max_slots) st->status = (uint32_t)JPK_E_CORRUPT;
 }
 
 // ---- comparator: the reference's own GPU kernel shape (CUDAInverse<<<40,3>>>, bwt.cpp:8-19, 226-229) ----------------
@@ -253,6 +295,7 @@ struct InvBufs {
     uint32_t *tilehist, *scan_scratch, *cum, *slot_len, *slot_next, *distA, *distB, *linkA, *linkB;
     int32_t *nxt;
     uint8_t *scratch;
+    InvState *state;
 };
 
 void inv_layout(Arena &a, size_t n, InvBufs &b, size_t &ntiles, size_t &nsplit, size_t &max_slots)
@@ -271,6 +314,7 @@ void inv_layout(Arena &a, size_t n, InvBufs &b, size_t &ntiles, size_t &nsplit, 
     b.linkA = a.get<uint32_t>(max_slots);
     b.linkB = a.get<uint32_t>(max_slots);
     b.scratch = a.get<uint8_t>(max_slots * CAP);
+    b.state = a.get<InvState>(1);
 }
 
 }  // namespace
@@ -286,7 +330,16 @@ size_t jpk_inv_bwt_arena_bytes(uint32_t n)
     return plan.need + (1u << 20);
 }
 
-int jpk_inv_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trailer, uint8_t *d_out)
+// Enqueues one inverse BWT on ctx->stream without any host round trip: the trailer index is read and validated on the device,
+// grids are launched for the upper bound of the slot count, and the verdict (InvState) is copied to d_verdict[0..4) -- device
+// memory of the caller that outlives the arena scratch -- by the last kernel.  The scratch comes from the START of the arena,
+// so consecutive calls on one stream share it (in-order stream).
+__global__ void k_inv_verdict(const InvState *__restrict__ st, uint32_t *__restrict__ out)
+{
+    if (threadIdx.x == 0) { out[0] = st->status; out[1] = st->I; out[2] = st->novf; out[3] = st->head_dist; }
+}
+
+int jpk_inv_bwt_enqueue(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trailer, uint8_t *d_out, uint32_t *d_verdict)
 {
     hipStream_t st = ctx->stream;
     const int32_t len = len_with_trailer - JPK_TRAILER_BYTES;
@@ -295,57 +348,61 @@ int jpk_inv_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trail
     const uint32_t n = (uint32_t)(len - rem);
     if (n == 0) {
         if (rem > 0) JPK_HIP(hipMemcpyAsync(d_out, d_in, (size_t)rem, hipMemcpyDeviceToDevice, st));
+        JPK_HIP(hipMemsetAsync(d_verdict, 0, 16, st));
         return JPK_OK;
     }
-    // trailer[0] = ISA[0] + 1 (bwt.cpp:57-61 / :134)
-    uint32_t I = 0;
-    JPK_HIP(hipMemcpyAsync(ctx->h_mail, d_in + len, 4, hipMemcpyDeviceToHost, st));
-    JPK_HIP(hipStreamSynchronize(st));
-    I = ctx->h_mail[0];
-    if (I < 1 || I > n) return JPK_E_CORRUPT;
-
     InvBufs b;
     size_t ntiles, nsplit, max_slots;
     Arena plan(ctx, true);
     inv_layout(plan, n, b, ntiles, nsplit, max_slots);
-    JPK_TRY(jpk_arena_ensure(ctx, plan.need));
+    if (!jpk_arena_fits(ctx, plan.need)) JPK_TRY(jpk_arena_ensure(ctx, plan.need));
     Arena real(ctx, false);
     inv_layout(real, n, b, ntiles, nsplit, max_slots);
 
+    hipLaunchKernelGGL(k_inv_prep, dim3(1), dim3(64), 0, st, d_in + len, n, b.state);
     JPK_LAUNCH(ctx, PROF_INV_HIST, n, k_hist, dim3((unsigned)ntiles), dim3(TB), d_in, n, b.tilehist, (uint32_t)ntiles);
     JPK_TRY(jpk_exclusive_sum_u32(ctx, b.tilehist, b.tilehist, 256 * ntiles, b.scan_scratch, nullptr));
     JPK_LAUNCH(ctx, PROF_INV_HIST, n, k_cum, dim3(1), dim3(256), b.tilehist, (uint32_t)ntiles, n, b.cum);
-    JPK_LAUNCH(ctx, PROF_INV_BUILD, n, k_build_nxt, dim3((unsigned)ntiles), dim3(TB), d_in, n, I, b.tilehist, (uint32_t)ntiles, b.nxt);
+    JPK_LAUNCH(ctx, PROF_INV_BUILD, n, (k_build_nxt<true>), dim3((unsigned)ntiles), dim3(TB), d_in, n, 0u, b.state, b.tilehist, (uint32_t)ntiles, b.nxt);
 
-    JPK_HIP(hipMemsetAsync(ctx->d_mail, 0, 16, st));
     int lut_shift = 0;
     while (((uint64_t)(n - 1) >> lut_shift) >= LUT) lut_shift++;
-    JPK_LAUNCH(ctx, PROF_INV_WALK, n, k_walk, dim3(jpk_grid(nsplit + 1, TB)), dim3(TB), b.nxt, b.cum, n, I, (uint32_t)nsplit, (uint32_t)lut_shift,
-                       b.scratch, b.slot_len, b.slot_next, ctx->d_mail, (uint32_t)max_slots);
-    uint32_t novf = 0;
-    JPK_TRY(jpk_read_mail(ctx, &novf, 1));
-    size_t nslots = nsplit + 1 + novf;
-    if (nslots > max_slots) return JPK_E_CORRUPT;
-    ctx->stats.inv_splitters = (int64_t)nsplit + 1;
-    ctx->stats.inv_overflow_slots = novf;
-
-    const unsigned g_s = jpk_grid(nslots, TB);
-    JPK_LAUNCH(ctx, PROF_INV_RANK, 0, k_rank_init, dim3(g_s), dim3(TB), b.slot_len, b.slot_next, (uint32_t)nslots, b.distA, b.linkA);
+    JPK_LAUNCH(ctx, PROF_INV_WALK, n, k_walk, dim3(jpk_grid(nsplit + 1, TB)), dim3(TB), b.nxt, b.cum, n, b.state, (uint32_t)nsplit, (uint32_t)lut_shift,
+                       b.scratch, b.slot_len, b.slot_next, (uint32_t)max_slots);
+    const unsigned g_s = jpk_grid(max_slots, TB);
+    JPK_LAUNCH(ctx, PROF_INV_RANK, 0, k_rank_init, dim3(g_s), dim3(TB), b.slot_len, b.slot_next, b.state, (uint32_t)nsplit, (uint32_t)max_slots, b.distA, b.linkA);
     uint32_t *di = b.distA, *li = b.linkA, *dout = b.distB, *lo = b.linkB;
-    int rounds = jpk_bits_for((uint32_t)nslots) + 1;
+    const int rounds = jpk_bits_for((uint32_t)max_slots) + 1;
     for (int r = 0; r < rounds; r++) {
-        JPK_LAUNCH(ctx, PROF_INV_RANK, 0, k_rank_jump, dim3(g_s), dim3(TB), di, li, (uint32_t)nslots, dout, lo);
+        JPK_LAUNCH(ctx, PROF_INV_RANK, 0, k_rank_jump, dim3(g_s), dim3(TB), di, li, b.state, (uint32_t)nsplit, (uint32_t)max_slots, dout, lo);
         uint32_t *t = di; di = dout; dout = t;
         t = li; li = lo; lo = t;
     }
-    JPK_LAUNCH(ctx, PROF_INV_RANK, 0, k_head_check, dim3(1), dim3(1), di, (uint32_t)nsplit, ctx->d_mail);
-    JPK_LAUNCH(ctx, PROF_INV_COPY, n, k_copy_out, dim3(jpk_grid(nslots * 16, TB)), dim3(TB), b.scratch, b.slot_len, di, (uint32_t)nslots, n, d_out);
+    JPK_LAUNCH(ctx, PROF_INV_RANK, 0, k_head_check, dim3(1), dim3(1), di, (uint32_t)nsplit, n, (uint32_t)max_slots, b.state);
+    JPK_LAUNCH(ctx, PROF_INV_COPY, n, k_copy_out, dim3(jpk_grid(max_slots * 16, TB)), dim3(TB), b.scratch, b.slot_len, di, b.state, (uint32_t)nsplit,
+               (uint32_t)max_slots, n, d_out);
     if (rem > 0) JPK_LAUNCH(ctx, PROF_INV_COPY, n, k_inv_tail, dim3(1), dim3(128), d_in, n, (uint32_t)len, d_out);
+    hipLaunchKernelGGL(k_inv_verdict, dim3(1), dim3(64), 0, st, b.state, d_verdict);
     JPK_HIP(hipGetLastError());
-    uint32_t chk[2] = {0, 0};
-    JPK_TRY(jpk_read_mail(ctx, chk, 2));
-    if (chk[1] != n) return JPK_E_CORRUPT;      // the chain from trailer[0] must cover the whole block
     return JPK_OK;
+}
+
+// the same, synchronous: one host round trip, at the end (the caller wants the status anyway)
+int jpk_inv_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trailer, uint8_t *d_out)
+{
+    uint32_t *verdict = ctx->d_mail + 16;
+    JPK_TRY(jpk_inv_bwt_enqueue(ctx, d_in, len_with_trailer, d_out, verdict));
+    JPK_HIP(hipMemcpyAsync(ctx->h_mail + 16, verdict, 16, hipMemcpyDeviceToHost, ctx->stream));
+    JPK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof_on) jpk_prof_resolve(ctx);
+    const uint32_t *v = ctx->h_mail + 16;
+    const int32_t len = len_with_trailer - JPK_TRAILER_BYTES;
+    const uint32_t n = (uint32_t)(len - len % JPK_BWT_UNITS);
+    if (n) {
+        ctx->stats.inv_splitters = (int64_t)((n + STRIDE - 1) / STRIDE) + 1;
+        ctx->stats.inv_overflow_slots = v[2];
+    }
+    return v[0] ? JPK_E_CORRUPT : JPK_OK;
 }
 
 // the 120-chain comparator: same Map build, then the literal chase.  *chase_ms = time of the chase kernel alone.
@@ -375,7 +432,7 @@ int jpk_inv_bwt_chains120_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_
     hipLaunchKernelGGL(k_hist, dim3((unsigned)ntiles), dim3(TB), 0, st, d_in, n, b.tilehist, (uint32_t)ntiles);
     JPK_TRY(jpk_exclusive_sum_u32(ctx, b.tilehist, b.tilehist, 256 * ntiles, b.scan_scratch, nullptr));
     hipLaunchKernelGGL(k_cum, dim3(1), dim3(256), 0, st, b.tilehist, (uint32_t)ntiles, n, b.cum);
-    hipLaunchKernelGGL(k_build_nxt, dim3((unsigned)ntiles), dim3(TB), 0, st, d_in, n, I, b.tilehist, (uint32_t)ntiles, b.nxt);
+    hipLaunchKernelGGL((k_build_nxt<false>), dim3((unsigned)ntiles), dim3(TB), 0, st, d_in, n, I, (const InvState *)nullptr, b.tilehist, (uint32_t)ntiles, b.nxt);
     hipEvent_t e0, e1;
     JPK_HIP(hipEventCreate(&e0));
     JPK_HIP(hipEventCreate(&e1));
