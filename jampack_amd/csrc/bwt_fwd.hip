@@ -112,7 +112,7 @@ __device__ __forceinline__ uint32_t wg_scan(const uint32_t *in, uint32_t *out, u
 __device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t j, uint32_t n)
 {
     if (j == 0) return true;
-    return keys[j] != keys[j - 1] || sa[j] + 7u > n || sa[j - 1] + 7u > n;
+    return ((keys[j] ^ keys[j - 1]) >> 8) != 0ull || sa[j] + 7u > n || sa[j - 1] + 7u > n;       // bits 7..0 carry T[sa-1], not key
 }
 
 // head words of one 4096-slot tile: HE[word] = heads | slots past the end (so that "the next slot is a head" is one shift),
@@ -184,9 +184,9 @@ __global__ __launch_bounds__(WG1) void k_r0_scan(uint32_t *__restrict__ tLast, u
 // group rank (= index of the run head) -> ISA; singletons are finished: BWT byte at their SA position (and SA itself for the
 // suffix-array probe); the rest is compacted into the active list
 __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n,
-                                                 const uint32_t *__restrict__ tCarry, const uint32_t *__restrict__ tOff, const uint8_t *__restrict__ T,
+                                                 const uint32_t *__restrict__ tCarry, const uint32_t *__restrict__ tOff,
                                                  uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
-                                                 uint32_t *__restrict__ a_sa, uint32_t *__restrict__ a_grp)
+                                                 uint32_t *__restrict__ a_sa, uint32_t *__restrict__ a_grp, uint8_t *__restrict__ a_prev)
 {
     __shared__ uint64_t HE[65];
     __shared__ uint64_t SV[64];            // survivor bits per word
@@ -223,15 +223,17 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                 const uint64_t le = hv & mask_upto(l);
                 const uint32_t grp = le ? base + word * 64 + top_bit(le) : (word ? LHW[word - 1] : carry) - 1u;
                 const uint32_t s = sa[j];
+                const uint8_t pv = (uint8_t)keys[j];                // T[s - 1], carried in the key's low byte since pass 0
                 ISA[s] = grp;
                 const uint64_t sv = SV[word];
                 if (!((sv >> l) & 1ull)) {
-                    bwt[j] = s ? T[s - 1] : (uint8_t)0;
+                    bwt[j] = pv;
                     if (SA) SA[j] = s;
                 } else {
                     const uint32_t pos = SW[word] + (uint32_t)__popcll(sv & mask_below(l));
                     a_sa[pos] = s;
                     a_grp[pos] = grp;
+                    a_prev[pos] = pv;
                 }
             }
         }
@@ -403,8 +405,8 @@ __global__ __launch_bounds__(TB) void k_win_pieces(const uint32_t *__restrict__ 
 // the sort / re-rank of all groups of <= SEG_TILE elements, one window per workgroup iteration
 __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const uint32_t *__restrict__ k2g,
                                                  const SaState *__restrict__ st, int par, int key_bits, const uint32_t *__restrict__ PH,
-                                                 const uint8_t *__restrict__ T, uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
-                                                 uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp)
+                                                 const uint8_t *__restrict__ a_prev, uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
+                                                 uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint8_t *__restrict__ b_prev)
 {
     // LDS diet (30 KB, five workgroups per CU instead of three): the group ranks g[] are only needed while the group boundaries
     // are worked out and share their 8 KB with the two index permutations of the sort; the suffix numbers and the group rank of
@@ -637,14 +639,17 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
                 if (nh[k]) run = ap[k];
                 const bool next_head = (q + 1 >= no) ? true : (k + 1 < SEG_ITEMS ? (nh[k + 1] != 0) : (firstflag[tid + 1] != 0));
                 const bool single = nh[k] && next_head;
-                const uint32_t s = a_sa[base + fo + src[q]];
+                const uint32_t from = base + fo + src[q];
+                const uint32_t s = a_sa[from];
+                const uint8_t pv = a_prev[from];                    // T[s - 1] travels with the suffix: no gather from the text
                 ISA[s] = run;      // (skipping the store for the sub-group that keeps the old rank costs more registers than it saves: 3.45 -> 3.83 ms)
                 if (single) {
-                    bwt[ap[k]] = s ? T[s - 1] : (uint8_t)0;
+                    bwt[ap[k]] = pv;
                     if (SA) SA[ap[k]] = s;
                 }
                 b_sa[base + fo + q] = s;
                 b_grp[base + fo + q] = run | (single ? DONE : 0u);
+                b_prev[base + fo + q] = pv;
             }
         }
     }
@@ -686,9 +691,9 @@ __global__ __launch_bounds__(TB) void k_lg_hist(const uint32_t *__restrict__ key
 }
 
 template <int DB>
-__global__ __launch_bounds__(TB) void k_lg_scatter(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint32_t *__restrict__ kout,
-                                                  uint32_t *__restrict__ vout, const Piece *__restrict__ pieces, const SaState *__restrict__ st, int shift,
-                                                  const uint32_t *__restrict__ S)
+__global__ __launch_bounds__(TB) void k_lg_scatter(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin, const uint8_t *__restrict__ pin,
+                                                  uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, uint8_t *__restrict__ pout,
+                                                  const Piece *__restrict__ pieces, const SaState *__restrict__ st, int shift, const uint32_t *__restrict__ S)
 {
     constexpr int NB = 1 << DB;
     __shared__ uint32_t cnt[WAVES][NB];
@@ -704,12 +709,14 @@ __global__ __launch_bounds__(TB) void k_lg_scatter(const uint32_t *__restrict__ 
         for (int d = threadIdx.x; d < NB; d += TB) gbase[d] = q.gs + (S[(size_t)q.fp * NB + (size_t)d * q.nt + q.tl] - s0);
         __syncthreads();
         uint32_t key[WIN_ITEMS], val[WIN_ITEMS], rnk[WIN_ITEMS];
+        uint8_t prv[WIN_ITEMS];                      // the suffix's BWT byte rides along (third member of the sorted record)
 #pragma unroll
         for (int k = 0; k < WIN_ITEMS; k++) {
             const uint32_t e = w * (64 * WIN_ITEMS) + k * 64 + l;
             const bool valid = e < q.count;
             key[k] = valid ? kin[q.begin + e] : 0u;
             val[k] = valid ? vin[q.begin + e] : 0u;
+            prv[k] = valid ? pin[q.begin + e] : (uint8_t)0;
             const uint32_t d = (key[k] >> shift) & (uint32_t)(NB - 1);
             const uint64_t mm = match_any<DB>(d, valid);
             const uint32_t below = (uint32_t)__popcll(mm & lt);
@@ -732,6 +739,7 @@ __global__ __launch_bounds__(TB) void k_lg_scatter(const uint32_t *__restrict__ 
                 const uint32_t dst = gbase[d] + cnt[w][d] + rnk[k];
                 kout[dst] = key[k];
                 vout[dst] = val[k];
+                pout[dst] = prv[k];
             }
         }
     }
@@ -787,10 +795,11 @@ __global__ __launch_bounds__(WG1) void k_lg_scan(uint32_t *__restrict__ pLast, c
 }
 
 // new ranks of the members of large groups -> ISA, finished suffixes -> BWT byte, everything back to the b-list
-__global__ __launch_bounds__(TB) void k_lg_finish(const uint32_t *__restrict__ key, const uint32_t *__restrict__ val, const uint32_t *__restrict__ a_grp,
+__global__ __launch_bounds__(TB) void k_lg_finish(const uint32_t *__restrict__ key, const uint32_t *__restrict__ val, const uint8_t *__restrict__ prv,
+                                                 const uint32_t *__restrict__ a_grp,
                                                  const Piece *__restrict__ pieces, const SaState *__restrict__ st, const uint32_t *__restrict__ pCarry,
-                                                 const uint8_t *__restrict__ T, uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
-                                                 uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp)
+                                                 uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
+                                                 uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint8_t *__restrict__ b_prev)
 {
     __shared__ uint64_t H[17];
     __shared__ uint32_t LHW[16];
@@ -826,14 +835,16 @@ __global__ __launch_bounds__(TB) void k_lg_finish(const uint32_t *__restrict__ k
                 else nh = (l < 63) ? ((hv >> (l + 1)) & 1ull) : (H[word + 1] & 1ull);
                 const bool single = head && nh;
                 const uint32_t s = val[j];
+                const uint8_t pv = prv[j];
                 if (hp != q.gs) ISA[s] = rank;                      // the first sub-group keeps the old group's rank
                 if (single) {
                     const uint32_t ap = G + (j - q.gs);
-                    bwt[ap] = s ? T[s - 1] : (uint8_t)0;
+                    bwt[ap] = pv;
                     if (SA) SA[ap] = s;
                 }
                 b_sa[j] = s;
                 b_grp[j] = rank | (single ? DONE : 0u);
+                b_prev[j] = pv;
             }
         }
     }
@@ -938,8 +949,9 @@ __global__ __launch_bounds__(WG1) void k_cmp_scan(uint32_t *__restrict__ tSurv, 
         if (round + 1 < JPK_SA_MAX_ROUNDS) st->round_m[round + 1] = total;
     }
 }
-__global__ __launch_bounds__(TB) void k_cmp_scatter(const uint32_t *__restrict__ b_sa, const uint32_t *__restrict__ b_grp, const SaState *__restrict__ st, int par,
-                                                   const uint32_t *__restrict__ tOff, uint32_t *__restrict__ a_sa, uint32_t *__restrict__ a_grp)
+__global__ __launch_bounds__(TB) void k_cmp_scatter(const uint32_t *__restrict__ b_sa, const uint32_t *__restrict__ b_grp, const uint8_t *__restrict__ b_prev,
+                                                   const SaState *__restrict__ st, int par, const uint32_t *__restrict__ tOff,
+                                                   uint32_t *__restrict__ a_sa, uint32_t *__restrict__ a_grp, uint8_t *__restrict__ a_prev)
 {
     __shared__ uint64_t SV[64];
     __shared__ uint32_t SW[64];
@@ -972,6 +984,7 @@ __global__ __launch_bounds__(TB) void k_cmp_scatter(const uint32_t *__restrict__
                 const uint32_t pos = SW[word] + (uint32_t)__popcll(SV[word] & mask_below(l));
                 a_sa[pos] = b_sa[j];
                 a_grp[pos] = gv[k];
+                a_prev[pos] = b_prev[j];
             }
         }
     }
@@ -1009,6 +1022,7 @@ struct SaBufs {
     uint32_t *tA, *tB;          // per-tile scalars
     uint32_t *FH, *LH, *PH, *NH, *PC, *pLast, *partial, *scratch;
     uint8_t *bwt;
+    uint8_t *a_prev, *b_prev, *p_alt;      // T[sa - 1] of every active suffix: travels with (sa, rank) through the rounds
     Piece *pieces;
     SaState *state;
 };
@@ -1036,6 +1050,9 @@ void sa_layout(Arena &a, size_t n, SaBufs &b)
     b.a_sa = a.get<uint32_t>(n);
     b.a_grp = a.get<uint32_t>(n);
     b.bwt = a.get<uint8_t>(n);
+    b.a_prev = a.get<uint8_t>(n);
+    b.b_prev = a.get<uint8_t>(n);
+    b.p_alt = a.get<uint8_t>(n);
     const size_t nbmax = 256;
     b.table = a.get<uint32_t>(nbmax * 2 * nwin);
     b.partial = a.get<uint32_t>(nbmax * 2 * nwin / SC_TILE + 64);
@@ -1060,14 +1077,15 @@ inline unsigned cap_grid(size_t work, unsigned per_block, unsigned cap)
 }
 
 template <int DB>
-void launch_lg_pass(jpk_ctx *ctx, SaBufs &b, const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int shift, unsigned gp, unsigned gt)
+void launch_lg_pass(jpk_ctx *ctx, SaBufs &b, const uint32_t *kin, const uint32_t *vin, const uint8_t *pin, uint32_t *kout, uint32_t *vout, uint8_t *pout, int shift,
+                    unsigned gp, unsigned gt)
 {
     constexpr uint32_t NB = 1u << DB;
     JPK_LAUNCH(ctx, PROF_LG_HIST, 0, (k_lg_hist<DB>), dim3(gp), dim3(TB), kin, b.pieces, b.state, shift, b.table);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_tab_reduce, dim3(gt), dim3(TB), b.table, b.state, NB, b.partial);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_tab_partials, dim3(1), dim3(WG1), b.partial, b.state, NB);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_tab_down, dim3(gt), dim3(TB), b.table, b.table, b.state, NB, b.partial);
-    JPK_LAUNCH(ctx, PROF_LG_SCATTER, 0, (k_lg_scatter<DB>), dim3(gp), dim3(TB), kin, vin, kout, vout, b.pieces, b.state, shift, b.table);
+    JPK_LAUNCH(ctx, PROF_LG_SCATTER, 0, (k_lg_scatter<DB>), dim3(gp), dim3(TB), kin, vin, pin, kout, vout, pout, b.pieces, b.state, shift, b.table);
 }
 
 // builds the BWT-in-SA-order bytes (b.bwt), the complete inverse suffix array (b.ISA) and, if b.SA is set, the suffix array
@@ -1104,7 +1122,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     const unsigned g_ct = cap_grid(n, CT, CAP);
     JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_count, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_r0_scan, dim3(1), dim3(WG1), b.tA, b.tB, n, b.state);
-    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, T, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp);
+    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev);
     ctx->stats.sa_rounds = 1;
 
     const int kbits = jpk_bits_for(n);             // key2 <= n, group rank < n
@@ -1132,30 +1150,32 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_count, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.state, par);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan2, dim3(1), dim3(WG1), b.PC, b.state, par, round);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_pieces, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.pieces, b.state, par);
-        JPK_LAUNCH(ctx, PROF_SA_SEG, 0, k_seg_round, dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, kbits, b.PH, T, b.ISA, b.bwt, b.SA,
-                   b.b_sa, b.b_grp);
+        JPK_LAUNCH(ctx, PROF_SA_SEG, 0, k_seg_round, dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, kbits, b.PH, b.a_prev, b.ISA, b.bwt, b.SA,
+                   b.b_sa, b.b_grp, b.b_prev);
         {   // large groups: lg_pass LSD passes over (key2, sa), ping-pong between (k2, a_sa) and (k2alt, sa_alt)
             uint32_t *kin = b.k2, *vin = b.a_sa, *kout = b.k2alt, *vout = b.sa_alt;
+            uint8_t *pin = b.a_prev, *pout = b.p_alt;
             for (int p = 0; p < lg_pass; p++) {
                 const int shift = p * lg_db;
                 switch (lg_db) {
-                case 4: launch_lg_pass<4>(ctx, b, kin, vin, kout, vout, shift, g_pc, g_tab); break;
-                case 5: launch_lg_pass<5>(ctx, b, kin, vin, kout, vout, shift, g_pc, g_tab); break;
-                case 6: launch_lg_pass<6>(ctx, b, kin, vin, kout, vout, shift, g_pc, g_tab); break;
-                case 7: launch_lg_pass<7>(ctx, b, kin, vin, kout, vout, shift, g_pc, g_tab); break;
-                default: launch_lg_pass<8>(ctx, b, kin, vin, kout, vout, shift, g_pc, g_tab); break;
+                case 4: launch_lg_pass<4>(ctx, b, kin, vin, pin, kout, vout, pout, shift, g_pc, g_tab); break;
+                case 5: launch_lg_pass<5>(ctx, b, kin, vin, pin, kout, vout, pout, shift, g_pc, g_tab); break;
+                case 6: launch_lg_pass<6>(ctx, b, kin, vin, pin, kout, vout, pout, shift, g_pc, g_tab); break;
+                case 7: launch_lg_pass<7>(ctx, b, kin, vin, pin, kout, vout, pout, shift, g_pc, g_tab); break;
+                default: launch_lg_pass<8>(ctx, b, kin, vin, pin, kout, vout, pout, shift, g_pc, g_tab); break;
                 }
                 uint32_t *tk = kin; kin = kout; kout = tk;
                 uint32_t *tv = vin; vin = vout; vout = tv;
+                uint8_t *tp = pin; pin = pout; pout = tp;
             }
             JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_lg_heads, dim3(g_pc), dim3(TB), kin, b.pieces, b.state, b.pLast);
             JPK_LAUNCH(ctx, PROF_SCAN, 0, k_lg_scan, dim3(1), dim3(WG1), b.pLast, b.state);
-            JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_lg_finish, dim3(g_pc), dim3(TB), kin, vin, b.a_grp, b.pieces, b.state, b.pLast, T, b.ISA, b.bwt, b.SA, b.b_sa,
-                       b.b_grp);
+            JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_lg_finish, dim3(g_pc), dim3(TB), kin, vin, pin, b.a_grp, b.pieces, b.state, b.pLast, b.ISA, b.bwt, b.SA, b.b_sa,
+                       b.b_grp, b.b_prev);
         }
         JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_cmp_count, dim3(g_cmp), dim3(TB), b.b_grp, b.state, par, b.tA);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_cmp_scan, dim3(1), dim3(WG1), b.tA, b.state, par, round);
-        JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_cmp_scatter, dim3(g_cmp), dim3(TB), b.b_sa, b.b_grp, b.state, par, b.tA, b.a_sa, b.a_grp);
+        JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_cmp_scatter, dim3(g_cmp), dim3(TB), b.b_sa, b.b_grp, b.b_prev, b.state, par, b.tA, b.a_sa, b.a_grp, b.a_prev);
         JPK_HIP(hipGetLastError());
         JPK_HIP(hipMemcpyAsync(&h_m[par], &b.state->m[par ^ 1], 4, hipMemcpyDeviceToHost, st));
         JPK_HIP(hipEventRecord(ctx->ev_sa[par], st));

@@ -20,7 +20,7 @@ constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
 
 // Pass 0 of the suffix sort reads its (key, value) pairs straight from the text: slot j holds suffix i = n-1-j, key = the
-// first 7 bytes of the suffix, big-endian in bits 63..8, zero padded past the end (bwt_fwd.hip, round 0).  Three aligned dword
+// first 7 bytes of the suffix, big-endian in bits 63..8, zero padded past the end (bwt_fwd.hip, round 0); bits 7..0 = T[i-1].  Three aligned dword
 // loads per slot (neighbouring lanes share them), a funnel shift and a byte swap; nothing beyond the dword that holds
 // T[n-1] is touched.
 struct TextSrc {
@@ -37,7 +37,10 @@ __device__ __forceinline__ uint64_t text_key7(const TextSrc &t, uint32_t i)
     uint64_t v = sh ? (lo >> sh) | ((uint64_t)w2 << (64u - sh)) : lo;            // bytes i .. i+7, little endian
     const uint32_t left = t.n - i;                                                  // >= 1
     if (left < 8u) v &= (1ull << (8u * left)) - 1ull;
-    return __builtin_bswap64(v) & ~0xFFull;
+    // The low byte of the key is never a sort digit (7 passes, bits 8..63): it carries T[i-1] (0 for suffix 0), the BWT byte of
+    // the suffix, so that no kernel has to gather it from the text once the suffix's SA position is known.
+    const uint32_t prev = i ? (uint32_t)reinterpret_cast<const uint8_t *>(t.tb)[a - 1u] : 0u;
+    return (__builtin_bswap64(v) & ~0xFFull) | prev;
 }
 
 template <bool TEXT>
