@@ -56,11 +56,17 @@ __global__ __launch_bounds__(TB) void k_enc_hist(const uint8_t *__restrict__ in,
     lp[threadIdx.x] = -1;
     __syncthreads();
     const uint8_t *src = in + (size_t)c * d.chunk;
-#pragma unroll 4
+    uint8_t sy[ATILE / TB];
+#pragma unroll
+    for (int it = 0; it < ATILE / TB; it++) {          // the tile's loads in flight together (clamped; masked below)
+        const uint32_t i = ts + it * TB + threadIdx.x;
+        sy[it] = src[i < clen ? i : clen - 1];
+    }
+#pragma unroll
     for (int it = 0; it < ATILE / TB; it++) {
         uint32_t i = ts + it * TB + threadIdx.x;
         if (i < clen) {
-            uint32_t s = src[i];
+            uint32_t s = sy[it];
             atomicAdd(&h[s], 1u);
             atomicMax(&lp[s], (int32_t)i);
         }
@@ -186,9 +192,16 @@ __global__ __launch_bounds__(TB) void k_rle_lz(const uint8_t *__restrict__ ranks
     const uint32_t tl = (clen - ts < (uint32_t)ATILE) ? clen - ts : (uint32_t)ATILE;
     const uint8_t *src = ranks + (size_t)c * d.chunk + ts;
     uint32_t first = 0xFFFFFFFFu;
+    uint8_t rv[ATILE / TB];
+#pragma unroll
+    for (int k = 0; k < ATILE / TB; k++) {            // loads first (clamped), all in flight
+        const uint32_t p = k * TB + threadIdx.x;
+        rv[k] = src[p < tl ? p : tl - 1];
+    }
+#pragma unroll
     for (int k = ATILE / TB - 1; k >= 0; k--) {
         uint32_t p = k * TB + threadIdx.x;
-        if (p < tl && src[p] != 0) first = p;
+        if (p < tl && rv[k] != 0) first = p;
     }
     __shared__ uint32_t sm[TB / 64 + 1];
     uint32_t tot;
@@ -322,10 +335,17 @@ __global__ __launch_bounds__(TB) void k_cls_count(const uint16_t *__restrict__ r
     __syncthreads();
     const uint16_t *src = rle + (size_t)c * rle_stride;
     uint32_t loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint16_t sv[ATILE / TB];
+#pragma unroll
+    for (int it = 0; it < ATILE / TB; it++) {          // loads first (clamped), all in flight
+        const uint32_t i = ts + it * TB + threadIdx.x;
+        sv[it] = src[i < n ? i : n - 1];
+    }
+#pragma unroll
     for (int it = 0; it < ATILE / TB; it++) {
         uint32_t i = ts + it * TB + threadIdx.x;
         if (i < n) {
-            int e = sym_class(src[i]);
+            int e = sym_class(sv[it]);
 #pragma unroll
             for (int k = 0; k < 8; k++) loc[k] += (e == k);
         }
@@ -373,19 +393,18 @@ __global__ __launch_bounds__(TB) void k_cls_ord(const uint16_t *__restrict__ rle
     const uint64_t lt = lanemask_lt();
     uint32_t sy[IT], rk[IT];
 #pragma unroll
+    for (int it = 0; it < IT; it++) {                  // the tile's loads in flight together (clamped; masked below)
+        const uint32_t i = ts + w * (64 * IT) + it * 64 + l;
+        sy[it] = src[i < n ? i : n - 1];
+    }
+#pragma unroll
     for (int it = 0; it < IT; it++) {
         uint32_t i = ts + w * (64 * IT) + it * 64 + l;
         bool valid = i < n;
-        uint32_t s = valid ? src[i] : 0;
+        uint32_t s = valid ? sy[it] : 0;
         sy[it] = s;
         uint32_t e = (uint32_t)sym_class(s);
-        uint64_t m = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 3; b++) {
-            bool bit = (e >> b) & 1u;
-            uint64_t bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
-        }
+        const uint64_t m = match_any<3>(e, valid);
         uint32_t below = (uint32_t)__popcll(m & lt);
         uint32_t cc = valid ? cnt[w][e] : 0;
         rk[it] = cc + below;
@@ -994,10 +1013,16 @@ __global__ __launch_bounds__(TB) void k_emit_count(const uint32_t *__restrict__ 
     if (tile * ETILE >= np) return;
     const size_t lane_stride = rans_lane_stride(rle_stride), cb = (size_t)c * 4 * lane_stride;
     uint32_t n = 0;
-#pragma unroll 4
+    uint32_t ew[ETILE / TB];
+#pragma unroll
+    for (int it = 0; it < ETILE / TB; it++) {          // loads first (clamped), all in flight
+        const uint32_t j = tile * ETILE + it * TB + threadIdx.x;
+        ew[it] = pair_emit(xs, recs, cb, lane_stride, j < np ? j : np - 1);
+    }
+#pragma unroll
     for (int it = 0; it < ETILE / TB; it++) {
         const uint32_t j = tile * ETILE + it * TB + threadIdx.x;
-        if (j < np) n += pair_emit(xs, recs, cb, lane_stride, j) >> 16;
+        if (j < np) n += ew[it] >> 16;
     }
     __shared__ uint32_t sm[TB / 64 + 1];
     uint32_t tot;
@@ -1101,8 +1126,10 @@ __global__ __launch_bounds__(TB) void k_put_payload(const uint32_t *__restrict__
     uint32_t e[16];
     uint32_t n = 0;
 #pragma unroll
+    for (int k = 0; k < 16; k++) e[k] = pair_emit(xs, recs, cb, lane_stride, j0 + k < np ? j0 + k : np - 1);     // loads first (clamped)
+#pragma unroll
     for (int k = 0; k < 16; k++) {
-        e[k] = (j0 + k < np) ? pair_emit(xs, recs, cb, lane_stride, j0 + k) : 0u;
+        if (j0 + k >= np) e[k] = 0u;
         n += e[k] >> 16;
     }
     // bytes emitted by the threads after me = block total - inclusive prefix

@@ -120,12 +120,23 @@ __device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const
 __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n, uint32_t base, uint64_t *HE)
 {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-#pragma unroll 4
-    for (int k = 0; k < CT_ITEMS; k++) {
-        const uint32_t j = base + w * (64 * CT_ITEMS) + k * 64 + l;
-        const bool he = (j >= n) || r0_head(keys, sa, j, n);
-        const uint64_t b = __ballot(he);
-        if (l == 0) HE[w * CT_ITEMS + k] = b;
+    // four slots at a time, their sixteen loads in flight together (clamped indices, no branch around a load)
+#pragma unroll
+    for (int k0 = 0; k0 < CT_ITEMS; k0 += 4) {
+        uint64_t kj[4], kp[4];
+        uint32_t sj[4], sp[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t j = base + w * (64 * CT_ITEMS) + (k0 + k) * 64 + l, jc = j < n ? j : n - 1, jp = jc ? jc - 1 : 0;
+            kj[k] = keys[jc]; kp[k] = keys[jp]; sj[k] = sa[jc]; sp[k] = sa[jp];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t j = base + w * (64 * CT_ITEMS) + (k0 + k) * 64 + l;
+            const bool he = (j >= n) || (j == 0) || ((kj[k] ^ kp[k]) >> 8) != 0ull || sj[k] + 7u > n || sp[k] + 7u > n;     // = r0_head
+            const uint64_t b = __ballot(he);
+            if (l == 0) HE[w * CT_ITEMS + k0 + k] = b;
+        }
     }
     if (threadIdx.x == 0) {
         const uint32_t jn = base + CT;
@@ -214,16 +225,27 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
             LHW[l] = last > carry ? last : carry;
         }
         __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < CT_ITEMS; k++) {
+#pragma unroll
+        for (int k0 = 0; k0 < CT_ITEMS; k0 += 4) {
+        uint32_t s4[4];
+        uint8_t p4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {                              // the loads of four slots in flight together
+            const uint32_t j = base + (w * CT_ITEMS + k0 + k) * 64 + l, jc = j < n ? j : n - 1;
+            s4[k] = sa[jc];
+            p4[k] = (uint8_t)keys[jc];                              // T[s - 1], carried in the key's low byte since pass 0
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int k = k0 + kk;
             const int word = w * CT_ITEMS + k;
             const uint32_t j = base + word * 64 + l;
             if (j < n) {
                 const uint64_t hv = HE[word] & valid_word(base + word * 64, n);
                 const uint64_t le = hv & mask_upto(l);
                 const uint32_t grp = le ? base + word * 64 + top_bit(le) : (word ? LHW[word - 1] : carry) - 1u;
-                const uint32_t s = sa[j];
-                const uint8_t pv = (uint8_t)keys[j];                // T[s - 1], carried in the key's low byte since pass 0
+                const uint32_t s = s4[kk];
+                const uint8_t pv = p4[kk];
                 ISA[s] = grp;
                 const uint64_t sv = SV[word];
                 if (!((sv >> l) & 1ull)) {
@@ -236,6 +258,7 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                     a_prev[pos] = pv;
                 }
             }
+        }
         }
     }
 }
@@ -253,24 +276,29 @@ __global__ __launch_bounds__(TB) void k_gather_win(const uint32_t *__restrict__ 
     for (uint32_t win = blockIdx.x; win < nwin; win += gridDim.x) {
         const uint32_t base = win * SEG_TILE;
         __syncthreads();
-        uint32_t s[WIN_ITEMS];
+        // every load of the window is issued without a branch around it (clamped indices, results masked afterwards), so that
+        // the list reads and then the rank gathers are all in flight together
+        uint32_t s[WIN_ITEMS], gj[WIN_ITEMS], gp[WIN_ITEMS];
 #pragma unroll
         for (int k = 0; k < WIN_ITEMS; k++) {
-            const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l;
-            s[k] = (j < m) ? a_sa[j] : NONE;
+            const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l, jc = j < m ? j : m - 1;
+            s[k] = a_sa[jc];
+            gj[k] = a_grp[jc];
+            gp[k] = a_grp[jc ? jc - 1 : 0];
         }
         uint32_t kv[WIN_ITEMS];
 #pragma unroll
         for (int k = 0; k < WIN_ITEMS; k++) {
             const uint64_t s2 = (uint64_t)s[k] + h;
-            kv[k] = (s[k] != NONE && s2 < n) ? ISA[s2] + 1u : 0u;
+            kv[k] = ISA[s2 < n ? s2 : 0];
+            kv[k] = (s2 < n) ? kv[k] + 1u : 0u;
         }
 #pragma unroll
         for (int k = 0; k < WIN_ITEMS; k++) {
             const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l;
             bool head = false;
             if (j < m) {
-                head = (j == 0) || (a_grp[j] != a_grp[j - 1]);
+                head = (j == 0) || (gj[k] != gp[k]);
                 k2[j] = kv[k];
             }
             const uint64_t b = __ballot(head);
@@ -435,7 +463,13 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
         const uint32_t avail = (m - base < (uint32_t)SEG_SPAN) ? m - base : (uint32_t)SEG_SPAN;
         const bool list_ends = (base + avail == m);
 
-        for (uint32_t p = tid; p < avail; p += TB) g[p] = a_grp[base + p];
+        {   // the span's eight loads per thread in flight together (clamped; only slots < avail are kept)
+            uint32_t gl[SEG_ITEMS];
+#pragma unroll
+            for (int k = 0; k < SEG_ITEMS; k++) { const uint32_t p = tid + k * TB; gl[k] = a_grp[base + (p < avail ? p : avail - 1)]; }
+#pragma unroll
+            for (int k = 0; k < SEG_ITEMS; k++) { const uint32_t p = tid + k * TB; if (p < avail) g[p] = gl[k]; }
+        }
         const uint32_t gprev = (base > 0) ? a_grp[base - 1] : 0xFFFFFFFFu;
         if (tid == 0) { s_fo = 0xFFFFFFFFu; s_oe = 0; }
         __syncthreads();
@@ -535,9 +569,18 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
                 }
             }
         }
-        for (uint32_t q = tid; q < no; q += TB) {
-            k2[q] = k2g[base + fo + q];
-            idxA[q] = (uint16_t)q;            // g[] is dead from here on (last read: the classification above)
+        {
+            uint32_t kl[SEG_ITEMS];
+#pragma unroll
+            for (int k = 0; k < SEG_ITEMS; k++) { const uint32_t q = tid + k * TB; kl[k] = k2g[base + fo + (q < no ? q : no - 1)]; }
+#pragma unroll
+            for (int k = 0; k < SEG_ITEMS; k++) {
+                const uint32_t q = tid + k * TB;
+                if (q < no) {
+                    k2[q] = kl[k];
+                    idxA[q] = (uint16_t)q;    // g[] is dead from here on (last read: the classification above)
+                }
+            }
         }
         __syncthreads();
         const uint32_t ngroups = (uint32_t)lgid[no - 1] + 1u;
@@ -675,10 +718,16 @@ __global__ __launch_bounds__(TB) void k_lg_hist(const uint32_t *__restrict__ key
         __syncthreads();
         for (int i = threadIdx.x; i < WAVES * HC * HS; i += TB) h[i] = 0;
         __syncthreads();
+        uint32_t kv[WIN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {                // loads first (clamped), then the LDS atomics
+            const uint32_t e = w * (64 * WIN_ITEMS) + k * 64 + l;
+            kv[k] = key[q.begin + (e < q.count ? e : q.count - 1)];
+        }
 #pragma unroll
         for (int k = 0; k < WIN_ITEMS; k++) {
             const uint32_t e = w * (64 * WIN_ITEMS) + k * 64 + l;
-            if (e < q.count) atomicAdd(&mine[(key[q.begin + e] >> shift) & (uint32_t)(NB - 1)], 1u);
+            if (e < q.count) atomicAdd(&mine[(kv[k] >> shift) & (uint32_t)(NB - 1)], 1u);
         }
         __syncthreads();
         for (int d = threadIdx.x; d < NB; d += TB) {
@@ -711,12 +760,17 @@ __global__ __launch_bounds__(TB) void k_lg_scatter(const uint32_t *__restrict__ 
         uint32_t key[WIN_ITEMS], val[WIN_ITEMS], rnk[WIN_ITEMS];
         uint8_t prv[WIN_ITEMS];                      // the suffix's BWT byte rides along (third member of the sorted record)
 #pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {                // the piece's loads in flight together (clamped; masked by `valid` below)
+            const uint32_t e = w * (64 * WIN_ITEMS) + k * 64 + l, ec = q.begin + (e < q.count ? e : q.count - 1);
+            key[k] = kin[ec];
+            val[k] = vin[ec];
+            prv[k] = pin[ec];
+        }
+#pragma unroll
         for (int k = 0; k < WIN_ITEMS; k++) {
             const uint32_t e = w * (64 * WIN_ITEMS) + k * 64 + l;
             const bool valid = e < q.count;
-            key[k] = valid ? kin[q.begin + e] : 0u;
-            val[k] = valid ? vin[q.begin + e] : 0u;
-            prv[k] = valid ? pin[q.begin + e] : (uint8_t)0;
+            if (!valid) key[k] = 0u;
             const uint32_t d = (key[k] >> shift) & (uint32_t)(NB - 1);
             const uint64_t mm = match_any<DB>(d, valid);
             const uint32_t below = (uint32_t)__popcll(mm & lt);
@@ -750,13 +804,20 @@ __global__ __launch_bounds__(TB) void k_lg_scatter(const uint32_t *__restrict__ 
 __device__ __forceinline__ void lg_piece_heads(const uint32_t *__restrict__ key, const Piece &q, uint64_t *H)
 {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    uint32_t kj[WIN_ITEMS], kp[WIN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < WIN_ITEMS; k++) {                    // loads first (clamped), all in flight
+        const uint32_t e = w * (64 * WIN_ITEMS) + k * 64 + l, j = q.begin + (e < q.count ? e : q.count - 1);
+        kj[k] = key[j];
+        kp[k] = key[j > q.gs ? j - 1 : j];
+    }
 #pragma unroll
     for (int k = 0; k < WIN_ITEMS; k++) {
         const uint32_t e = w * (64 * WIN_ITEMS) + k * 64 + l;
         bool head = false;
         if (e < q.count) {
             const uint32_t j = q.begin + e;
-            head = (j == q.gs) || (key[j] != key[j - 1]);
+            head = (j == q.gs) || (kj[k] != kp[k]);
         }
         const uint64_t b = __ballot(head);
         if (l == 0) H[w * WIN_ITEMS + k] = b;
@@ -819,6 +880,14 @@ __global__ __launch_bounds__(TB) void k_lg_finish(const uint32_t *__restrict__ k
         }
         __syncthreads();
         const uint32_t G = a_grp[q.gs] & ~DONE;            // rank of the old group = SA position of its first member
+        uint32_t sl[WIN_ITEMS];
+        uint8_t pl[WIN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {              // the piece's loads in flight together (clamped)
+            const uint32_t e = (w * WIN_ITEMS + k) * 64 + l, j = q.begin + (e < q.count ? e : q.count - 1);
+            sl[k] = val[j];
+            pl[k] = prv[j];
+        }
 #pragma unroll
         for (int k = 0; k < WIN_ITEMS; k++) {
             const int word = w * WIN_ITEMS + k;
@@ -834,8 +903,8 @@ __global__ __launch_bounds__(TB) void k_lg_finish(const uint32_t *__restrict__ k
                 if (e + 1 == q.count) nh = H[16] & 1ull;
                 else nh = (l < 63) ? ((hv >> (l + 1)) & 1ull) : (H[word + 1] & 1ull);
                 const bool single = head && nh;
-                const uint32_t s = val[j];
-                const uint8_t pv = prv[j];
+                const uint32_t s = sl[k];
+                const uint8_t pv = pl[k];
                 if (hp != q.gs) ISA[s] = rank;                      // the first sub-group keeps the old group's rank
                 if (single) {
                     const uint32_t ap = G + (j - q.gs);
@@ -927,10 +996,16 @@ __global__ __launch_bounds__(TB) void k_cmp_count(const uint32_t *__restrict__ b
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * CT;
         uint32_t c = 0;
-#pragma unroll 4
+        uint32_t gv[CT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < CT_ITEMS; k++) {                // loads first, all in flight (clamped, masked below)
+            const uint32_t j = base + w * (64 * CT_ITEMS) + k * 64 + l;
+            gv[k] = b_grp[j < m ? j : m - 1];
+        }
+#pragma unroll
         for (int k = 0; k < CT_ITEMS; k++) {
             const uint32_t j = base + w * (64 * CT_ITEMS) + k * 64 + l;
-            c += (j < m && !(b_grp[j] & DONE)) ? 1u : 0u;
+            c += (j < m && !(gv[k] & DONE)) ? 1u : 0u;
         }
         c = wave_sum(c);
         __syncthreads();
@@ -961,11 +1036,19 @@ __global__ __launch_bounds__(TB) void k_cmp_scatter(const uint32_t *__restrict__
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * CT;
         __syncthreads();
-        uint32_t gv[CT_ITEMS];
+        uint32_t gv[CT_ITEMS], sv[CT_ITEMS];
+        uint8_t pv[CT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < CT_ITEMS; k++) {                // every load of the tile in flight at once (clamped, masked below)
+            const uint32_t j = base + w * (64 * CT_ITEMS) + k * 64 + l, jc = j < m ? j : m - 1;
+            gv[k] = b_grp[jc];
+            sv[k] = b_sa[jc];
+            pv[k] = b_prev[jc];
+        }
 #pragma unroll
         for (int k = 0; k < CT_ITEMS; k++) {
             const uint32_t j = base + w * (64 * CT_ITEMS) + k * 64 + l;
-            gv[k] = (j < m) ? b_grp[j] : DONE;
+            if (j >= m) gv[k] = DONE;
             const uint64_t b = __ballot(!(gv[k] & DONE));
             if (l == 0) SV[w * CT_ITEMS + k] = b;
         }
@@ -979,12 +1062,11 @@ __global__ __launch_bounds__(TB) void k_cmp_scatter(const uint32_t *__restrict__
 #pragma unroll
         for (int k = 0; k < CT_ITEMS; k++) {
             const int word = w * CT_ITEMS + k;
-            const uint32_t j = base + word * 64 + l;
             if (!(gv[k] & DONE)) {
                 const uint32_t pos = SW[word] + (uint32_t)__popcll(SV[word] & mask_below(l));
-                a_sa[pos] = b_sa[j];
+                a_sa[pos] = sv[k];
                 a_grp[pos] = gv[k];
-                a_prev[pos] = b_prev[j];
+                a_prev[pos] = pv[k];
             }
         }
     }

@@ -61,11 +61,17 @@ __global__ __launch_bounds__(TB) void k_hist(const uint8_t *__restrict__ B, uint
     __syncthreads();
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const size_t base = (size_t)blockIdx.x * TILE + (size_t)w * (64 * ITEMS) + l;
-#pragma unroll 8
+    // loads first, all in flight (slots past the end re-read the last byte and are masked): a load inside `if (i < n)` makes the
+    // compiler wait for each one in turn
+    uint8_t sy[ITEMS];
+#pragma unroll
     for (int it = 0; it < ITEMS; it++) {
-        size_t i = base + (size_t)it * 64;
-        if (i < n) atomicAdd(&h[w][B[i]], 1u);
+        const size_t i = base + (size_t)it * 64;
+        sy[it] = B[i < n ? i : n - 1];
     }
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++)
+        if (base + (size_t)it * 64 < n) atomicAdd(&h[w][sy[it]], 1u);
     __syncthreads();
     for (int d = threadIdx.x; d < 256; d += TB)
         tilehist[(size_t)d * ntiles + blockIdx.x] = h[0][d] + h[1][d] + h[2][d] + h[3][d];
@@ -97,10 +103,15 @@ __global__ __launch_bounds__(TB) void k_build_nxt(const uint8_t *__restrict__ B,
     uint8_t sym[ITEMS];
     uint16_t rnk[ITEMS];
 #pragma unroll
+    for (int it = 0; it < ITEMS; it++) {              // all loads in flight before the first match
+        const size_t i = base + (size_t)it * 64;
+        sym[it] = B[i < n ? i : n - 1];
+    }
+#pragma unroll
     for (int it = 0; it < ITEMS; it++) {
         size_t i = base + (size_t)it * 64;
         bool valid = i < n;
-        uint32_t d = valid ? B[i] : 0;
+        uint32_t d = valid ? sym[it] : 0;
         sym[it] = (uint8_t)d;
         uint64_t m = match_any8(d, valid);
         uint32_t below = (uint32_t)__popcll(m & lt);

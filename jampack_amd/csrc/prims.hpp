@@ -81,17 +81,23 @@ __device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t *sm, ui
 }
 
 // lanes of this wave whose BITS-bit digit equals mine (valid lanes only)
+// m = AND_b (bit_b ? ballot_b : ~ballot_b) = ~ OR_b (ballot_b ^ D_b) with D_b = bit b of my digit replicated over a word (one
+// v_bfe_i32, which also feeds the ballot's compare): five vector instructions per bit on the two halves of the lane mask
+// instead of the seven or eight of the select form -- the match is the bulk of every radix kernel's VALU work.
 template <int BITS>
 __device__ __forceinline__ uint64_t match_any(uint32_t d, bool valid)
 {
-    uint64_t m = __ballot(valid);
+    uint32_t lo = 0, hi = 0;
 #pragma unroll
     for (int b = 0; b < BITS; b++) {
-        const bool bit = (d >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
+        uint32_t D;                                                              // 0 or ~0; asm: the compiler would expand the bit-field extract into two shifts
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(D) : "v"(d), "n"(b));
+        const uint64_t bal = __ballot(D != 0u);
+        lo |= (uint32_t)bal ^ D;
+        hi |= (uint32_t)(bal >> 32) ^ D;
     }
-    return m;
+    const uint64_t v = __ballot(valid);
+    return (((uint64_t)~hi << 32) | (uint64_t)~lo) & v;
 }
 __device__ __forceinline__ uint64_t match_any8(uint32_t d, bool valid) { return match_any<8>(d, valid); }
 

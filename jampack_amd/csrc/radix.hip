@@ -36,11 +36,35 @@ __device__ __forceinline__ uint64_t text_key7(const TextSrc &t, uint32_t i)
     const uint64_t lo = ((uint64_t)w1 << 32) | w0;
     uint64_t v = sh ? (lo >> sh) | ((uint64_t)w2 << (64u - sh)) : lo;            // bytes i .. i+7, little endian
     const uint32_t left = t.n - i;                                                  // >= 1
-    if (left < 8u) v &= (1ull << (8u * left)) - 1ull;
+    v &= (left < 8u) ? (1ull << (8u * left)) - 1ull : ~0ull;
     // The low byte of the key is never a sort digit (7 passes, bits 8..63): it carries T[i-1] (0 for suffix 0), the BWT byte of
     // the suffix, so that no kernel has to gather it from the text once the suffix's SA position is known.
-    const uint32_t prev = i ? (uint32_t)reinterpret_cast<const uint8_t *>(t.tb)[a - 1u] : 0u;
+    uint32_t prev = (uint32_t)reinterpret_cast<const uint8_t *>(t.tb)[a - (i ? 1u : 0u)];        // (no branch around the load)
+    prev = i ? prev : 0u;
     return (__builtin_bswap64(v) & ~0xFFull) | prev;
+}
+
+// The sixteen pairs of a thread, all loads issued back to back: no branch around a load (slots past the end re-read the last
+// pair and are zeroed afterwards).  With the loads inside `valid ? .. : 0` the compiler put an s_waitcnt vmcnt(0) behind every
+// one of them -- a full memory latency per 64 elements instead of per tile.
+template <bool TEXT>
+__device__ __forceinline__ void rs_load_tile(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, const TextSrc &txt, size_t n, size_t base,
+                                             uint64_t (&key)[RS_ITEMS], uint32_t (&val)[RS_ITEMS])
+{
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; it++) {
+        const size_t i = base + (size_t)it * 64, ic = i < n ? i : n - 1;
+        if (TEXT) {
+            val[it] = (uint32_t)(n - 1 - ic);
+            key[it] = text_key7(txt, val[it]);
+        } else {
+            key[it] = kin[ic];
+            val[it] = vin[ic];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; it++)
+        if (base + (size_t)it * 64 >= n) { key[it] = 0; val[it] = 0; }
 }
 
 template <bool TEXT>
@@ -52,18 +76,21 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *__restri
     __syncthreads();
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const size_t base = (size_t)blockIdx.x * RS_TILE + (size_t)w * (64 * RS_ITEMS) + l;
+    // all sixteen loads of a thread are issued before the first one is used (no branch around a load: slots past the end re-read
+    // the last element and are masked afterwards) -- with a load inside `if (i < n)` the compiler waits for every load in turn
+    uint32_t dig[RS_ITEMS];
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++) {
-        size_t i = base + (size_t)it * 64;
-        if (i < n) {
-            uint32_t d;
-            if (TEXT) {                                // digit of byte (56 - shift) / 8 of the suffix: one text byte
-                const uint32_t pos = (uint32_t)(n - 1 - i) + (uint32_t)((56 - shift) >> 3);
-                d = (pos < txt.n) ? reinterpret_cast<const uint8_t *>(txt.tb)[pos + txt.off] : 0u;
-            } else d = (uint32_t)(keys[i] >> shift) & 255u;
-            atomicAdd(&h[w][d], 1u);
-        }
+        const size_t i = base + (size_t)it * 64, ic = i < n ? i : n - 1;
+        if (TEXT) {                                    // digit of byte (56 - shift) / 8 of the suffix: one text byte
+            const uint32_t pos = (uint32_t)(n - 1 - ic) + (uint32_t)((56 - shift) >> 3);
+            dig[it] = reinterpret_cast<const uint8_t *>(txt.tb)[(pos < txt.n ? pos : txt.n - 1u) + txt.off];
+            if (pos >= txt.n) dig[it] = 0u;
+        } else dig[it] = (uint32_t)(keys[ic] >> shift) & 255u;
     }
+#pragma unroll
+    for (int it = 0; it < RS_ITEMS; it++)
+        if (base + (size_t)it * 64 < n) atomicAdd(&h[w][dig[it]], 1u);
     __syncthreads();
     for (int d = threadIdx.x; d < 256; d += RS_THREADS) {
         uint32_t s = 0;
@@ -89,17 +116,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *__res
     uint32_t val[RS_ITEMS];
     uint32_t rnk[RS_ITEMS];
     const uint64_t lt = lanemask_lt();
+    rs_load_tile<TEXT>(kin, vin, txt, n, base, key, val);
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++) {
         size_t i = base + (size_t)it * 64;
         bool valid = i < n;
-        if (TEXT) {
-            val[it] = valid ? (uint32_t)(n - 1 - i) : 0u;
-            key[it] = valid ? text_key7(txt, val[it]) : 0;
-        } else {
-            key[it] = valid ? kin[i] : 0;
-            val[it] = valid ? vin[i] : 0;
-        }
         uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
         uint64_t m = match_any8(d, valid);
         uint32_t below = (uint32_t)__popcll(m & lt);
@@ -152,17 +173,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter_staged(const uint64_t
     uint32_t val[RS_ITEMS];
     uint32_t rnk[RS_ITEMS];
     const uint64_t lt = lanemask_lt();
+    rs_load_tile<TEXT>(kin, vin, txt, n, base, key, val);
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++) {
         size_t i = base + (size_t)it * 64;
         bool valid = i < n;
-        if (TEXT) {
-            val[it] = valid ? (uint32_t)(n - 1 - i) : 0u;
-            key[it] = valid ? text_key7(txt, val[it]) : 0;
-        } else {
-            key[it] = valid ? kin[i] : 0;
-            val[it] = valid ? vin[i] : 0;
-        }
         uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
         uint64_t m = match_any8(d, valid);
         uint32_t below = (uint32_t)__popcll(m & lt);
