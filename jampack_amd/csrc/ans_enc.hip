@@ -799,38 +799,29 @@ __device__ __forceinline__ uint32_t emit_word(uint32_t x, uint32_t xmax)
 // After renormalisation xr < freq << 15, so q = xr / freq < 2^15 and 65536 - freq < 2^16: the second product fits the
 // 24-bit multiply-add, which also ignores the shift count kept in the top byte of r.w.
 // two consecutive steps (turns ta, tb) in one block: the compiler adds a wait state after every asm statement
-//
-// Round 3: ten vector instructions per step instead of twelve.
-//   * The state travels WITHOUT the bias of the step that produced it: the producer ends in q * w + xr, and the consumer's
-//     lane-rotating move -- a DPP operand modifier, free on any VOP2 -- becomes  x = rotate(x') + biasL,  biasL = the left
-//     neighbour's bias, which is constant for the sixteen steps of a batch (one rotate per batch; lane 0 of a row takes lane 15's
-//     bias of the PREVIOUS batch, because that is the step its state comes from).
-//   * Renormalisation by shift amount: b1 = x >= xmax, b2 = x >= min(xmax, 2^23) << 8 (== (x >> 8) >= xmax for every state
-//     < 2^31; the threshold saturates at 2^31, which no state reaches), s = b2 ? 16 : b1 ? 8 : 0, xr = x >> s -- two compares,
-//     two selects, one shift instead of two shifts, two compares and two selects.
-// Wait states: two instructions between a v_cmp that writes a mask and the select that reads it (b1: cmp b2 + the capture;
-// b2: the capture + select s1), two between the write of the new state and the next step's DPP read (s_nop 1).
 #define JPK_RANS_STEP_ASM(XIN, XPREV, XOUT, TURN)                                                        \
-        "v_add_u32_dpp " XIN ", " XPREV ", %[bl] row_ror:1 row_mask:0xf bank_mask:0xf\n\t"              \
-        "v_cmp_ge_u32_e64 %[b1], " XIN ", %[xmax]\n\t"  /* b1 = x >= xmax: at least one byte leaves */    \
-        "v_cmp_ge_u32_e64 %[b2], " XIN ", %[xhi]\n\t"   /* b2 = (x >> 8) >= xmax: two bytes leave */      \
-        "v_cndmask_b32_e64 %[keep], %[keep], " XIN ", " TURN "\n\t"  /* my turn: remember the state I started from */ \
-        "v_cndmask_b32_e64 %[sh], 0, 8, %[b1]\n\t"                                                       \
-        "v_cndmask_b32_e64 %[sh], %[sh], 16, %[b2]\n\t"                                                  \
-        "v_lshrrev_b32 %[xr], %[sh], " XIN "\n\t"                                                        \
-        "v_mul_hi_u32 %[q], %[xr], %[rcp]\n\t"                                                           \
+        "v_mov_b32_dpp " XIN ", " XPREV " row_ror:1 row_mask:0xf bank_mask:0xf\n\t"                       \
+        "v_lshrrev_b32 %[x8], 8, " XIN "\n\t"                                                             \
+        "v_cmp_ge_u32_e64 %[b2], %[x8], %[xmax]\n\t"    /* b2 = (x >> 8) >= xmax: two bytes leave (implies b1) */ \
+        "v_cmp_ge_u32_e64 %[b1], " XIN ", %[xmax]\n\t"  /* b1 = x >= xmax: one byte leaves */              \
+        "v_lshrrev_b32 %[x16], 16, " XIN "\n\t"                                                           \
+        "v_cndmask_b32_e64 %[u], %[x8], %[x16], %[b2]\n\t"     /* u = b2 ? x >> 16 : x >> 8 */            \
+        "v_cndmask_b32_e64 %[xr], " XIN ", %[u], %[b1]\n\t"    /* xr = b1 ? u : x */                      \
+        "v_mul_hi_u32 %[q], %[xr], %[rcp]\n\t"                                                            \
         "v_lshrrev_b32_sdwa %[q], %[w], %[q] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n\t" \
-        "v_mad_u32_u24 " XOUT ", %[q], %[w], %[xr]\n\t"  /* == ((xr / freq) << 16) + xr % freq  (the bias is added by the consumer) */ \
-        "s_nop 1\n\t"
-__device__ __forceinline__ uint32_t rans_step_turn2(uint32_t xprev, const uint4 r, uint32_t bl, uint32_t xhi, uint32_t &keep, uint64_t ta, uint64_t tb)
+        "v_add_u32 %[t], %[xr], %[bias]\n\t"                                                              \
+        "v_mad_u32_u24 " XOUT ", %[q], %[w], %[t]\n\t"  /* == ((xr / freq) << 16) + xr % freq + low */     \
+        "v_cndmask_b32_e64 %[keep], %[keep], " XIN ", " TURN "\n\t"  /* my turn: remember the state I started from */ \
+        "s_nop 0\n\t"
+__device__ __forceinline__ uint32_t rans_step_turn2(uint32_t xprev, const uint4 r, uint32_t &keep, uint64_t ta, uint64_t tb)
 {
-    uint32_t xin, sh, xr, q, xm, xn;
+    uint32_t xin, x8, x16, u, xr, q, t, xm, xn;
     uint64_t b1, b2;
     asm(JPK_RANS_STEP_ASM("%[xin]", "%[xprev]", "%[xm]", "%[ta]")
         JPK_RANS_STEP_ASM("%[xin]", "%[xm]", "%[xn]", "%[tb]")
-        : [xin] "=&v"(xin), [sh] "=&v"(sh), [xr] "=&v"(xr), [q] "=&v"(q), [xm] "=&v"(xm),
+        : [xin] "=&v"(xin), [x8] "=&v"(x8), [x16] "=&v"(x16), [u] "=&v"(u), [xr] "=&v"(xr), [q] "=&v"(q), [t] "=&v"(t), [xm] "=&v"(xm),
           [xn] "=&v"(xn), [b1] "=&s"(b1), [b2] "=&s"(b2), [keep] "+v"(keep)
-        : [xprev] "v"(xprev), [xmax] "v"(r.x), [rcp] "v"(r.y), [bl] "v"(bl), [xhi] "v"(xhi), [w] "v"(r.w), [ta] "s"(ta), [tb] "s"(tb));
+        : [xprev] "v"(xprev), [xmax] "v"(r.x), [rcp] "v"(r.y), [bias] "v"(r.z), [w] "v"(r.w), [ta] "s"(ta), [tb] "s"(tb));
     return xn;
 }
 
@@ -866,7 +857,6 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
     const int32_t nbatch = (int32_t)((np - 1) / 4) / 16 + 1;
     int32_t K = 16 * nbatch - 1 - s;                               // this lane's step index in the current batch
     uint32_t x = RANS_L;                                           // lane 15 of a row hands the start state to lane 0
-    uint32_t bias_prev = 0;                                        // this lane's bias in the previous batch (the start state carries none)
     // Record loads are issued from inline asm so that the wait counts are ours: loads and stores share vmcnt and retire in
     // order, and the compiler (which has to be conservative across the early exits below) waited with vmcnt(6), i.e. for the
     // kept-state stores of the last three batches as well -- a store acknowledgement on the chain of every batch.  Sixteen
@@ -886,14 +876,8 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
         asm volatile("s_waitcnt vmcnt(30)" : "+v"(R) : : "memory");                                        \
         uint32_t keep = 0;                                                                                 \
         const uint4 rr = make_uint4(R.x, R.y, R.z, R.w);                                                   \
-        /* bias of the step whose state I receive: my left neighbour's of this batch; lane 0 of a row: lane 15's of the last one */ \
-        const uint32_t bl_cur = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)rr.z, 0x121 /* row_ror:1 */, 0xf, 0xf, false); \
-        const uint32_t bl_old = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bias_prev, 0x121, 0xf, 0xf, false); \
-        const uint32_t bl = (s == 0) ? bl_old : bl_cur;                                                    \
-        const uint32_t xhi = min(rr.x, 1u << 23) << 8;                                                     \
-        bias_prev = rr.z;                                                                                  \
         _Pragma("unroll") for (int st = 0; st < 16; st += 2)                                               \
-            x = rans_step_turn2(x, rr, bl, xhi, keep, 0x0001000100010001ull << st, 0x0001000100010001ull << (st + 1)); \
+            x = rans_step_turn2(x, rr, keep, 0x0001000100010001ull << st, 0x0001000100010001ull << (st + 1)); \
         xo[KK] = keep;                                                                                     \
         asm volatile("" : : : "memory");                                                                   \
     }
@@ -985,7 +969,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
 #undef JPK_LOADREC
 #undef JPK_DUMMYST
 #undef JPK_BATCH
-    if (s == 15) fstate[(size_t)c * 4 + chain] = x + bias_prev;   // the last batch ends at step 0: lane 15 holds each chain's final state, less its own bias
+    if (s == 15) fstate[(size_t)c * 4 + chain] = x;               // the last batch ends at step 0: lane 15 holds each chain's final state
     if (t == 0) {
         // diagnostics: shader cycles and 100 MHz ticks this chunk's chains took (jpk_stats.enc_chain_*)
         stamp[2 * (size_t)c] = __builtin_amdgcn_s_memtime() - t0c;
