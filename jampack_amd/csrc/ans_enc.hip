@@ -50,10 +50,10 @@ __global__ __launch_bounds__(TB) void k_enc_hist(const uint8_t *__restrict__ in,
     const uint32_t c = chunk_of(d, blockIdx.y), t = blockIdx.x;
     const uint32_t clen = chunk_len(d, c), ts = t * ATILE;
     if (ts >= clen) return;
-    __shared__ uint32_t h[256];
-    __shared__ int32_t lp[256];
-    h[threadIdx.x] = 0;
-    lp[threadIdx.x] = -1;
+    __shared__ uint32_t h[TB / 64][256];
+    __shared__ int32_t lp[TB / 64][256];
+#pragma unroll
+    for (int k = 0; k < TB / 64; k++) { h[k][threadIdx.x] = 0; lp[k][threadIdx.x] = -1; }
     __syncthreads();
     const uint8_t *src = in + (size_t)c * d.chunk;
     uint8_t sy[ATILE / TB];
@@ -62,19 +62,30 @@ __global__ __launch_bounds__(TB) void k_enc_hist(const uint8_t *__restrict__ in,
         const uint32_t i = ts + it * TB + threadIdx.x;
         sy[it] = src[i < clen ? i : clen - 1];
     }
+    // The input is a BWT image: runs of equal bytes, so most lanes of a wave hit the same bin.  Counted by wave match (ballots; the
+    // first lane of each set of equal bytes adds their number and records the position of the set's LAST lane -- positions grow
+    // with the lane and with the iteration, so a plain store keeps the maximum) on per-wave tables, no LDS atomics.
+    const int w = threadIdx.x >> 6;
+    const uint64_t lt = lanemask_lt();
 #pragma unroll
     for (int it = 0; it < ATILE / TB; it++) {
-        uint32_t i = ts + it * TB + threadIdx.x;
-        if (i < clen) {
-            uint32_t s = sy[it];
-            atomicAdd(&h[s], 1u);
-            atomicMax(&lp[s], (int32_t)i);
+        const uint32_t i = ts + it * TB + threadIdx.x;
+        const bool valid = i < clen;
+        const uint32_t s = sy[it];
+        const uint64_t m = match_any8(s, valid);
+        if (valid && (m & lt) == 0ull) {
+            h[w][s] += (uint32_t)__popcll(m);
+            lp[w][s] = (int32_t)(i - (uint32_t)lane_id() + (63u - (uint32_t)__clzll((long long)m)));
         }
     }
     __syncthreads();
     size_t o = ((size_t)c * d.tpc + t) * 256 + threadIdx.x;
-    tilecnt[o] = h[threadIdx.x];
-    lastpos[o] = lp[threadIdx.x];
+    uint32_t hs = 0;
+    int32_t lm = -1;
+#pragma unroll
+    for (int k = 0; k < TB / 64; k++) { hs += h[k][threadIdx.x]; lm = lp[k][threadIdx.x] > lm ? lp[k][threadIdx.x] : lm; }
+    tilecnt[o] = hs;
+    lastpos[o] = lm;
 }
 
 // per chunk: Freq[], per-tile prefix counts, carried last-occurrence table, bucket starts in the order of

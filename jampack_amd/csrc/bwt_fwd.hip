@@ -116,27 +116,40 @@ __device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const
 }
 
 // head words of one 4096-slot tile: HE[word] = heads | slots past the end (so that "the next slot is a head" is one shift),
-// HE[64] bit 0 = head flag of the first slot of the next tile
-__device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n, uint32_t base, uint64_t *HE)
+// HE[64] bit 0 = head flag of the first slot of the next tile.  Every thread loads its sixteen (key, suffix) pairs ONCE, all loads
+// in flight together (clamped indices, no branch around a load), and hands them back to the caller; the key in front of a slot
+// comes from the neighbouring lane (DPP wave shift; lane 0: lane 63 of the row before, the wave's first row: one extra load),
+// and "the suffix in front is shorter than 7 bytes" is the shifted ballot of the row's own "short" bits.
+__device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n, uint32_t base, uint64_t *HE,
+                                              uint64_t (&kj)[CT_ITEMS], uint32_t (&sj)[CT_ITEMS])
 {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    // four slots at a time, their sixteen loads in flight together (clamped indices, no branch around a load)
+    const uint32_t j0 = base + w * (64 * CT_ITEMS);
 #pragma unroll
-    for (int k0 = 0; k0 < CT_ITEMS; k0 += 4) {
-        uint64_t kj[4], kp[4];
-        uint32_t sj[4], sp[4];
+    for (int k = 0; k < CT_ITEMS; k++) {
+        const uint32_t j = j0 + k * 64 + l, jc = j < n ? j : n - 1;
+        kj[k] = keys[jc];
+        sj[k] = sa[jc];
+    }
+    // the pair in front of the wave's first slot (uniform)
+    const uint32_t jb = (j0 && j0 <= n) ? j0 - 1 : 0;
+    const uint64_t kb = keys[jb];
+    const uint32_t sb = sa[jb];
+    uint32_t plo = (uint32_t)kb, phi = (uint32_t)(kb >> 32);
+    uint64_t carry_short = (j0 && sb + 7u > n) ? 1ull : 0ull;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t j = base + w * (64 * CT_ITEMS) + (k0 + k) * 64 + l, jc = j < n ? j : n - 1, jp = jc ? jc - 1 : 0;
-            kj[k] = keys[jc]; kp[k] = keys[jp]; sj[k] = sa[jc]; sp[k] = sa[jp];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t j = base + w * (64 * CT_ITEMS) + (k0 + k) * 64 + l;
-            const bool he = (j >= n) || (j == 0) || ((kj[k] ^ kp[k]) >> 8) != 0ull || sj[k] + 7u > n || sp[k] + 7u > n;     // = r0_head
-            const uint64_t b = __ballot(he);
-            if (l == 0) HE[w * CT_ITEMS + k0 + k] = b;
-        }
+    for (int k = 0; k < CT_ITEMS; k++) {
+        const uint32_t j = j0 + k * 64 + l;
+        const uint32_t lo = (uint32_t)kj[k], hi = (uint32_t)(kj[k] >> 32);
+        const uint32_t qlo = (uint32_t)__builtin_amdgcn_update_dpp((int)plo, (int)lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        const uint32_t qhi = (uint32_t)__builtin_amdgcn_update_dpp((int)phi, (int)hi, 0x138, 0xf, 0xf, false);
+        const bool differs = (((lo ^ qlo) >> 8) | (hi ^ qhi)) != 0u;              // bits 7..0 carry T[sa-1], not key
+        const uint64_t S = __ballot(sj[k] + 7u > n);                                 // a suffix with fewer than 7 bytes is a group of its own
+        const uint64_t b = __ballot(differs || j >= n || j == 0) | S | (S << 1) | carry_short;
+        if (l == 0) HE[w * CT_ITEMS + k] = b;
+        carry_short = S >> 63;
+        plo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+        phi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
     }
     if (threadIdx.x == 0) {
         const uint32_t jn = base + CT;
@@ -159,7 +172,9 @@ __global__ __launch_bounds__(TB) void k_r0_count(const uint64_t *__restrict__ ke
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * CT;
         __syncthreads();
-        r0_tile_heads(keys, sa, n, base, HE);
+        uint64_t kj[CT_ITEMS];
+        uint32_t sj[CT_ITEMS];
+        r0_tile_heads(keys, sa, n, base, HE, kj, sj);
         __syncthreads();
         if (threadIdx.x < 64) {
             const int l = threadIdx.x;
@@ -208,7 +223,9 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * CT;
         __syncthreads();
-        r0_tile_heads(keys, sa, n, base, HE);
+        uint64_t kj[CT_ITEMS];
+        uint32_t sj[CT_ITEMS];
+        r0_tile_heads(keys, sa, n, base, HE, kj, sj);
         __syncthreads();
         const uint32_t carry = tCarry[tile];
         if (threadIdx.x < 64) {
@@ -226,26 +243,15 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
         }
         __syncthreads();
 #pragma unroll
-        for (int k0 = 0; k0 < CT_ITEMS; k0 += 4) {
-        uint32_t s4[4];
-        uint8_t p4[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {                              // the loads of four slots in flight together
-            const uint32_t j = base + (w * CT_ITEMS + k0 + k) * 64 + l, jc = j < n ? j : n - 1;
-            s4[k] = sa[jc];
-            p4[k] = (uint8_t)keys[jc];                              // T[s - 1], carried in the key's low byte since pass 0
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            const int k = k0 + kk;
+        for (int k = 0; k < CT_ITEMS; k++) {
             const int word = w * CT_ITEMS + k;
             const uint32_t j = base + word * 64 + l;
             if (j < n) {
                 const uint64_t hv = HE[word] & valid_word(base + word * 64, n);
                 const uint64_t le = hv & mask_upto(l);
                 const uint32_t grp = le ? base + word * 64 + top_bit(le) : (word ? LHW[word - 1] : carry) - 1u;
-                const uint32_t s = s4[kk];
-                const uint8_t pv = p4[kk];
+                const uint32_t s = sj[k];                           // (loaded once, by r0_tile_heads)
+                const uint8_t pv = (uint8_t)kj[k];                  // T[s - 1], carried in the key's low byte since pass 0
                 ISA[s] = grp;
                 const uint64_t sv = SV[word];
                 if (!((sv >> l) & 1ull)) {
@@ -258,7 +264,6 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                     a_prev[pos] = pv;
                 }
             }
-        }
         }
     }
 }
@@ -706,17 +711,18 @@ __global__ __launch_bounds__(TB) void k_lg_hist(const uint32_t *__restrict__ key
                                                uint32_t *__restrict__ table)
 {
     constexpr int NB = 1 << DB;
-    // the members of one group share the upper digits of their keys (ranks inside one old group), and LDS atomics on one
-    // address serialise: HC copies of the table per wave (lane l adds to copy l % HC), NB + 1 words apart (different banks)
-    constexpr int HC = 8, HS = NB + 1;
-    __shared__ uint32_t h[WAVES * HC * HS];
+    // the members of one group share the upper digits of their keys (ranks inside one old group): counted by wave match -- the
+    // lanes with equal digits are found by ballots and one of them adds their number to the wave's counter (plain LDS
+    // read-modify-write, one lane per address) -- instead of LDS atomics that serialise on the shared bins
+    __shared__ uint32_t h[WAVES * NB];
     const uint32_t np = st->npieces;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    uint32_t *mine = h + (w * HC + (l & (HC - 1))) * HS;
+    uint32_t *mine = h + w * NB;
+    const uint64_t lt = lanemask_lt();
     for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
         const Piece q = pieces[p];
         __syncthreads();
-        for (int i = threadIdx.x; i < WAVES * HC * HS; i += TB) h[i] = 0;
+        for (int i = threadIdx.x; i < WAVES * NB; i += TB) h[i] = 0;
         __syncthreads();
         uint32_t kv[WIN_ITEMS];
 #pragma unroll
@@ -727,13 +733,16 @@ __global__ __launch_bounds__(TB) void k_lg_hist(const uint32_t *__restrict__ key
 #pragma unroll
         for (int k = 0; k < WIN_ITEMS; k++) {
             const uint32_t e = w * (64 * WIN_ITEMS) + k * 64 + l;
-            if (e < q.count) atomicAdd(&mine[(kv[k] >> shift) & (uint32_t)(NB - 1)], 1u);
+            const bool valid = e < q.count;
+            const uint32_t d = (kv[k] >> shift) & (uint32_t)(NB - 1);
+            const uint64_t m = match_any<DB>(d, valid);
+            if (valid && (m & lt) == 0ull) mine[d] += (uint32_t)__popcll(m);
         }
         __syncthreads();
         for (int d = threadIdx.x; d < NB; d += TB) {
             uint32_t s = 0;
 #pragma unroll
-            for (int k = 0; k < WAVES * HC; k++) s += h[k * HS + d];
+            for (int k = 0; k < WAVES; k++) s += h[k * NB + d];
             table[(size_t)q.fp * NB + (size_t)d * q.nt + q.tl] = s;
         }
     }

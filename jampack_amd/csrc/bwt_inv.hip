@@ -69,9 +69,14 @@ __global__ __launch_bounds__(TB) void k_hist(const uint8_t *__restrict__ B, uint
         const size_t i = base + (size_t)it * 64;
         sy[it] = B[i < n ? i : n - 1];
     }
+    // counted by wave match, not LDS atomics: a BWT image is runs of equal bytes, i.e. most lanes of a wave hit one bin
+    const uint64_t lt = lanemask_lt();
 #pragma unroll
-    for (int it = 0; it < ITEMS; it++)
-        if (base + (size_t)it * 64 < n) atomicAdd(&h[w][sy[it]], 1u);
+    for (int it = 0; it < ITEMS; it++) {
+        const bool valid = base + (size_t)it * 64 < n;
+        const uint64_t m = match_any8(sy[it], valid);
+        if (valid && (m & lt) == 0ull) h[w][sy[it]] += (uint32_t)__popcll(m);
+    }
     __syncthreads();
     for (int d = threadIdx.x; d < 256; d += TB)
         tilehist[(size_t)d * ntiles + blockIdx.x] = h[0][d] + h[1][d] + h[2][d] + h[3][d];

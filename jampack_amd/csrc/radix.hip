@@ -88,9 +88,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *__restri
             if (pos >= txt.n) dig[it] = 0u;
         } else dig[it] = (uint32_t)(keys[ic] >> shift) & 255u;
     }
+    // counting by wave match instead of LDS atomics: the lanes of a wave that hold the same digit are found with eight ballots
+    // and ONE of them adds their number to the wave's counter -- plain LDS read-modify-write, one lane per address.  Text digits
+    // are skewed (a tenth of the lanes of a wave hit the same bin): the atomic form spent 92 % of its LDS cycles in same-address
+    // conflicts and cost about as much as the whole scatter pass.
+    const uint64_t lt = lanemask_lt();
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; it++)
-        if (base + (size_t)it * 64 < n) atomicAdd(&h[w][dig[it]], 1u);
+    for (int it = 0; it < RS_ITEMS; it++) {
+        const bool valid = base + (size_t)it * 64 < n;
+        const uint64_t m = match_any8(dig[it], valid);
+        if (valid && (m & lt) == 0ull) h[w][dig[it]] += (uint32_t)__popcll(m);
+    }
     __syncthreads();
     for (int d = threadIdx.x; d < 256; d += RS_THREADS) {
         uint32_t s = 0;
