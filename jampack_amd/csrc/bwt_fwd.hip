@@ -436,7 +436,8 @@ __global__ __launch_bounds__(TB) void k_win_pieces(const uint32_t *__restrict__ 
 }
 
 // the sort / re-rank of all groups of <= SEG_TILE elements, one window per workgroup iteration
-__global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const uint32_t *__restrict__ k2g,
+template <int MINW>       // minimum waves per SIMD the register allocation must allow (5 = as many workgroups per CU as the LDS admits)
+__global__ __launch_bounds__(TB, MINW) void k_seg_round(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const uint32_t *__restrict__ k2g,
                                                  const SaState *__restrict__ st, int par, int key_bits, const uint32_t *__restrict__ PH,
                                                  const uint8_t *__restrict__ a_prev, uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
                                                  uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint8_t *__restrict__ b_prev)
@@ -655,6 +656,18 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
         // ---- re-rank (blocked 8 per thread over the sorted order) ----
         uint32_t ap[SEG_ITEMS], nh[SEG_ITEMS];
         uint32_t hmax = 0;
+        // the eight suffixes (and their carried BWT bytes) this thread will place, and the old ranks of its eight positions: all
+        // loads issued here, in flight together (clamped), used after the scan below
+        uint32_t sv[SEG_ITEMS], og[SEG_ITEMS];
+        uint8_t pvv[SEG_ITEMS];
+#pragma unroll
+        for (int k = 0; k < SEG_ITEMS; k++) {
+            const uint32_t q = p0 + k, qc = q < no ? q : no - 1;
+            const uint32_t from = base + fo + src[qc];
+            sv[k] = a_sa[from];
+            pvv[k] = a_prev[from];                                  // T[s - 1] travels with the suffix: no gather from the text
+            og[k] = a_grp[base + fo + qc];
+        }
 #pragma unroll
         for (int k = 0; k < SEG_ITEMS; k++) {
             const uint32_t q = p0 + k;
@@ -662,7 +675,7 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
             if (q < no) {
                 const uint32_t id = src[q];
                 const uint32_t pos = fo + q;                        // groups keep their positions through the sort
-                ap[k] = a_grp[base + pos] + (pos - (uint32_t)gsl[pos]);
+                ap[k] = og[k] + (pos - (uint32_t)gsl[pos]);
                 bool head = (q == 0);
                 if (!head) {
                     const uint32_t pid = src[q - 1];
@@ -687,10 +700,9 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
                 if (nh[k]) run = ap[k];
                 const bool next_head = (q + 1 >= no) ? true : (k + 1 < SEG_ITEMS ? (nh[k + 1] != 0) : (firstflag[tid + 1] != 0));
                 const bool single = nh[k] && next_head;
-                const uint32_t from = base + fo + src[q];
-                const uint32_t s = a_sa[from];
-                const uint8_t pv = a_prev[from];                    // T[s - 1] travels with the suffix: no gather from the text
-                ISA[s] = run;      // (skipping the store for the sub-group that keeps the old rank costs more registers than it saves: 3.45 -> 3.83 ms)
+                const uint32_t s = sv[k];
+                const uint8_t pv = pvv[k];
+                if (run != og[k]) ISA[s] = run;                     // the sub-group that sorts first keeps the old group's rank: no store
                 if (single) {
                     bwt[ap[k]] = pv;
                     if (SA) SA[ap[k]] = s;
@@ -1213,7 +1225,10 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     const unsigned g_ct = cap_grid(n, CT, CAP);
     JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_count, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_r0_scan, dim3(1), dim3(WG1), b.tA, b.tB, n, b.state);
-    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev);
+    // experiment knob (JPK_OCC_MEM=<bytes of dynamic LDS>): caps the workgroups per CU of the kernels that only wait for random
+    // accesses, so that the compute-bound kernels of other blocks in flight find wave slots beside them
+    static const size_t occ_mem = [] { const char *e = getenv("JPK_OCC_MEM"); const int v = e ? atoi(e) : 0; return (size_t)(v < 0 ? 0 : (v > 65536 ? 65536 : v)); }();
+    JPK_LAUNCH_LDS(ctx, PROF_SA_RERANK, n, occ_mem, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev);
     ctx->stats.sa_rounds = 1;
 
     const int kbits = jpk_bits_for(n);             // key2 <= n, group rank < n
@@ -1235,13 +1250,16 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         const unsigned g_pc = cap_grid(pc_bound, 1, CAP);
         const unsigned g_tab = cap_grid(pc_bound << lg_db, SC_TILE, CAP);
         const uint32_t hh = (h < n) ? (uint32_t)h : n;
-        JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, hh, b.ISA, b.k2, b.FH, b.LH);
+        JPK_LAUNCH_LDS(ctx, PROF_SA_KEYS, 0, occ_mem, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, hh, b.ISA, b.k2, b.FH, b.LH);
         const unsigned g_wm = cap_grid((size_t)bound / SEG_TILE + 1, TB, 256);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan1, dim3(1), dim3(WG1), b.FH, b.LH, b.PH, b.NH, b.state, par);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_count, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.state, par);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan2, dim3(1), dim3(WG1), b.PC, b.state, par, round);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_pieces, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.pieces, b.state, par);
-        JPK_LAUNCH(ctx, PROF_SA_SEG, 0, k_seg_round, dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, kbits, b.PH, b.a_prev, b.ISA, b.bwt, b.SA,
+        static const int seg_occ = [] { const char *e = getenv("JPK_SEG_OCC"); return e ? atoi(e) : 4; }();
+        if (seg_occ >= 5) JPK_LAUNCH(ctx, PROF_SA_SEG, 0, (k_seg_round<5>), dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, kbits, b.PH, b.a_prev, b.ISA, b.bwt, b.SA,
+                   b.b_sa, b.b_grp, b.b_prev);
+        else JPK_LAUNCH(ctx, PROF_SA_SEG, 0, (k_seg_round<4>), dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, kbits, b.PH, b.a_prev, b.ISA, b.bwt, b.SA,
                    b.b_sa, b.b_grp, b.b_prev);
         {   // large groups: lg_pass LSD passes over (key2, sa), ping-pong between (k2, a_sa) and (k2alt, sa_alt)
             uint32_t *kin = b.k2, *vin = b.a_sa, *kout = b.k2alt, *vout = b.sa_alt;
@@ -1261,7 +1279,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             }
             JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_lg_heads, dim3(g_pc), dim3(TB), kin, b.pieces, b.state, b.pLast);
             JPK_LAUNCH(ctx, PROF_SCAN, 0, k_lg_scan, dim3(1), dim3(WG1), b.pLast, b.state);
-            JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_lg_finish, dim3(g_pc), dim3(TB), kin, vin, pin, b.a_grp, b.pieces, b.state, b.pLast, b.ISA, b.bwt, b.SA, b.b_sa,
+            JPK_LAUNCH_LDS(ctx, PROF_SA_RERANK, 0, occ_mem, k_lg_finish, dim3(g_pc), dim3(TB), kin, vin, pin, b.a_grp, b.pieces, b.state, b.pLast, b.ISA, b.bwt, b.SA, b.b_sa,
                        b.b_grp, b.b_prev);
         }
         JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_cmp_count, dim3(g_cmp), dim3(TB), b.b_grp, b.state, par, b.tA);

@@ -2,7 +2,7 @@
 # round 3, GPU call 3: BWT byte carried with the suffix + 10-instruction rANS step: tests, stage profiles, contexts sweep
 set -u
 REPO=$PWD
-OUT=$REPO/gpurun_out/r3f
+OUT=$REPO/gpurun_out/r3g
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 export JAMPACK_CORPUS_CACHE=/tmp/jpk_corpus
