@@ -161,56 +161,58 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *__res
 // pairs at their position in the TILE-sorted order, and the stores then walk that order -- consecutive lanes write consecutive
 // addresses inside one digit's run (whole 64-byte lines for every run of >= 8 pairs) instead of the 2-3 pairs per digit that one
 // load instruction's 64 lanes happen to share.  One 32 KB staging buffer is used twice (keys, then values).
-template <bool TEXT>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter_staged(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, TextSrc txt,
-                                                                 uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n, int shift,
-                                                                 const uint32_t *__restrict__ tileoff, uint32_t ntiles)
+// FULL: the tile has all RS_TILE pairs (every tile but the last): no bounds logic at all, and the loads go through a wave-uniform
+// base pointer with 32-bit lane offsets (the general form computes a 64-bit address per load).
+template <bool TEXT, bool FULL>
+__device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, const TextSrc &txt,
+                                                       uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n, int shift,
+                                                       const uint32_t *__restrict__ tileoff, uint32_t ntiles, uint32_t tile, uint32_t (*cnt)[256],
+                                                       uint32_t *gbase, uint64_t *stage, uint32_t *sm)
 {
-    __shared__ uint32_t cnt[RS_WAVES][256];
-    __shared__ uint32_t gbase[256];          // global offset of the tile's run of digit d, minus the run's start inside the tile
-    __shared__ uint32_t tstart[257];
-    __shared__ uint64_t stage[RS_TILE];
-    __shared__ uint32_t sm[RS_THREADS / 64 + 1];
-    for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
-    __syncthreads();
-    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const size_t tbase = (size_t)blockIdx.x * RS_TILE;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = threadIdx.x & 63;
+    const size_t tbase = (size_t)tile * RS_TILE;
     const size_t base = tbase + (size_t)w * (64 * RS_ITEMS) + l;
-    const uint32_t tcount = (n - tbase < (size_t)RS_TILE) ? (uint32_t)(n - tbase) : (uint32_t)RS_TILE;
+    const uint32_t tcount = FULL ? (uint32_t)RS_TILE : (uint32_t)(n - tbase);
     uint64_t key[RS_ITEMS];
     uint32_t val[RS_ITEMS];
     uint32_t rnk[RS_ITEMS];
     const uint64_t lt = lanemask_lt();
-    rs_load_tile<TEXT>(kin, vin, txt, n, base, key, val);
+    if (FULL && !TEXT) {
+        const uint64_t *kw = kin + tbase + (size_t)w * (64 * RS_ITEMS);      // wave-uniform
+        const uint32_t *vw = vin + tbase + (size_t)w * (64 * RS_ITEMS);
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; it++) { key[it] = kw[(uint32_t)(it * 64 + l)]; val[it] = vw[(uint32_t)(it * 64 + l)]; }
+    } else rs_load_tile<TEXT>(kin, vin, txt, n, base, key, val);
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++) {
-        size_t i = base + (size_t)it * 64;
-        bool valid = i < n;
-        uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
-        uint64_t m = match_any8(d, valid);
-        uint32_t below = (uint32_t)__popcll(m & lt);
-        uint32_t c = valid ? cnt[w][d] : 0;
+        const bool valid = FULL || base + (size_t)it * 64 < n;
+        const uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
+        const uint64_t m = match_any8(d, valid);
+        const uint32_t below = (uint32_t)__popcll(m & lt);
+        const uint32_t c = valid ? cnt[w][d] : 0;
         rnk[it] = c + below;
         if (valid && below == 0) cnt[w][d] = c + (uint32_t)__popcll(m);
     }
     __syncthreads();
-    {   // thread d: exclusive scan across waves of digit d, then across digits
+    {   // thread d: exclusive scan across waves of digit d, then across digits; cnt[k][d] becomes the position, inside the
+        // tile-sorted order, of wave k's first pair with digit d
         const int d = threadIdx.x;
-        uint32_t s = 0;
+        uint32_t c4[RS_WAVES], s = 0;
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; k++) { uint32_t t = cnt[k][d]; cnt[k][d] = s; s += t; }
+        for (int k = 0; k < RS_WAVES; k++) { c4[k] = s; s += cnt[k][d]; }
         const uint32_t inc = block_incl_scan<OpSum>(s, sm, nullptr);
-        tstart[d] = inc - s;
-        gbase[d] = tileoff[(size_t)d * ntiles + blockIdx.x] - (inc - s);
-        if (d == 255) tstart[256] = inc;
+        const uint32_t ts = inc - s;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; k++) cnt[k][d] = ts + c4[k];
+        gbase[d] = tileoff[(size_t)d * ntiles + tile] - ts;
     }
     __syncthreads();
     uint32_t pos[RS_ITEMS];
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++) {
         const uint32_t d = (uint32_t)(key[it] >> shift) & 255u;
-        pos[it] = tstart[d] + cnt[w][d] + rnk[it];
-        if (base + (size_t)it * 64 < n) stage[pos[it]] = key[it];
+        pos[it] = cnt[w][d] + rnk[it];
+        if (FULL || base + (size_t)it * 64 < n) stage[pos[it]] = key[it];
     }
     __syncthreads();
     uint32_t dstv[RS_ITEMS];
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter_staged(const uint64_t
     for (int it = 0; it < RS_ITEMS; it++) {
         const uint32_t p = (uint32_t)it * RS_THREADS + threadIdx.x;
         dstv[it] = 0xFFFFFFFFu;
-        if (p < tcount) {
+        if (FULL || p < tcount) {
             const uint64_t k = stage[p];
             const uint32_t d = (uint32_t)(k >> shift) & 255u;
             dstv[it] = gbase[d] + p;
@@ -229,13 +231,39 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter_staged(const uint64_t
     uint32_t *stage32 = reinterpret_cast<uint32_t *>(stage);
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++)
-        if (base + (size_t)it * 64 < n) stage32[pos[it]] = val[it];
+        if (FULL || base + (size_t)it * 64 < n) stage32[pos[it]] = val[it];
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++) {
         const uint32_t p = (uint32_t)it * RS_THREADS + threadIdx.x;
-        if (p < tcount) vout[dstv[it]] = stage32[p];
+        if (FULL || p < tcount) vout[dstv[it]] = stage32[p];
     }
+}
+
+// two launches per pass: the full tiles (no bounds logic) and, if n is not a multiple of the tile, the last tile alone
+template <bool TEXT, bool FULL>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter_staged(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, TextSrc txt,
+                                                                 uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n, int shift,
+                                                                 const uint32_t *__restrict__ tileoff, uint32_t ntiles, uint32_t tile0)
+{
+    __shared__ uint32_t cnt[RS_WAVES][256];
+    __shared__ uint32_t gbase[256];          // global offset of the tile's run of digit d, minus the run's start inside the tile
+    __shared__ uint64_t stage[RS_TILE];
+    __shared__ uint32_t sm[RS_THREADS / 64 + 1];
+    for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    rs_scatter_staged_tile<TEXT, FULL>(kin, vin, txt, kout, vout, n, shift, tileoff, ntiles, tile0 + blockIdx.x, cnt, gbase, stage, sm);
+}
+
+template <bool TEXT>
+void launch_rs_scatter_staged(jpk_ctx *ctx, const uint64_t *kin, const uint32_t *vin, const TextSrc &txt, uint64_t *kout, uint32_t *vout, size_t n, int shift,
+                              const uint32_t *tileoff, uint32_t ntiles)
+{
+    const uint32_t nfull = (uint32_t)(n / RS_TILE);
+    if (nfull) JPK_LAUNCH(ctx, PROF_RS_SCATTER, (size_t)nfull * RS_TILE, (k_rs_scatter_staged<TEXT, true>), dim3(nfull), dim3(RS_THREADS), kin, vin, txt, kout, vout, n, shift,
+                          tileoff, ntiles, 0u);
+    if (nfull < ntiles) JPK_LAUNCH(ctx, PROF_RS_SCATTER, n - (size_t)nfull * RS_TILE, (k_rs_scatter_staged<TEXT, false>), dim3(1), dim3(RS_THREADS), kin, vin, txt, kout, vout, n,
+                                   shift, tileoff, ntiles, nfull);
 }
 
 // JPK_RS_STAGED=0 keeps the direct scatter (register -> global) for comparison
@@ -272,7 +300,7 @@ int jpk_radix_sort_pairs_u64_nocopy(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals
         const TextSrc none = {nullptr, 0u, 0u};
         JPK_LAUNCH(ctx, PROF_RS_HIST, n, (k_rs_hist<false>), dim3(ntiles), dim3(RS_THREADS), ki, none, n, shifts[p], hist, ntiles);
         JPK_TRY(jpk_exclusive_sum_u32(ctx, hist, hist, table, scan_scratch, nullptr));
-        if (rs_staged()) JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter_staged<false>), dim3(ntiles), dim3(RS_THREADS), ki, vi, none, ko, vo, n, shifts[p], hist, ntiles);
+        if (rs_staged()) launch_rs_scatter_staged<false>(ctx, ki, vi, none, ko, vo, n, shifts[p], hist, ntiles);
         else JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter<false>), dim3(ntiles), dim3(RS_THREADS), ki, vi, none, ko, vo, n, shifts[p], hist, ntiles);
         uint64_t *tk = ki; ki = ko; ko = tk;
         uint32_t *tv = vi; vi = vo; vo = tv;
@@ -322,15 +350,14 @@ int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n32, ui
         if (p == 0) {
             JPK_LAUNCH(ctx, PROF_RS_HIST, n, (k_rs_hist<true>), dim3(ntiles), dim3(RS_THREADS), (const uint64_t *)nullptr, txt, n, shift, hist, ntiles);
             JPK_TRY(jpk_exclusive_sum_u32(ctx, hist, hist, table, scan_scratch, nullptr));
-            if (rs_staged()) JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter_staged<true>), dim3(ntiles), dim3(RS_THREADS), (const uint64_t *)nullptr, (const uint32_t *)nullptr, txt,
-                       keysB, valsB, n, shift, hist, ntiles);
+            if (rs_staged()) launch_rs_scatter_staged<true>(ctx, nullptr, nullptr, txt, keysB, valsB, n, shift, hist, ntiles);
             else JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter<true>), dim3(ntiles), dim3(RS_THREADS), (const uint64_t *)nullptr, (const uint32_t *)nullptr, txt,
                        keysB, valsB, n, shift, hist, ntiles);
             continue;
         }
         JPK_LAUNCH(ctx, PROF_RS_HIST, n, (k_rs_hist<false>), dim3(ntiles), dim3(RS_THREADS), ki, none, n, shift, hist, ntiles);
         JPK_TRY(jpk_exclusive_sum_u32(ctx, hist, hist, table, scan_scratch, nullptr));
-        if (rs_staged()) JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter_staged<false>), dim3(ntiles), dim3(RS_THREADS), ki, vi, none, ko, vo, n, shift, hist, ntiles);
+        if (rs_staged()) launch_rs_scatter_staged<false>(ctx, ki, vi, none, ko, vo, n, shift, hist, ntiles);
         else JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter<false>), dim3(ntiles), dim3(RS_THREADS), ki, vi, none, ko, vo, n, shift, hist, ntiles);
         uint64_t *tk = ki; ki = ko; ko = tk;
         uint32_t *tv = vi; vi = vo; vo = tv;
