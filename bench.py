@@ -220,8 +220,9 @@ def per_block_size(jam, corpus, torch, dev, device_index: int, in_flight: int):
     out = {}
     ctx = jam.Context(device_index, None)
     try:
-        # (block MiB, blocks of the stream, blocks timed one at a time)
-        for bm, nstream, nsingle in ((1, 64, 8), (64, 4, 2), (256, 2, 1)):
+        # (block MiB, blocks of the stream, blocks timed one at a time, blocks in flight of the streamed compress: a 1 MiB block is
+        # one chunk = one 5 ms chain on one of 1024 SIMDs, so small blocks want many in flight -- the library admits up to 16)
+        for bm, nstream, nsingle, nfl in ((1, 64, 8, 16), (64, 4, 2, in_flight), (256, 2, 1, in_flight)):
             bs = bm * MiB
             nuniq = min(nstream, (256 * MiB) // bs)
             srcs = [d_all[(k % nuniq) * bs: (k % nuniq) * bs + bs] for k in range(nstream)]
@@ -246,10 +247,10 @@ def per_block_size(jam, corpus, torch, dev, device_index: int, in_flight: int):
             ok = all(bk1[k] == bs and bool(torch.equal(backs[k], srcs[k])) for k in range(nsingle))
             ref = [outs[k][: sz1[k]].clone() for k in range(nsingle)]
             # streamed
-            ctx.blocks_compress(srcs, [bs] * nstream, outs, [cap] * nstream, in_flight)
+            ctx.blocks_compress(srcs, [bs] * nstream, outs, [cap] * nstream, nfl)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            szs, st = ctx.blocks_compress(srcs, [bs] * nstream, outs, [cap] * nstream, in_flight)
+            szs, st = ctx.blocks_compress(srcs, [bs] * nstream, outs, [cap] * nstream, nfl)
             torch.cuda.synchronize()
             tcs = (time.perf_counter() - t0) / nstream
             ok = ok and st == [0] * nstream and all(szs[k] == sz1[k] and bool(torch.equal(outs[k][: szs[k]], ref[k])) for k in range(nsingle))
@@ -261,7 +262,7 @@ def per_block_size(jam, corpus, torch, dev, device_index: int, in_flight: int):
             tds = (time.perf_counter() - t0) / nstream
             ok = ok and st == [0] * nstream and all(bks[k] == bs and bool(torch.equal(backs[k], srcs[k])) for k in range(nstream))
             mb = bs / 1e6
-            out[f"{bm}MiB"] = {"block_bytes": bs, "stream_blocks": nstream, "in_flight": min(in_flight, nstream),
+            out[f"{bm}MiB"] = {"block_bytes": bs, "stream_blocks": nstream, "in_flight": min(nfl, nstream),
                                "compress_MBps": {"one_at_a_time": round(mb / tc1, 1), "streamed": round(mb / tcs, 1)},
                                "decompress_MBps": {"one_at_a_time": round(mb / td1, 1), "streamed": round(mb / tds, 1)},
                                "compressed_ratio": round(sum(szs) / (bs * nstream), 4), "same_bytes": bool(ok)}

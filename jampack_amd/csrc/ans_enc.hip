@@ -599,17 +599,39 @@ __device__ __forceinline__ void ad_for_each(const AdRec &r, const AdStream &st, 
     }
 }
 
-// run one exact trajectory over the items [t0,t1) writing the model outputs (ans.cpp:159-176)
+// run one exact trajectory over the items [t0,t1) writing the model outputs (ans.cpp:159-176).
+// Exponent entries: the entry's value BEFORE every symbol goes to its own history row hist[t] -- sixteen values per two 16-byte
+// stores, no condition and no branch in the loop; k_pairs picks entry e (low) and entry e + 1 (high) of its symbol from the seven
+// rows.  (Round 2 stored low / high per symbol from whichever lane matched the symbol's class: two compares, two exec-masked
+// 2-byte stores and their branches per symbol and lane -- twelve of the eighteen instructions of the loop.)
 __device__ __forceinline__ int32_t ad_run_write(const AdRec &r, const AdStream &st, uint32_t t0, uint32_t t1, int32_t x,
-                                                uint16_t *__restrict__ lo, uint16_t *__restrict__ hi, uint32_t *__restrict__ ma)
+                                                uint16_t *__restrict__ hist, uint32_t *__restrict__ ma)
 {
     if (r.exp) {
         const int i = r.i;
-        ad_for_each(r, st, t0, t1, [&](uint32_t t, int e) {
-            if (e == i) lo[t] = (uint16_t)x;
-            if (e + 1 == i) hi[t] = (uint16_t)(x - 1);
-            x = adapt_step(x, i, e, 8);
-        });
+        const uint8_t *p = st.c8;
+        uint32_t t = t0;
+        while (t < t1 && (t & 15u)) { hist[t] = (uint16_t)x; x = adapt_step(x, i, (int)(p[t] & 7u), 8); t++; }
+        if (t + 16 <= t1) {
+            uint4 v = *reinterpret_cast<const uint4 *>(p + t);
+            for (; t + 16 <= t1; t += 16) {
+                const uint32_t tn = (t + 32 <= t1) ? t + 16 : t;
+                const uint4 nv = *reinterpret_cast<const uint4 *>(p + tn);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                uint32_t o[8];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k & 1) o[k >> 1] |= (uint32_t)x << 16;
+                    else o[k >> 1] = (uint32_t)x & 0xffffu;
+                    x = adapt_step(x, i, (int)((w[k >> 2] >> (8 * (k & 3))) & 7u), 8);
+                }
+                uint4 *q = reinterpret_cast<uint4 *>(hist + t);
+                q[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                q[1] = make_uint4(o[4], o[5], o[6], o[7]);
+                v = nv;
+            }
+        }
+        while (t < t1) { hist[t] = (uint16_t)x; x = adapt_step(x, i, (int)(p[t] & 7u), 8); t++; }
     } else {
         ad_for_each(r, st, t0, t1, [&](uint32_t t, int m) {
             const uint32_t l0 = m ? (uint32_t)x : 0u, fr = m ? 65536u - (uint32_t)x : (uint32_t)x;
@@ -622,7 +644,7 @@ __device__ __forceinline__ int32_t ad_run_write(const AdRec &r, const AdStream &
 
 struct AdArgs {
     const uint8_t *cls8; const uint32_t *clist; size_t rle_stride; const uint32_t *rlen; const uint32_t *clstotal;
-    uint16_t *explo, *exphi; uint32_t *mantad;
+    uint16_t *exph; uint32_t *mantad;       // exph: [chunk][7 exponent entries][rle_stride] history of every entry
     uint32_t *seg_flag; int32_t *seg_lo, *seg_end, *seg_start; uint16_t *seg_tab;
 };
 
@@ -647,8 +669,7 @@ __global__ __launch_bounds__(64) void k_adapt_a(EncDims d, AdArgs a)
     const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
     if (lo == hi) {
         a.seg_flag[so] = 1u;
-        a.seg_end[so] = ad_run_write(r, st, t0, t1, lo, a.explo + (size_t)c * a.rle_stride, a.exphi + (size_t)c * a.rle_stride,
-                                     a.mantad + (size_t)c * a.rle_stride);
+        a.seg_end[so] = ad_run_write(r, st, t0, t1, lo, a.exph + ((size_t)c * 7 + (rec < 7 ? rec : 0)) * a.rle_stride, a.mantad + (size_t)c * a.rle_stride);
         return;
     }
     // unresolved: k_adapt_tab tabulates the 32 candidate start states lo .. lo+31 (hi - lo <= 31 after the warm-up)
@@ -712,8 +733,7 @@ __global__ __launch_bounds__(64) void k_adapt_c(EncDims d, AdArgs a)
     const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
     if (a.seg_flag[so]) return;
     const uint32_t t0 = k * ATILE, t1 = (t0 + ATILE < st.n) ? t0 + ATILE : st.n;
-    ad_run_write(r, st, t0, t1, a.seg_start[so], a.explo + (size_t)c * a.rle_stride, a.exphi + (size_t)c * a.rle_stride,
-                 a.mantad + (size_t)c * a.rle_stride);
+    ad_run_write(r, st, t0, t1, a.seg_start[so], a.exph + ((size_t)c * 7 + (rec < 7 ? rec : 0)) * a.rle_stride, a.mantad + (size_t)c * a.rle_stride);
 }
 
 // rANS records in coding order.  Pair j = 2t (exponent) / 2t+1 (mantissa) belongs to state lane j & 3; the
@@ -740,7 +760,7 @@ __device__ __forceinline__ uint4 rans_record(uint32_t lo, uint32_t fr)
 }
 
 __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
-                                             const uint16_t *__restrict__ explo, const uint16_t *__restrict__ exphi, const uint32_t *__restrict__ mantad,
+                                             const uint16_t *__restrict__ exph, const uint32_t *__restrict__ mantad,
                                              const uint32_t *__restrict__ ord, const uint32_t *__restrict__ qcdf, uint4 *__restrict__ recs,
                                              uint16_t *__restrict__ fr16, uint32_t *__restrict__ pairs_plain)
 {
@@ -767,8 +787,11 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
     const uint32_t s = rle[o];
     const int e = sym_class(s);
     const uint32_t m = s - (uint32_t)class_base(e);
-    const uint32_t l0 = (e == 0) ? 0u : explo[o];
-    const uint32_t h0 = (e == 7) ? 65536u : (uint32_t)exphi[o] + 1u;
+    // cumulative frequencies of the exponent model before this symbol: entry e (low) and entry e + 1 (high end), from the history
+    // rows of the seven adaptive entries; entry 0 is 0 and entry 8 is 65536 by definition
+    const uint16_t *hrow = exph + (size_t)c * 7 * rle_stride + t;
+    const uint32_t l0 = (e == 0) ? 0u : hrow[(size_t)(e - 1) * rle_stride];
+    const uint32_t h0 = (e == 7) ? 65536u : (uint32_t)hrow[(size_t)e * rle_stride];
     uint32_t l1, f1;
     if (e < 2) { const uint32_t p = mantad[o]; l1 = p & 0xffffu; f1 = p >> 16; }
     else {
@@ -1151,7 +1174,7 @@ struct EncBufs {
     uint32_t *clscnt, *clstotal, *ord, *qhist, *qcdf, *dens, *cmap;
     uint8_t *cls8; uint32_t *clist;
     uint32_t *seg_flag; int32_t *seg_lo, *seg_end, *seg_start; uint16_t *seg_tab;
-    uint16_t *explo, *exphi; uint32_t *mantad, *pairs; uint4 *recs; uint16_t *fr16;
+    uint16_t *exph; uint32_t *mantad, *pairs; uint4 *recs; uint16_t *fr16;
     uint32_t *xs, *etsum, *fstate, *csize;
     uint64_t *stamp;
     uint8_t *hdr; uint32_t *hsize; uint64_t *outoff;
@@ -1187,8 +1210,7 @@ void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what)
         b.ord = a.get<uint32_t>((size_t)d.nch * stride);
         b.qhist = a.get<uint32_t>((size_t)d.nch * 6 * NQ * QSTRIDE);
         b.qcdf = a.get<uint32_t>((size_t)d.nch * 6 * NQ * QSTRIDE);
-        b.explo = a.get<uint16_t>((size_t)d.nch * stride);
-        b.exphi = a.get<uint16_t>((size_t)d.nch * stride);
+        b.exph = a.get<uint16_t>((size_t)d.nch * 7 * stride);
         b.mantad = a.get<uint32_t>((size_t)d.nch * stride);
         b.cls8 = a.get<uint8_t>((size_t)d.nch * stride + 64);
         b.clist = a.get<uint32_t>((size_t)d.nch * 2 * ((stride + 3) & ~(size_t)3) + 64);
@@ -1286,13 +1308,13 @@ int run_model(jpk_ctx *ctx, const uint16_t *d_rle, const uint32_t *d_rlen, const
     JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_quasi_build, dim3(NQ, 6, d.ncl), dim3(64), d, b.clstotal, b.qhist, b.qcdf);
     AdArgs aa;
     aa.cls8 = b.cls8; aa.clist = b.clist; aa.rle_stride = stride; aa.rlen = d_rlen; aa.clstotal = b.clstotal;
-    aa.explo = b.explo; aa.exphi = b.exphi; aa.mantad = b.mantad;
+    aa.exph = b.exph; aa.mantad = b.mantad;
     aa.seg_flag = b.seg_flag; aa.seg_lo = b.seg_lo; aa.seg_end = b.seg_end; aa.seg_start = b.seg_start; aa.seg_tab = b.seg_tab;
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_a, dim3((d.tpc + 3) / 4, d.ncl), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_tab, dim3((d.tpc + 1) / 2, 9, d.ncl), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_b, dim3(jpk_grid((size_t)d.ncl * 16, 64)), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_c, dim3((d.tpc + 3) / 4, d.ncl), dim3(64), d, aa);
-    JPK_LAUNCH(ctx, PROF_ENC_PAIRS, 0, k_pairs, dim3(jpk_grid(stride, TB) + 1, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.explo, b.exphi, b.mantad, b.ord,
+    JPK_LAUNCH(ctx, PROF_ENC_PAIRS, 0, k_pairs, dim3(jpk_grid(stride, TB) + 1, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.exph, b.mantad, b.ord,
                        b.qcdf, b.recs, b.fr16, b.pairs);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
