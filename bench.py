@@ -53,19 +53,19 @@ ALG_BYTES_PER_UNIT = {
     "k_rs_hist": (8, "sorted (key,value) pair", "hbm"),
     "k_rs_scatter": (24, "sorted (key,value) pair", "hbm"),
     "k_lg_hist": (4, "member of a large group x pass", "hbm"),
-    "k_lg_scatter": (16, "member of a large group x pass", "hbm"),
+    "k_lg_scatter": (18, "member of a large group x pass", "hbm"),
     "k_gather_win": (16, "active suffix", "hbm-random"),
-    "k_seg_round": (24, "active suffix in a group <= 1024", "lds"),
-    "k_r0_*/k_lg_finish/k_cmp_*": (20, "suffix", "hbm-random"),
+    "k_seg_round": (26, "active suffix in a group <= 1024", "lds"),
+    "k_r0_*/k_lg_finish/k_cmp_*": (22, "suffix", "hbm-random"),
     "k_bwt_image": (2, "block byte", "hbm"),
     "k_enc_hist/k_enc_prep": (1, "block byte", "hbm"),
     "k_enc_mtf": (2, "block byte", "issue"),
     "k_rle_*": (2, "block byte", "hbm"),
     "k_cls_*/k_quasi_build": (9, "RLE0 symbol", "hbm"),
-    "k_adaptive": (15, "RLE0 symbol", "issue"),
-    "k_pairs": (44, "RLE0 symbol", "hbm"),
+    "k_adaptive": (22, "RLE0 symbol", "issue"),
+    "k_pairs": (46, "RLE0 symbol", "hbm"),
     "k_rans_lanes": (20, "rANS pair", "issue"),
-    "k_emit_*/k_put_*": (25, "rANS pair", "hbm"),
+    "k_emit_*/k_put_*": (13, "rANS pair", "hbm"),
 }
 # algorithmic bytes per block byte of the four stages (c = compressed size / block size)
 STAGE_ALG = {"forward_bwt": lambda c: 10.0, "ans_encode": lambda c: 4.0 + c, "ans_decode": lambda c: 4.0 + c, "inverse_bwt": lambda c: 12.0}

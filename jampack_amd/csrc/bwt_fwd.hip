@@ -436,8 +436,7 @@ __global__ __launch_bounds__(TB) void k_win_pieces(const uint32_t *__restrict__ 
 }
 
 // the sort / re-rank of all groups of <= SEG_TILE elements, one window per workgroup iteration
-template <int MINW>       // minimum waves per SIMD the register allocation must allow (5 = as many workgroups per CU as the LDS admits)
-__global__ __launch_bounds__(TB, MINW) void k_seg_round(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const uint32_t *__restrict__ k2g,
+__global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const uint32_t *__restrict__ k2g,
                                                  const SaState *__restrict__ st, int par, int key_bits, const uint32_t *__restrict__ PH,
                                                  const uint8_t *__restrict__ a_prev, uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
                                                  uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint8_t *__restrict__ b_prev)
@@ -1225,10 +1224,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     const unsigned g_ct = cap_grid(n, CT, CAP);
     JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_count, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_r0_scan, dim3(1), dim3(WG1), b.tA, b.tB, n, b.state);
-    // experiment knob (JPK_OCC_MEM=<bytes of dynamic LDS>): caps the workgroups per CU of the kernels that only wait for random
-    // accesses, so that the compute-bound kernels of other blocks in flight find wave slots beside them
-    static const size_t occ_mem = [] { const char *e = getenv("JPK_OCC_MEM"); const int v = e ? atoi(e) : 0; return (size_t)(v < 0 ? 0 : (v > 65536 ? 65536 : v)); }();
-    JPK_LAUNCH_LDS(ctx, PROF_SA_RERANK, n, occ_mem, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev);
+    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev);
     ctx->stats.sa_rounds = 1;
 
     const int kbits = jpk_bits_for(n);             // key2 <= n, group rank < n
@@ -1250,16 +1246,13 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         const unsigned g_pc = cap_grid(pc_bound, 1, CAP);
         const unsigned g_tab = cap_grid(pc_bound << lg_db, SC_TILE, CAP);
         const uint32_t hh = (h < n) ? (uint32_t)h : n;
-        JPK_LAUNCH_LDS(ctx, PROF_SA_KEYS, 0, occ_mem, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, hh, b.ISA, b.k2, b.FH, b.LH);
+        JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, hh, b.ISA, b.k2, b.FH, b.LH);
         const unsigned g_wm = cap_grid((size_t)bound / SEG_TILE + 1, TB, 256);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan1, dim3(1), dim3(WG1), b.FH, b.LH, b.PH, b.NH, b.state, par);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_count, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.state, par);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan2, dim3(1), dim3(WG1), b.PC, b.state, par, round);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_pieces, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.pieces, b.state, par);
-        static const int seg_occ = [] { const char *e = getenv("JPK_SEG_OCC"); return e ? atoi(e) : 4; }();
-        if (seg_occ >= 5) JPK_LAUNCH(ctx, PROF_SA_SEG, 0, (k_seg_round<5>), dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, kbits, b.PH, b.a_prev, b.ISA, b.bwt, b.SA,
-                   b.b_sa, b.b_grp, b.b_prev);
-        else JPK_LAUNCH(ctx, PROF_SA_SEG, 0, (k_seg_round<4>), dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, kbits, b.PH, b.a_prev, b.ISA, b.bwt, b.SA,
+        JPK_LAUNCH(ctx, PROF_SA_SEG, 0, k_seg_round, dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, kbits, b.PH, b.a_prev, b.ISA, b.bwt, b.SA,
                    b.b_sa, b.b_grp, b.b_prev);
         {   // large groups: lg_pass LSD passes over (key2, sa), ping-pong between (k2, a_sa) and (k2alt, sa_alt)
             uint32_t *kin = b.k2, *vin = b.a_sa, *kout = b.k2alt, *vout = b.sa_alt;
@@ -1279,7 +1272,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             }
             JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_lg_heads, dim3(g_pc), dim3(TB), kin, b.pieces, b.state, b.pLast);
             JPK_LAUNCH(ctx, PROF_SCAN, 0, k_lg_scan, dim3(1), dim3(WG1), b.pLast, b.state);
-            JPK_LAUNCH_LDS(ctx, PROF_SA_RERANK, 0, occ_mem, k_lg_finish, dim3(g_pc), dim3(TB), kin, vin, pin, b.a_grp, b.pieces, b.state, b.pLast, b.ISA, b.bwt, b.SA, b.b_sa,
+            JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_lg_finish, dim3(g_pc), dim3(TB), kin, vin, pin, b.a_grp, b.pieces, b.state, b.pLast, b.ISA, b.bwt, b.SA, b.b_sa,
                        b.b_grp, b.b_prev);
         }
         JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_cmp_count, dim3(g_cmp), dim3(TB), b.b_grp, b.state, par, b.tA);

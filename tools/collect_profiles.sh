@@ -3,7 +3,7 @@
 # Produces gpurun_out/<tag>/: PMC passes + summary, rocprofv3 kernel stats of the bench command, bench lines, worst cases.
 # (counters and traces in separate runs; the program itself after `--`)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -39,5 +39,23 @@ NLIST=1,4,8,16,24,32,48,64 python3 tools/dec_scaling.py batch > "$OUT/decode_bat
 python3 tools/stage_scaling.py 2>/dev/null | grep contexts > "$OUT/stage_scaling.txt"
 python3 tools/chunk_lens.py 2>/dev/null | grep -E "chunks|k_dec_" > "$OUT/decode_chain_lengths.txt"
 ls -la "$OUT"
-python3 tools/block_sizes.py 2>/dev/null > "$OUT/block_sizes.txt"
+python3 tools/block_sizes.py 1,8,64,128 2>/dev/null > "$OUT/block_sizes.txt"
 python3 tools/batch_compress.py 2>/dev/null | grep "in flight" > "$OUT/blocks_compress_call.txt"
+# 5. round 3: the floor of the suffix sort, the drop-in block loop with 16 threads, the N > 1 code path on one GPU, SQ counters
+tools/_bin/sa_floor > "$OUT/sa_floor.txt" 2>&1
+python3 - <<'PY'
+import sys
+sys.path.insert(0, ".")
+from jampack_amd import corpus
+d, _ = corpus.load_or_make("enwik9", start=0, count=4 * (64 << 20))
+with open("/tmp/pipe_in16.bin", "wb") as f:
+    for _ in range(4):
+        d.tofile(f)
+PY
+make -C jampack_amd/csrc/shim > /dev/null
+( jampack_amd/csrc/shim/jam_block_pipeline /tmp/pipe_in16.bin 64 8 | tail -1; jampack_amd/csrc/shim/jam_block_pipeline /tmp/pipe_in16.bin 64 16 | tail -1; JPK_COMBINE_US=-1 jampack_amd/csrc/shim/jam_block_pipeline /tmp/pipe_in16.bin 64 16 | tail -1 | sed 's/$/   [JPK_COMBINE_US=-1: combiner off]/' ) > "$OUT/block_pipeline_threads.txt" 2>&1
+JPK_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --steps 4 --warmup 2 --no-extras --contexts 2 2>/dev/null | tail -1 > "$OUT/bench_two_ranks_one_gpu.json"
+JPK_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --steps 2 --warmup 1 --no-extras --contexts 2 --workload enwik9 --limit-bytes 402653184 2>/dev/null | tail -1 > "$OUT/bench_two_ranks_one_gpu_enwik9_384mib.json"
+bash tools/pmc_sq.sh gpurun_out/$TAG/sq_fwd fwd > /dev/null 2>&1
+bash tools/pmc_sq.sh gpurun_out/$TAG/sq_enc enc > /dev/null 2>&1
+ls -la "$OUT"
