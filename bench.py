@@ -218,12 +218,18 @@ def per_block_size(jam, corpus, torch, dev, device_index: int, in_flight: int):
     data, _ = corpus.load_or_make("enwik9", start=0, count=256 * MiB)
     d_all = torch.from_numpy(np.ascontiguousarray(data)).to(dev)
     out = {}
-    ctx = jam.Context(device_index, None)
+    ctx = None
     try:
         # (block MiB, blocks of the stream, blocks timed one at a time, blocks in flight of the streamed compress: a 1 MiB block is
         # one chunk = one 5 ms chain on one of 1024 SIMDs, so small blocks want many in flight -- the library admits up to 16)
         for bm, nstream, nsingle, nfl in ((1, 64, 8, 16), (64, 4, 2, in_flight), (256, 2, 1, in_flight)):
             bs = bm * MiB
+            # a fresh context per size, and the previous size's worker contexts (and their streams) released first: streams are
+            # dealt onto the hardware queues round robin at creation, leftovers of a finished leg should not sit beside this one
+            if ctx is not None:
+                ctx.close()
+            jam.shutdown()
+            ctx = jam.Context(device_index, None)
             nuniq = min(nstream, (256 * MiB) // bs)
             srcs = [d_all[(k % nuniq) * bs: (k % nuniq) * bs + bs] for k in range(nstream)]
             cap = jam.ans_capacity(bs + jam.TRAILER)
@@ -232,6 +238,7 @@ def per_block_size(jam, corpus, torch, dev, device_index: int, in_flight: int):
             backs = [torch.empty(bs, dtype=torch.uint8, device=dev) for _ in range(nstream)]
             single = torch.empty(cap, dtype=torch.uint8, device=dev)
             # one at a time
+            ctx.block_compress(srcs[0], bs, single, cap)
             ctx.block_compress(srcs[0], bs, single, cap)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -269,8 +276,9 @@ def per_block_size(jam, corpus, torch, dev, device_index: int, in_flight: int):
             del outs, backs, single, ref, srcs
             torch.cuda.empty_cache()
     finally:
-        ctx.close()
-        jam.shutdown()                 # the batch call's worker contexts (a 256 MiB block's arena is ~17 GB each)
+        if ctx is not None:
+            ctx.close()
+        jam.shutdown()                 # the batch call's worker contexts (a 256 MiB block's arena is ~20 GB each)
     out["note"] = ("enwik9-like text; one_at_a_time = one block per call; streamed = all blocks of the stream through one jpk_dev_blocks_compress / "
                    "jpk_dev_blocks_decompress call; HBM resident; MB/s of uncompressed bytes")
     return out
@@ -520,6 +528,16 @@ def main():
                                  "alg_bytes_per_launch": round(d0["alg_bytes_per_unit"] * d0["units"] / d0["launches"]),
                                  "note": f"dominant kernel class by total time over 4 passes of the timed loop ({nctx} blocks in flight: one chain launch per block, stretched by the other blocks' kernels); achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream); traffic = PMC bytes per launch of the same command from profiles/{pmc_file}; peak = HBM spec; limited_by says what the class is really bound by (DESIGN.md section 4)"}
             extra_["roofline_kernels"] = rows[:8]
+            # the same for the dominant kernel among those that FILL the machine (the chain above is 65 waves on 1024 SIMDs: its
+            # launches are long, its share of the chip is 6 %): what a reader who wants "the kernel that costs the most GPU" looks for
+            wide = next((r for r in rows if r["limited_by"] != "issue"), None)
+            if wide:
+                wt, wf = pmc_traffic(wide["kernel"], 4, wide["launches"])
+                extra_["roofline_wide"] = {"kernel": wide["kernel"], "bound": "hbm" if wide["limited_by"].startswith("hbm") else wide["limited_by"],
+                                          "achieved": wide["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": wide["frac"], "traffic": wt,
+                                          "avg_launch_us": wide["avg_launch_us"], "launches": wide["launches"],
+                                          "alg_bytes_per_launch": round(wide["alg_bytes_per_unit"] * wide["units"] / wide["launches"]),
+                                          "note": "largest total time among the kernel classes whose grids fill the chip, same 4 passes of the timed loop, same accounting"}
             one = next((r for r in rows1 if r["kernel"] == d0["kernel"]), None)
             if one:
                 extra_["roofline"]["one_block_at_a_time"] = {"avg_launch_us": one["avg_launch_us"], "launches": one["launches"], "achieved": one["achieved"], "frac": one["frac"],
