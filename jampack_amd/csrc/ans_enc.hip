@@ -119,21 +119,30 @@ __global__ __launch_bounds__(256) void k_enc_prep(EncDims d, uint32_t *__restric
     bstart[(size_t)c * 256 + s] = b;
 }
 
-// one wave per tile: wave-sequential MTF by time stamps + bucket scatter (rank.cpp:69-87).
-// The 256 time stamps live in 4 registers per lane for the rank (4 x v_cmp -> popcount); a per-wave LDS mirror
-// gives the previous occurrence of the current symbol and the bucket write positions with wave-uniform LDS accesses.
-// Only run HEADS are walked serially (a repeat has rank 0, leaves the recency order unchanged and lands right behind its
-// head in the same bucket): a ballot marks them in each 64-byte group, the loop visits the set bits, and every lane then
-// derives its own (destination, rank) from the record of the head at or before it.  All loop control is wave-uniform
-// (scalar branches, no exec-mask loops): the wave index is read with readfirstlane.
+// one wave per tile: wave-sequential MTF on the recency list itself + bucket scatter (rank.cpp:69-87).
+// The list lives in 4 registers per lane: lane p of lst_j holds the symbol at list position 64 j + p (0xFFFF behind the symbols seen
+// so far in the chunk: a symbol's first occurrence has rank = number of distinct symbols before it, i.e. it sits at the first free
+// position).  A head's rank is its position -- one v_cmp + s_ff1 when it is among the first 64, which is nearly every head of a BWT
+// image -- and the move to front is one DPP wave_shr:1 under a lane mask (positions below it move down by one, the symbol enters at
+// lane 0).  Positions 64.. are searched, and the shift carried from register to register, only when the first compare misses.  The
+// list at the start of the tile is rebuilt from the carried last-occurrence stamps: position = number of symbols with a later stamp.
+// Only run HEADS are walked serially (a repeat has rank 0, leaves the list unchanged and lands right behind its head in the same
+// bucket): a ballot marks them in each 64-byte group, the loop visits the set bits, and every lane then derives its own
+// (destination, rank) from the record of the head at or before it.  All loop control is wave-uniform (scalar branches, no exec-mask
+// loops): the wave index is read with readfirstlane.  A per-wave LDS table holds the bucket write positions (wave-uniform accesses).
+__device__ __forceinline__ uint32_t mtf_shr1(uint32_t carry_in, uint32_t v)          // lane i <- lane i - 1, lane 0 <- carry_in
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)carry_in, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
 __global__ __launch_bounds__(TB) void k_enc_mtf(const uint8_t *__restrict__ in, EncDims d, const uint32_t *__restrict__ tilebase,
                                                const int32_t *__restrict__ prevlast, const uint32_t *__restrict__ bstart,
                                                uint8_t *__restrict__ ranks)
 {
     struct WaveLds {                       // one per wave; neighbours in one struct so that pairs of accesses share an address register
-        int32_t last[256];                 // time stamp of the last occurrence of every symbol (mirror of the registers)
         uint32_t pos[256];                 // next write position of every symbol's bucket
         uint32_t dst[64], rk[64];          // (bucket position, rank) of the heads of the group in flight
+        uint32_t lst[256];                 // the list at the start of the tile, while it is built
     };
     __shared__ WaveLds s_w[TB / 64];
     const uint32_t c = chunk_of(d, blockIdx.y);
@@ -143,18 +152,40 @@ __global__ __launch_bounds__(TB) void k_enc_mtf(const uint8_t *__restrict__ in, 
     if (ts >= clen) return;
     const int l = lane_id();
     const size_t o = ((size_t)c * d.tpc + t) * 256;
-    int32_t last0 = prevlast[o + l], last1 = prevlast[o + 64 + l], last2 = prevlast[o + 128 + l], last3 = prevlast[o + 192 + l];
+    const int32_t last0 = prevlast[o + l], last1 = prevlast[o + 64 + l], last2 = prevlast[o + 128 + l], last3 = prevlast[o + 192 + l];
     const uint32_t *bs = bstart + (size_t)c * 256;
     WaveLds &L = s_w[w];
-    L.last[l] = last0; L.last[64 + l] = last1; L.last[128 + l] = last2; L.last[192 + l] = last3;
-#pragma unroll
-    for (int qq = 0; qq < 4; qq++) L.pos[qq * 64 + l] = bs[qq * 64 + l] + tilebase[o + qq * 64 + l];
     const uint8_t *src = in + (size_t)c * d.chunk;
     uint8_t *dst = ranks + (size_t)c * d.chunk;
     const uint32_t te = (ts + ATILE < clen) ? ts + ATILE : clen;
-    const uint32_t sym0 = (uint32_t)l, sym1 = (uint32_t)l + 64u, sym2 = (uint32_t)l + 128u, sym3 = (uint32_t)l + 192u;     // my four symbols
-    uint32_t prevc = 256;                                                     // no byte before the tile: its first byte is a head
     uint32_t bn = ((uint32_t)l < te - ts) ? src[ts + l] : 0x100u;             // group in flight
+#pragma unroll
+    for (int qq = 0; qq < 4; qq++) {
+        L.pos[qq * 64 + l] = bs[qq * 64 + l] + tilebase[o + qq * 64 + l];
+        L.lst[qq * 64 + l] = 0xFFFFu;
+    }
+    // the list before the tile: every symbol seen so far goes to position #{symbols with a later stamp} (stamps are positions: distinct)
+    uint32_t nseen = 0;
+#define JPK_MTF_PLACE(LASTJ, J)                                                                                                   \
+    {                                                                                                                             \
+        uint64_t sm = __ballot(LASTJ >= 0);                                                                                       \
+        nseen += (uint32_t)__popcll(sm);                                                                                          \
+        while (sm) {                                                                                                              \
+            const uint32_t ln = (uint32_t)__builtin_ctzll(sm);                                                                    \
+            sm &= sm - 1;                                                                                                         \
+            const int32_t own = __builtin_amdgcn_readlane(LASTJ, (int)ln);                                                        \
+            const uint32_t at = (uint32_t)__popcll(__ballot(last0 > own)) + (uint32_t)__popcll(__ballot(last1 > own)) +           \
+                                (uint32_t)__popcll(__ballot(last2 > own)) + (uint32_t)__popcll(__ballot(last3 > own));            \
+            L.lst[at] = (uint32_t)(J) * 64u + ln;                              /* every lane stores the same value */              \
+        }                                                                                                                         \
+    }
+    JPK_MTF_PLACE(last0, 0)
+    JPK_MTF_PLACE(last1, 1)
+    JPK_MTF_PLACE(last2, 2)
+    JPK_MTF_PLACE(last3, 3)
+#undef JPK_MTF_PLACE
+    uint32_t lst0 = L.lst[l], lst1 = L.lst[64 + l], lst2 = L.lst[128 + l], lst3 = L.lst[192 + l];
+    uint32_t prevc = 256;                                                     // no byte before the tile: its first byte is a head
     for (uint32_t i0 = ts; i0 < te; i0 += 64) {
         const uint32_t nvalid = (te - i0 < 64u) ? te - i0 : 64u;
         const uint32_t b = bn;
@@ -168,16 +199,45 @@ __global__ __launch_bounds__(TB) void k_enc_mtf(const uint8_t *__restrict__ in, 
             rem &= rem - 1;
             const uint32_t nk = rem ? (uint32_t)__builtin_ctzll(rem) : nvalid;
             const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)k);
-            const int32_t own = L.last[cc];
             const uint32_t dpos = L.pos[cc];
-            const uint32_t rank = (uint32_t)__popcll(__ballot(last0 > own)) + (uint32_t)__popcll(__ballot(last1 > own)) +
-                                  (uint32_t)__popcll(__ballot(last2 > own)) + (uint32_t)__popcll(__ballot(last3 > own));
-            const int32_t nv = (int32_t)(i0 + k);
-            last0 = (sym0 == cc) ? nv : last0;         // branch-free: one of the four compares hits in one lane
-            last1 = (sym1 == cc) ? nv : last1;
-            last2 = (sym2 == cc) ? nv : last2;
-            last3 = (sym3 == cc) ? nv : last3;
-            L.last[cc] = nv;                           // every lane stores the same value
+            const uint64_t m0 = __ballot(lst0 == cc);
+            uint32_t rank;
+            if (m0) {                                          // among the first 64: the common case
+                rank = (uint32_t)__builtin_ctzll(m0);
+                const uint32_t sh = mtf_shr1(cc, lst0);
+                lst0 = ((uint32_t)l <= rank) ? sh : lst0;
+            } else {
+                const uint64_t m1 = __ballot(lst1 == cc), m2 = __ballot(lst2 == cc), m3 = __ballot(lst3 == cc);
+                if (m1) rank = 64u + (uint32_t)__builtin_ctzll(m1);
+                else if (m2) rank = 128u + (uint32_t)__builtin_ctzll(m2);
+                else if (m3) rank = 192u + (uint32_t)__builtin_ctzll(m3);
+                else rank = nseen++;                           // first occurrence in the chunk: enters from the first free position
+                const uint32_t j = rank >> 6, q = rank & 63u;
+                const bool part = (uint32_t)l <= q;            // lanes that move in the register holding the position
+                if (j == 0) {
+                    const uint32_t sh = mtf_shr1(cc, lst0);
+                    lst0 = part ? sh : lst0;
+                } else {
+                    const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)lst0, 63);
+                    lst0 = mtf_shr1(cc, lst0);
+                    if (j == 1) {
+                        const uint32_t sh = mtf_shr1(c1, lst1);
+                        lst1 = part ? sh : lst1;
+                    } else {
+                        const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)lst1, 63);
+                        lst1 = mtf_shr1(c1, lst1);
+                        if (j == 2) {
+                            const uint32_t sh = mtf_shr1(c2, lst2);
+                            lst2 = part ? sh : lst2;
+                        } else {
+                            const uint32_t c3 = (uint32_t)__builtin_amdgcn_readlane((int)lst2, 63);
+                            lst2 = mtf_shr1(c2, lst2);
+                            const uint32_t sh = mtf_shr1(c3, lst3);
+                            lst3 = part ? sh : lst3;
+                        }
+                    }
+                }
+            }
             L.pos[cc] = dpos + (nk - k);
             L.dst[k] = dpos;
             L.rk[k] = rank;
@@ -751,7 +811,12 @@ __device__ __forceinline__ uint4 rans_record(uint32_t lo, uint32_t fr)
     uint32_t rcp, shift, bias = lo;
     if (fr >= 2) {
         const int sh = 32 - __clz((int)(fr - 1));
-        rcp = (uint32_t)((((uint64_t)1 << (sh + 31)) + fr - 1) / fr);
+        // ceil(2^(sh+31) / fr) without a 64-bit division: D = fr << (16 - sh) lies in (2^15, 2^16], 2^(sh+31) / fr == 2^47 / D, and
+        // 2^47 = 2^16 * (qh * D + rh)  =>  quotient = (qh << 16) + (rh << 16) / D   (rh < D <= 2^16: everything fits 32 bits)
+        const uint32_t D = fr << (16 - sh);
+        const uint32_t qh = 0x80000000u / D, rh = 0x80000000u - qh * D;
+        const uint32_t ql = (rh << 16) / D, rem = (rh << 16) - ql * D;
+        rcp = (qh << 16) + ql + (rem ? 1u : 0u);
         shift = (uint32_t)(sh - 1);
     } else {
         rcp = 0xFFFFFFFFu; shift = 0; bias = lo + 65535u;
