@@ -194,19 +194,20 @@ __global__ __launch_bounds__(TB) void k_enc_mtf(const uint8_t *__restrict__ in, 
         uint32_t pb = (uint32_t)__builtin_amdgcn_update_dpp((int)prevc, (int)b, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
         uint64_t rem = __ballot((uint32_t)l < nvalid && (b != pb || l == 0));     // lane 0 is always walked: a repeat gets rank 0 there
         const uint64_t heads = rem;
+        // length of the run that starts at my lane (used by head lanes only): distance to the next head, or to the end of the group
+        const uint64_t above = (heads >> 1) >> l;
+        const uint32_t runlen = above ? (uint32_t)__builtin_ctzll(above) + 1u : nvalid - (uint32_t)l;
         while (rem) {
             const uint32_t k = (uint32_t)__builtin_ctzll(rem);
             rem &= rem - 1;
-            const uint32_t nk = rem ? (uint32_t)__builtin_ctzll(rem) : nvalid;
             const uint32_t cc = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)k);
+            const uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)runlen, (int)k);
             const uint32_t dpos = L.pos[cc];
             const uint64_t m0 = __ballot(lst0 == cc);
             uint32_t rank;
             if (m0) {                                          // among the first 64: the common case
                 rank = (uint32_t)__builtin_ctzll(m0);
-                const uint32_t sh = mtf_shr1(cc, lst0);
-                lst0 = ((uint32_t)l <= rank) ? sh : lst0;
-            } else {
+            } else {                                           // search the rest; shift the registers behind the first here
                 const uint64_t m1 = __ballot(lst1 == cc), m2 = __ballot(lst2 == cc), m3 = __ballot(lst3 == cc);
                 if (m1) rank = 64u + (uint32_t)__builtin_ctzll(m1);
                 else if (m2) rank = 128u + (uint32_t)__builtin_ctzll(m2);
@@ -214,12 +215,8 @@ __global__ __launch_bounds__(TB) void k_enc_mtf(const uint8_t *__restrict__ in, 
                 else rank = nseen++;                           // first occurrence in the chunk: enters from the first free position
                 const uint32_t j = rank >> 6, q = rank & 63u;
                 const bool part = (uint32_t)l <= q;            // lanes that move in the register holding the position
-                if (j == 0) {
-                    const uint32_t sh = mtf_shr1(cc, lst0);
-                    lst0 = part ? sh : lst0;
-                } else {
+                if (j >= 1) {
                     const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)lst0, 63);
-                    lst0 = mtf_shr1(cc, lst0);
                     if (j == 1) {
                         const uint32_t sh = mtf_shr1(c1, lst1);
                         lst1 = part ? sh : lst1;
@@ -238,7 +235,11 @@ __global__ __launch_bounds__(TB) void k_enc_mtf(const uint8_t *__restrict__ in, 
                     }
                 }
             }
-            L.pos[cc] = dpos + (nk - k);
+            {                                                  // first register: positions 0 .. min(rank, 63) move down, the symbol enters at 0
+                const uint32_t sh = mtf_shr1(cc, lst0);
+                lst0 = ((uint32_t)l <= rank) ? sh : lst0;
+            }
+            L.pos[cc] = dpos + run;
             L.dst[k] = dpos;
             L.rk[k] = rank;
         }
@@ -704,16 +705,17 @@ __device__ __forceinline__ int32_t ad_run_write(const AdRec &r, const AdStream &
 
 struct AdArgs {
     const uint8_t *cls8; const uint32_t *clist; size_t rle_stride; const uint32_t *rlen; const uint32_t *clstotal;
+    const uint32_t *clsbase;                // [chunk][tile][8]: symbols of every class in front of the tile (k_cls_prefix)
     uint16_t *exph; uint32_t *mantad;       // exph: [chunk][7 exponent entries][rle_stride] history of every entry
     uint32_t *seg_flag; int32_t *seg_lo, *seg_end, *seg_start; uint16_t *seg_tab;
 };
 
-// lanes = 4 segments x 16 recurrence slots (9 used)
+// lanes = 64 consecutive segments of ONE recurrence (grid y): the exponent / mantissa code paths and the item widths differ, a wave
+// that mixed recurrences would walk both paths one after the other with half its lanes off
 __global__ __launch_bounds__(64) void k_adapt_a(EncDims d, AdArgs a)
 {
-    const uint32_t c = chunk_of(d, blockIdx.y), rec = threadIdx.x & 15u;
-    const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 4);
-    if (rec >= 9) return;
+    const uint32_t c = chunk_of(d, blockIdx.z), rec = blockIdx.y;
+    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
     const AdRec r(rec);
     const AdStream st = ad_stream(r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
     const uint32_t nt = (st.n + ATILE - 1) / ATILE;
@@ -732,13 +734,49 @@ __global__ __launch_bounds__(64) void k_adapt_a(EncDims d, AdArgs a)
         a.seg_end[so] = ad_run_write(r, st, t0, t1, lo, a.exph + ((size_t)c * 7 + (rec < 7 ? rec : 0)) * a.rle_stride, a.mantad + (size_t)c * a.rle_stride);
         return;
     }
-    // unresolved: k_adapt_tab tabulates the 32 candidate start states lo .. lo+31 (hi - lo <= 31 after the warm-up)
-    a.seg_flag[so] = 0u;
+    // unresolved: k_adapt_tab tabulates the 32 candidate start states lo .. lo+31 (hi - lo <= 31 after the warm-up).
+    // Except the one case that makes most of them: an exponent entry above every class that occurs (rare large classes).  Its mix is
+    // smax at every step, hi never left smax (one other step would have dropped it for good: nothing climbs back to smax from
+    // below), lo stalled at smax - 31, and all 32 states in between are fixed points of that step.  If no symbol of the segment
+    // reaches the entry either, the segment's transfer is the identity and its history row a constant: no table, no second walk.
+    uint32_t flag = 0u;
+    if (r.exp && hi == r.smax() && lo == r.smax() - 31) {
+        const uint32_t *cb = a.clsbase + ((size_t)c * d.tpc + k) * 8;
+        uint32_t reach = 0;                                    // symbols of the segment with class >= i
+        for (int e = r.i; e < 8; e++) reach += ((k + 1 < nt) ? cb[8 + e] : a.clstotal[(size_t)c * 8 + e]) - cb[e];
+        if (reach == 0) flag = 2u;
+    }
+    a.seg_flag[so] = flag;
     a.seg_lo[so] = lo;
     a.seg_end[so] = hi;          // re-used as the interval's upper end until k_adapt_b has run
 }
 
-// transfer table of an unresolved segment: 32 lanes = 32 candidate start states walk the segment together (the
+// unresolved segments, second chance: walk the two ends of the interval through the segment itself.  The step is monotone in the
+// state, so if the ends meet every start state in between reaches that same end state: the segment's transfer is a constant and no
+// table is needed (flag 3; k_adapt_c still re-runs it for the outputs once k_adapt_b knows its start).  That is the usual fate of
+// an interval left open by a quiet warm-up (no symbol reached the entry for 1280 items, then one does inside the segment: the
+// 32 stalled states drop together, contract by 31/32 per step on the climb back and merge within ~130 steps).
+__global__ __launch_bounds__(64) void k_adapt_ext(EncDims d, AdArgs a)
+{
+    const uint32_t c = chunk_of(d, blockIdx.z), rec = blockIdx.y;
+    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+    const AdRec r(rec);
+    const AdStream st = ad_stream(r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
+    const uint32_t nt = (st.n + ATILE - 1) / ATILE;
+    if (k >= nt) return;
+    const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
+    if (a.seg_flag[so]) return;
+    const uint32_t t0 = k * ATILE, t1 = (t0 + ATILE < st.n) ? t0 + ATILE : st.n;
+    int32_t lo = a.seg_lo[so], hi = a.seg_end[so];
+    const int i = r.i, A = r.A;
+    ad_for_each(r, st, t0, t1, [&](uint32_t, int sy) { lo = adapt_step(lo, i, sy, A); hi = adapt_step(hi, i, sy, A); });
+    if (lo == hi) {
+        a.seg_flag[so] = 3u;
+        a.seg_end[so] = lo;
+    }
+}
+
+// transfer table of a segment that is still unresolved: 32 lanes = 32 candidate start states walk the segment together (the
 // item loads are wave-uniform), instead of one lane walking it 32 times
 __global__ __launch_bounds__(64) void k_adapt_tab(EncDims d, AdArgs a)
 {
@@ -771,7 +809,10 @@ __global__ __launch_bounds__(64) void k_adapt_b(EncDims d, AdArgs a)
     int32_t x = r.init();
     for (uint32_t k = 0; k < nt; k++) {
         const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
-        if (a.seg_flag[so]) x = a.seg_end[so];
+        const uint32_t flag = a.seg_flag[so];
+        if (flag == 1u) x = a.seg_end[so];
+        else if (flag == 2u) a.seg_start[so] = x;             // identity segment: the state passes through
+        else if (flag == 3u) { a.seg_start[so] = x; x = a.seg_end[so]; }      // constant transfer
         else {
             a.seg_start[so] = x;
             int q = x - a.seg_lo[so];
@@ -783,16 +824,24 @@ __global__ __launch_bounds__(64) void k_adapt_b(EncDims d, AdArgs a)
 
 __global__ __launch_bounds__(64) void k_adapt_c(EncDims d, AdArgs a)
 {
-    const uint32_t c = chunk_of(d, blockIdx.y), rec = threadIdx.x & 15u;
-    const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 4);
-    if (rec >= 9) return;
+    const uint32_t c = chunk_of(d, blockIdx.z), rec = blockIdx.y;
+    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
     const AdRec r(rec);
     const AdStream st = ad_stream(r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
     const uint32_t nt = (st.n + ATILE - 1) / ATILE;
     if (k >= nt) return;
     const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
-    if (a.seg_flag[so]) return;
+    const uint32_t flag = a.seg_flag[so];
+    if (flag == 1u) return;
     const uint32_t t0 = k * ATILE, t1 = (t0 + ATILE < st.n) ? t0 + ATILE : st.n;
+    if (flag == 2u) {                                          // identity segment (exponent entries only): a constant row
+        uint16_t *hist = a.exph + ((size_t)c * 7 + rec) * a.rle_stride;
+        const uint32_t x = (uint32_t)a.seg_start[so] & 0xffffu, xx = x | (x << 16);
+        uint32_t t = t0;                                       // t0 is a multiple of ATILE: 16-byte aligned in its row
+        for (; t + 8 <= t1; t += 8) *reinterpret_cast<uint4 *>(hist + t) = make_uint4(xx, xx, xx, xx);
+        for (; t < t1; t++) hist[t] = (uint16_t)x;
+        return;
+    }
     ad_run_write(r, st, t0, t1, a.seg_start[so], a.exph + ((size_t)c * 7 + (rec < 7 ? rec : 0)) * a.rle_stride, a.mantad + (size_t)c * a.rle_stride);
 }
 
@@ -1372,13 +1421,14 @@ int run_model(jpk_ctx *ctx, const uint16_t *d_rle, const uint32_t *d_rlen, const
     JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_cls_ord, dim3(d.tpc, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.clscnt, b.ord, b.qhist, b.cls8, b.clist);
     JPK_LAUNCH(ctx, PROF_ENC_CLASS, 0, k_quasi_build, dim3(NQ, 6, d.ncl), dim3(64), d, b.clstotal, b.qhist, b.qcdf);
     AdArgs aa;
-    aa.cls8 = b.cls8; aa.clist = b.clist; aa.rle_stride = stride; aa.rlen = d_rlen; aa.clstotal = b.clstotal;
+    aa.cls8 = b.cls8; aa.clist = b.clist; aa.rle_stride = stride; aa.rlen = d_rlen; aa.clstotal = b.clstotal; aa.clsbase = b.clscnt;
     aa.exph = b.exph; aa.mantad = b.mantad;
     aa.seg_flag = b.seg_flag; aa.seg_lo = b.seg_lo; aa.seg_end = b.seg_end; aa.seg_start = b.seg_start; aa.seg_tab = b.seg_tab;
-    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_a, dim3((d.tpc + 3) / 4, d.ncl), dim3(64), d, aa);
+    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_a, dim3((d.tpc + 63) / 64, 9, d.ncl), dim3(64), d, aa);
+    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_ext, dim3((d.tpc + 63) / 64, 9, d.ncl), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_tab, dim3((d.tpc + 1) / 2, 9, d.ncl), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_b, dim3(jpk_grid((size_t)d.ncl * 16, 64)), dim3(64), d, aa);
-    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_c, dim3((d.tpc + 3) / 4, d.ncl), dim3(64), d, aa);
+    JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_c, dim3((d.tpc + 63) / 64, 9, d.ncl), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_PAIRS, 0, k_pairs, dim3(jpk_grid(stride, TB) + 1, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.exph, b.mantad, b.ord,
                        b.qcdf, b.recs, b.fr16, b.pairs);
     JPK_HIP(hipGetLastError());
