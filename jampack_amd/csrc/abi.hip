@@ -505,29 +505,60 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
         // what the batch decoder can need for this block at most: rank array + 2-byte RLE0 symbols + chunk tables
         bound += (size_t)mc * 3 + ((size_t)in_len[b] / 275 + 2) * 1100 + 4096;
     }
-    // arena: [inverse-BWT scratch of the largest block][BWT images of all blocks][the batch decoder's buffers]; sized once so that
-    // it cannot move while the images sit in it
-    // [inverse-BWT scratch][one verdict per block][BWT images][the batch decoder's buffers]
-    const size_t inv_bytes = jpk_align(jpk_inv_bwt_arena_bytes(nmax), 4096) + jpk_align((size_t)nblocks * 16 + 64, 4096);
+    // arena: [inverse-BWT scratch of the largest block x lanes][one verdict per block][BWT images of all blocks][the batch
+    // decoder's buffers]; sized once so that it cannot move while the images sit in it.
+    // Lanes: an inverse BWT is ~30 dependent launches of which only the walk fills the chip (1.6 of 2.5 ms for 64 MiB, the rest
+    // is 20-microsecond rank-jump rounds and launch gaps), so up to three run side by side, each on its own stream with its own
+    // scratch, behind one event on the decode stream.
+    static const int max_lanes = [] { const char *e = getenv("JPK_INV_LANES"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > jpk_ctx::ENC_GROUPS ? jpk_ctx::ENC_GROUPS : v); }();
+    int lanes = nblocks < max_lanes ? nblocks : max_lanes;
+    hipStream_t lane_stream[jpk_ctx::ENC_GROUPS] = {ctx->stream, nullptr, nullptr, nullptr};
+    for (int k = 1; k < lanes; k++) {
+        if (!ctx->aux[k - 1] && hipStreamCreateWithFlags(&ctx->aux[k - 1], hipStreamNonBlocking) != hipSuccess) { ctx->aux[k - 1] = nullptr; lanes = k; break; }
+        lane_stream[k] = ctx->aux[k - 1];
+    }
+    const size_t inv_one = jpk_align(jpk_inv_bwt_arena_bytes(nmax), 4096), verdict_bytes = jpk_align((size_t)nblocks * 16 + 64, 4096);
+    const size_t inv_bytes = inv_one * (size_t)lanes + verdict_bytes;
     JPK_TRY(jpk_arena_ensure(ctx, inv_bytes + mid_total + bound + (1u << 20)));
-    uint32_t *d_verdict = reinterpret_cast<uint32_t *>(ctx->arena + inv_bytes - jpk_align((size_t)nblocks * 16 + 64, 4096));
+    uint32_t *d_verdict = reinterpret_cast<uint32_t *>(ctx->arena + inv_bytes - verdict_bytes);
     std::vector<uint8_t *> mid((size_t)nblocks);
     {
         size_t off = inv_bytes;
         for (int b = 0; b < nblocks; b++) { mid[b] = ctx->arena + off; off += jpk_align((size_t)mid_cap[b] + 64); }
     }
     JPK_TRY(jpk_ans_decode_batch(ctx, nblocks, d_in, in_len, mid.data(), mid_cap.data(), mid_len.data(), stp, inv_bytes + mid_total));
-    // the inverse BWTs are enqueued back to back, without a host round trip between them (trailer index, slot count and the
-    // head check stay on the device); their verdicts come back in one copy
+    // the inverse BWTs are enqueued without a host round trip between them (trailer index, slot count and the head check stay
+    // on the device); their verdicts come back in one copy
     std::vector<int> ran;
-    for (int b = 0; b < nblocks; b++) {
-        out_len[b] = 0;
-        if (stp[b] != JPK_OK) continue;
-        if (mid_len[b] < JPK_TRAILER_BYTES) { stp[b] = JPK_E_CORRUPT; continue; }
-        if (mid_len[b] - JPK_TRAILER_BYTES > out_cap[b]) { stp[b] = JPK_E_CAPACITY; continue; }
-        const int rc = jpk_inv_bwt_enqueue(ctx, mid[b], mid_len[b], d_out[b], d_verdict + 4 * (size_t)b);
-        if (rc != JPK_OK) { stp[b] = rc; continue; }
-        ran.push_back(b);
+    {
+        struct Restore {                                       // whatever happens below, the context gets its stream and base back
+            jpk_ctx *c; hipStream_t s;
+            ~Restore() { c->stream = s; c->arena_base = 0; }
+        } restore{ctx, ctx->stream};
+        hipStream_t main_stream = ctx->stream;
+        if (lanes > 1) {
+            JPK_HIP(hipEventRecord(ctx->ev_batch, main_stream));       // the decoded images are complete
+            for (int k = 1; k < lanes; k++) JPK_HIP(hipStreamWaitEvent(lane_stream[k], ctx->ev_batch, 0));
+        }
+        int next = 0;
+        for (int b = 0; b < nblocks; b++) {
+            out_len[b] = 0;
+            if (stp[b] != JPK_OK) continue;
+            if (mid_len[b] < JPK_TRAILER_BYTES) { stp[b] = JPK_E_CORRUPT; continue; }
+            if (mid_len[b] - JPK_TRAILER_BYTES > out_cap[b]) { stp[b] = JPK_E_CAPACITY; continue; }
+            const int k = next % lanes;
+            ctx->stream = lane_stream[k];
+            ctx->arena_base = inv_one * (size_t)k;
+            const int rc = jpk_inv_bwt_enqueue(ctx, mid[b], mid_len[b], d_out[b], d_verdict + 4 * (size_t)b);
+            if (rc != JPK_OK) { stp[b] = rc; continue; }
+            ran.push_back(b);
+            next++;
+        }
+        ctx->stream = main_stream;
+        for (int k = 1; k < lanes; k++) {                      // the main stream continues behind every lane
+            JPK_HIP(hipEventRecord(ctx->ev_done[k], lane_stream[k]));
+            JPK_HIP(hipStreamWaitEvent(main_stream, ctx->ev_done[k], 0));
+        }
     }
     std::vector<uint32_t> verdict((size_t)nblocks * 4);
     if (!ran.empty()) JPK_HIP(hipMemcpyAsync(verdict.data(), d_verdict, (size_t)nblocks * 16, hipMemcpyDeviceToHost, ctx->stream));

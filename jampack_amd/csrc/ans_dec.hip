@@ -681,12 +681,14 @@ __global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ bl
     const uint8_t *R = B.ranks + ci.out_off;     // rank array
     uint8_t *T = B.out + ci.out_off;             // decoded symbols
     const jpk_gbytes Tg = (jpk_gbytes)T;
-    __shared__ uint8_t rows[256][64];             // one byte per rank: 16 KiB, so that six chunks fit a CU (24 KiB each)
+    __shared__ uint8_t rows[256][64];             // one byte per rank: 16 KiB
     __shared__ uint32_t stage[64];                // landing zone of the top-up in flight (LDS-DMA writes one dword per lane)
     __shared__ RankMeta meta[256];
     __shared__ RankSpan span[256];
-    __shared__ uint32_t sf[256];
-    __shared__ uint32_t lst[256];
+    // 22 784 bytes in all: seven chains per CU (160 KiB).  The frequency table and the start list are only needed until the rows
+    // are filled and live in the rows' own memory until then (with their own 2 KiB the kernel took 24.3 KiB: six per CU).
+    uint32_t *const sf = reinterpret_cast<uint32_t *>(&rows[0][0]);
+    uint32_t *const lst = sf + 256;
     const int32_t *fq = freq + (size_t)c * 256;
     for (int s = l; s < 256; s += 64) { sf[s] = (uint32_t)fq[s]; lst[s] = 0; }
     __syncthreads();
@@ -711,6 +713,10 @@ __global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ bl
         uniq += (f > 0);
     }
     uniq = rfl(wave_sum(uniq));
+    __syncthreads();
+    uint32_t L0 = lst[l];
+    uint32_t P = (l < 48) ? (lst[64 + 4 * l] | (lst[65 + 4 * l] << 8) | (lst[66 + 4 * l] << 16) | (lst[67 + 4 * l] << 24)) : 0u;
+    __syncthreads();                               // the start list has been read: its memory becomes rows
     // first window of every bucket (the offsets come from registers so the 256 loads pipeline)
 #pragma unroll
     for (int k = 0; k < 4; k++)
@@ -719,8 +725,6 @@ __global__ __launch_bounds__(64) void k_dec_rank(const DecBlock *__restrict__ bl
             rows[j + 64 * k][l] = (g + l < ge) ? R[g + l] : (uint8_t)0xFF;
         }
     __syncthreads();
-    uint32_t L0 = lst[l];
-    uint32_t P = (l < 48) ? (lst[64 + 4 * l] | (lst[65 + 4 * l] << 8) | (lst[66 + 4 * l] << 16) | (lst[67 + 4 * l] << 24)) : 0u;
     uint32_t sym = (uint32_t)__builtin_amdgcn_readlane((int)L0, 0);
     uint32_t psym = 256;                                         // row with a top-up in flight (256 = none)
     uint32_t poff = 0, pcnt = 0;                                 // ... its entries land at rows[psym][poff .. poff + pcnt)
@@ -926,7 +930,7 @@ int jpk_ans_decode_batch(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in, con
     }
     JPK_LAUNCH_LDS(ctx, PROF_DEC_RANS, 2 * rle_total, lds_cap, k_dec_rans, dim3(g), dim3(64), d_tab, info, order, d_status);
     JPK_LAUNCH(ctx, PROF_DEC_RLE, rle_total, k_dec_rle, dim3(g), dim3(1024), d_tab, info, d_status);
-    JPK_LAUNCH_LDS(ctx, PROF_DEC_RANK, out_total, (lds_cap > 24576 ? lds_cap - 24576 : 0), k_dec_rank, dim3(g), dim3(64), d_tab, info, order, freq, d_status);
+    JPK_LAUNCH_LDS(ctx, PROF_DEC_RANK, out_total, (lds_cap > 22784 ? lds_cap - 22784 : 0), k_dec_rank, dim3(g), dim3(64), d_tab, info, order, freq, d_status);
     JPK_HIP(hipGetLastError());
     std::vector<uint32_t> hs((size_t)nblk);
     JPK_HIP(hipMemcpyAsync(hs.data(), d_status, (size_t)nblk * 4, hipMemcpyDeviceToHost, st));

@@ -348,8 +348,9 @@ size_t jpk_inv_bwt_arena_bytes(uint32_t n)
 
 // Enqueues one inverse BWT on ctx->stream without any host round trip: the trailer index is read and validated on the device,
 // grids are launched for the upper bound of the slot count, and the verdict (InvState) is copied to d_verdict[0..4) -- device
-// memory of the caller that outlives the arena scratch -- by the last kernel.  The scratch comes from the START of the arena,
-// so consecutive calls on one stream share it (in-order stream).
+// memory of the caller that outlives the arena scratch -- by the last kernel.  The scratch starts at ctx->arena_base (0 outside
+// a batch), so consecutive calls on one stream share it (in-order stream); a batch that runs several inverse BWTs side by side
+// gives each lane its own base and its own stream (jpk_dev_blocks_decompress).
 __global__ void k_inv_verdict(const InvState *__restrict__ st, uint32_t *__restrict__ out)
 {
     if (threadIdx.x == 0) { out[0] = st->status; out[1] = st->I; out[2] = st->novf; out[3] = st->head_dist; }
@@ -371,7 +372,10 @@ int jpk_inv_bwt_enqueue(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trai
     size_t ntiles, nsplit, max_slots;
     Arena plan(ctx, true);
     inv_layout(plan, n, b, ntiles, nsplit, max_slots);
-    if (!jpk_arena_fits(ctx, plan.need)) JPK_TRY(jpk_arena_ensure(ctx, plan.need));
+    if (!jpk_arena_fits(ctx, ctx->arena_base + plan.need)) {
+        if (ctx->arena_base) return JPK_E_ALLOC;                 // a batch has sized the arena and keeps buffers in it: it must not move
+        JPK_TRY(jpk_arena_ensure(ctx, plan.need));
+    }
     Arena real(ctx, false);
     inv_layout(real, n, b, ntiles, nsplit, max_slots);
 

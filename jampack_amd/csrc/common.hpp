@@ -59,6 +59,7 @@ struct jpk_ctx {
     uint8_t *arena = nullptr;
     size_t arena_cap = 0;
     size_t arena_off = 0;
+    size_t arena_base = 0;           // where the bump allocator starts (non-zero while a batch runs several stage instances side by side)
     // small pinned host mailbox for device->host scalars
     uint32_t *h_mail = nullptr;   // 256 words pinned
     uint32_t *d_mail = nullptr;   // 256 words device
@@ -101,7 +102,7 @@ struct Arena {
     jpk_ctx *c;
     size_t need = 0;      // planning pass accumulates here
     bool planning;
-    Arena(jpk_ctx *ctx, bool plan) : c(ctx), planning(plan) { if (!plan) c->arena_off = 0; }
+    Arena(jpk_ctx *ctx, bool plan) : c(ctx), planning(plan) { if (!plan) c->arena_off = c->arena_base; }
     template <typename T> T *get(size_t count)
     {
         size_t bytes = jpk_align(count * sizeof(T) + 64);
