@@ -511,7 +511,10 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
     // is 20-microsecond rank-jump rounds and launch gaps), so up to three run side by side, each on its own stream with its own
     // scratch, behind one event on the decode stream.
     static const int max_lanes = [] { const char *e = getenv("JPK_INV_LANES"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > jpk_ctx::ENC_GROUPS ? jpk_ctx::ENC_GROUPS : v); }();
-    int lanes = nblocks < max_lanes ? nblocks : max_lanes;
+    // Only a batch with many blocks gets lanes: they save the latency part of each inverse BWT (~1 ms of 2.5), nothing next to
+    // the 270 ms of a small batch's chains, and every extra stream of a context lands on a hardware queue that another
+    // context's chain kernels may be using (eight contexts decoding 2-block passes lost 18 % with a second stream each).
+    int lanes = nblocks < 8 ? 1 : max_lanes;
     hipStream_t lane_stream[jpk_ctx::ENC_GROUPS] = {ctx->stream, nullptr, nullptr, nullptr};
     for (int k = 1; k < lanes; k++) {
         if (!ctx->aux[k - 1] && hipStreamCreateWithFlags(&ctx->aux[k - 1], hipStreamNonBlocking) != hipSuccess) { ctx->aux[k - 1] = nullptr; lanes = k; break; }
