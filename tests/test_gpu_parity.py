@@ -56,6 +56,30 @@ def test_rank_coding_equals_oracle(jam, oracle, kind):
         assert np.array_equal(back, t), f"{kind} n={n} decode: {_first_diff(back, t)}"
 
 
+@pytest.mark.parametrize("distinct", [1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256])
+def test_rank_coding_at_the_list_register_boundaries(jam, oracle, distinct):
+    """k_enc_mtf keeps the recency list in four 64-lane registers: alphabets that end exactly at, one short of and one past a
+    register boundary, walked (a) round robin (every rank = distinct - 1: the deepest position, first occurrences enter at the
+    first free one), (b) at random with runs, (c) round robin in descending symbol order after a prefix that has seen only half
+    of the alphabet (tiles that start with a partly filled list); lengths that cross several 4 KiB tiles, ragged at the end."""
+    rng = np.random.default_rng(1000 + distinct)
+    syms = rng.permutation(256)[:distinct].astype(np.uint8)
+    n = 3 * 4096 + 17
+    cases = {
+        "round_robin": syms[np.arange(n) % distinct],
+        "random_runs": np.repeat(syms[rng.integers(0, distinct, n)], rng.integers(1, 4, n))[:n],
+        "half_then_all": np.concatenate([syms[: max(1, distinct // 2)][np.arange(5000) % max(1, distinct // 2)],
+                                         syms[::-1][np.arange(n - 5000) % distinct]]),
+    }
+    for name, t in cases.items():
+        t = np.ascontiguousarray(t, dtype=np.uint8)
+        r, f = jam.Postcoder().Encode(t)
+        er, ef = oracle.rank_encode(t)
+        assert np.array_equal(f, ef), f"{name}: freq differs"
+        assert np.array_equal(r, er), f"{name}: {_first_diff(r, er)}"
+        assert np.array_equal(jam.Postcoder().Decode(er, ef), t), name
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_ans_encode_equals_oracle(jam, oracle, kind):
     for n in [0, 1, 100, 4097, 70_000, 1 << 20, (1 << 20) + 480, 2_500_000]:
@@ -63,6 +87,25 @@ def test_ans_encode_equals_oracle(jam, oracle, kind):
         got = jam.Ans().Encode(x)
         exp = oracle.ans_encode(x)
         assert np.array_equal(got, exp), f"{kind} n={n}: {_first_diff(got, exp)}"
+
+
+@pytest.mark.parametrize("spacing", [1500, 3000, 6000, 20000, 0])
+def test_ans_encode_with_quiet_stretches_between_rare_classes(jam, oracle, spacing):
+    """The adaptive exponent entries are solved in 4096-symbol segments after a 1280-symbol warm-up (k_adapt_a / ext / tab / b / c).
+    A stream whose symbols stay in one low class for thousands of symbols and then shows ONE symbol of a high class exercises
+    the cases apart: spacing 0 = never (every segment of the upper entries is the identity), 20000 = quiet warm-up and quiet
+    segment mostly, 6000 / 3000 = a quiet warm-up and one visitor inside the segment (the two ends of the interval meet), 1500 = a
+    visitor in most warm-ups.  Two alternating bytes give rank 1 throughout; the visitors rotate through 200 other bytes, so their
+    ranks -- and classes -- are large."""
+    n = (1 << 20) + 4321
+    t = np.where(np.arange(n) % 2 == 0, 7, 9).astype(np.uint8)
+    if spacing:
+        pos = np.arange(spacing, n, spacing)
+        t[pos] = (20 + (np.arange(len(pos)) * 37) % 200).astype(np.uint8)
+    got = jam.Ans().Encode(t)
+    exp = oracle.ans_encode(t)
+    assert np.array_equal(got, exp), _first_diff(got, exp)
+    assert np.array_equal(jam.Ans().Decode(exp, len(t), threads=4), t)
 
 
 @pytest.mark.parametrize("kind", KINDS)
