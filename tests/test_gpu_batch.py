@@ -75,6 +75,33 @@ def test_corrupt_block_is_isolated(gpu, oracle):
     assert ctx.block_decompress(good, len(comp[0]), ok, len(blocks[0])) == len(blocks[0]) and np.array_equal(ok.cpu().numpy(), blocks[0])
 
 
+def test_bad_trailer_index_is_isolated_in_a_batch_with_inverse_lanes(gpu, oracle):
+    """Eight blocks or more: the inverse BWTs of a batch run on three lanes (own stream, own scratch).  Two of nine blocks carry a
+    primary index outside [1, n] -- their rANS streams decode, their inverse BWTs refuse on the device -- and are reported in
+    their own slots; the seven others, on whichever lane, are exact; the call is repeated on the same context."""
+    torch, jam, ctx = gpu
+    dev = torch.device("cuda", 0)
+    kinds = ["text_survey", "runs", "dna", "text", "geometric", "silesia", "random", "text_survey", "two"]
+    sizes = [1_500_000, 700_000, 300_001, 2_000_000, 120, 1_048_576, 90_000, 1_200_007, 5_000]
+    blocks = [jam.corpus.make(k, n, 900 + i) for i, (k, n) in enumerate(zip(kinds, sizes))]
+    comp = []
+    for i, t in enumerate(blocks):
+        bw = oracle.bwt_forward(t)
+        if i in (2, 7):
+            tr = bw[len(bw) - jam.TRAILER:].view(np.int32)
+            tr[0] = len(t) + 7 if i == 2 else 0              # the primary index (bwt.cpp:171-174 reads this one): beyond the block / below 1
+        comp.append(oracle.ans_encode(bw))
+    d_in = [torch.from_numpy(c).to(dev) for c in comp]
+    for rep in range(2):
+        d_out = [torch.full((max(len(t), 1),), 0xEE, dtype=torch.uint8, device=dev) for t in blocks]
+        n, st = ctx.blocks_decompress(d_in, [len(c) for c in comp], d_out, [len(t) for t in blocks])
+        for i, t in enumerate(blocks):
+            if i in (2, 7):
+                assert st[i] == -3 and n[i] == 0, (rep, i, st[i])
+            else:
+                assert st[i] == 0 and n[i] == len(t) and np.array_equal(d_out[i][: n[i]].cpu().numpy(), t), (rep, i)
+
+
 def test_more_than_1024_chains_longest_first(gpu, oracle):
     """A batch with more chunk chains than one launch wave of the GPU (> 1024) takes the longest-first launch order (k_dec_order)
     and drops the one-chain-per-SIMD LDS reservation: 1104 blocks (138 distinct ones of ragged sizes and mixed content, eight
