@@ -79,25 +79,39 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *__restri
     // all sixteen loads of a thread are issued before the first one is used (no branch around a load: slots past the end re-read
     // the last element and are masked afterwards) -- with a load inside `if (i < n)` the compiler waits for every load in turn
     uint32_t dig[RS_ITEMS];
-#pragma unroll
-    for (int it = 0; it < RS_ITEMS; it++) {
-        const size_t i = base + (size_t)it * 64, ic = i < n ? i : n - 1;
-        if (TEXT) {                                    // digit of byte (56 - shift) / 8 of the suffix: one text byte
-            const uint32_t pos = (uint32_t)(n - 1 - ic) + (uint32_t)((56 - shift) >> 3);
-            dig[it] = reinterpret_cast<const uint8_t *>(txt.tb)[(pos < txt.n ? pos : txt.n - 1u) + txt.off];
-            if (pos >= txt.n) dig[it] = 0u;
-        } else dig[it] = (uint32_t)(keys[ic] >> shift) & 255u;
-    }
+    const uint64_t lt = lanemask_lt();
     // counting by wave match instead of LDS atomics: the lanes of a wave that hold the same digit are found with eight ballots
     // and ONE of them adds their number to the wave's counter -- plain LDS read-modify-write, one lane per address.  Text digits
     // are skewed (a tenth of the lanes of a wave hit the same bin): the atomic form spent 92 % of its LDS cycles in same-address
     // conflicts and cost about as much as the whole scatter pass.
-    const uint64_t lt = lanemask_lt();
+    if (!TEXT && (shift & 7) == 0 && (size_t)(blockIdx.x + 1) * RS_TILE <= n) {
+        // a whole tile of keys and a digit that is a byte of the key (every pass of the suffix sort): the digit is loaded as that
+        // byte from a wave-uniform base with the item offset in the instruction -- no clamp, no 64-bit shift, no validity masks
+        const uint8_t *bp = reinterpret_cast<const uint8_t *>(keys + (size_t)blockIdx.x * RS_TILE + (size_t)w * (64 * RS_ITEMS)) + (shift >> 3);
+        const uint32_t lo = (uint32_t)l * 8u;
 #pragma unroll
-    for (int it = 0; it < RS_ITEMS; it++) {
-        const bool valid = base + (size_t)it * 64 < n;
-        const uint64_t m = match_any8(dig[it], valid);
-        if (valid && (m & lt) == 0ull) h[w][dig[it]] += (uint32_t)__popcll(m);
+        for (int it = 0; it < RS_ITEMS; it++) dig[it] = bp[lo + (uint32_t)it * 512u];
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; it++) {
+            const uint64_t m = match_any8(dig[it], true);
+            if ((m & lt) == 0ull) h[w][dig[it]] += (uint32_t)__popcll(m);
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; it++) {
+            const size_t i = base + (size_t)it * 64, ic = i < n ? i : n - 1;
+            if (TEXT) {                                    // digit of byte (56 - shift) / 8 of the suffix: one text byte
+                const uint32_t pos = (uint32_t)(n - 1 - ic) + (uint32_t)((56 - shift) >> 3);
+                dig[it] = reinterpret_cast<const uint8_t *>(txt.tb)[(pos < txt.n ? pos : txt.n - 1u) + txt.off];
+                if (pos >= txt.n) dig[it] = 0u;
+            } else dig[it] = (uint32_t)(keys[ic] >> shift) & 255u;
+        }
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; it++) {
+            const bool valid = base + (size_t)it * 64 < n;
+            const uint64_t m = match_any8(dig[it], valid);
+            if (valid && (m & lt) == 0ull) h[w][dig[it]] += (uint32_t)__popcll(m);
+        }
     }
     __syncthreads();
     for (int d = threadIdx.x; d < 256; d += RS_THREADS) {
