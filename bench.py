@@ -208,9 +208,10 @@ def cpu_baseline(blocks, sample_mib: int):
 
 def per_block_size(jam, corpus, torch, dev, device_index: int, in_flight: int):
     """BASELINE.json's metric is "per block size"; Options.BlockSize is a first-class option of the reference (format.hpp:20-22,
-    main.cpp:78) and SURVEY 8d names {1, 64, 256 MiB}.  For each size, on the first 256 MiB of the enwik9-like text stream:
+    main.cpp:78) and SURVEY 8d names {1, 64, 256 MiB}; 8 MiB is the reference's default.  For each size, on the first 256 MiB of the
+    enwik9-like text stream:
       one_at_a_time   one block per call (jpk_dev_block_compress / _decompress), the next call starts when the last one returned;
-      streamed        the blocks of a 64 / 256 / 512 MiB stream through ONE jpk_dev_blocks_compress call (`in_flight` blocks in
+      streamed        the blocks of a 64 / 256 / 256 / 512 MiB stream through ONE jpk_dev_blocks_compress call (`in_flight` blocks in
                       flight) and ONE jpk_dev_blocks_decompress call (one grid per serial kernel over all blocks);
       same_bytes      streamed output == one-at-a-time output for every block, and every round trip == the input.
     Inputs and outputs resident in HBM; wall clock around synchronised calls; each leg warmed once."""
@@ -222,7 +223,8 @@ def per_block_size(jam, corpus, torch, dev, device_index: int, in_flight: int):
     try:
         # (block MiB, blocks of the stream, blocks timed one at a time, blocks in flight of the streamed compress: a 1 MiB block is
         # one chunk = one 5 ms chain on one of 1024 SIMDs, so small blocks want many in flight -- the library admits up to 16)
-        for bm, nstream, nsingle, nfl in ((1, 64, 8, 16), (64, 4, 2, in_flight), (256, 2, 1, in_flight)):
+        # 8 MiB is the reference's DEFAULT_BLOCKSIZE (format.hpp:20)
+        for bm, nstream, nsingle, nfl in ((1, 64, 8, 16), (8, 32, 4, 16), (64, 4, 2, in_flight), (256, 2, 1, in_flight)):
             bs = bm * MiB
             # a fresh context per size, and the previous size's worker contexts (and their streams) released first: streams are
             # dealt onto the hardware queues round robin at creation, leftovers of a finished leg should not sit beside this one
