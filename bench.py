@@ -44,7 +44,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
 
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 # algorithmic HBM bytes per processed unit of every timed kernel class, and what the class is
 # actually limited by ("hbm": streaming traffic; "hbm-random": 4-byte gathers/scatters, ~55 G accesses/s whatever the bytes;
@@ -77,7 +77,7 @@ def pmc_traffic(kernel_class: str, passes: float, launches: int):
     half-count of wide coalesced loads, MI355X_MICROARCH.md section HBM).  The encoder's launch shape follows the blocks in
     flight, so the file's bytes per PASS over the workload are scaled to the `launches` that `passes` passes took here.
     None if no PMC summary is committed."""
-    for rnd in (PROFILE_ROUND, "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if os.path.exists(path):
             break
@@ -203,7 +203,139 @@ def cpu_baseline(blocks, sample_mib: int):
             t.join()
         dt = time.perf_counter() - t0
         res["blocks_in_parallel"] = {"compress_MBps": round(sum(len(p) for p in parts) / 1e6 / dt, 3), "blocks": len(parts), "threads_per_block": per}
+        try:
+            res["throughput_mode"] = cpu_throughput_mode(impl, n)
+        except Exception as ex:       # noqa: BLE001 -- (host memory: 64 blocks x ~0.5 GB of suffix arrays)
+            res["throughput_mode"] = {"error": repr(ex)}
     return res, enc, n
+
+
+def physical_cores() -> int:
+    """distinct (package, core) pairs of the CPUs this process may run on; falls back to the logical count"""
+    try:
+        allowed = os.sched_getaffinity(0)
+        seen, cpu, phys = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("processor"):
+                cpu = int(ln.split(":")[1])
+            elif ln.startswith("physical id"):
+                phys = int(ln.split(":")[1])
+            elif ln.startswith("core id") and cpu in allowed:
+                seen.add((phys, int(ln.split(":")[1])))
+        if seen:
+            return len(seen)
+    except (OSError, ValueError, AttributeError):
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_throughput_mode(impl, block_bytes: int):
+    """The mode the reference itself would be run in on this box: Jampack::Compress / Decompress give every block to its own OpenMP
+    thread (jampack.cpp:215, 313) -- B = min(physical cores, 64) DISTINCT blocks at once, ONE reference thread each, compress
+    (ForwardBwt + Ans::Encode) and decompress (Ans::Decode + InverseBwt), aggregate MB/s of uncompressed bytes.  The blocks are
+    windows of `block_bytes` at 3 MiB strides over the first 256 MiB of the enwik9-like stream (distinct blocks, one corpus
+    generation).  About 10-20 s of wall time for both legs."""
+    import threading
+    from jampack_amd import corpus
+    MiB = 1 << 20
+    nb = max(1, min(physical_cores(), 64))
+    # host memory: a block in flight holds its suffix array / Map (4 B per byte), its images and buffers: ~7 B per byte; use at most
+    # half of what the box (or the cgroup) has free
+    avail = None
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable"):
+                avail = int(ln.split()[1]) * 1024
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            cur = int(open("/sys/fs/cgroup/memory.current").read())
+            avail = min(avail or (1 << 62), int(lim) - cur)
+    except (OSError, ValueError):
+        pass
+    if avail:
+        nb = max(1, min(nb, int(avail // 2 // (7 * block_bytes))))
+    data, _ = corpus.load_or_make("enwik9", start=0, count=256 * MiB)
+    stride = min(3 * MiB, max(0, (len(data) - block_bytes)) // max(nb - 1, 1))
+    stride -= stride % 120
+    parts = [np.ascontiguousarray(data[k * stride: k * stride + block_bytes]) for k in range(nb)]
+    impl.set_threads(1)
+    encs, backs = [None] * nb, [None] * nb
+
+    def comp(k):
+        encs[k] = impl.ans_encode(impl.bwt_forward(parts[k]))
+
+    def decomp(k):
+        backs[k] = impl.bwt_inverse(impl.ans_decode(encs[k], len(parts[k]) + 480, threads=1), threads=1)
+
+    out = {"blocks": nb, "block_bytes": int(block_bytes), "threads_per_block": 1, "physical_cores": physical_cores()}
+    for name, fn in (("compress_MBps", comp), ("decompress_MBps", decomp)):
+        th = [threading.Thread(target=fn, args=(k,)) for k in range(nb)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        out[name] = round(nb * block_bytes / 1e6 / dt, 1)
+        out[name.replace("_MBps", "_s")] = round(dt, 2)
+    out["round_trip_ok"] = bool(all(b is not None and np.array_equal(b, p) for b, p in zip(backs, parts)))
+    out["note"] = ("the reference's own multi-block mode (jampack.cpp:215, 313): one block per thread, blocks in parallel; aggregate over all blocks, "
+                   "compressed and decompressed at once; windows at 3 MiB strides over the enwik9-like stream")
+    return out
+
+
+def host_buffers(jam, corpus):
+    """PCIe-inclusive rates of the drop-in entry points (never `value`): jpk_block_compress / jpk_block_decompress through PAGEABLE
+    host buffers, T threads each with a context of its own borrowed from the library (what jam_block_pipeline does through the
+    shim, jampack.cpp:205-224 / 286-317), on sixteen 64 MiB blocks of the enwik9-like stream; H2D, kernels, D2H and the host copies
+    all inside the timed region."""
+    import threading
+    MiB = 1 << 20
+    bs, nb = 64 * MiB, 16
+    data, _ = corpus.load_or_make("enwik9", start=0, count=256 * MiB)
+    stride = (len(data) - bs) // (nb - 1)
+    parts = [np.ascontiguousarray(data[k * stride: k * stride + bs]) for k in range(nb)]
+    out = {"blocks": nb, "block_bytes": bs}
+    comp = [None] * nb
+    try:
+        for T in (1, 8, 16):
+            res = {}
+            for leg in ("compress", "decompress"):
+                back = [None] * nb
+                nxt = [0]
+                lock = threading.Lock()
+
+                def work():
+                    while True:
+                        with lock:
+                            k = nxt[0]
+                            nxt[0] += 1
+                        if k >= nb:
+                            return
+                        if leg == "compress":
+                            comp[k] = jam.block_compress(parts[k])
+                        else:
+                            back[k] = jam.block_decompress(comp[k], bs)
+
+                if T == 1 and leg == "compress":
+                    jam.block_compress(parts[0])            # the first call of the process sizes an arena and loads code: not timed
+                th = [threading.Thread(target=work) for _ in range(T)]
+                t0 = time.perf_counter()
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                dt = time.perf_counter() - t0
+                res[leg + "_MBps"] = round(nb * bs / 1e6 / dt, 1)
+                if leg == "decompress":
+                    res["round_trip_ok"] = bool(all(np.array_equal(b, p) for b, p in zip(back, parts)))
+            out[f"threads_{T}"] = res
+            jam.shutdown()                                   # the threads' contexts (6 GB arenas) go back before the next T
+    finally:
+        jam.shutdown()
+    out["note"] = ("pageable host buffers in, pageable host buffers out, every block through jpk_block_compress / jpk_block_decompress on T host threads "
+                   "(one library context per thread); MB/s of uncompressed bytes, PCIe and host copies included")
+    return out
 
 
 def per_block_size(jam, corpus, torch, dev, device_index: int, in_flight: int):
@@ -765,6 +897,11 @@ def main():
                 extra["per_block_size"] = per_block_size(jam, corpus, torch, dev, local_rank, nctx)
             except Exception as ex:       # noqa: BLE001 -- an extra must never take the headline down
                 extra["per_block_size"] = {"error": repr(ex)}
+        if not args.no_block_sizes and not args.limit_bytes:
+            try:
+                extra["host_buffers"] = host_buffers(jam, corpus)
+            except Exception as ex:       # noqa: BLE001
+                extra["host_buffers"] = {"error": repr(ex)}
         if not args.no_cpu_baseline:
             try:
                 cb, ref_enc, n = cpu_baseline(blocks, args.cpu_sample_mib)

@@ -801,6 +801,53 @@ void batch_ctx_release(int device, jpk_ctx *c, uint64_t generation)
 }
 }  // namespace
 
+namespace {
+// Small blocks -- the reference's default block is 8 MiB, its smallest 1 MiB (format.hpp:20-22), and Jampack::Compress feeds
+// `Threads` of them at a time (jampack.cpp:205-224) -- are compressed in GROUPS: one suffix sort over the blocks of a group
+// (jpk_fwd_bwt_group_device), one set of entropy grids over all their chunks (jpk_ans_encode_group_device), one host
+// synchronisation per group instead of ~200 launches and a synchronisation per block.  Bytes per block are those of
+// jpk_dev_block_compress.
+constexpr int32_t GROUP_BLOCK_MAX = 16 << 20;       // blocks up to this size are grouped
+size_t group_target_bytes()
+{
+    static const size_t v = [] { const char *e = getenv("JPK_GROUP_MIB"); const long m = e ? atol(e) : 16; return (size_t)(m < 1 ? 1 : (m > 512 ? 512 : m)) << 20; }();
+    return v;
+}
+
+int group_compress(jpk_ctx *c, int nb, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out, const int32_t *out_cap, int32_t *out_len,
+                   int32_t *status)
+{
+    std::vector<uint32_t> first((size_t)nb);
+    std::vector<int32_t> mid((size_t)nb);
+    uint64_t nlen_total = 0;
+    uint32_t nch = 0;
+    for (int b = 0; b < nb; b++) {
+        first[b] = nch;
+        mid[b] = in_len[b] + JPK_TRAILER_BYTES;
+        nch += ((uint32_t)mid[b] + JPK_ANS_CHUNK - 1) / JPK_ANS_CHUNK;
+        nlen_total += (uint32_t)in_len[b] - (uint32_t)in_len[b] % JPK_BWT_UNITS;
+    }
+    const size_t stage_bytes = (size_t)nch * JPK_ANS_CHUNK;
+    JPK_TRY(buf_ensure(c, &c->stage_out, &c->stage_out_cap, stage_bytes));
+    const size_t a_sort = jpk_fwd_bwt_group_arena_bytes((uint32_t)nlen_total, nb), a_enc = jpk_ans_encode_group_arena_bytes(nch, nb);
+    // (+ room for the encoder's capacity sink: a block that does not fit its buffer is written there instead)
+    JPK_TRY(jpk_arena_ensure(c, (a_sort > a_enc ? a_sort : a_enc) + (size_t)GROUP_BLOCK_MAX + (1u << 20)));
+    std::vector<uint8_t *> img((size_t)nb);
+    for (int b = 0; b < nb; b++) {
+        img[b] = c->stage_out + (size_t)first[b] * JPK_ANS_CHUNK;
+        // bwt.cpp:35: a block shorter than 120 bytes leaves its 480 trailer bytes alone -- defined bytes here, as in jpk_dev_block_compress
+        if (in_len[b] < JPK_BWT_UNITS) JPK_HIP(hipMemsetAsync(img[b], 0, (size_t)mid[b], c->stream));
+    }
+    JPK_TRY(jpk_gate_enter(c));
+    int rc = jpk_fwd_bwt_group_device(c, nb, d_in, in_len, img.data());
+    if (rc == JPK_OK) rc = jpk_ans_encode_group_device(c, nb, c->stage_out, first.data(), mid.data(), d_out, out_cap, out_len, status);   // synchronises
+    jpk_gate_leave(c);
+    if (rc == JPK_OK) jpk_sa_stats_sync(c);
+    else (void)hipStreamSynchronize(c->stream);            // the pinned tables and the staged images stay valid until the queue is empty
+    return rc;
+}
+}  // namespace
+
 extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out,
                                        const int32_t *out_cap, int32_t *out_len, int32_t *status, int32_t in_flight)
 {
@@ -812,8 +859,25 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
         if (in_len[b] < 0 || out_cap[b] < 0 || !d_out[b] || (in_len[b] > 0 && !d_in[b])) return JPK_E_ARG;
     std::vector<int32_t> st_local((size_t)nblocks);
     int32_t *stp = status ? status : st_local.data();
+    // tasks: a large block, or a group of consecutive small ones (at least two, up to the target size / 256 blocks)
+    struct Task { int first, count; };
+    std::vector<Task> tasks;
+    {
+        static const bool grouping = [] { const char *e = getenv("JPK_GROUP"); return e ? atoi(e) != 0 : true; }();
+        const size_t target = group_target_bytes();
+        int b = 0;
+        while (b < nblocks) {
+            if (!grouping || in_len[b] > GROUP_BLOCK_MAX) { tasks.push_back(Task{b, 1}); b++; continue; }
+            int e = b;
+            size_t bytes = 0;
+            while (e < nblocks && in_len[e] <= GROUP_BLOCK_MAX && e - b < 256 && (e == b || bytes + (size_t)in_len[e] <= target)) { bytes += (size_t)in_len[e]; e++; }
+            tasks.push_back(Task{b, e - b});
+            b = e;
+        }
+    }
+    const int ntasks = (int)tasks.size();
     int nw = in_flight > 0 ? in_flight : 4;
-    if (nw > nblocks) nw = nblocks;
+    if (nw > ntasks) nw = ntasks;
     if (nw > 16) nw = 16;
     uint64_t generation;
     { CtxPool &p = pool(); std::lock_guard<std::mutex> g(p.mu); generation = p.generation; }
@@ -827,10 +891,17 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
         if (hipSetDevice(c->device) != hipSuccess) return;                  // a fresh thread starts on device 0
         if (c != ctx && hipStreamWaitEvent(c->stream, ctx->ev_batch, 0) != hipSuccess) return;   // leaves its share to the others
         for (;;) {
-            const int b = next.fetch_add(1, std::memory_order_relaxed);
-            if (b >= nblocks) return;
-            out_len[b] = 0;
-            stp[b] = jpk_dev_block_compress(c, d_in[b], in_len[b], d_out[b], out_cap[b], &out_len[b]);
+            const int k = next.fetch_add(1, std::memory_order_relaxed);
+            if (k >= ntasks) return;
+            const int b = tasks[(size_t)k].first, nb = tasks[(size_t)k].count;
+            if (nb == 1) {
+                out_len[b] = 0;
+                stp[b] = jpk_dev_block_compress(c, d_in[b], in_len[b], d_out[b], out_cap[b], &out_len[b]);
+                continue;
+            }
+            const int rc = group_compress(c, nb, d_in + b, in_len + b, d_out + b, out_cap + b, out_len + b, stp + b);
+            if (rc != JPK_OK)                                   // the group as a whole failed (allocation, device): every block says so
+                for (int j = b; j < b + nb; j++) { out_len[j] = 0; stp[j] = rc; }
         }
     };
     // workers 1 .. nw-1 on contexts of their own; a worker that cannot get one (or a thread that cannot be started) leaves its

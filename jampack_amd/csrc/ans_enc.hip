@@ -32,10 +32,15 @@ struct EncDims {
     uint32_t ncl;         // chunks of this launch group (<= nch)
     const uint32_t *cmap; // launch index -> chunk id (null: identity).  The densest chunks are launched first as their own
                           // group so that their rANS chains start while the other chunks are still in the parallel stages.
+    // group encode (the images of several blocks, each starting at a chunk boundary of one staging buffer: jpk_ans_encode_group_device)
+    const uint32_t *clen; // bytes of every chunk (null: one block, the formula below)
+    const uint32_t *cblk; // block of every chunk
+    uint8_t *const *bout; // output buffer of every block (device array)
 };
 __device__ __forceinline__ uint32_t chunk_of(const EncDims &d, uint32_t i) { return d.cmap ? d.cmap[i] : i; }
 __device__ __forceinline__ uint32_t chunk_len(const EncDims &d, uint32_t c)
 {
+    if (d.clen) return d.clen[c];
     uint64_t beg = (uint64_t)c * d.chunk;
     uint64_t left = d.len - beg;
     return left < d.chunk ? (uint32_t)left : d.chunk;
@@ -973,19 +978,42 @@ __device__ __forceinline__ uint32_t rans_step_turn2(uint32_t xprev, const uint4 
     return xn;
 }
 
-// One wave per chunk; no LDS.  The four chains of a chunk (pair j -> chain j & 3, ans.cpp:189-208) own one row of
-// 16 lanes each; lane s of a row holds the record of step K - s of the current batch of 16 steps (one coalesced
-// 16-byte global load per lane per batch, eight batches prefetched).  The state travels: every step all lanes run
-// the same twelve instructions on the state handed over by their left neighbour (DPP row rotate, no LDS, no
-// readlane), so after step t lane t holds the chain's true state and the others compute values nobody uses.  A lane
-// keeps the state it was handed on its own turn; per batch the wave stores those 64 states (one coalesced 4-byte store)
-// and nothing else: the emitted bytes and their stream positions are a pure function of (state before the step, record)
-// and are computed afterwards by wide kernels (k_emit_count / k_emit_prefix / k_put_payload).  This wave is the serial
-// floor of the whole stage -- 13 issue slots per step plus ~1 per step of batch overhead.
-// Steps past a chain's last pair use the identity records k_pairs has written.
+// One wave per chunk.  The four chains of a chunk (pair j -> chain j & 3, ans.cpp:189-208) own one row of
+// 16 lanes each; lane s of a row holds the record of step K - s of the current batch of 16 steps.  The state travels: every step
+// all lanes run the same twelve instructions on the state handed over by their left neighbour (DPP row rotate, no readlane), so
+// after step t lane t holds the chain's true state and the others compute values nobody uses.  A lane keeps the state it was
+// handed on its own turn; per batch the wave stores those 64 states (one coalesced 4-byte store) and nothing else: the emitted
+// bytes and their stream positions are a pure function of (state before the step, record) and are computed afterwards by wide
+// kernels (k_emit_count / k_emit_prefix / k_put_payload).  This wave is the serial floor of the whole stage -- 13 issue slots per
+// step plus ~1 per step of batch overhead.  Steps past a chain's last pair use the identity records k_pairs has written.
+//
+// Record prefetch, correct by construction (round 4).  Sixteen batches of records are in flight (~6 us of steps: enough to cover a
+// record load while suffix-sort kernels of another block saturate the memory system).  Rounds 2-3 kept them in sixteen register
+// tuples loaded from inline asm, which the compiler believed to be valid from the asm statement on: a register copy it chose to
+// insert (loop back-edge, spill) before the hand-counted s_waitcnt copied stale registers -- timing-dependent wrong bytes, guarded
+// only by a regex over the assembly.  Now the records land in an LDS ring (global_load_lds_dwordx4: 1 KiB per wave-instruction,
+// lane l -> ring[slot][l]) and NO register holds data in flight: a record becomes a register value through an ordinary ds_read
+// that the compiler tracks itself (lgkmcnt), placed behind an asm s_waitcnt with a memory clobber that it cannot be moved across.
+// What remains hand-counted is vmcnt, and the count is exact by program text: every vector-memory instruction of the loop (one
+// LDS-DMA load, one state store per batch) is issued from asm volatile, loads and stores share vmcnt and retire in order, and
+// anything the compiler might add (a spill) is YOUNGER than the load being waited for or older than all of them, which can only make
+// the wait stricter.  tests/test_chain_codegen.py checks the generated loop for exactly that instruction census.
+constexpr int RANS_RING = 16;                   // batches of records in flight
+constexpr int RANS_SLACK = 16 * RANS_RING;      // records in front of the record array: the prefetches of batches that do not exist read there
+// One statement per batch for the three instructions that touch vector memory or M0: the LDS-DMA load takes its LDS address from
+// M0 and needs one instruction between the SALU write of M0 and itself (the state store is that instruction), and M0 is
+// compiler-reserved: the kernel uses it nowhere else (tests/test_chain_codegen.py checks), so it is not saved.  Addresses: a
+// wave-uniform base in SGPRs + a 32-bit lane offset + an immediate -- inside the sixteen-fold unrolled loop body nothing is computed.
+#define JPK_RING_STORE_LOAD(SLOT, SOFF, LOFF)                                                                          \
+    asm volatile("s_mov_b32 m0, %[slot]\n\t"                                                                           \
+                 "global_store_dword %[xoff], %[keep], %[xbase] offset:" #SOFF "\n\t"                                  \
+                 "global_load_lds_dwordx4 %[roff], %[rbase] offset:" #LOFF                                             \
+                 : : [slot] "s"(ring0 + (uint32_t)(SLOT) * 1024u), [xoff] "v"(xoff), [keep] "v"(keep), [xbase] "s"(xbase), [roff] "v"(roff), [rbase] "s"(rbase)   \
+                 : "memory")
 __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ recs, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
                                                   uint32_t *__restrict__ xs, uint32_t *__restrict__ fstate, uint64_t *__restrict__ stamp)
 {
+    __shared__ uint4 ring[RANS_RING][64];
     const uint64_t t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
     // this wave is a long dependent chain: let it win the issue arbitration against the wide kernels of other chunks /
     // blocks that share its SIMD (priority, then age)
@@ -1000,123 +1028,67 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
     }
     const int chain = t >> 4, s = t & 15;
     const size_t lane_stride = rans_lane_stride(rle_stride);
-    const uint4 *rc = recs + ((size_t)c * 4 + chain) * lane_stride;
-    uint32_t *xo = xs + ((size_t)c * 4 + chain) * lane_stride;
     const int32_t nbatch = (int32_t)((np - 1) / 4) / 16 + 1;
-    int32_t K = 16 * nbatch - 1 - s;                               // this lane's step index in the current batch
+    const int32_t K0 = 16 * nbatch - 1 - s;                        // this lane's step index in the first batch
     uint32_t x = RANS_L;                                           // lane 15 of a row hands the start state to lane 0
-    // Record loads are issued from inline asm so that the wait counts are ours: loads and stores share vmcnt and retire in
-    // order, and the compiler (which has to be conservative across the early exits below) waited with vmcnt(6), i.e. for the
-    // kept-state stores of the last three batches as well -- a store acknowledgement on the chain of every batch.  Sixteen
-    // batches (~6 us of steps) are in flight, enough to cover a record load while suffix-sort kernels of another block
-    // saturate the memory system; in steady state 15 loads and 15 stores are younger than the record a batch is about to
-    // use: vmcnt(30).  Fifteen dummy stores in the prologue make the very first batches look like steady state.
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#define JPK_LOADREC(R, KK)                                                                                 \
-    {                                                                                                      \
-        const int32_t kk_ = (KK) < 0 ? 0 : (KK);              /* prefetches past the last batch re-read record 0 */ \
-        const uint4 *p_ = rc + kk_;                                                                        \
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(R) : "v"(p_) : "memory");                    \
+    const uint32_t ring0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&ring[0][0];     // LDS byte address
+    // wave-uniform bases (SGPR pairs) and 32-bit lane offsets in bytes.  The record base sits RANS_SLACK records in front of the
+    // chunk's first record, so that the offset of a prefetch past the last batch (step index down to -256) stays non-negative: those
+    // loads read the slack enc_layout leaves in front of the array (or the chains of the chunk before) and nobody uses them.
+    const uint4 *rbase = recs + (size_t)c * 4 * lane_stride - RANS_SLACK;
+    uint32_t *xbase = xs + (size_t)c * 4 * lane_stride;
+    uint32_t roff = (uint32_t)(((size_t)chain * lane_stride + (size_t)(K0 + RANS_SLACK)) * 16u);
+    uint32_t xoff = (uint32_t)(((size_t)chain * lane_stride + (size_t)K0) * 4u);
+    // prologue: the first sixteen batches' records, all landed before the loop starts -- one memory latency per chunk -- so that
+    // from here on the steady-state count below holds for every wait
+#define JPK_RING_PROLOGUE(SLOT, LOFF)                                                                                   \
+    asm volatile("s_mov_b32 m0, %[slot]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[roff], %[rbase] offset:" #LOFF          \
+                 : : [slot] "s"(ring0 + (uint32_t)(SLOT) * 1024u), [roff] "v"(roff), [rbase] "s"(rbase) : "memory")
+    JPK_RING_PROLOGUE(0, 0);      JPK_RING_PROLOGUE(1, -256);   JPK_RING_PROLOGUE(2, -512);   JPK_RING_PROLOGUE(3, -768);
+    JPK_RING_PROLOGUE(4, -1024);  JPK_RING_PROLOGUE(5, -1280);  JPK_RING_PROLOGUE(6, -1536);  JPK_RING_PROLOGUE(7, -1792);
+    JPK_RING_PROLOGUE(8, -2048);  JPK_RING_PROLOGUE(9, -2304);  JPK_RING_PROLOGUE(10, -2560); JPK_RING_PROLOGUE(11, -2816);
+    JPK_RING_PROLOGUE(12, -3072); JPK_RING_PROLOGUE(13, -3328); JPK_RING_PROLOGUE(14, -3584); JPK_RING_PROLOGUE(15, -3840);
+#undef JPK_RING_PROLOGUE
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+    roff -= 16u * 256u;                                            // from here on: the lane's record sixteen batches ahead
+    uint4 cur = ring[0][t];
+    // One batch: the record of the NEXT batch (slot k + 1) was requested sixteen batches ago minus one; issued after it, in program
+    // order: the stores of 14 batches and the loads of 14 batches -- vmcnt(28) -- (the first fifteen batches read slots the
+    // prologue has drained).  It becomes a register value through an ordinary LDS read behind the wait, used one batch later.
+    // Then 16 steps of every chain on `cur`, the store of the kept states, and the request for batch + 16 into the slot `cur` came from.
+#define JPK_BATCH(KSLOT, SOFF, LOFF)                                                                                    \
+    {                                                                                                                   \
+        asm volatile("s_waitcnt vmcnt(28)" : : : "memory");                                                             \
+        const uint4 nxt = ring[((KSLOT) + 1) & (RANS_RING - 1)][t];                                                     \
+        _Pragma("unroll") for (int st = 0; st < 16; st += 2)                                                            \
+            x = rans_step_turn2(x, cur, keep, 0x0001000100010001ull << st, 0x0001000100010001ull << (st + 1));          \
+        JPK_RING_STORE_LOAD(KSLOT, SOFF, LOFF);                                                                         \
+        cur = nxt;                                                                                                      \
     }
-    // one batch = wait for its records, 16 steps of every chain (lane s: step KK), one store of the kept states
-#define JPK_BATCH(R, KK)                                                                                   \
-    {                                                                                                      \
-        asm volatile("s_waitcnt vmcnt(30)" : "+v"(R) : : "memory");                                        \
-        uint32_t keep = 0;                                                                                 \
-        const uint4 rr = make_uint4(R.x, R.y, R.z, R.w);                                                   \
-        _Pragma("unroll") for (int st = 0; st < 16; st += 2)                                               \
-            x = rans_step_turn2(x, rr, keep, 0x0001000100010001ull << st, 0x0001000100010001ull << (st + 1)); \
-        xo[KK] = keep;                                                                                     \
-        asm volatile("" : : : "memory");                                                                   \
+    uint32_t keep = 0;                                             // (every lane's turn comes once per batch and overwrites it)
+    for (int32_t left = nbatch; left > 0; left -= RANS_RING) {    // batches left when the body starts
+        JPK_BATCH(0, 0, 0)            if (left <= 1) break;
+        JPK_BATCH(1, -64, -256)       if (left <= 2) break;
+        JPK_BATCH(2, -128, -512)      if (left <= 3) break;
+        JPK_BATCH(3, -192, -768)      if (left <= 4) break;
+        JPK_BATCH(4, -256, -1024)     if (left <= 5) break;
+        JPK_BATCH(5, -320, -1280)     if (left <= 6) break;
+        JPK_BATCH(6, -384, -1536)     if (left <= 7) break;
+        JPK_BATCH(7, -448, -1792)     if (left <= 8) break;
+        JPK_BATCH(8, -512, -2048)     if (left <= 9) break;
+        JPK_BATCH(9, -576, -2304)     if (left <= 10) break;
+        JPK_BATCH(10, -640, -2560)    if (left <= 11) break;
+        JPK_BATCH(11, -704, -2816)    if (left <= 12) break;
+        JPK_BATCH(12, -768, -3072)    if (left <= 13) break;
+        JPK_BATCH(13, -832, -3328)    if (left <= 14) break;
+        JPK_BATCH(14, -896, -3584)    if (left <= 15) break;
+        JPK_BATCH(15, -960, -3840)
+        xoff -= 16u * 64u;
+        roff -= 16u * 256u;
     }
-    // (asm, so that the compiler cannot merge them)
-#define JPK_DUMMYST { uint32_t *q_ = xo + K; const uint32_t z_ = 0u; asm volatile("global_store_dword %0, %1, off" : : "v"(q_), "v"(z_) : "memory"); }
-    u32x4 r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15;
-    JPK_LOADREC(r0, K - 0)
-    JPK_DUMMYST
-    JPK_LOADREC(r1, K - 16)
-    JPK_DUMMYST
-    JPK_LOADREC(r2, K - 32)
-    JPK_DUMMYST
-    JPK_LOADREC(r3, K - 48)
-    JPK_DUMMYST
-    JPK_LOADREC(r4, K - 64)
-    JPK_DUMMYST
-    JPK_LOADREC(r5, K - 80)
-    JPK_DUMMYST
-    JPK_LOADREC(r6, K - 96)
-    JPK_DUMMYST
-    JPK_LOADREC(r7, K - 112)
-    JPK_DUMMYST
-    JPK_LOADREC(r8, K - 128)
-    JPK_DUMMYST
-    JPK_LOADREC(r9, K - 144)
-    JPK_DUMMYST
-    JPK_LOADREC(r10, K - 160)
-    JPK_DUMMYST
-    JPK_LOADREC(r11, K - 176)
-    JPK_DUMMYST
-    JPK_LOADREC(r12, K - 192)
-    JPK_DUMMYST
-    JPK_LOADREC(r13, K - 208)
-    JPK_DUMMYST
-    JPK_LOADREC(r14, K - 224)
-    JPK_DUMMYST
-    JPK_LOADREC(r15, K - 240)
-    for (int32_t b = 0; b < nbatch; b += 16) {
-        JPK_BATCH(r0, K - 0)
-        if (b + 1 >= nbatch) break;
-        JPK_LOADREC(r0, K - 256)
-        JPK_BATCH(r1, K - 16)
-        if (b + 2 >= nbatch) break;
-        JPK_LOADREC(r1, K - 272)
-        JPK_BATCH(r2, K - 32)
-        if (b + 3 >= nbatch) break;
-        JPK_LOADREC(r2, K - 288)
-        JPK_BATCH(r3, K - 48)
-        if (b + 4 >= nbatch) break;
-        JPK_LOADREC(r3, K - 304)
-        JPK_BATCH(r4, K - 64)
-        if (b + 5 >= nbatch) break;
-        JPK_LOADREC(r4, K - 320)
-        JPK_BATCH(r5, K - 80)
-        if (b + 6 >= nbatch) break;
-        JPK_LOADREC(r5, K - 336)
-        JPK_BATCH(r6, K - 96)
-        if (b + 7 >= nbatch) break;
-        JPK_LOADREC(r6, K - 352)
-        JPK_BATCH(r7, K - 112)
-        if (b + 8 >= nbatch) break;
-        JPK_LOADREC(r7, K - 368)
-        JPK_BATCH(r8, K - 128)
-        if (b + 9 >= nbatch) break;
-        JPK_LOADREC(r8, K - 384)
-        JPK_BATCH(r9, K - 144)
-        if (b + 10 >= nbatch) break;
-        JPK_LOADREC(r9, K - 400)
-        JPK_BATCH(r10, K - 160)
-        if (b + 11 >= nbatch) break;
-        JPK_LOADREC(r10, K - 416)
-        JPK_BATCH(r11, K - 176)
-        if (b + 12 >= nbatch) break;
-        JPK_LOADREC(r11, K - 432)
-        JPK_BATCH(r12, K - 192)
-        if (b + 13 >= nbatch) break;
-        JPK_LOADREC(r12, K - 448)
-        JPK_BATCH(r13, K - 208)
-        if (b + 14 >= nbatch) break;
-        JPK_LOADREC(r13, K - 464)
-        JPK_BATCH(r14, K - 224)
-        if (b + 15 >= nbatch) break;
-        JPK_LOADREC(r14, K - 480)
-        JPK_BATCH(r15, K - 240)
-        JPK_LOADREC(r15, K - 496)
-        K -= 256;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");            // the prefetches of batches that do not exist
-#undef JPK_LOADREC
-#undef JPK_DUMMYST
 #undef JPK_BATCH
+#undef JPK_RING_STORE_LOAD
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");            // the prefetches of batches that do not exist must land before the LDS is released
     if (s == 15) fstate[(size_t)c * 4 + chain] = x;               // the last batch ends at step 0: lane 15 holds each chain's final state
     if (t == 0) {
         // diagnostics: shader cycles and 100 MHz ticks this chunk's chains took (jpk_stats.enc_chain_*)
@@ -1214,6 +1186,7 @@ __global__ __launch_bounds__(64) void k_out_offsets(EncDims d, const uint32_t *_
     uint64_t o = 0, rs = 0;
     uint32_t worst = 0;                      // the chunk whose chains ran longest
     for (uint32_t c = 0; c < d.nch; c++) {
+        if (d.cblk && c && d.cblk[c] != d.cblk[c - 1]) o = 0;      // group encode: every block's stream starts at 0 of its own buffer
         outoff[c] = o;
         o += (uint64_t)hsize[c] + csize[c];
         rs += rlen[c];
@@ -1233,7 +1206,7 @@ __global__ __launch_bounds__(TB) void k_put_headers(EncDims d, const uint8_t *__
                                                    const uint64_t *__restrict__ outoff, const uint32_t *__restrict__ fstate, uint8_t *__restrict__ out)
 {
     const uint32_t c = blockIdx.x;
-    uint8_t *o = out + outoff[c];
+    uint8_t *o = (d.cblk ? d.bout[d.cblk[c]] : out) + outoff[c];
     const uint32_t hs = hsize[c];
     for (uint32_t i = threadIdx.x; i < hs; i += TB) o[i] = hdr[(size_t)c * HDR_MAX + i];
     if (threadIdx.x < 16) {
@@ -1269,7 +1242,7 @@ __global__ __launch_bounds__(TB) void k_put_payload(const uint32_t *__restrict__
     uint32_t tot;
     const uint32_t inc = block_incl_scan<OpSum>(n, sm, &tot);
     uint32_t after = tsuf[(size_t)c * etpc + tile] + (tot - inc);       // bytes of all pairs after my 16
-    uint8_t *end = out + outoff[c] + hsize[c] + csize[c];
+    uint8_t *end = (d.cblk ? d.bout[d.cblk[c]] : out) + outoff[c] + hsize[c] + csize[c];
 #pragma unroll
     for (int k = 15; k >= 0; k--) {
         const uint32_t cnt = e[k] >> 16;
@@ -1334,7 +1307,7 @@ void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what)
         b.seg_end = a.get<int32_t>(segs);
         b.seg_start = a.get<int32_t>(segs);
         b.seg_tab = a.get<uint16_t>(segs * 32);
-        b.recs = a.get<uint4>((size_t)d.nch * 4 * rans_lane_stride(stride));
+        b.recs = a.get<uint4>((size_t)d.nch * 4 * rans_lane_stride(stride) + RANS_SLACK) + (a.planning ? 0 : RANS_SLACK);   // slack in front: k_rans_lanes' prefetches past the last batch
         b.fr16 = a.get<uint16_t>((size_t)d.nch * 4 * rans_lane_stride(stride));
         b.pairs = (what & LAY_PLAIN) ? a.get<uint32_t>((size_t)d.nch * stride * 2) : nullptr;
     }
@@ -1359,6 +1332,9 @@ EncDims make_dims(uint32_t len, uint32_t chunk)
     d.tpc = (chunk + ATILE - 1) / ATILE;
     d.ncl = d.nch;
     d.cmap = nullptr;
+    d.clen = nullptr;
+    d.cblk = nullptr;
+    d.bout = nullptr;
     return d;
 }
 
@@ -1449,22 +1425,13 @@ size_t jpk_ans_encode_arena_bytes(uint32_t len)
     return plan.need;
 }
 
-int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
+namespace {
+// everything of the stage up to the chunks' output offsets, enqueued on ctx->stream (and the group streams): rank coding, RLE0,
+// models, the rANS chains, emit counts, headers, offsets.  `d` describes the chunks (one block: make_dims; a group of blocks: the
+// per-chunk tables), `inflight_n` the blocks the device is compressing right now (drives the launch grouping).
+int encode_core(jpk_ctx *ctx, const uint8_t *d_in, const EncDims &d, EncBufs &b, int inflight_n)
 {
-    const JpkCompressInflight inflight(ctx->device);      // blocks of this device in their forward BWT or entropy encode right now, this one included
-    *out_len = 0;
-    ctx->stats.ans_chunks = 0;
-    ctx->stats.ans_rle_symbols = 0;
-    if (len == 0) return JPK_OK;
     hipStream_t st = ctx->stream;
-    const EncDims d = make_dims((uint32_t)len, ANS_CHUNK);
-    EncBufs b;
-    Arena plan(ctx, true);
-    enc_layout(plan, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
-    JPK_TRY(jpk_arena_ensure(ctx, plan.need));
-    Arena real(ctx, false);
-    enc_layout(real, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
-
     const size_t stride = d.chunk;
     JPK_HIP(hipMemsetAsync(b.qhist, 0, (size_t)d.nch * 6 * NQ * QSTRIDE * 4, st));
     // The stage is bounded by the longest rANS chain (the densest chunk), a single wave, and several of the parallel
@@ -1487,7 +1454,7 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     // Graded launch groups shorten ONE block (its longest chains start after a sixteenth of the parallel work) but cost throughput
     // when other blocks fill the machine anyway (more kernels, more streams on the hardware queues): 4 groups alone, 2 beside one
     // other block, 1 beside two or more (default bench, 4 blocks in flight: 3.23 / 3.32 / 3.46 GB/s with 4 / 2 / 1 groups)
-    int ngroups = jpk_enc_groups_for(inflight.n, d.nch);
+    int ngroups = jpk_enc_groups_for(inflight_n, d.nch);
     static const int groups_env = [] { const char *e = getenv("JPK_ENC_GROUPS"); return e ? atoi(e) : 0; }();
     if (groups_env >= 1 && groups_env <= jpk_ctx::ENC_GROUPS && (uint32_t)groups_env <= d.nch) ngroups = groups_env;
     // group streams are created when a block first needs them and then stay with the context (parked while the device is busy
@@ -1550,6 +1517,28 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_headers, dim3(d.nch), dim3(256), d, b.freq, b.csize, b.rlen, b.hdr, b.hsize);
     JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_out_offsets, dim3(1), dim3(64), d, b.csize, b.rlen, b.hsize, b.outoff, ctx->d_mail, b.stamp);
     JPK_HIP(hipGetLastError());
+    return JPK_OK;
+}
+}  // namespace
+
+int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out, int32_t out_cap, int32_t *out_len)
+{
+    const JpkCompressInflight inflight(ctx->device);      // blocks of this device in their forward BWT or entropy encode right now, this one included
+    *out_len = 0;
+    ctx->stats.ans_chunks = 0;
+    ctx->stats.ans_rle_symbols = 0;
+    if (len == 0) return JPK_OK;
+    hipStream_t st = ctx->stream;
+    const EncDims d = make_dims((uint32_t)len, ANS_CHUNK);
+    EncBufs b;
+    Arena plan(ctx, true);
+    enc_layout(plan, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
+    JPK_TRY(jpk_arena_ensure(ctx, plan.need));
+    Arena real(ctx, false);
+    enc_layout(real, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
+
+    JPK_TRY(encode_core(ctx, d_in, d, b, inflight.n));
+    const size_t stride = d.chunk;
     uint32_t mail[9];
     JPK_TRY(jpk_read_mail(ctx, mail, 9));
     ctx->stats.enc_chain_cycles = (int64_t)(((uint64_t)mail[5] << 32) | mail[4]);
@@ -1573,6 +1562,89 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     JPK_HIP(hipGetLastError());
     JPK_HIP(hipStreamSynchronize(st));
     *out_len = (int32_t)total;
+    return JPK_OK;
+}
+
+// ---- group encode: the images of several (small) blocks through ONE set of grids ---------------------------------------------
+// Chunks are independent (ans.cpp:136-140), so the chunks of all blocks of a group run through the same launches; a block's image
+// starts at a chunk boundary of the staging buffer `d_stage` (block b at first_chunk[b] * 1 MiB), every chunk knows its length, its
+// block and, through the block, its output buffer; offsets restart at every block.  One host synchronisation per group.
+size_t jpk_ans_encode_group_arena_bytes(uint32_t nchunks, int nblk)
+{
+    EncDims d = make_dims(nchunks * ANS_CHUNK, ANS_CHUNK);
+    EncBufs b;
+    jpk_ctx dummy;
+    Arena plan(&dummy, true);
+    enc_layout(plan, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
+    plan.get<uint32_t>(nchunks);
+    plan.get<uint32_t>(nchunks);
+    plan.get<uint8_t *>((size_t)nblk);
+    return plan.need;
+}
+
+// The arena (from ctx->arena_base on) must hold jpk_ans_encode_group_arena_bytes(); the caller has sized it.
+int jpk_ans_encode_group_device(jpk_ctx *ctx, int nblk, const uint8_t *d_stage, const uint32_t *first_chunk, const int32_t *mid_len, uint8_t *const *d_out,
+                                const int32_t *out_cap, int32_t *out_len, int32_t *status)
+{
+    const JpkCompressInflight inflight(ctx->device);
+    hipStream_t st = ctx->stream;
+    std::vector<uint32_t> clen, cblk;
+    for (int b = 0; b < nblk; b++) {
+        out_len[b] = 0;
+        status[b] = JPK_OK;
+        const uint32_t ml = (uint32_t)mid_len[b], nc = (ml + ANS_CHUNK - 1) / ANS_CHUNK;
+        if (clen.size() != first_chunk[b]) return JPK_E_ARG;                   // images are laid out back to back, in block order
+        for (uint32_t k = 0; k < nc; k++) {
+            clen.push_back(k + 1 < nc ? (uint32_t)ANS_CHUNK : ml - k * (uint32_t)ANS_CHUNK);
+            cblk.push_back((uint32_t)b);
+        }
+    }
+    const uint32_t nch = (uint32_t)clen.size();
+    if (nch == 0) return JPK_OK;
+    EncDims d = make_dims(nch * ANS_CHUNK, ANS_CHUNK);
+    EncBufs b;
+    Arena real(ctx, false);
+    enc_layout(real, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
+    uint32_t *d_clen = real.get<uint32_t>(nch), *d_cblk = real.get<uint32_t>(nch);
+    uint8_t **d_bout = real.get<uint8_t *>((size_t)nblk);
+    if (ctx->arena_off > ctx->arena_cap) return JPK_E_ALLOC;
+    JPK_HIP(hipMemcpyAsync(d_clen, clen.data(), sizeof(uint32_t) * nch, hipMemcpyHostToDevice, st));
+    JPK_HIP(hipMemcpyAsync(d_cblk, cblk.data(), sizeof(uint32_t) * nch, hipMemcpyHostToDevice, st));
+    JPK_HIP(hipMemcpyAsync(d_bout, d_out, sizeof(uint8_t *) * (size_t)nblk, hipMemcpyHostToDevice, st));
+    d.clen = d_clen;
+    d.cblk = d_cblk;
+    d.bout = d_bout;
+    JPK_TRY(encode_core(ctx, d_stage, d, b, inflight.n));
+    // sizes: header + payload of every chunk; one copy, the group's only host synchronisation before the payload is placed
+    std::vector<uint32_t> hs(nch), cs(nch);
+    JPK_HIP(hipMemcpyAsync(hs.data(), b.hsize, sizeof(uint32_t) * nch, hipMemcpyDeviceToHost, st));
+    JPK_HIP(hipMemcpyAsync(cs.data(), b.csize, sizeof(uint32_t) * nch, hipMemcpyDeviceToHost, st));
+    JPK_HIP(hipStreamSynchronize(st));
+    std::vector<uint64_t> tot((size_t)nblk, 0);
+    for (uint32_t c = 0; c < nch; c++) tot[cblk[c]] += (uint64_t)hs[c] + cs[c];
+    bool all_fit = true;
+    for (int k = 0; k < nblk; k++)
+        if (tot[k] > (uint64_t)out_cap[k]) { status[k] = JPK_E_CAPACITY; all_fit = false; }
+    if (!all_fit) {
+        // a block that does not fit its buffer must not be written: its chunks get a null... simplest exact behaviour: place only the
+        // blocks that fit, by pointing the others at a scratch sink inside the arena sized for the largest of them
+        uint64_t worst = 0;
+        for (int k = 0; k < nblk; k++) if (status[k] != JPK_OK && tot[k] > worst) worst = tot[k];
+        uint8_t *sink = real.get<uint8_t>((size_t)worst);
+        if (ctx->arena_off > ctx->arena_cap) return JPK_E_CAPACITY;            // no room for the sink: report the group as failed
+        std::vector<uint8_t *> outs(d_out, d_out + nblk);
+        for (int k = 0; k < nblk; k++) if (status[k] != JPK_OK) outs[k] = sink;
+        JPK_HIP(hipMemcpyAsync(d_bout, outs.data(), sizeof(uint8_t *) * (size_t)nblk, hipMemcpyHostToDevice, st));
+        JPK_HIP(hipStreamSynchronize(st));                                     // (`outs` is a local: the copy must have read it)
+    }
+    const size_t stride = d.chunk;
+    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_headers, dim3(d.nch), dim3(TB), d, b.hdr, b.hsize, b.outoff, b.fstate, (uint8_t *)nullptr);
+    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_payload, dim3(emit_tiles_per_chunk(stride), d.nch), dim3(TB), b.xs, b.fr16, stride, d, b.rlen, b.etsum,
+               emit_tiles_per_chunk(stride), b.csize, b.hsize, b.outoff, (uint8_t *)nullptr);
+    JPK_HIP(hipGetLastError());
+    JPK_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < nblk; k++) if (status[k] == JPK_OK) out_len[k] = (int32_t)tot[k];
+    ctx->stats.ans_chunks = (int32_t)nch;
     return JPK_OK;
 }
 

@@ -33,6 +33,13 @@ constexpr int TB = 256;
 constexpr int WAVES = TB / 64;
 constexpr uint32_t DONE = 0x80000000u;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+// Bit 30 of a group rank in the active list (ranks are SA positions < n <= JPK_MAX_BLOCKSIZE < 2^30): the suffix starts inside a run
+// of >= 7 equal bytes.  Such suffixes do not double their way through the run (log2(run / 7) rounds, each over every member of the
+// run: an all-zero 64 MiB block took 25 rounds): round 1 sorts their group by (does the run end in a smaller or a larger byte, run
+// length) -- the complete order among suffixes that start with the same byte repeated, see k_gather_win -- and from round 2 on they
+// compare at the END of their run (distance = remaining run length, uniform inside the group by then) instead of at distance h.
+constexpr uint32_t RUNF = 0x40000000u;
+static_assert((uint64_t)JPK_MAX_BLOCKSIZE < (1ull << 30), "bit 30 of a rank is free");
 
 constexpr int CT = 4096;                   // slots per tile of the streaming kernels (count / scatter), 16 per thread
 constexpr int CT_ITEMS = CT / TB;          // 16: slot(w, k, l) = tile * CT + w * 1024 + k * 64 + l  -> ballot = one 64-bit word
@@ -49,6 +56,7 @@ struct SaState {
     uint32_t m[2];                         // unresolved suffixes: round r reads m[r & 1] and writes m[(r + 1) & 1]
     uint32_t npieces;                      // pieces of large groups in the current round
     uint32_t lc;                           // members of large groups in the current round
+    uint32_t nrun;                         // unresolved suffixes after round 0 that start inside a run of >= 7 equal bytes
     uint32_t round_m[JPK_SA_MAX_ROUNDS];   // per round: unresolved suffixes when it starts
     uint32_t round_lc[JPK_SA_MAX_ROUNDS];  // per round: of those, members of groups > SEG_TILE
 };
@@ -109,10 +117,14 @@ __device__ __forceinline__ uint32_t wg_scan(const uint32_t *in, uint32_t *out, u
 // front -- plain suffix order even when the text contains 0x00 -- and the low byte of the key needs no sort pass.
 
 // head of an equal-key run; a suffix with fewer than 7 bytes is always a group of its own
-__device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t j, uint32_t n)
+// Group sort (bend != null: several blocks sorted as one text, the key's low byte = block number, see radix.hip): the whole key
+// takes part in the comparison, and a suffix is "short" when fewer than 7 bytes are left in ITS block.
+__device__ __forceinline__ uint32_t r0_end(uint64_t key, uint32_t n, const uint32_t *__restrict__ bend) { return bend ? bend[(uint32_t)key & 255u] : n; }
+__device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t j, uint32_t n, const uint32_t *__restrict__ bend)
 {
     if (j == 0) return true;
-    return ((keys[j] ^ keys[j - 1]) >> 8) != 0ull || sa[j] + 7u > n || sa[j - 1] + 7u > n;       // bits 7..0 carry T[sa-1], not key
+    const uint64_t a = keys[j], b = keys[j - 1];
+    return ((a ^ b) >> (bend ? 0 : 8)) != 0ull || sa[j] + 7u > r0_end(a, n, bend) || sa[j - 1] + 7u > r0_end(b, n, bend);   // bits 7..0 carry T[sa-1], not key
 }
 
 // head words of one 4096-slot tile: HE[word] = heads | slots past the end (so that "the next slot is a head" is one shift),
@@ -121,7 +133,7 @@ __device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const
 // comes from the neighbouring lane (DPP wave shift; lane 0: lane 63 of the row before, the wave's first row: one extra load),
 // and "the suffix in front is shorter than 7 bytes" is the shifted ballot of the row's own "short" bits.
 __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n, uint32_t base, uint64_t *HE,
-                                              uint64_t (&kj)[CT_ITEMS], uint32_t (&sj)[CT_ITEMS])
+                                              uint64_t (&kj)[CT_ITEMS], uint32_t (&sj)[CT_ITEMS], const uint32_t *__restrict__ bend)
 {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const uint32_t j0 = base + w * (64 * CT_ITEMS);
@@ -136,15 +148,16 @@ __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys,
     const uint64_t kb = keys[jb];
     const uint32_t sb = sa[jb];
     uint32_t plo = (uint32_t)kb, phi = (uint32_t)(kb >> 32);
-    uint64_t carry_short = (j0 && sb + 7u > n) ? 1ull : 0ull;
+    uint64_t carry_short = (j0 && sb + 7u > r0_end(kb, n, bend)) ? 1ull : 0ull;
+    const int low_shift = bend ? 0 : 8;                                              // bits 7..0 carry T[sa-1], not key -- or the block number, which is key
 #pragma unroll
     for (int k = 0; k < CT_ITEMS; k++) {
         const uint32_t j = j0 + k * 64 + l;
         const uint32_t lo = (uint32_t)kj[k], hi = (uint32_t)(kj[k] >> 32);
         const uint32_t qlo = (uint32_t)__builtin_amdgcn_update_dpp((int)plo, (int)lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
         const uint32_t qhi = (uint32_t)__builtin_amdgcn_update_dpp((int)phi, (int)hi, 0x138, 0xf, 0xf, false);
-        const bool differs = (((lo ^ qlo) >> 8) | (hi ^ qhi)) != 0u;              // bits 7..0 carry T[sa-1], not key
-        const uint64_t S = __ballot(sj[k] + 7u > n);                                 // a suffix with fewer than 7 bytes is a group of its own
+        const bool differs = (((lo ^ qlo) >> low_shift) | (hi ^ qhi)) != 0u;
+        const uint64_t S = __ballot(sj[k] + 7u > r0_end(kj[k], n, bend));            // a suffix with fewer than 7 bytes is a group of its own
         const uint64_t b = __ballot(differs || j >= n || j == 0) | S | (S << 1) | carry_short;
         if (l == 0) HE[w * CT_ITEMS + k] = b;
         carry_short = S >> 63;
@@ -153,7 +166,7 @@ __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys,
     }
     if (threadIdx.x == 0) {
         const uint32_t jn = base + CT;
-        HE[64] = (jn >= n || r0_head(keys, sa, jn, n)) ? 1ull : 0ull;
+        HE[64] = (jn >= n || r0_head(keys, sa, jn, n, bend)) ? 1ull : 0ull;
     }
 }
 __device__ __forceinline__ uint64_t valid_word(uint32_t word_base, uint32_t n)
@@ -165,7 +178,7 @@ __device__ __forceinline__ uint64_t valid_word(uint32_t word_base, uint32_t n)
 
 // per tile: 1 + position of its last head (0: none), number of suffixes that stay unresolved
 __global__ __launch_bounds__(TB) void k_r0_count(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n,
-                                                uint32_t *__restrict__ tLast, uint32_t *__restrict__ tSurv)
+                                                uint32_t *__restrict__ tLast, uint32_t *__restrict__ tSurv, const uint32_t *__restrict__ bend)
 {
     __shared__ uint64_t HE[65];
     const uint32_t ntiles = (n + CT - 1) / CT;
@@ -174,7 +187,7 @@ __global__ __launch_bounds__(TB) void k_r0_count(const uint64_t *__restrict__ ke
         __syncthreads();
         uint64_t kj[CT_ITEMS];
         uint32_t sj[CT_ITEMS];
-        r0_tile_heads(keys, sa, n, base, HE, kj, sj);
+        r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend);
         __syncthreads();
         if (threadIdx.x < 64) {
             const int l = threadIdx.x;
@@ -212,7 +225,8 @@ __global__ __launch_bounds__(WG1) void k_r0_scan(uint32_t *__restrict__ tLast, u
 __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n,
                                                  const uint32_t *__restrict__ tCarry, const uint32_t *__restrict__ tOff,
                                                  uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
-                                                 uint32_t *__restrict__ a_sa, uint32_t *__restrict__ a_grp, uint8_t *__restrict__ a_prev)
+                                                 uint32_t *__restrict__ a_sa, uint32_t *__restrict__ a_grp, uint8_t *__restrict__ a_prev, SaState *__restrict__ st,
+                                                 const uint32_t *__restrict__ bend)
 {
     __shared__ uint64_t HE[65];
     __shared__ uint64_t SV[64];            // survivor bits per word
@@ -225,7 +239,7 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
         __syncthreads();
         uint64_t kj[CT_ITEMS];
         uint32_t sj[CT_ITEMS];
-        r0_tile_heads(keys, sa, n, base, HE, kj, sj);
+        r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend);
         __syncthreads();
         const uint32_t carry = tCarry[tile];
         if (threadIdx.x < 64) {
@@ -242,6 +256,7 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
             LHW[l] = last > carry ? last : carry;
         }
         __syncthreads();
+        uint32_t nrun = 0;
 #pragma unroll
         for (int k = 0; k < CT_ITEMS; k++) {
             const int word = w * CT_ITEMS + k;
@@ -251,7 +266,7 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                 const uint64_t le = hv & mask_upto(l);
                 const uint32_t grp = le ? base + word * 64 + top_bit(le) : (word ? LHW[word - 1] : carry) - 1u;
                 const uint32_t s = sj[k];                           // (loaded once, by r0_tile_heads)
-                const uint8_t pv = (uint8_t)kj[k];                  // T[s - 1], carried in the key's low byte since pass 0
+                const uint8_t pv = (uint8_t)kj[k];                  // T[s - 1], carried in the key's low byte since pass 0 (group sort: the block number)
                 ISA[s] = grp;
                 const uint64_t sv = SV[word];
                 if (!((sv >> l) & 1ull)) {
@@ -259,20 +274,104 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                     if (SA) SA[j] = s;
                 } else {
                     const uint32_t pos = SW[word] + (uint32_t)__popcll(sv & mask_below(l));
+                    // seven equal bytes (a survivor has all seven: short suffixes are groups of their own): a run member
+                    const uint64_t k7 = kj[k] >> 8;
+                    const bool inrun = k7 == (k7 >> 48) * 0x01010101010101ull;
+                    nrun += inrun ? 1u : 0u;
                     a_sa[pos] = s;
-                    a_grp[pos] = grp;
+                    a_grp[pos] = grp | (inrun ? RUNF : 0u);
                     a_prev[pos] = pv;
                 }
             }
+        }
+        if (__ballot(nrun != 0)) {                                   // (rare: text has few runs of seven)
+            nrun = wave_sum(nrun);
+            if (l == 0) atomicAdd(&st->nrun, nrun);
+        }
+    }
+}
+
+// ---- run lengths (only when round 0 left run members behind: every kernel returns at once otherwise) -------------------
+// RL[i] = number of bytes equal to T[i] from i on (the remaining length of the run i lies in) = (next position whose byte differs
+// from its successor) + 1 - i.  Per 4096-byte tile: first boundary position; suffix-min over the tiles; fill.
+__device__ __forceinline__ bool run_ends_at(const uint8_t *__restrict__ T, const uint8_t *__restrict__ blk, uint32_t i, uint32_t n)
+{
+    return i + 1 == n || T[i] != T[i + 1] || (blk && blk[i] != blk[i + 1]);        // (group sort: a run stops at the end of its block)
+}
+__global__ __launch_bounds__(TB) void k_run_first(const uint8_t *__restrict__ T, uint32_t n, const SaState *__restrict__ st, uint32_t *__restrict__ tFirst,
+                                                 const uint8_t *__restrict__ blk)
+{
+    if (st->nrun == 0) return;
+    __shared__ uint32_t sm[TB / 64 + 1];
+    const uint32_t ntiles = (n + CT - 1) / CT;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * CT;
+        uint32_t first = NONE;
+#pragma unroll
+        for (int k = CT_ITEMS - 1; k >= 0; k--) {
+            const uint32_t i = base + k * TB + threadIdx.x;
+            if (i < n && run_ends_at(T, blk, i, n)) first = i;
+        }
+        uint32_t tot;
+        block_incl_scan<OpMin>(first, sm, &tot);
+        if (threadIdx.x == 0) tFirst[tile] = tot;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(WG1) void k_run_scan(uint32_t *__restrict__ tFirst, uint32_t n, const SaState *__restrict__ st)
+{
+    if (st->nrun == 0) return;
+    __shared__ uint32_t sm[WG1 / 64 + 1];
+    // tFirst[tile] <- first boundary in any LATER tile (exclusive suffix min); position n - 1 is always a boundary
+    wg_scan<OpMin, true, true>(tFirst, tFirst, (n + CT - 1) / CT, NONE, sm);
+}
+__global__ __launch_bounds__(TB) void k_run_fill(const uint8_t *__restrict__ T, uint32_t n, const SaState *__restrict__ st, const uint32_t *__restrict__ tAfter,
+                                                uint32_t *__restrict__ RL, const uint8_t *__restrict__ blk)
+{
+    if (st->nrun == 0) return;
+    __shared__ uint32_t sm[TB / 64 + 1];
+    const uint32_t ntiles = (n + CT - 1) / CT;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * CT, p0 = base + threadIdx.x * CT_ITEMS;        // blocked: sixteen consecutive positions per thread
+        uint32_t bits = 0, first = NONE;
+#pragma unroll
+        for (int k = CT_ITEMS - 1; k >= 0; k--) {
+            const uint32_t i = p0 + k;
+            if (i < n && run_ends_at(T, blk, i, n)) { bits |= 1u << k; first = i; }
+        }
+        // first boundary in the segments of the threads AFTER me: inclusive min-scan over the threads in reverse order
+        __shared__ uint32_t rv[TB];
+        __syncthreads();                                                              // rv of the previous tile has been read
+        rv[TB - 1 - threadIdx.x] = first;
+        __syncthreads();
+        const uint32_t rinc = block_incl_scan<OpMin>(rv[threadIdx.x], sm, nullptr);   // index u: min over the threads >= TB - 1 - u
+        __syncthreads();
+        rv[threadIdx.x] = rinc;
+        __syncthreads();
+        uint32_t nb = (threadIdx.x == TB - 1) ? NONE : rv[TB - 2 - threadIdx.x];
+        if (nb == NONE) nb = tAfter[tile];
+#pragma unroll
+        for (int k = CT_ITEMS - 1; k >= 0; k--) {
+            const uint32_t i = p0 + k;
+            if (bits & (1u << k)) nb = i;
+            if (i < n) RL[i] = nb + 1u - i;
         }
     }
 }
 
 // ---- doubling rounds -------------------------------------------------------------------------------------------------
 // key2 of every active suffix + head words per window -> FH / LH = 1 + first / last head position of the window (0: none)
+// Run members (RUNF, see the constant): among suffixes that start with the same byte c repeated, the order is
+//   [run ends in a byte < c, or at the end of the text: ascending run length]  <  [run ends in a byte > c: descending run length]
+// (A = c^a x.., B = c^b y.. with a < b differ at offset a: x against c), ties = same kind and length, decided by the suffix behind
+// the run.  Round 1 (h = 7, the group is everything that starts with c^7): key2 = L for the first kind, 2n - L for the second --
+// no rank is gathered.  Later rounds: the groups of run members have one run length L each, so they compare at distance
+// max(h, L): the rank of the suffix behind the run, whatever the run's length.
 __global__ __launch_bounds__(TB) void k_gather_win(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const SaState *__restrict__ st,
                                                   int par, uint32_t n, uint32_t h, const uint32_t *__restrict__ ISA, uint32_t *__restrict__ k2,
-                                                  uint32_t *__restrict__ FH, uint32_t *__restrict__ LH)
+                                                  uint32_t *__restrict__ FH, uint32_t *__restrict__ LH,
+                                                  const uint8_t *__restrict__ T, const uint32_t *__restrict__ RL, int first_round,
+                                                  const uint8_t *__restrict__ a_blk, const uint32_t *__restrict__ bend)
 {
     __shared__ uint64_t H[16];
     const uint32_t m = st->m[par];
@@ -291,12 +390,39 @@ __global__ __launch_bounds__(TB) void k_gather_win(const uint32_t *__restrict__ 
             gj[k] = a_grp[jc];
             gp[k] = a_grp[jc ? jc - 1 : 0];
         }
-        uint32_t kv[WIN_ITEMS];
+        uint32_t kv[WIN_ITEMS], lim[WIN_ITEMS];
+        bool anyrun = false;
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) lim[k] = n;
+        if (bend) {                          // group sort: a suffix ends with its block (the block number rides in the byte array)
+#pragma unroll
+            for (int k = 0; k < WIN_ITEMS; k++) {
+                const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l;
+                lim[k] = bend[a_blk[j < m ? j : m - 1]];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < WIN_ITEMS; k++) {
             const uint64_t s2 = (uint64_t)s[k] + h;
-            kv[k] = ISA[s2 < n ? s2 : 0];
-            kv[k] = (s2 < n) ? kv[k] + 1u : 0u;
+            kv[k] = ISA[s2 < lim[k] ? s2 : 0];
+            kv[k] = (s2 < lim[k]) ? kv[k] + 1u : 0u;
+            anyrun |= (gj[k] & RUNF) != 0u;
+        }
+        if (__ballot(anyrun)) {                                      // wave-uniform and rare: text has few runs of seven equal bytes
+#pragma unroll
+            for (int k = 0; k < WIN_ITEMS; k++) {
+                const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l;
+                if (j < m && (gj[k] & RUNF)) {
+                    const uint32_t L = RL[s[k]];
+                    const uint64_t e = (uint64_t)s[k] + L;          // first position behind the run (<= n)
+                    if (first_round) {
+                        const bool down = e >= lim[k] || T[e] < T[s[k]];
+                        kv[k] = down ? L : 2u * n - L;               // L in [7, n]: the two kinds cannot collide (2n - L >= n >= L, equal only for L = n: one suffix)
+                    } else if (L > h) {
+                        kv[k] = e < lim[k] ? ISA[e] + 1u : 0u;
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < WIN_ITEMS; k++) {
@@ -667,6 +793,9 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
             pvv[k] = a_prev[from];                                  // T[s - 1] travels with the suffix: no gather from the text
             og[k] = a_grp[base + fo + qc];
         }
+        uint32_t rf[SEG_ITEMS];                                     // run-member flag of the group at my positions (rides with the rank)
+#pragma unroll
+        for (int k = 0; k < SEG_ITEMS; k++) { rf[k] = og[k] & RUNF; og[k] &= ~RUNF; }
 #pragma unroll
         for (int k = 0; k < SEG_ITEMS; k++) {
             const uint32_t q = p0 + k;
@@ -707,7 +836,7 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
                     if (SA) SA[ap[k]] = s;
                 }
                 b_sa[base + fo + q] = s;
-                b_grp[base + fo + q] = run | (single ? DONE : 0u);
+                b_grp[base + fo + q] = run | (single ? DONE : 0u) | rf[k];
                 b_prev[base + fo + q] = pv;
             }
         }
@@ -899,7 +1028,9 @@ __global__ __launch_bounds__(TB) void k_lg_finish(const uint32_t *__restrict__ k
             if (l < 16) LHW[l] = last > carry ? last : carry;
         }
         __syncthreads();
-        const uint32_t G = a_grp[q.gs] & ~DONE;            // rank of the old group = SA position of its first member
+        const uint32_t G0 = a_grp[q.gs];
+        const uint32_t G = G0 & ~(DONE | RUNF);            // rank of the old group = SA position of its first member
+        const uint32_t rf = G0 & RUNF;                     // run-member flag: rides with the rank
         uint32_t sl[WIN_ITEMS];
         uint8_t pl[WIN_ITEMS];
 #pragma unroll
@@ -932,7 +1063,7 @@ __global__ __launch_bounds__(TB) void k_lg_finish(const uint32_t *__restrict__ k
                     if (SA) SA[ap] = s;
                 }
                 b_sa[j] = s;
-                b_grp[j] = rank | (single ? DONE : 0u);
+                b_grp[j] = rank | (single ? DONE : 0u) | rf;
                 b_prev[j] = pv;
             }
         }
@@ -1125,13 +1256,16 @@ struct SaBufs {
     uint32_t *FH, *LH, *PH, *NH, *PC, *pLast, *partial, *scratch;
     uint8_t *bwt;
     uint8_t *a_prev, *b_prev, *p_alt;      // T[sa - 1] of every active suffix: travels with (sa, rank) through the rounds
+    uint32_t *RL;                          // remaining run length per text position (written only when round 0 leaves run members behind)
+    const uint8_t *blk = nullptr;          // group sort: block number of every text position, and where every block ends (device)
+    const uint32_t *bend = nullptr;
     Piece *pieces;
     SaState *state;
 };
 
 int lg_digit_bits(uint32_t n, int *npass)
 {
-    const int kbits = jpk_bits_for(n);             // key2 <= n
+    const int kbits = jpk_bits_for(2u * n);        // key2 <= n, or < 2n for a run member in round 1
     int np = (kbits + 7) / 8;
     if (np < 1) np = 1;
     int db = (kbits + np - 1) / np;
@@ -1155,6 +1289,7 @@ void sa_layout(Arena &a, size_t n, SaBufs &b)
     b.a_prev = a.get<uint8_t>(n);
     b.b_prev = a.get<uint8_t>(n);
     b.p_alt = a.get<uint8_t>(n);
+    b.RL = a.get<uint32_t>(n);
     const size_t nbmax = 256;
     b.table = a.get<uint32_t>(nbmax * 2 * nwin);
     b.partial = a.get<uint32_t>(nbmax * 2 * nwin / SC_TILE + 64);
@@ -1209,7 +1344,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     JPK_HIP(hipMemsetAsync(b.state, 0, sizeof(SaState), st));
     uint64_t *ks = b.keysA;
     uint32_t *vs = b.valsA;
-    JPK_TRY(jpk_radix_sort_suffix_keys7(ctx, T, n, b.keysA, b.valsA, b.keysB, b.valsB, b.scratch, &ks, &vs));
+    JPK_TRY(jpk_radix_sort_suffix_keys7(ctx, T, n, b.keysA, b.valsA, b.keysB, b.valsB, b.scratch, &ks, &vs, b.blk, b.bend));
     ctx->stats.sa_sorted_elems += n;
     // The sorted pairs sit in (ks, vs).  The other pair of radix buffers is free from here on, the pair that holds the result
     // once k_r0_finish has read it: the doubling rounds live in them.
@@ -1222,12 +1357,16 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     b.sa_alt = reinterpret_cast<uint32_t *>(ks) + n;
 
     const unsigned g_ct = cap_grid(n, CT, CAP);
-    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_count, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB);
+    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_count, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.bend);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_r0_scan, dim3(1), dim3(WG1), b.tA, b.tB, n, b.state);
-    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev);
+    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev, b.state, b.bend);
     ctx->stats.sa_rounds = 1;
+    // remaining run lengths, only if round 0 left members of runs of >= 7 equal bytes behind (the kernels return at once otherwise)
+    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_first, dim3(cap_grid(n, CT, 4096)), dim3(TB), T, n, b.state, b.tA, b.blk);
+    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_scan, dim3(1), dim3(WG1), b.tA, n, b.state);
+    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_fill, dim3(cap_grid(n, CT, 4096)), dim3(TB), T, n, b.state, b.tA, b.RL, b.blk);
 
-    const int kbits = jpk_bits_for(n);             // key2 <= n, group rank < n
+    const int kbits = jpk_bits_for(2u * n);        // key2 <= n (a rank + 1), or <= 2n - 7 for a run member in round 1; group rank < n
     int lg_pass = 0;
     const int lg_db = lg_digit_bits(n, &lg_pass);
     // The host learns the number of unresolved suffixes one round late: round r is enqueued with the grid bound of round r-2's
@@ -1246,7 +1385,8 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         const unsigned g_pc = cap_grid(pc_bound, 1, CAP);
         const unsigned g_tab = cap_grid(pc_bound << lg_db, SC_TILE, CAP);
         const uint32_t hh = (h < n) ? (uint32_t)h : n;
-        JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, hh, b.ISA, b.k2, b.FH, b.LH);
+        JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, hh, b.ISA, b.k2, b.FH, b.LH, T, b.RL, round == 1 ? 1 : 0,
+                   b.a_prev, b.bend);
         const unsigned g_wm = cap_grid((size_t)bound / SEG_TILE + 1, TB, 256);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan1, dim3(1), dim3(WG1), b.FH, b.LH, b.PH, b.NH, b.state, par);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_count, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.state, par);
@@ -1339,6 +1479,117 @@ int jpk_suffix_array_device(jpk_ctx *ctx, const uint8_t *d_t, int32_t n, int32_t
     sa_layout(real, (size_t)n, b);
     b.SA = reinterpret_cast<uint32_t *>(d_sa);
     return build_sa(ctx, d_t, (uint32_t)n, b);
+}
+
+// ---- group sort: the forward BWTs of several (small) blocks as ONE suffix sort ------------------------------------------------
+// Jampack's default block is 8 MiB and its smallest 1 MiB (format.hpp:20-22); a block costs ~200 dependent launches whatever its
+// size, so small blocks are sorted together: their sorted parts are laid end to end as one text, every suffix stops at the end of
+// its own block, and the block number is the sort's most significant digit -- block b's suffixes then occupy exactly the slots
+// [start_b, start_b + nlen_b) of the common suffix array, ranks and positions are global, and each block's image and trailer come
+// out of its own slice (bwt.cpp:44-61 per block).  In this mode the byte that rides with every active suffix is its block number
+// (the end of its block is one table lookup away), so the BWT bytes are gathered from the text at the end: T[SA[i] - 1].
+namespace {
+struct GroupBlk {
+    const uint8_t *src;        // the block as the caller gave it
+    uint8_t *img;              // where its image goes (len + 480 bytes)
+    uint32_t start, nlen, len; // slice of the common text / suffix array; bytes of the block
+    uint32_t pad;
+};
+__global__ __launch_bounds__(TB) void k_group_concat(const GroupBlk *__restrict__ gb, uint8_t *__restrict__ C, uint8_t *__restrict__ blk)
+{
+    const GroupBlk g = gb[blockIdx.y];
+    for (uint32_t base = blockIdx.x * TB * 16; base < g.nlen; base += gridDim.x * TB * 16) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t p = base + k * TB + threadIdx.x;
+            if (p < g.nlen) { C[g.start + p] = g.src[p]; blk[g.start + p] = (uint8_t)blockIdx.y; }
+        }
+    }
+}
+__global__ __launch_bounds__(TB) void k_group_image(const GroupBlk *__restrict__ gb, const uint8_t *__restrict__ C, const uint32_t *__restrict__ SA,
+                                                   const uint32_t *__restrict__ ISA)
+{
+    const GroupBlk g = gb[blockIdx.y];
+    if (blockIdx.x == 0) {
+        // raw tail (bwt.cpp:32-33) and, if anything was sorted, the 120 sampled ranks (bwt.cpp:58-61); a block shorter than 120
+        // bytes leaves its trailer alone (bwt.cpp:35; the caller has zeroed the image)
+        const uint32_t t = threadIdx.x;
+        if (t < g.len - g.nlen) g.img[g.nlen + t] = g.src[g.nlen + t];
+        if (g.nlen && t < JPK_BWT_UNITS) {
+            const uint32_t v = ISA[g.start + (size_t)t * (g.nlen / JPK_BWT_UNITS)] - g.start + 1u;
+            uint8_t *p = g.img + g.len + 4 * t;
+            p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+        }
+    }
+    if (g.nlen == 0) return;
+    const uint32_t idx = ISA[g.start] - g.start;                     // row of the block's suffix 0: dropped, the image starts with T[nlen-1]
+    for (uint32_t i = blockIdx.x * TB + threadIdx.x; i < g.nlen; i += gridDim.x * TB) {
+        if (i == 0) g.img[0] = C[g.start + g.nlen - 1];
+        if (i != idx) g.img[(i < idx) ? i + 1 : i] = C[SA[g.start + i] - 1];
+    }
+}
+}  // namespace
+
+size_t jpk_fwd_bwt_group_arena_bytes(uint32_t total_nlen, int nblk)
+{
+    SaBufs b;
+    jpk_ctx dummy;
+    Arena plan(&dummy, true);
+    sa_layout(plan, total_nlen ? total_nlen : 1, b);
+    plan.get<uint8_t>(total_nlen);            // common text
+    plan.get<uint8_t>(total_nlen);            // block number per position
+    plan.get<uint32_t>(total_nlen);           // suffix array (the BWT bytes are gathered through it)
+    plan.get<uint32_t>((size_t)nblk + 1);
+    plan.get<GroupBlk>((size_t)nblk);
+    return plan.need;
+}
+
+// d_in[b] / len[b]: the blocks; d_img[b]: len[b] + 480 bytes each (zeroed by the caller when len[b] < 120).  At most 256 blocks, the
+// sum of their sorted parts < 2^30.  Everything is enqueued on ctx->stream; the arena (at ctx->arena_base) must hold
+// jpk_fwd_bwt_group_arena_bytes().
+int jpk_fwd_bwt_group_device(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in, const int32_t *len, uint8_t *const *d_img)
+{
+    if (nblk <= 0) return JPK_OK;
+    if (nblk > 256) return JPK_E_ARG;
+    // the two small tables are staged in the context's pinned page (16 KB: 256 x 32 B + 257 x 4 B), which outlives this call -- the
+    // copies below are asynchronous; a context runs one call at a time and every caller synchronises before the next
+    static_assert(sizeof(GroupBlk) * 256 + 4 * 257 <= 4096 * 4, "tables fit the pinned page");
+    GroupBlk *gb = reinterpret_cast<GroupBlk *>(ctx->h_map);
+    uint32_t *bend = ctx->h_map + sizeof(GroupBlk) * 256 / 4;
+    uint64_t total = 0;
+    uint32_t maxlen = 1;
+    for (int b = 0; b < nblk; b++) {
+        const uint32_t l = (uint32_t)len[b], nl = l - l % JPK_BWT_UNITS;
+        gb[b] = GroupBlk{d_in[b], d_img[b], (uint32_t)total, nl, l, 0u};
+        total += nl;
+        bend[b] = (uint32_t)total;
+        if (l > maxlen) maxlen = l;
+    }
+    if (total >= (1ull << 30)) return JPK_E_ARG;
+    const uint32_t N = (uint32_t)total;
+    const JpkCompressInflight inflight(ctx->device);
+    SaBufs sb;
+    Arena real(ctx, false);
+    sa_layout(real, N ? N : 1, sb);
+    uint8_t *C = real.get<uint8_t>(N);
+    uint8_t *blk = real.get<uint8_t>(N);
+    uint32_t *SA = real.get<uint32_t>(N);
+    uint32_t *d_bend = real.get<uint32_t>((size_t)nblk + 1);
+    GroupBlk *d_gb = real.get<GroupBlk>((size_t)nblk);
+    if (ctx->arena_off > ctx->arena_cap) return JPK_E_ALLOC;
+    JPK_HIP(hipMemcpyAsync(d_bend, bend, sizeof(uint32_t) * (size_t)nblk, hipMemcpyHostToDevice, ctx->stream));
+    JPK_HIP(hipMemcpyAsync(d_gb, gb, sizeof(GroupBlk) * (size_t)nblk, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned gx = cap_grid(maxlen, TB * 16, 1024);
+    if (N) {
+        hipLaunchKernelGGL(k_group_concat, dim3(gx, nblk), dim3(TB), 0, ctx->stream, d_gb, C, blk);
+        sb.SA = SA;
+        sb.blk = blk;
+        sb.bend = d_bend;
+        JPK_TRY(build_sa(ctx, C, N, sb));
+    }
+    JPK_LAUNCH(ctx, PROF_BWT_GATHER, N, k_group_image, dim3(cap_grid(maxlen, TB * 4, 4096), nblk), dim3(TB), d_gb, C, SA, sb.ISA);
+    JPK_HIP(hipGetLastError());
+    return JPK_OK;
 }
 
 int jpk_fwd_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out)

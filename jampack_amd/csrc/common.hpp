@@ -141,7 +141,7 @@ int jpk_radix_sort_pairs_u64(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint6
 int jpk_radix_sort_pairs_u64_nocopy(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_alt, uint32_t *vals_alt, size_t n,
                                     const int *shifts, int nshifts, uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out);
 int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n, uint64_t *keysA, uint32_t *valsA, uint64_t *keysB, uint32_t *valsB,
-                                uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out);
+                                uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out, const uint8_t *blk = nullptr, const uint32_t *bend = nullptr);
 // Heavy-phase gate (experiment, off by default -- see gate_on() in abi.hip for the numbers): the GPU-saturating phases of the
 // blocks in flight on one device -- the suffix sort and the wide kernels of the entropy stage in front of the rANS chains --
 // run one block after the other on the GPU, in the order the blocks arrive here, while the chains (a few waves that run for
@@ -171,6 +171,9 @@ void jpk_sa_stats_sync(jpk_ctx *ctx);
 // ---- stage drivers (device buffers) -----------------------------------------------------------------
 int jpk_fwd_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out);
 int jpk_suffix_array_device(jpk_ctx *ctx, const uint8_t *d_t, int32_t n, int32_t *d_sa);
+// several small blocks as ONE suffix sort (bwt_fwd.hip): images to d_img[b] (len[b] + 480 bytes each); enqueued, no synchronisation
+int jpk_fwd_bwt_group_device(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in, const int32_t *len, uint8_t *const *d_img);
+size_t jpk_fwd_bwt_group_arena_bytes(uint32_t total_nlen, int nblk);
 int jpk_inv_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trailer, uint8_t *d_out);
 // no host round trip: d_verdict[0..4) (device) receives {status, trailer index, overflow slots, bytes the head chain covers}
 int jpk_inv_bwt_enqueue(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_with_trailer, uint8_t *d_out, uint32_t *d_verdict);
@@ -179,6 +182,9 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
 int jpk_ans_decode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out, int32_t out_cap, int32_t *out_len);
 int jpk_ans_decode_batch(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out, const int32_t *out_cap,
                          int32_t *out_len, int32_t *status, size_t arena_skip);
+int jpk_ans_encode_group_device(jpk_ctx *ctx, int nblk, const uint8_t *d_stage, const uint32_t *first_chunk, const int32_t *mid_len, uint8_t *const *d_out,
+                                const int32_t *out_cap, int32_t *out_len, int32_t *status);
+size_t jpk_ans_encode_group_arena_bytes(uint32_t nchunks, int nblk);
 size_t jpk_inv_bwt_arena_bytes(uint32_t n);
 size_t jpk_fwd_bwt_arena_bytes(uint32_t n);
 size_t jpk_ans_encode_arena_bytes(uint32_t len);

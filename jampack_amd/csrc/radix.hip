@@ -27,6 +27,10 @@ struct TextSrc {
     const uint32_t *tb;      // T rounded down to a dword boundary
     uint32_t off;            // T - tb (0..3)
     uint32_t n;
+    // group sort (several blocks in one text, jpk_fwd_bwt_group_device): the block of every position and where each block ends -- a
+    // suffix stops at the end of ITS block, and the key's low byte carries the block number (the last, most significant digit)
+    const uint8_t *blk;      // null: one block
+    const uint32_t *bend;
 };
 __device__ __forceinline__ uint64_t text_key7(const TextSrc &t, uint32_t i)
 {
@@ -35,6 +39,12 @@ __device__ __forceinline__ uint64_t text_key7(const TextSrc &t, uint32_t i)
     const uint32_t w0 = t.tb[wi], w1 = t.tb[wi + 1 < lastw ? wi + 1 : lastw], w2 = t.tb[wi + 2 < lastw ? wi + 2 : lastw];
     const uint64_t lo = ((uint64_t)w1 << 32) | w0;
     uint64_t v = sh ? (lo >> sh) | ((uint64_t)w2 << (64u - sh)) : lo;            // bytes i .. i+7, little endian
+    if (t.blk) {                                                                    // (uniform branch)
+        const uint32_t b = t.blk[i];
+        const uint32_t left = t.bend[b] - i;                                        // bytes left in the suffix's own block, >= 1
+        v &= (left < 8u) ? (1ull << (8u * left)) - 1ull : ~0ull;
+        return (__builtin_bswap64(v) & ~0xFFull) | b;                               // low byte: the block number, the sort's last digit
+    }
     const uint32_t left = t.n - i;                                                  // >= 1
     v &= (left < 8u) ? (1ull << (8u * left)) - 1ull : ~0ull;
     // The low byte of the key is never a sort digit (7 passes, bits 8..63): it carries T[i-1] (0 for suffix 0), the BWT byte of
@@ -101,9 +111,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *__restri
         for (int it = 0; it < RS_ITEMS; it++) {
             const size_t i = base + (size_t)it * 64, ic = i < n ? i : n - 1;
             if (TEXT) {                                    // digit of byte (56 - shift) / 8 of the suffix: one text byte
-                const uint32_t pos = (uint32_t)(n - 1 - ic) + (uint32_t)((56 - shift) >> 3);
+                const uint32_t i0 = (uint32_t)(n - 1 - ic), pos = i0 + (uint32_t)((56 - shift) >> 3);
                 dig[it] = reinterpret_cast<const uint8_t *>(txt.tb)[(pos < txt.n ? pos : txt.n - 1u) + txt.off];
-                if (pos >= txt.n) dig[it] = 0u;
+                const uint32_t lim = txt.blk ? txt.bend[txt.blk[i0]] : txt.n;          // the suffix ends with its block
+                if (pos >= lim) dig[it] = 0u;
             } else dig[it] = (uint32_t)(keys[ic] >> shift) & 255u;
         }
 #pragma unroll
@@ -311,7 +322,7 @@ int jpk_radix_sort_pairs_u64_nocopy(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals
     uint64_t *ki = keys, *ko = keys_alt;
     uint32_t *vi = vals, *vo = vals_alt;
     for (int p = 0; p < nshifts; p++) {
-        const TextSrc none = {nullptr, 0u, 0u};
+        const TextSrc none = {nullptr, 0u, 0u, nullptr, nullptr};
         JPK_LAUNCH(ctx, PROF_RS_HIST, n, (k_rs_hist<false>), dim3(ntiles), dim3(RS_THREADS), ki, none, n, shifts[p], hist, ntiles);
         JPK_TRY(jpk_exclusive_sum_u32(ctx, hist, hist, table, scan_scratch, nullptr));
         if (rs_staged()) launch_rs_scatter_staged<false>(ctx, ki, vi, none, ko, vo, n, shifts[p], hist, ntiles);
@@ -342,7 +353,7 @@ int jpk_radix_sort_pairs_u64(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint6
 // keys from the text on the fly, so no key array is written or read for it.  Result: (keysB, valsB) -- 7 passes, the first one
 // lands in B.
 int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n32, uint64_t *keysA, uint32_t *valsA, uint64_t *keysB, uint32_t *valsB,
-                                uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out)
+                                uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out, const uint8_t *blk, const uint32_t *bend)
 {
     const size_t n = n32;
     *keys_out = keysB;
@@ -356,11 +367,14 @@ int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n32, ui
     txt.off = (uint32_t)((uintptr_t)T & 3u);
     txt.tb = reinterpret_cast<const uint32_t *>(T - txt.off);
     txt.n = n32;
-    const TextSrc none = {nullptr, 0u, 0u};
+    txt.blk = blk;
+    txt.bend = bend;
+    const TextSrc none = {nullptr, 0u, 0u, nullptr, nullptr};
     uint64_t *ki = keysB, *ko = keysA;        // after pass 0 the pairs are in B
     uint32_t *vi = valsB, *vo = valsA;
-    for (int p = 0; p < 7; p++) {
-        const int shift = 8 * (p + 1);
+    const int npass = blk ? 8 : 7;                // group sort: one more pass, on the block number in the key's low byte
+    for (int p = 0; p < npass; p++) {
+        const int shift = p < 7 ? 8 * (p + 1) : 0;
         if (p == 0) {
             JPK_LAUNCH(ctx, PROF_RS_HIST, n, (k_rs_hist<true>), dim3(ntiles), dim3(RS_THREADS), (const uint64_t *)nullptr, txt, n, shift, hist, ntiles);
             JPK_TRY(jpk_exclusive_sum_u32(ctx, hist, hist, table, scan_scratch, nullptr));

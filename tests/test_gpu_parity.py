@@ -35,6 +35,41 @@ def test_forward_bwt_equals_oracle(jam, oracle, kind):
         assert np.array_equal(got, exp), f"{kind} n={n}: {_first_diff(got, exp)}"
 
 
+def _run_cases():
+    """inputs built around runs of >= 7 equal bytes (the suffix sort's run members, bwt_fwd.hip RUNF): runs that end in a smaller
+    byte, in a larger byte and at the end of the text, of every length around 7 and around the doubling distances, beside each other"""
+    rng = np.random.default_rng(4)
+    out = {}
+    out["one_run_all"] = np.full(2400, 7, np.uint8)
+    out["run_then_smaller"] = np.concatenate([np.full(1000, 9, np.uint8), np.full(200, 3, np.uint8)])
+    out["run_then_larger"] = np.concatenate([np.full(1000, 9, np.uint8), np.full(200, 200, np.uint8)])
+    lens = [1, 2, 6, 7, 8, 13, 14, 15, 27, 28, 29, 55, 56, 57, 100, 1000, 5000]
+    parts = []
+    for k, L in enumerate(lens * 3):
+        parts.append(np.full(L, 50, np.uint8))
+        parts.append(np.array([[10], [90], [10, 90], [90, 10]][k % 4], np.uint8))
+    out["mixed_exits"] = np.concatenate(parts)
+    out["ends_in_run"] = np.concatenate([out["mixed_exits"], np.full(777, 50, np.uint8)])
+    out["periodic_runs"] = np.tile(np.concatenate([np.zeros(300, np.uint8), np.ones(1, np.uint8)]), 40)
+    out["two_symbol_runs"] = np.repeat(rng.integers(0, 2, 400).astype(np.uint8) * 255, rng.integers(1, 40, 400))
+    out["equal_runs_different_tails"] = np.concatenate([np.concatenate([np.full(64, 33, np.uint8), rng.integers(34, 40, 5).astype(np.uint8)]) for _ in range(60)])
+    out["zero_120k"] = np.zeros(120_000, np.uint8)
+    out["ff_then_text"] = None
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(_run_cases()))
+def test_forward_bwt_of_run_inputs_equals_oracle(jam, oracle, name):
+    t = _run_cases()[name]
+    if t is None:
+        t = np.concatenate([np.full(30_000, 255, np.uint8), jam.corpus.make("text", 50_000, 3), np.zeros(20_000, np.uint8)])
+    for cut in (0, 1, 61):                              # the raw tail (len % 120) moves with the cut
+        u = t[: len(t) - cut]
+        got = jam.Bwt().ForwardBwt(u)
+        exp = oracle.bwt_forward(u)
+        assert np.array_equal(got, exp), f"{name} n={len(u)}: {_first_diff(got, exp)}"
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_inverse_bwt_equals_input(jam, oracle, kind):
     for n in SIZES:
