@@ -78,7 +78,8 @@ typedef struct jpk_stats {
 JPK_API int jpk_ctx_create(jpk_ctx **out, int device, void *hip_stream);
 JPK_API void jpk_ctx_destroy(jpk_ctx *ctx);
 JPK_API int jpk_ctx_stats(jpk_ctx *ctx, jpk_stats *out);
-/* pre-size the HBM arena for blocks up to max_block_bytes (otherwise it grows on demand) */
+/* pre-size the HBM arena for blocks up to max_block_bytes (otherwise it grows on demand): the maximum of the four stages' own
+ * layouts (jpk_debug_arena_bytes).  JPK_E_ARG for max_block_bytes < 0 or > JPK_MAX_BLOCKSIZE, JPK_E_ALLOC when HBM is short. */
 JPK_API int jpk_ctx_reserve(jpk_ctx *ctx, int64_t max_block_bytes);
 /* per-kernel timing with HIP events recorded on the context's stream: enable = 1 on, 2 on + reset, 0 off + reset.
  * id < jpk_ctx_profile_count(); units = elements the timed launches processed (see DESIGN.md for bytes per unit). */
@@ -229,6 +230,10 @@ JPK_API int64_t jpk_debug_arena_bytes(int64_t block_bytes, int stage);
  * in microseconds, default 300; negative: never merge> in the environment. */
 JPK_API int jpk_debug_combiner_last_batch(int device);
 JPK_API int jpk_debug_enc_groups(int device, int32_t nch);
+/* Hooks that CHANGE live state work only in a process with JPK_DEBUG_HOOKS=1 in its environment (JPK_E_ARG otherwise):
+ * jpk_debug_compress_inflight with delta != 0, and jpk_debug_combiner_fail_next(n): the next n merged decode passes fail as a
+ * whole before they run -- every merged request must then come back through its own thread's single-block path. */
+JPK_API int jpk_debug_combiner_fail_next(int n);
 
 #ifdef __cplusplus
 }

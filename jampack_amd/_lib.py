@@ -97,6 +97,7 @@ _SIGS = {
     "jpk_debug_enc_groups": (C.c_int, [C.c_int, C.c_int32]),
     "jpk_debug_arena_bytes": (C.c_int64, [C.c_int64, C.c_int]),
     "jpk_debug_combiner_last_batch": (C.c_int, [C.c_int]),
+    "jpk_debug_combiner_fail_next": (C.c_int, [C.c_int]),
 }
 
 ABI_SYMBOLS = tuple(_SIGS)

@@ -279,8 +279,9 @@ extern "C" int jpk_ctx_reserve(jpk_ctx *ctx, int64_t max_block_bytes)
     if (!ctx || max_block_bytes < 0) return JPK_E_ARG;
     JPK_HIP(hipSetDevice(ctx->device));
     if (max_block_bytes > (int64_t)JPK_MAX_BLOCKSIZE) return JPK_E_ARG;
-    // the largest of the four stages' own layouts (their planning passes), not a guess: forward BWT ~39 n, rANS encode ~41 n
-    // worst case, inverse BWT ~10 n, rANS decode 3 n + chunk tables
+    // the largest of the four stages' own layouts (their planning passes), not a guess (jpk_debug_arena_bytes; DESIGN.md section 3,
+    // tests/test_abi_and_host.py pins the factors): forward BWT ~46 n, rANS encode -- see jpk_ans_encode_arena_bytes --, inverse BWT
+    // ~10 n, rANS decode 3 n + chunk tables.  Blocks above JPK_MAX_BLOCKSIZE are refused with JPK_E_ARG.
     const uint32_t n = (uint32_t)max_block_bytes, mid = n + JPK_TRAILER_BYTES;
     size_t need = jpk_fwd_bwt_arena_bytes(n);
     const size_t enc = jpk_ans_encode_arena_bytes(mid), inv = jpk_inv_bwt_arena_bytes(n);
@@ -346,10 +347,14 @@ int jpk_enc_groups_for(int inflight, uint32_t nch)
     if (ngroups < 1) ngroups = 1;
     return ngroups;
 }
-// test hooks (host logic only, no device call): the per-device accounting and the grouping rule
+// test hooks (host logic only, no device call): the per-device accounting and the grouping rule.  The hooks that CHANGE live state
+// (this one with delta != 0, jpk_debug_combiner_fail_next) work only in a process that sets JPK_DEBUG_HOOKS=1: no caller of the
+// product library can move the in-flight count that drives the encoder's launch grouping by accident.
+static bool debug_hooks_on() { const char *e = getenv("JPK_DEBUG_HOOKS"); return e && atoi(e) != 0; }
 extern "C" int jpk_debug_compress_inflight(int device, int delta)
 {
     if (device < 0 || device >= 64) return JPK_E_ARG;
+    if (delta != 0 && !debug_hooks_on()) return JPK_E_ARG;
     if (delta > 0) return jpk_compress_inflight_enter(device);
     if (delta < 0) { jpk_compress_inflight_leave(device); return g_compress_inflight[device].load(std::memory_order_relaxed); }
     return g_compress_inflight[device].load(std::memory_order_relaxed);
@@ -535,9 +540,15 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
     std::vector<int> ran;
     {
         struct Restore {                                       // whatever happens below, the context gets its stream and base back
-            jpk_ctx *c; hipStream_t s;
-            ~Restore() { c->stream = s; c->arena_base = 0; }
-        } restore{ctx, ctx->stream};
+            jpk_ctx *c; hipStream_t s; hipStream_t *lane; int lanes; bool failed = true;
+            ~Restore()
+            {
+                c->stream = s; c->arena_base = 0;
+                // an early return leaves inverse BWTs queued on the lane streams that read the images and write the arena and the
+                // callers' buffers: nothing may reuse the arena before they have drained (the main stream never waited for them)
+                if (failed) for (int k = 1; k < lanes; k++) if (lane[k]) (void)hipStreamSynchronize(lane[k]);
+            }
+        } restore{ctx, ctx->stream, lane_stream, lanes};
         hipStream_t main_stream = ctx->stream;
         if (lanes > 1) {
             JPK_HIP(hipEventRecord(ctx->ev_batch, main_stream));       // the decoded images are complete
@@ -562,6 +573,7 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
             JPK_HIP(hipEventRecord(ctx->ev_done[k], lane_stream[k]));
             JPK_HIP(hipStreamWaitEvent(main_stream, ctx->ev_done[k], 0));
         }
+        restore.failed = false;
     }
     std::vector<uint32_t> verdict((size_t)nblocks * 4);
     if (!ran.empty()) JPK_HIP(hipMemcpyAsync(verdict.data(), d_verdict, (size_t)nblocks * 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -1034,6 +1046,7 @@ struct DecReq {
     hipEvent_t staged;              // the request's input has reached the device
     int32_t out_len = 0, status = JPK_OK;
     bool done = false;
+    bool alone = false;             // the merged pass did not take place for this request: its own thread decodes it on its own context
 };
 struct Combiner {
     std::mutex mu;
@@ -1051,6 +1064,16 @@ int combine_grace_us()
     return v;
 }
 }  // namespace
+
+// test hook (JPK_DEBUG_HOOKS=1 only): the next `n` merged decode passes are treated as failed as a whole before they run, as if the
+// combiner context could not be had -- every merged request must then come back through its own thread's single-block path
+namespace { std::atomic<int> g_combiner_fail_next{0}; }
+extern "C" int jpk_debug_combiner_fail_next(int n)
+{
+    if (!debug_hooks_on() || n < 0) return JPK_E_ARG;
+    g_combiner_fail_next.store(n);
+    return JPK_OK;
+}
 
 // test hook: requests the most recent combined decode on `device` carried (1 = a lone caller took the single-block path)
 extern "C" int jpk_debug_combiner_last_batch(int device)
@@ -1105,14 +1128,30 @@ extern "C" int jpk_ans_decode(const uint8_t *in, int32_t in_len, uint8_t *out, i
             batch.swap(cb.pending);
             cb.collecting = false;                                   // the next arrival leads a batch of its own, beside this one
         }
+        // the merged pass is bounded: requests beyond JPK_COMBINE_MAX_MIB (default 2048) of output capacity stay with their own
+        // threads, so that the hidden combiner context's arena (~3 bytes per output byte) cannot grow without limit
+        static const size_t max_bytes = [] { const char *e = getenv("JPK_COMBINE_MAX_MIB"); const long m = e ? atol(e) : 2048; return (size_t)(m < 1 ? 1 : m) << 20; }();
+        std::vector<DecReq *> turned_away;
+        {
+            size_t bytes = 0;
+            std::vector<DecReq *> kept;
+            for (DecReq *r : batch) {
+                if (!kept.empty() && bytes + (size_t)r->out_cap > max_bytes) { r->alone = true; turned_away.push_back(r); continue; }
+                bytes += (size_t)r->out_cap;
+                kept.push_back(r);
+            }
+            batch.swap(kept);
+        }
         const int nb = (int)batch.size();
         int rc = JPK_OK;
-        if (nb == 1) {
+        if (nb == 1 && batch[0] != &req) { batch[0]->alone = true; turned_away.push_back(batch[0]); batch.clear(); }
+        else if (nb == 1) {
             rc = jpk_dev_ans_decode(ctx, req.d_in, req.in_len, req.d_out, req.out_cap, &req.out_len);       // the single-block path, as ever
             req.status = rc;
         } else {
             jpk_ctx *cc = nullptr;
-            rc = batch_ctx_acquire(ctx->device, &cc);
+            if (g_combiner_fail_next.load() > 0 && g_combiner_fail_next.fetch_sub(1) > 0) rc = JPK_E_ALLOC;     // (test hook)
+            else rc = batch_ctx_acquire(ctx->device, &cc);
             uint64_t generation;
             { CtxPool &p = pool(); std::lock_guard<std::mutex> g(p.mu); generation = p.generation; }
             if (rc == JPK_OK) {
@@ -1124,18 +1163,26 @@ extern "C" int jpk_ans_decode(const uint8_t *in, int32_t in_len, uint8_t *out, i
                     if (hipStreamWaitEvent(cc->stream, batch[b]->staged, 0) != hipSuccess) rc = JPK_E_DEVICE;
                 }
                 if (rc == JPK_OK) rc = jpk_ans_decode_batch(cc, nb, ins.data(), il.data(), outs.data(), oc.data(), ol.data(), st.data(), 0);   // synchronises cc->stream
-                for (int b = 0; b < nb; b++) { batch[b]->out_len = rc == JPK_OK ? ol[b] : 0; batch[b]->status = rc == JPK_OK ? st[b] : rc; }
+                if (rc != JPK_OK) (void)hipStreamSynchronize(cc->stream);      // nothing of the failed pass may still touch the requests' buffers
+                for (int b = 0; b < nb && rc == JPK_OK; b++) { batch[b]->out_len = ol[b]; batch[b]->status = st[b]; }
                 batch_ctx_release(ctx->device, cc, generation);
-            } else {
-                for (int b = 0; b < nb; b++) batch[b]->status = rc;
             }
+            // The pass as a WHOLE failed (no combiner context, its arena for N blocks did not fit beside the callers' own arenas, a
+            // stream error): that says nothing about any single request -- each would have gone through on the single-block path
+            // with its own context.  Every thread retries its own request alone (per-block statuses of a pass that ran stand).
+            if (rc != JPK_OK)
+                for (int b = 0; b < nb; b++) { batch[b]->alone = true; batch[b]->status = JPK_OK; batch[b]->out_len = 0; }
         }
         {
             std::lock_guard<std::mutex> lk(cb.mu);
             cb.last_batch = nb;
             for (DecReq *r : batch) r->done = true;
+            for (DecReq *r : turned_away) r->done = true;
         }
         cb.cv.notify_all();
+    }
+    if (req.alone) {
+        req.status = jpk_dev_ans_decode(ctx, req.d_in, req.in_len, req.d_out, req.out_cap, &req.out_len);
     }
     if (req.status != JPK_OK) return req.status;
     if (req.out_len > 0) JPK_HIP(hipMemcpyAsync(out, ctx->stage_res, (size_t)req.out_len, hipMemcpyDeviceToHost, ctx->stream));

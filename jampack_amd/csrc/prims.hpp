@@ -84,18 +84,28 @@ __device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t *sm, ui
 // m = AND_b (bit_b ? ballot_b : ~ballot_b) = ~ OR_b (ballot_b ^ D_b) with D_b = bit b of my digit replicated over a word (one
 // v_bfe_i32, which also feeds the ballot's compare): five vector instructions per bit on the two halves of the lane mask
 // instead of the seven or eight of the select form -- the match is the bulk of every radix kernel's VALU work.
+// (the bit index is a template parameter, so the asm immediate is a constant expression whatever the optimisation level does with loops)
+template <int B, int BITS>
+struct MatchBits {
+    static __device__ __forceinline__ void run(uint32_t d, uint32_t &lo, uint32_t &hi)
+    {
+        uint32_t D;                                                              // 0 or ~0; asm: the compiler would expand the bit-field extract into two shifts
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(D) : "v"(d), "n"(B));
+        const uint64_t bal = __ballot(D != 0u);
+        lo |= (uint32_t)bal ^ D;
+        hi |= (uint32_t)(bal >> 32) ^ D;
+        MatchBits<B + 1, BITS>::run(d, lo, hi);
+    }
+};
+template <int BITS>
+struct MatchBits<BITS, BITS> {
+    static __device__ __forceinline__ void run(uint32_t, uint32_t &, uint32_t &) {}
+};
 template <int BITS>
 __device__ __forceinline__ uint64_t match_any(uint32_t d, bool valid)
 {
     uint32_t lo = 0, hi = 0;
-#pragma unroll
-    for (int b = 0; b < BITS; b++) {
-        uint32_t D;                                                              // 0 or ~0; asm: the compiler would expand the bit-field extract into two shifts
-        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(D) : "v"(d), "n"(b));
-        const uint64_t bal = __ballot(D != 0u);
-        lo |= (uint32_t)bal ^ D;
-        hi |= (uint32_t)(bal >> 32) ^ D;
-    }
+    MatchBits<0, BITS>::run(d, lo, hi);
     const uint64_t v = __ballot(valid);
     return (((uint64_t)~hi << 32) | (uint64_t)~lo) & v;
 }

@@ -46,9 +46,9 @@ def gather_blocks(local: list[torch.Tensor], dst: int = 0, group=None, device=No
       1. ONE fixed-size all_gather of an int64 vector [count, size_0 .. size_{max_local-1}] per rank, read back with one
          device-to-host copy -- the only host synchronisation.  `max_local` = the largest number of blocks any rank can own
          (ceil(nblocks / world) for the b mod world ownership); without it one extra all_reduce(MAX) finds it.
-      2. every other rank with bytes sends ONE flat buffer to dst, dst posts one receive of exactly that size per such rank
-         (batch_isend_irecv = grouped ncclSend/ncclRecv over each GPU's direct xGMI link with RCCL; plain send/recv with gloo).
-         No padding, no zero fill, no clone.
+      2. every other rank sends each of its non-empty blocks straight from the block's tensor, dst posts the matching receives
+         into consecutive slices of one buffer per rank (batch_isend_irecv = grouped ncclSend/ncclRecv over each GPU's direct xGMI
+         link with RCCL; plain send/recv with gloo).  No padding, no zero fill, no concatenation, no clone.
     With a stream-ordered backend (nccl) the receives are ordered on the current stream: synchronise it before the host reads.
     """
     world = dist.get_world_size(group)
@@ -60,27 +60,39 @@ def gather_blocks(local: list[torch.Tensor], dst: int = 0, group=None, device=No
         n = torch.tensor([len(local)], dtype=torch.int64, device=dev)
         dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
         max_local = int(n.item())
-    if len(local) > max_local:
-        raise ValueError(f"gather_blocks: {len(local)} local blocks but max_local={max_local}")
+    # A rank that owns more blocks than `max_local` must not raise on its own while the others enter the collective (they would
+    # wait for it forever): it takes part with its true count in slot 0 and a truncated size list, every rank reads the table,
+    # and EVERY rank raises.  (`max_local` itself must be the same number on all ranks: it is the shape of the collective.)
     width = max_local + 1
-    meta = torch.tensor([len(local)] + [int(t.numel()) for t in local] + [0] * (max_local - len(local)), dtype=torch.int64).to(dev)
+    sizes = [int(t.numel()) for t in local][:max_local]
+    meta = torch.tensor([len(local)] + sizes + [0] * (max_local - len(sizes)), dtype=torch.int64).to(dev)
     allmeta = torch.empty(world * width, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(allmeta, meta, group=group)
     table = allmeta.cpu().view(world, width).tolist()          # the one host synchronisation
+    over = [(r, row[0]) for r, row in enumerate(table) if row[0] > max_local]
+    if over:
+        raise ValueError(f"gather_blocks: rank(s) {over} own more blocks than max_local={max_local} (raised on every rank)")
     totals = [sum(row[1:1 + row[0]]) for row in table]
 
     def peer(r):                                               # P2POp takes global ranks
         return dist.get_global_rank(group, r) if group is not None else r
 
+    # One message per non-empty block, sent straight from the block's own tensor (no concatenation copy on the sender); dst
+    # posts the matching receives into consecutive slices of ONE buffer per rank (messages between two ranks match in order).
     ops, bufs = [], {}
     if rank == dst:
         for r in range(world):
             if r != dst and totals[r] > 0:
                 bufs[r] = torch.empty(totals[r], dtype=torch.uint8, device=dev)
-                ops.append(dist.P2POp(dist.irecv, bufs[r], peer(r), group))
-    elif totals[rank] > 0:
-        flat = local[0] if len(local) == 1 else torch.cat(local)
-        ops.append(dist.P2POp(dist.isend, flat.contiguous().to(dev), peer(dst), group))
+                o = 0
+                for sz in table[r][1:1 + table[r][0]]:
+                    if sz:
+                        ops.append(dist.P2POp(dist.irecv, bufs[r][o:o + sz], peer(r), group))
+                    o += sz
+    else:
+        for t in local:
+            if t.numel():
+                ops.append(dist.P2POp(dist.isend, t.contiguous().to(dev), peer(dst), group))
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()

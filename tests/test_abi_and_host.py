@@ -149,6 +149,10 @@ def test_encoder_launch_grouping_follows_the_load_of_its_own_device():
     l = lib()
     nch = 65                                   # a 64 MiB block: 64 full chunks + the trailer chunk
     assert l.jpk_debug_compress_inflight(0, 0) == 0 and l.jpk_debug_compress_inflight(1, 0) == 0
+    # the hooks that change live state are refused unless the process asks for them
+    os.environ.pop("JPK_DEBUG_HOOKS", None)
+    assert l.jpk_debug_compress_inflight(0, 1) == -1 and l.jpk_debug_compress_inflight(0, 0) == 0 and l.jpk_debug_combiner_fail_next(1) == -1
+    os.environ["JPK_DEBUG_HOOKS"] = "1"
     assert l.jpk_debug_enc_groups(0, nch) == 4 and l.jpk_debug_enc_groups(1, nch) == 4        # alone: four graded groups
     try:
         assert [l.jpk_debug_compress_inflight(0, 1) for _ in range(3)] == [1, 2, 3]

@@ -235,6 +235,45 @@ def test_concurrent_decode_calls_share_one_batched_pass(gpu, oracle):
     assert np.array_equal(jam.Ans().Decode(encs[1], len(bwts[1])), bwts[1])
 
 
+def test_a_merged_pass_that_fails_as_a_whole_sends_every_request_back_to_its_own_thread(gpu, oracle):
+    """when the batched pass cannot run at all (no combiner context, its arena does not fit, a stream error) that says
+    nothing about any single request -- each thread decodes its own request on its own context, a corrupt stream still fails
+    alone.  The failure is injected through jpk_debug_combiner_fail_next (JPK_DEBUG_HOOKS=1)."""
+    jam = gpu
+    lib = jam.lib()
+    os.environ["JPK_DEBUG_HOOKS"] = "1"
+    kinds = [("text_survey", 3_000_000), ("random", 400_001), ("runs", 1_100_000), ("text", 2_000_000), ("dna", 900_000), ("zero", 1_200_000)]
+    srcs = [jam.corpus.make(k, n, 70 + i) for i, (k, n) in enumerate(kinds)]
+    bwts = [oracle.bwt_forward(t) for t in srcs]
+    encs = [oracle.ans_encode(b) for b in bwts]
+    bad = encs[1].copy()
+    bad[300] ^= 0x40
+    assert np.array_equal(jam.Ans().Decode(encs[0], len(bwts[0])), bwts[0])
+    got, err = {}, {}
+    start = threading.Barrier(len(srcs) + 1)
+
+    def work(k, stream, n):
+        start.wait()
+        try:
+            got[k] = jam.Ans().Decode(stream, n)
+        except jam.JampackError as e:
+            err[k] = e.status
+
+    for rep in range(3):
+        got.clear(); err.clear()
+        start.reset()
+        assert lib.jpk_debug_combiner_fail_next(4) == 0          # whatever merged passes this round forms: all fail as a whole
+        th = [threading.Thread(target=work, args=(k, encs[k], len(bwts[k]))) for k in range(len(srcs))]
+        th.append(threading.Thread(target=work, args=("bad", bad, len(bwts[1]))))
+        [x.start() for x in th]
+        [x.join() for x in th]
+        assert err == {"bad": -3}, err
+        for k in range(len(srcs)):
+            assert np.array_equal(got[k], bwts[k]), (rep, k)
+    assert lib.jpk_debug_combiner_fail_next(0) == 0
+    os.environ.pop("JPK_DEBUG_HOOKS", None)
+
+
 HOST_COPY_NORMAL = 200e9     # bytes/s sixteen threads copying 64 MiB buffers reach on a quiet MI355X host (230 GB/s measured in round 3)
 
 

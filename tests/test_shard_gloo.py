@@ -57,3 +57,32 @@ def test_block_ownership_is_a_partition():
         for r in range(world):
             seen += shard.my_blocks(15, r, world)
         assert sorted(seen) == list(range(15))
+
+
+def _worker_mismatch(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jampack_amd import shard
+    local = [torch.zeros(10, dtype=torch.uint8) for _ in range(3 if rank == 1 else 1)]     # rank 1 owns more than max_local = 2
+    try:
+        shard.gather_blocks(local, dst=0, max_local=2)
+        q.put((rank, "no error"))
+    except ValueError as e:
+        q.put((rank, "raised" if "every rank" in str(e) else str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_max_local_violation_raises_on_every_rank_instead_of_hanging():
+    """a rank that owns more blocks than max_local used to raise alone while the others entered the all_gather"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29850 + os.getpid() % 100
+    procs = [ctx.Process(target=_worker_mismatch, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, "raised"), (1, "raised")], res
