@@ -1004,10 +1004,12 @@ constexpr int RANS_SLACK = 16 * RANS_RING;      // records in front of the recor
 // M0 and needs one instruction between the SALU write of M0 and itself (the state store is that instruction), and M0 is
 // compiler-reserved: the kernel uses it nowhere else (tests/test_chain_codegen.py checks), so it is not saved.  Addresses: a
 // wave-uniform base in SGPRs + a 32-bit lane offset + an immediate -- inside the sixteen-fold unrolled loop body nothing is computed.
-#define JPK_RING_STORE_LOAD(SLOT, SOFF, LOFF)                                                                          \
+// (The LDS-DMA load carries no immediate: its instruction offset moves the LDS address as well as the global one -- measured the
+// hard way -- so the lane offset of the records is stepped by one v_add per batch; the store's offset is an immediate.)
+#define JPK_RING_STORE_LOAD(SLOT, SOFF)                                                                                \
     asm volatile("s_mov_b32 m0, %[slot]\n\t"                                                                           \
                  "global_store_dword %[xoff], %[keep], %[xbase] offset:" #SOFF "\n\t"                                  \
-                 "global_load_lds_dwordx4 %[roff], %[rbase] offset:" #LOFF                                             \
+                 "global_load_lds_dwordx4 %[roff], %[rbase]"                                                           \
                  : : [slot] "s"(ring0 + (uint32_t)(SLOT) * 1024u), [xoff] "v"(xoff), [keep] "v"(keep), [xbase] "s"(xbase), [roff] "v"(roff), [rbase] "s"(rbase)   \
                  : "memory")
 __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ recs, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
@@ -1041,50 +1043,50 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
     uint32_t xoff = (uint32_t)(((size_t)chain * lane_stride + (size_t)K0) * 4u);
     // prologue: the first sixteen batches' records, all landed before the loop starts -- one memory latency per chunk -- so that
     // from here on the steady-state count below holds for every wait
-#define JPK_RING_PROLOGUE(SLOT, LOFF)                                                                                   \
-    asm volatile("s_mov_b32 m0, %[slot]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[roff], %[rbase] offset:" #LOFF          \
-                 : : [slot] "s"(ring0 + (uint32_t)(SLOT) * 1024u), [roff] "v"(roff), [rbase] "s"(rbase) : "memory")
-    JPK_RING_PROLOGUE(0, 0);      JPK_RING_PROLOGUE(1, -256);   JPK_RING_PROLOGUE(2, -512);   JPK_RING_PROLOGUE(3, -768);
-    JPK_RING_PROLOGUE(4, -1024);  JPK_RING_PROLOGUE(5, -1280);  JPK_RING_PROLOGUE(6, -1536);  JPK_RING_PROLOGUE(7, -1792);
-    JPK_RING_PROLOGUE(8, -2048);  JPK_RING_PROLOGUE(9, -2304);  JPK_RING_PROLOGUE(10, -2560); JPK_RING_PROLOGUE(11, -2816);
-    JPK_RING_PROLOGUE(12, -3072); JPK_RING_PROLOGUE(13, -3328); JPK_RING_PROLOGUE(14, -3584); JPK_RING_PROLOGUE(15, -3840);
+#define JPK_RING_PROLOGUE(SLOT)                                                                                         \
+    asm volatile("s_mov_b32 m0, %[slot]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[roff], %[rbase]"                        \
+                 : : [slot] "s"(ring0 + (uint32_t)(SLOT) * 1024u), [roff] "v"(roff), [rbase] "s"(rbase) : "memory");      \
+    roff -= 256u;
+    JPK_RING_PROLOGUE(0)  JPK_RING_PROLOGUE(1)  JPK_RING_PROLOGUE(2)  JPK_RING_PROLOGUE(3)
+    JPK_RING_PROLOGUE(4)  JPK_RING_PROLOGUE(5)  JPK_RING_PROLOGUE(6)  JPK_RING_PROLOGUE(7)
+    JPK_RING_PROLOGUE(8)  JPK_RING_PROLOGUE(9)  JPK_RING_PROLOGUE(10) JPK_RING_PROLOGUE(11)
+    JPK_RING_PROLOGUE(12) JPK_RING_PROLOGUE(13) JPK_RING_PROLOGUE(14) JPK_RING_PROLOGUE(15)
 #undef JPK_RING_PROLOGUE
-    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-    roff -= 16u * 256u;                                            // from here on: the lane's record sixteen batches ahead
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");            // (roff now points at the lane's record sixteen batches ahead)
     uint4 cur = ring[0][t];
     // One batch: the record of the NEXT batch (slot k + 1) was requested sixteen batches ago minus one; issued after it, in program
     // order: the stores of 14 batches and the loads of 14 batches -- vmcnt(28) -- (the first fifteen batches read slots the
     // prologue has drained).  It becomes a register value through an ordinary LDS read behind the wait, used one batch later.
     // Then 16 steps of every chain on `cur`, the store of the kept states, and the request for batch + 16 into the slot `cur` came from.
-#define JPK_BATCH(KSLOT, SOFF, LOFF)                                                                                    \
+#define JPK_BATCH(KSLOT, SOFF)                                                                                          \
     {                                                                                                                   \
         asm volatile("s_waitcnt vmcnt(28)" : : : "memory");                                                             \
         const uint4 nxt = ring[((KSLOT) + 1) & (RANS_RING - 1)][t];                                                     \
         _Pragma("unroll") for (int st = 0; st < 16; st += 2)                                                            \
             x = rans_step_turn2(x, cur, keep, 0x0001000100010001ull << st, 0x0001000100010001ull << (st + 1));          \
-        JPK_RING_STORE_LOAD(KSLOT, SOFF, LOFF);                                                                         \
+        JPK_RING_STORE_LOAD(KSLOT, SOFF);                                                                               \
+        roff -= 256u;                                                                                                   \
         cur = nxt;                                                                                                      \
     }
     uint32_t keep = 0;                                             // (every lane's turn comes once per batch and overwrites it)
     for (int32_t left = nbatch; left > 0; left -= RANS_RING) {    // batches left when the body starts
-        JPK_BATCH(0, 0, 0)            if (left <= 1) break;
-        JPK_BATCH(1, -64, -256)       if (left <= 2) break;
-        JPK_BATCH(2, -128, -512)      if (left <= 3) break;
-        JPK_BATCH(3, -192, -768)      if (left <= 4) break;
-        JPK_BATCH(4, -256, -1024)     if (left <= 5) break;
-        JPK_BATCH(5, -320, -1280)     if (left <= 6) break;
-        JPK_BATCH(6, -384, -1536)     if (left <= 7) break;
-        JPK_BATCH(7, -448, -1792)     if (left <= 8) break;
-        JPK_BATCH(8, -512, -2048)     if (left <= 9) break;
-        JPK_BATCH(9, -576, -2304)     if (left <= 10) break;
-        JPK_BATCH(10, -640, -2560)    if (left <= 11) break;
-        JPK_BATCH(11, -704, -2816)    if (left <= 12) break;
-        JPK_BATCH(12, -768, -3072)    if (left <= 13) break;
-        JPK_BATCH(13, -832, -3328)    if (left <= 14) break;
-        JPK_BATCH(14, -896, -3584)    if (left <= 15) break;
-        JPK_BATCH(15, -960, -3840)
+        JPK_BATCH(0, 0)        if (left <= 1) break;
+        JPK_BATCH(1, -64)      if (left <= 2) break;
+        JPK_BATCH(2, -128)     if (left <= 3) break;
+        JPK_BATCH(3, -192)     if (left <= 4) break;
+        JPK_BATCH(4, -256)     if (left <= 5) break;
+        JPK_BATCH(5, -320)     if (left <= 6) break;
+        JPK_BATCH(6, -384)     if (left <= 7) break;
+        JPK_BATCH(7, -448)     if (left <= 8) break;
+        JPK_BATCH(8, -512)     if (left <= 9) break;
+        JPK_BATCH(9, -576)     if (left <= 10) break;
+        JPK_BATCH(10, -640)    if (left <= 11) break;
+        JPK_BATCH(11, -704)    if (left <= 12) break;
+        JPK_BATCH(12, -768)    if (left <= 13) break;
+        JPK_BATCH(13, -832)    if (left <= 14) break;
+        JPK_BATCH(14, -896)    if (left <= 15) break;
+        JPK_BATCH(15, -960)
         xoff -= 16u * 64u;
-        roff -= 16u * 256u;
     }
 #undef JPK_BATCH
 #undef JPK_RING_STORE_LOAD

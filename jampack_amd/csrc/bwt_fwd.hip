@@ -361,12 +361,17 @@ __global__ __launch_bounds__(TB) void k_run_fill(const uint8_t *__restrict__ T, 
 
 // ---- doubling rounds -------------------------------------------------------------------------------------------------
 // key2 of every active suffix + head words per window -> FH / LH = 1 + first / last head position of the window (0: none)
-// Run members (RUNF, see the constant): among suffixes that start with the same byte c repeated, the order is
+// Run members (RUNF, see the constant).  Among suffixes that start with the same byte c repeated, the order is
 //   [run ends in a byte < c, or at the end of the text: ascending run length]  <  [run ends in a byte > c: descending run length]
 // (A = c^a x.., B = c^b y.. with a < b differ at offset a: x against c), ties = same kind and length, decided by the suffix behind
-// the run.  Round 1 (h = 7, the group is everything that starts with c^7): key2 = L for the first kind, 2n - L for the second --
-// no rank is gathered.  Later rounds: the groups of run members have one run length L each, so they compare at distance
-// max(h, L): the rank of the suffix behind the run, whatever the run's length.
+// the run.  The invariant of prefix doubling -- at the start of the round with distance h every group shares its first h bytes,
+// so every rank read at distance h resolves h more -- must hold for them too:
+//   round 1 (h = 7, the group is everything that starts with c^7): the ordinary key2 = rank7(s + 7) + 1 already places the members
+//     with fewer than 14 equal bytes; those with 14 or more all read the rank G of their own group there.  They get
+//     G + 1 + (L for the first kind, 2n - L for the second), keys above G + 1 move up by 2n: one key, every group 14-ordered.
+//   later rounds: a group of run members with L >= 14 has one kind and one run length, so it may compare at distance max(h, L)
+//     -- the rank of the suffix behind the run, whatever the run's length: it shares L >= that many bytes (L > h) or is h-ordered
+//     like everybody else, and gains >= h either way.  An all-zero block is sorted after round 1.
 __global__ __launch_bounds__(TB) void k_gather_win(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const SaState *__restrict__ st,
                                                   int par, uint32_t n, uint32_t h, const uint32_t *__restrict__ ISA, uint32_t *__restrict__ k2,
                                                   uint32_t *__restrict__ FH, uint32_t *__restrict__ LH,
@@ -413,13 +418,22 @@ __global__ __launch_bounds__(TB) void k_gather_win(const uint32_t *__restrict__ 
             for (int k = 0; k < WIN_ITEMS; k++) {
                 const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l;
                 if (j < m && (gj[k] & RUNF)) {
-                    const uint32_t L = RL[s[k]];
-                    const uint64_t e = (uint64_t)s[k] + L;          // first position behind the run (<= n)
+                    const uint32_t G1 = (gj[k] & ~(RUNF | DONE)) + 1u;  // key2 of "the suffix 7 further is still in my group": 14 equal bytes
                     if (first_round) {
-                        const bool down = e >= lim[k] || T[e] < T[s[k]];
-                        kv[k] = down ? L : 2u * n - L;               // L in [7, n]: the two kinds cannot collide (2n - L >= n >= L, equal only for L = n: one suffix)
-                    } else if (L > h) {
-                        kv[k] = e < lim[k] ? ISA[e] + 1u : 0u;
+                        // every key keeps its place relative to the group's own rank; the members with >= 14 equal bytes, which
+                        // all tie there, are spread over the 2n values behind it by (kind, run length)
+                        if (kv[k] == G1) {
+                            const uint32_t L = RL[s[k]];
+                            const uint64_t e = (uint64_t)s[k] + L;  // first position behind the run
+                            const bool down = e >= lim[k] || T[e] < T[s[k]];
+                            kv[k] = G1 + (down ? L : 2u * n - L);    // L in [14, n]: the kinds cannot collide (2n - L >= n >= L, equal only for L = n: one suffix)
+                        } else if (kv[k] > G1) kv[k] += 2u * n;
+                    } else {
+                        const uint32_t L = RL[s[k]];
+                        if (L >= 14u && L > h) {                     // (a descendant of a c^7 group with a shorter run is an ordinary suffix)
+                            const uint64_t e = (uint64_t)s[k] + L;
+                            kv[k] = e < lim[k] ? ISA[e] + 1u : 0u;
+                        }
                     }
                 }
             }
@@ -1265,7 +1279,7 @@ struct SaBufs {
 
 int lg_digit_bits(uint32_t n, int *npass)
 {
-    const int kbits = jpk_bits_for(2u * n);        // key2 <= n, or < 2n for a run member in round 1
+    const int kbits = jpk_bits_for(3u * n);        // key2 <= n, or <= 3n in a group of run members in round 1
     int np = (kbits + 7) / 8;
     if (np < 1) np = 1;
     int db = (kbits + np - 1) / np;
@@ -1366,7 +1380,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_scan, dim3(1), dim3(WG1), b.tA, n, b.state);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_fill, dim3(cap_grid(n, CT, 4096)), dim3(TB), T, n, b.state, b.tA, b.RL, b.blk);
 
-    const int kbits = jpk_bits_for(2u * n);        // key2 <= n (a rank + 1), or <= 2n - 7 for a run member in round 1; group rank < n
+    const int kbits = jpk_bits_for(3u * n);        // key2 <= n (a rank + 1); round 1 spreads the keys of groups of run members up to 3n; group rank < n
     int lg_pass = 0;
     const int lg_db = lg_digit_bits(n, &lg_pass);
     // The host learns the number of unresolved suffixes one round late: round r is enqueued with the grid bound of round r-2's

@@ -12,12 +12,16 @@
 #include <stdio.h>
 
 namespace {
-__device__ __forceinline__ bool stopped(const volatile uint32_t *flag) { return __atomic_load_n(flag, __ATOMIC_RELAXED) != 0u; }
+// The stop flag lives in DEVICE memory (the host raises it with a 4-byte copy on a second stream) and is polled by one lane per
+// workgroup: 131 072 threads polling a pinned HOST word over PCIe starved the command processor's own reads of the AQL packets and
+// kernel arguments of every other stream -- the first version of this tool measured that, not interference (profiles/r04_interference.txt).
+__device__ __forceinline__ bool stopped(const volatile uint32_t *flag) { return __hip_atomic_load(const_cast<const uint32_t *>(flag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u; }
 
 __global__ __launch_bounds__(256) void k_hog(int kind, const volatile uint32_t *flag, const uint4 *big, size_t big_n16, const uint32_t *table, uint32_t table_mask,
                                             unsigned long long *work)
 {
     __shared__ uint32_t lds[4096];
+    __shared__ uint32_t s_stop;
     uint32_t x = threadIdx.x * 2654435761u + blockIdx.x, y = x ^ 0x9E3779B9u, z = 0, w = 1;
     unsigned long long done = 0;
     for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = i;
@@ -50,7 +54,11 @@ __global__ __launch_bounds__(256) void k_hog(int kind, const volatile uint32_t *
             __builtin_amdgcn_s_sleep(64);
             done += 1;
         }
-        if (stopped(flag) || __builtin_amdgcn_s_memrealtime() - t_start > 600000000ull) break;
+        if (threadIdx.x == 0) s_stop = (stopped(flag) || __builtin_amdgcn_s_memrealtime() - t_start > 600000000ull) ? 1u : 0u;
+        __syncthreads();
+        const uint32_t stop = s_stop;
+        __syncthreads();
+        if (stop) break;
     }
     if ((x ^ y ^ z ^ w) == 0x12345u) lds[0] = x;                  // keep the work alive
     atomicAdd(work, done);
@@ -58,8 +66,8 @@ __global__ __launch_bounds__(256) void k_hog(int kind, const volatile uint32_t *
 }
 
 struct Hog {
-    hipStream_t stream = nullptr;
-    uint32_t *flag = nullptr;           // pinned host memory, mapped
+    hipStream_t stream = nullptr, ctl = nullptr;
+    uint32_t *flag = nullptr;           // device memory
     uint4 *big = nullptr;
     uint32_t *table = nullptr;
     unsigned long long *work = nullptr;
@@ -75,7 +83,8 @@ extern "C" int hog_init(void)
     if (hipGetDeviceProperties(&p, 0) != hipSuccess) return -1;
     H.cus = p.multiProcessorCount;
     if (hipStreamCreateWithFlags(&H.stream, hipStreamNonBlocking) != hipSuccess) return -2;
-    if (hipHostMalloc((void **)&H.flag, 64, hipHostMallocMapped) != hipSuccess) return -3;
+    if (hipStreamCreateWithFlags(&H.ctl, hipStreamNonBlocking) != hipSuccess) return -2;
+    if (hipMalloc((void **)&H.flag, 64) != hipSuccess) return -3;
     H.big_n16 = ((size_t)2 << 30) / 16;
     if (hipMalloc((void **)&H.big, H.big_n16 * 16) != hipSuccess) return -4;
     if (hipMalloc((void **)&H.table, (size_t)256 << 20) != hipSuccess) return -5;
@@ -88,10 +97,9 @@ extern "C" int hog_init(void)
 
 extern "C" int hog_start(int kind, int wgs_per_cu)
 {
-    *H.flag = 0;
-    hipMemsetAsync(H.work, 0, 8, H.stream);
-    uint32_t *dflag;
-    if (hipHostGetDevicePointer((void **)&dflag, H.flag, 0) != hipSuccess) return -1;
+    (void)hipMemsetAsync(H.flag, 0, 4, H.stream);
+    (void)hipMemsetAsync(H.work, 0, 8, H.stream);
+    uint32_t *dflag = H.flag;
     hipLaunchKernelGGL(k_hog, dim3(H.cus * wgs_per_cu), dim3(256), 0, H.stream, kind, dflag, H.big, H.big_n16, H.table, (uint32_t)((64u << 20) - 1), H.work);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
@@ -99,8 +107,10 @@ extern "C" int hog_start(int kind, int wgs_per_cu)
 // stops the hog; returns its work units (valu: multiply-adds per lane / lds: accesses per lane / stream: bytes per lane / gather: accesses per lane)
 extern "C" double hog_stop(void)
 {
-    __atomic_store_n(H.flag, 1u, __ATOMIC_RELEASE);
-    hipStreamSynchronize(H.stream);
+    static const uint32_t one = 1u;
+    (void)hipMemcpyAsync(H.flag, &one, 4, hipMemcpyHostToDevice, H.ctl);
+    (void)hipStreamSynchronize(H.ctl);
+    (void)hipStreamSynchronize(H.stream);
     unsigned long long w = 0;
     hipMemcpy(&w, H.work, 8, hipMemcpyDeviceToHost);
     return (double)w;
