@@ -230,6 +230,17 @@ JPK_API int64_t jpk_debug_arena_bytes(int64_t block_bytes, int stage);
  * in microseconds, default 300; negative: never merge> in the environment. */
 JPK_API int jpk_debug_combiner_last_batch(int device);
 JPK_API int jpk_debug_enc_groups(int device, int32_t nch);
+/* The block loop of Jampack::Compress (jampack.cpp:205-224) over the GPUs of one node, natively: block b is compressed on the
+ * (b mod G)-th device of `device_mask` (bit d = device d, 0 = every visible gfx950 device; one worker thread and context per
+ * device; `in[b]` are HOST buffers), and the compressed blocks are gathered in block order into `d_out`, a buffer of out_cap bytes
+ * on the FIRST device of the mask: block b occupies [out_off[b], out_off[b + 1]) (out_off has nblocks + 1 entries).  The gather is
+ * one ncclSend / ncclRecv pair of exactly the block's bytes per block of a non-root device, grouped, over a single-process RCCL
+ * communicator (ncclCommInitAll) that the library loads at first use and keeps until jpk_shutdown; the root's own blocks are
+ * device-to-device copies (JPK_MULTI_FORCE_RCCL=1: through RCCL as well).  status[b] (nullable) receives every block's status.
+ * jpk_debug_multi_plan: the ownership rule alone, for `ndev_visible` devices (no device call). */
+JPK_API int jpk_blocks_compress_multi(uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, uint8_t *d_out, int64_t out_cap,
+                                      int64_t *out_off, int32_t *status);
+JPK_API int jpk_debug_multi_plan(uint64_t device_mask, int32_t ndev_visible, int32_t nblocks, int32_t *owner);
 /* Hooks that CHANGE live state work only in a process with JPK_DEBUG_HOOKS=1 in its environment (JPK_E_ARG otherwise):
  * jpk_debug_compress_inflight with delta != 0, and jpk_debug_combiner_fail_next(n): the next n merged decode passes fail as a
  * whole before they run -- every merged request must then come back through its own thread's single-block path. */

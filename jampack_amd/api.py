@@ -401,3 +401,25 @@ class Context:
 
     def model_pairs(self, d_rle, rlen, d_pairs):
         _chk(lib().jpk_dev_model_pairs(self._h, _dptr(d_rle), rlen, _dptr(d_pairs)), "jpk_dev_model_pairs")
+
+
+def multi_plan(device_mask: int, ndev_visible: int, nblocks: int):
+    """jpk_debug_multi_plan: (devices taking part, owner device of every block) -- host logic only"""
+    own = (C.c_int32 * max(nblocks, 1))()
+    g = lib().jpk_debug_multi_plan(device_mask, ndev_visible, nblocks, own)
+    _chk(g if g < 0 else 0, "jpk_debug_multi_plan")
+    return g, list(own)[:nblocks]
+
+
+def blocks_compress_multi(blocks, d_out, out_cap: int, device_mask: int = 0):
+    """jpk_blocks_compress_multi: host blocks -> compressed blocks gathered in block order into `d_out` (a device buffer on the first
+    device of the mask; anything with data_ptr() or an int address).  Returns (offsets [nblocks + 1], status [nblocks])."""
+    arrs = [_np_u8(b) for b in blocks]
+    n = len(arrs)
+    P, I = C.c_void_p * max(n, 1), C.c_int32 * max(n, 1)
+    ins = P(*[a.ctypes.data if len(a) else None for a in arrs])
+    lens = I(*[len(a) for a in arrs])
+    off = (C.c_int64 * (n + 1))()
+    st = I()
+    _chk(lib().jpk_blocks_compress_multi(device_mask, n, ins, lens, _dptr(d_out), out_cap, off, st), "jpk_blocks_compress_multi")
+    return list(off), list(st)[:n]

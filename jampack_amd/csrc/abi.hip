@@ -934,6 +934,188 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
     return JPK_OK;
 }
 
+// ---- jpk_blocks_compress_multi: the block loop of Jampack::Compress over the GPUs of one node, natively ---------------------------
+// Blocks are independent (jampack.cpp:215-219), so block b goes to device devices[b mod G] -- one worker thread and context per device,
+// the thread moves its blocks in from host memory and compresses them there -- and the only exchange is the gather of the compressed
+// blocks on the root (the first device of the mask), in block order = the order of the in-order CompWriteBlock loop
+// (jampack.cpp:220-224): sizes are known on the host, so every non-root device sends each block with ONE ncclSend of exactly its
+// bytes and the root posts the matching ncclRecv at the block's final offset (grouped: ncclGroupStart/End over a single-process
+// communicator from ncclCommInitAll; every pair of GPUs has a direct xGMI link).  RCCL is loaded at first use (dlopen): the library
+// has no link-time dependency on it, and a one-device mask never touches it unless JPK_MULTI_FORCE_RCCL=1 asks for the root's own
+// blocks to travel through a send/receive to itself (exercises the path on a 1-GPU box).
+#include <dlfcn.h>
+namespace {
+typedef struct jpkNcclComm *jpk_nccl_comm_t;
+struct Rccl {
+    void *h = nullptr;
+    int (*CommInitAll)(jpk_nccl_comm_t *, int, const int *) = nullptr;
+    int (*CommDestroy)(jpk_nccl_comm_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, jpk_nccl_comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, jpk_nccl_comm_t, hipStream_t) = nullptr;
+    bool ok = false;
+};
+constexpr int NCCL_UINT8 = 1;                        // ncclUint8 (rccl.h: ncclInt8 = 0, ncclUint8 = 1)
+Rccl &rccl()
+{
+    static Rccl r = [] {
+        Rccl q;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { q.h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (q.h) break; }
+        if (!q.h) return q;
+        q.CommInitAll = (decltype(q.CommInitAll))dlsym(q.h, "ncclCommInitAll");
+        q.CommDestroy = (decltype(q.CommDestroy))dlsym(q.h, "ncclCommDestroy");
+        q.GroupStart = (decltype(q.GroupStart))dlsym(q.h, "ncclGroupStart");
+        q.GroupEnd = (decltype(q.GroupEnd))dlsym(q.h, "ncclGroupEnd");
+        q.Send = (decltype(q.Send))dlsym(q.h, "ncclSend");
+        q.Recv = (decltype(q.Recv))dlsym(q.h, "ncclRecv");
+        q.ok = q.CommInitAll && q.CommDestroy && q.GroupStart && q.GroupEnd && q.Send && q.Recv;
+        return q;
+    }();
+    return r;
+}
+// one communicator set per device list, kept until jpk_shutdown
+struct MultiComm { std::vector<int> devices; std::vector<jpk_nccl_comm_t> comms; };
+std::vector<MultiComm> &multi_comms() { static std::vector<MultiComm> v; return v; }
+std::mutex &multi_mu() { static std::mutex m; return m; }
+
+// devices of the mask that exist among `ndev` visible devices, ascending (mask 0 = all)
+std::vector<int> multi_devices(uint64_t mask, int ndev)
+{
+    std::vector<int> d;
+    for (int k = 0; k < ndev && k < 64; k++)
+        if (!mask || ((mask >> k) & 1u)) d.push_back(k);
+    return d;
+}
+}  // namespace
+
+// host-logic probe (no device call): owner[b] = the device block b of `nblocks` would run on for `device_mask` when `ndev_visible`
+// devices are visible; returns the number of devices taking part (the root is the first of them)
+extern "C" int jpk_debug_multi_plan(uint64_t device_mask, int32_t ndev_visible, int32_t nblocks, int32_t *owner)
+{
+    if (ndev_visible < 0 || nblocks < 0 || (nblocks > 0 && !owner)) return JPK_E_ARG;
+    const std::vector<int> dv = multi_devices(device_mask, ndev_visible);
+    if (dv.empty()) return JPK_E_NODEVICE;
+    for (int b = 0; b < nblocks; b++) owner[b] = dv[(size_t)b % dv.size()];
+    return (int)dv.size();
+}
+
+extern "C" int jpk_blocks_compress_multi(uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, uint8_t *d_out, int64_t out_cap,
+                                         int64_t *out_off, int32_t *status)
+{
+    if (nblocks < 0 || out_cap < 0 || !out_off || (nblocks > 0 && (!in || !in_len || !d_out))) return JPK_E_ARG;
+    out_off[0] = 0;
+    if (nblocks == 0) return JPK_OK;
+    for (int b = 0; b < nblocks; b++)
+        if (in_len[b] < 0 || (in_len[b] > 0 && !in[b])) return JPK_E_ARG;
+    const int ndev = jpk_device_count();
+    if (ndev <= 0) return JPK_E_NODEVICE;
+    std::vector<int> devs;
+    for (int d : multi_devices(device_mask, ndev)) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) continue;
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("JPK_ALLOW_ANY_ARCH")) continue;
+        devs.push_back(d);
+    }
+    if (devs.empty()) return JPK_E_NODEVICE;
+    const int G = (int)devs.size(), root = devs[0];
+    std::vector<int32_t> st_local((size_t)nblocks), olen((size_t)nblocks, 0);
+    int32_t *stp = status ? status : st_local.data();
+    uint64_t generation;
+    { CtxPool &p = pool(); std::lock_guard<std::mutex> g(p.mu); generation = p.generation; }
+
+    // per device: context, one input staging buffer (largest block), one output buffer per owned block (carved from one allocation)
+    struct Dev { jpk_ctx *c = nullptr; uint8_t *outs = nullptr; std::vector<int> blocks; std::vector<size_t> off; int rc = JPK_OK; };
+    std::vector<Dev> dv((size_t)G);
+    for (int b = 0; b < nblocks; b++) dv[(size_t)(b % G)].blocks.push_back(b);
+    auto cap_of = [](int32_t len) { return (size_t)((int64_t)(len + JPK_TRAILER_BYTES) * 5 / 4) + 4096 + 1400 * ((size_t)(len + JPK_TRAILER_BYTES) / JPK_ANS_CHUNK + 1); };
+    auto work = [&](int g) {
+        Dev &D = dv[(size_t)g];
+        if (D.blocks.empty()) return;
+        if (hipSetDevice(devs[(size_t)g]) != hipSuccess) { D.rc = JPK_E_DEVICE; return; }
+        if ((D.rc = batch_ctx_acquire(devs[(size_t)g], &D.c)) != JPK_OK) return;
+        size_t total = 0, maxin = 0;
+        for (int b : D.blocks) { D.off.push_back(total); total += jpk_align(cap_of(in_len[b]), 256); if ((size_t)in_len[b] > maxin) maxin = (size_t)in_len[b]; }
+        if (hipMalloc((void **)&D.outs, total + 256) != hipSuccess) { D.outs = nullptr; D.rc = JPK_E_ALLOC; return; }
+        if ((D.rc = buf_ensure(D.c, &D.c->stage_in, &D.c->stage_in_cap, maxin + 64)) != JPK_OK) return;
+        for (size_t k = 0; k < D.blocks.size(); k++) {
+            const int b = D.blocks[k];
+            if (in_len[b] && hipMemcpyAsync(D.c->stage_in, in[b], (size_t)in_len[b], hipMemcpyHostToDevice, D.c->stream) != hipSuccess) { stp[b] = JPK_E_DEVICE; continue; }
+            const size_t cap = cap_of(in_len[b]);
+            stp[b] = jpk_dev_block_compress(D.c, D.c->stage_in, in_len[b], D.outs + D.off[k], (int32_t)(cap > 0x7fffffff ? 0x7fffffff : cap), &olen[b]);   // synchronises
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int g = 1; g < G; g++) { try { th.emplace_back(work, g); } catch (...) { dv[(size_t)g].rc = JPK_E_DEVICE; } }
+        work(0);
+        for (auto &t : th) t.join();
+    }
+    int rc = JPK_OK;
+    for (int g = 0; g < G; g++) if (dv[(size_t)g].rc != JPK_OK) rc = dv[(size_t)g].rc;
+    for (int b = 0; b < nblocks && rc == JPK_OK; b++) if (stp[b] != JPK_OK) rc = stp[b];
+    int64_t total = 0;
+    for (int b = 0; b < nblocks; b++) { out_off[b] = total; total += olen[b]; }
+    out_off[nblocks] = total;
+    if (rc == JPK_OK && total > out_cap) rc = JPK_E_CAPACITY;
+
+    // the gather: root's own blocks are device-to-device copies; the others travel over RCCL, one send / receive pair per block
+    static const bool force_rccl = [] { const char *e = getenv("JPK_MULTI_FORCE_RCCL"); return e && atoi(e) != 0; }();
+    const bool use_rccl = rc == JPK_OK && (G > 1 || force_rccl);
+    std::vector<jpk_nccl_comm_t> comms;              // (a copy: the cache may grow under another caller)
+    if (use_rccl) {
+        std::lock_guard<std::mutex> lk(multi_mu());
+        if (!rccl().ok) rc = JPK_E_DEVICE;
+        else {
+            for (auto &m : multi_comms()) if (m.devices == devs) comms = m.comms;
+            if (comms.empty()) {
+                MultiComm m;
+                m.devices = devs;
+                m.comms.resize((size_t)G);
+                if (rccl().CommInitAll(m.comms.data(), G, devs.data()) != 0) rc = JPK_E_DEVICE;
+                else { multi_comms().push_back(m); comms = m.comms; }
+            }
+        }
+    }
+    if (rc == JPK_OK) {
+        if (hipSetDevice(root) != hipSuccess) rc = JPK_E_DEVICE;
+        Dev &R = dv[0];
+        hipStream_t rs = R.c ? R.c->stream : nullptr;
+        if (rc == JPK_OK && use_rccl && !comms.empty()) {
+            bool grouped = rccl().GroupStart() == 0;
+            for (int g = 0; g < G && grouped; g++) {
+                Dev &D = dv[(size_t)g];
+                if (g == 0 && !force_rccl) continue;
+                for (size_t k = 0; k < D.blocks.size(); k++) {
+                    const int b = D.blocks[k];
+                    if (olen[b] == 0) continue;
+                    if (rccl().Send(D.outs + D.off[k], (size_t)olen[b], NCCL_UINT8, 0, comms[(size_t)g], D.c->stream) != 0) rc = JPK_E_DEVICE;
+                    if (rccl().Recv(d_out + out_off[b], (size_t)olen[b], NCCL_UINT8, g, comms[0], rs) != 0) rc = JPK_E_DEVICE;
+                }
+            }
+            if (!grouped || rccl().GroupEnd() != 0) rc = JPK_E_DEVICE;
+        }
+        if (rc == JPK_OK && !(use_rccl && force_rccl))
+            for (size_t k = 0; k < R.blocks.size(); k++) {
+                const int b = R.blocks[k];
+                if (olen[b] && hipMemcpyAsync(d_out + out_off[b], R.outs + R.off[k], (size_t)olen[b], hipMemcpyDeviceToDevice, rs) != hipSuccess) rc = JPK_E_DEVICE;
+            }
+        // every stream that took part has finished before the per-device buffers go away
+        for (int g = 0; g < G; g++) {
+            Dev &D = dv[(size_t)g];
+            if (!D.c) continue;
+            if (hipSetDevice(devs[(size_t)g]) != hipSuccess || hipStreamSynchronize(D.c->stream) != hipSuccess) rc = rc == JPK_OK ? JPK_E_DEVICE : rc;
+        }
+    }
+    for (int g = 0; g < G; g++) {
+        Dev &D = dv[(size_t)g];
+        if (hipSetDevice(devs[(size_t)g]) == hipSuccess && D.outs) (void)hipFree(D.outs);
+        if (D.c) batch_ctx_release(devs[(size_t)g], D.c, generation);
+    }
+    (void)hipSetDevice(root);
+    return rc;
+}
+
 extern "C" int jpk_init(uint64_t device_mask)
 {
     CtxPool &p = pool();
@@ -970,6 +1152,12 @@ extern "C" void jpk_shutdown(void)
     for (jpk_ctx *c : batch_all()) jpk_ctx_destroy(c);      // the batch-compress workers' contexts
     batch_all().clear();
     for (auto &v : batch_idle()) v.clear();
+    {
+        std::lock_guard<std::mutex> lk(multi_mu());
+        for (auto &m : multi_comms())
+            for (jpk_nccl_comm_t cm : m.comms) if (cm && rccl().ok) (void)rccl().CommDestroy(cm);
+        multi_comms().clear();
+    }
     p.devices.clear();
     p.generation++;
     p.next_thread = 0;

@@ -205,3 +205,24 @@ def test_decoded_size_rejects_more_rle_symbols_than_bytes():
     with pytest.raises(jampack_amd.JampackError) as e:
         ans_decoded_size(bad)
     assert e.value.status == -3
+
+
+def test_multi_device_ownership_and_order():
+    """jpk_blocks_compress_multi's plan (host logic): block b on the (b mod G)-th device of the mask, the first device is the root;
+    a mask that names no visible device is an error; the header declares the entry points and the library exports them"""
+    import subprocess
+    from jampack_amd import api, lib
+    g, own = api.multi_plan(0, 8, 15)                     # BASELINE config 4: 15 blocks over 8 GPUs
+    assert g == 8 and own == [b % 8 for b in range(15)]
+    g, own = api.multi_plan(0b10100100, 8, 7)             # devices 2, 5, 7
+    assert g == 3 and own == [2, 5, 7, 2, 5, 7, 2]
+    g, own = api.multi_plan(0b1, 1, 4)
+    assert g == 1 and own == [0, 0, 0, 0]
+    assert lib().jpk_debug_multi_plan(0b100, 2, 3, (ctypes.c_int32 * 3)()) == -6        # device 2 of 2 visible: none
+    assert lib().jpk_debug_multi_plan(0, 8, -1, None) == -1
+    # every rank's blocks come back in block order: the offsets of block b follow those of block b - 1 whatever device ran it
+    hdr = open(os.path.join(ROOT, "include", "jampack_abi.h")).read()
+    assert "jpk_blocks_compress_multi" in hdr and "jpk_debug_multi_plan" in hdr
+    # no link-time dependency on RCCL: it is loaded at first use
+    out = subprocess.run(["ldd", os.path.join(ROOT, "jampack_amd", "libjampack_amd.so")], capture_output=True, text=True).stdout
+    assert "rccl" not in out
