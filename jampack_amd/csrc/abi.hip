@@ -820,10 +820,32 @@ namespace {
 // synchronisation per group instead of ~200 launches and a synchronisation per block.  Bytes per block are those of
 // jpk_dev_block_compress.
 constexpr int32_t GROUP_BLOCK_MAX = 16 << 20;       // blocks up to this size are grouped
-size_t group_target_bytes()
+// Bytes per group: large groups amortise best (a 256 MiB stream of 1 MiB blocks: 4.6 GB/s in groups of 64 MiB, 4.2 in groups of
+// 16, 2.9 in groups of 8; of 8 MiB blocks: 3.6 / 3.5 / 3.1 -- profiles/r04_group_size.txt), but a short stream still wants several
+// groups in flight: a quarter of the small blocks' bytes, between 8 and 64 MiB.  JPK_GROUP_MIB fixes it.
+size_t group_target_bytes(size_t small_bytes_total)
 {
-    static const size_t v = [] { const char *e = getenv("JPK_GROUP_MIB"); const long m = e ? atol(e) : 16; return (size_t)(m < 1 ? 1 : (m > 512 ? 512 : m)) << 20; }();
-    return v;
+    static const long fixed = [] { const char *e = getenv("JPK_GROUP_MIB"); return e ? atol(e) : 0L; }();
+    if (fixed > 0) return (size_t)(fixed > 512 ? 512 : fixed) << 20;
+    size_t t = small_bytes_total / 4;
+    if (t < ((size_t)8 << 20)) t = (size_t)8 << 20;
+    if (t > ((size_t)64 << 20)) t = (size_t)64 << 20;
+    return t;
+}
+
+// what a group of these blocks needs: the staging buffer for the images and the arena (the larger of the two stages' layouts + the
+// encoder's capacity sink)
+void group_needs(int nb, const int32_t *in_len, size_t *stage_bytes, size_t *arena_bytes)
+{
+    uint64_t nlen_total = 0;
+    uint32_t nch = 0;
+    for (int b = 0; b < nb; b++) {
+        nch += ((uint32_t)in_len[b] + JPK_TRAILER_BYTES + JPK_ANS_CHUNK - 1) / JPK_ANS_CHUNK;
+        nlen_total += (uint32_t)in_len[b] - (uint32_t)in_len[b] % JPK_BWT_UNITS;
+    }
+    *stage_bytes = (size_t)nch * JPK_ANS_CHUNK;
+    const size_t a_sort = jpk_fwd_bwt_group_arena_bytes((uint32_t)nlen_total, nb), a_enc = jpk_ans_encode_group_arena_bytes(nch, nb);
+    *arena_bytes = (a_sort > a_enc ? a_sort : a_enc) + (size_t)GROUP_BLOCK_MAX + (1u << 20);
 }
 
 int group_compress(jpk_ctx *c, int nb, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out, const int32_t *out_cap, int32_t *out_len,
@@ -839,11 +861,11 @@ int group_compress(jpk_ctx *c, int nb, const uint8_t *const *d_in, const int32_t
         nch += ((uint32_t)mid[b] + JPK_ANS_CHUNK - 1) / JPK_ANS_CHUNK;
         nlen_total += (uint32_t)in_len[b] - (uint32_t)in_len[b] % JPK_BWT_UNITS;
     }
-    const size_t stage_bytes = (size_t)nch * JPK_ANS_CHUNK;
+    (void)nlen_total;
+    size_t stage_bytes, arena_bytes;
+    group_needs(nb, in_len, &stage_bytes, &arena_bytes);
     JPK_TRY(buf_ensure(c, &c->stage_out, &c->stage_out_cap, stage_bytes));
-    const size_t a_sort = jpk_fwd_bwt_group_arena_bytes((uint32_t)nlen_total, nb), a_enc = jpk_ans_encode_group_arena_bytes(nch, nb);
-    // (+ room for the encoder's capacity sink: a block that does not fit its buffer is written there instead)
-    JPK_TRY(jpk_arena_ensure(c, (a_sort > a_enc ? a_sort : a_enc) + (size_t)GROUP_BLOCK_MAX + (1u << 20)));
+    JPK_TRY(jpk_arena_ensure(c, arena_bytes));
     std::vector<uint8_t *> img((size_t)nb);
     for (int b = 0; b < nb; b++) {
         img[b] = c->stage_out + (size_t)first[b] * JPK_ANS_CHUNK;
@@ -876,7 +898,9 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
     std::vector<Task> tasks;
     {
         static const bool grouping = [] { const char *e = getenv("JPK_GROUP"); return e ? atoi(e) != 0 : true; }();
-        const size_t target = group_target_bytes();
+        size_t small_total = 0;
+        for (int k = 0; k < nblocks; k++) if (in_len[k] <= GROUP_BLOCK_MAX) small_total += (size_t)in_len[k];
+        const size_t target = group_target_bytes(small_total);
         int b = 0;
         while (b < nblocks) {
             if (!grouping || in_len[b] > GROUP_BLOCK_MAX) { tasks.push_back(Task{b, 1}); b++; continue; }
@@ -888,6 +912,16 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
         }
     }
     const int ntasks = (int)tasks.size();
+    // every worker sizes its staging buffer and arena for the largest group once, before it takes its first task: which worker gets
+    // which group changes from call to call, and an arena that grows in the middle of a call costs a free + malloc + synchronise
+    size_t max_stage = 0, max_arena = 0;
+    for (const Task &t : tasks)
+        if (t.count > 1) {
+            size_t sb, ab;
+            group_needs(t.count, in_len + t.first, &sb, &ab);
+            if (sb > max_stage) max_stage = sb;
+            if (ab > max_arena) max_arena = ab;
+        }
     int nw = in_flight > 0 ? in_flight : 4;
     if (nw > ntasks) nw = ntasks;
     if (nw > 16) nw = 16;
@@ -902,6 +936,9 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
     auto work = [&](jpk_ctx *c) {
         if (hipSetDevice(c->device) != hipSuccess) return;                  // a fresh thread starts on device 0
         if (c != ctx && hipStreamWaitEvent(c->stream, ctx->ev_batch, 0) != hipSuccess) return;   // leaves its share to the others
+        if (max_arena && (buf_ensure(c, &c->stage_out, &c->stage_out_cap, max_stage) != JPK_OK || jpk_arena_ensure(c, max_arena) != JPK_OK)) {
+            // no room for the largest group on this context: the groups say so themselves when they get here (single blocks may still fit)
+        }
         for (;;) {
             const int k = next.fetch_add(1, std::memory_order_relaxed);
             if (k >= ntasks) return;
