@@ -188,11 +188,26 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *__res
 // load instruction's 64 lanes happen to share.  One 32 KB staging buffer is used twice (keys, then values).
 // FULL: the tile has all RS_TILE pairs (every tile but the last): no bounds logic at all, and the loads go through a wave-uniform
 // base pointer with 32-bit lane offsets (the general form computes a 64-bit address per load).
-template <bool TEXT, bool FULL>
+// One-pass variant (round 4, "Onesweep"): no histogram pass and no scan in front of the scatter.  The GLOBAL digit offsets of every
+// pass of the suffix sort are known before the first one (the digits are text bytes: one byte histogram of the text, k_os_*), and a
+// tile learns how many pairs with its digit the tiles before it hold by decoupled look-back: every tile publishes, per digit, first
+// its own count (flag 1) and then the inclusive prefix (flag 2) in one 32-bit word (flag << 30 | count, counts < 2^30), thread d
+// walks back from tile - 1 adding counts until it meets a prefix.  Tiles take their numbers from a ticket counter, so a tile only
+// ever waits for tiles that started before it.  The words are read and written with agent-scope atomics (the XCDs' L2s are not
+// coherent with each other).  Two status arrays alternate between the passes; a tile zeroes its row of the other one.
+struct OsArgs {
+    uint32_t *status;          // [ntiles][256] of this pass
+    uint32_t *status_next;     // ... of the next pass: zeroed row by row
+    const uint32_t *gdig;      // [256] exclusive global offsets of this pass's digit
+    uint32_t *ticket;          // tile numbers of this pass
+};
+constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_PFX = 2u << 30, OS_MASK = (1u << 30) - 1u;
+
+template <bool TEXT, bool FULL, bool LOOKBACK = false>
 __device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, const TextSrc &txt,
                                                        uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n, int shift,
                                                        const uint32_t *__restrict__ tileoff, uint32_t ntiles, uint32_t tile, uint32_t (*cnt)[256],
-                                                       uint32_t *gbase, uint64_t *stage, uint32_t *sm)
+                                                       uint32_t *gbase, uint64_t *stage, uint32_t *sm, const OsArgs *os = nullptr)
 {
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = threadIdx.x & 63;
     const size_t tbase = (size_t)tile * RS_TILE;
@@ -229,7 +244,45 @@ __device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restric
         const uint32_t ts = inc - s;
 #pragma unroll
         for (int k = 0; k < RS_WAVES; k++) cnt[k][d] = ts + c4[k];
-        gbase[d] = tileoff[(size_t)d * ntiles + tile] - ts;
+        uint32_t goff;
+        if (LOOKBACK) {
+            uint32_t *row = os->status + (size_t)tile * 256u;
+            uint32_t excl = 0;
+            if (tile == 0) __hip_atomic_store(row + d, OS_FLAG_PFX | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else {
+                __hip_atomic_store(row + d, OS_FLAG_AGG | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // The walk is latency: every word comes from the memory side (~1.5 us), and with ~1000 tiles resident a tile finds
+                // aggregates, not prefixes, for a long way back.  Eight rows are requested at once and consumed in order; the walk
+                // stops at the first prefix, an unpublished word is polled alone.
+                constexpr int LB = 8;
+                uint32_t back = 1;                                           // rows behind `tile` of the next word to consume
+                bool done = false;
+                while (!done) {
+                    uint32_t v[LB];
+#pragma unroll
+                    for (int k = 0; k < LB; k++) {
+                        const uint32_t b = back + (uint32_t)k;
+                        v[k] = b <= tile ? __hip_atomic_load(row + d - (size_t)b * 256u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < LB; k++) {
+                        if (done) break;
+                        uint32_t w = v[k];
+                        if ((w >> 30) == 0u) {                                // not published yet (rows past tile 0 are never reached: tile 0 is a prefix)
+                            const uint32_t *q = row + d - (size_t)(back + (uint32_t)k) * 256u;
+                            while (((w = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 30) == 0u) __builtin_amdgcn_s_sleep(1);
+                        }
+                        excl += w & OS_MASK;
+                        if ((w >> 30) == 2u) done = true;
+                    }
+                    back += LB;
+                }
+                __hip_atomic_store(row + d, OS_FLAG_PFX | (excl + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            os->status_next[(size_t)tile * 256u + d] = 0u;
+            goff = os->gdig[d] + excl;
+        } else goff = tileoff[(size_t)d * ntiles + tile];
+        gbase[d] = goff - ts;
     }
     __syncthreads();
     uint32_t pos[RS_ITEMS];
@@ -280,6 +333,78 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter_staged(const uint64_t
     rs_scatter_staged_tile<TEXT, FULL>(kin, vin, txt, kout, vout, n, shift, tileoff, ntiles, tile0 + blockIdx.x, cnt, gbase, stage, sm);
 }
 
+// (two launches per pass, like the two-pass form: the full tiles -- no bounds logic, a third of the registers -- and then the last,
+// partial tile alone; it takes the next ticket and finds every prefix published)
+template <bool TEXT, bool FULL>
+__global__ __launch_bounds__(RS_THREADS) void k_os_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, TextSrc txt,
+                                                          uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n, int shift, uint32_t ntiles, OsArgs os)
+{
+    __shared__ uint32_t cnt[RS_WAVES][256];
+    __shared__ uint32_t gbase[256];
+    __shared__ uint64_t stage[RS_TILE];
+    __shared__ uint32_t sm[RS_THREADS / 64 + 1];
+    __shared__ uint32_t s_tile;
+    if (threadIdx.x == 0) s_tile = atomicAdd(os.ticket, 1u);
+    for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    rs_scatter_staged_tile<TEXT, FULL, true>(kin, vin, txt, kout, vout, n, shift, nullptr, ntiles, tile, cnt, gbase, stage, sm, &os);
+}
+template <bool TEXT>
+void launch_os_scatter(jpk_ctx *ctx, const uint64_t *kin, const uint32_t *vin, const TextSrc &txt, uint64_t *kout, uint32_t *vout, size_t n, int shift, uint32_t ntiles,
+                       const OsArgs &os)
+{
+    const uint32_t nfull = (uint32_t)(n / RS_TILE);
+    if (nfull) JPK_LAUNCH(ctx, PROF_RS_SCATTER, (size_t)nfull * RS_TILE, (k_os_scatter<TEXT, true>), dim3(nfull), dim3(RS_THREADS), kin, vin, txt, kout, vout, n, shift, ntiles, os);
+    if (nfull < ntiles) JPK_LAUNCH(ctx, PROF_RS_SCATTER, n - (size_t)nfull * RS_TILE, (k_os_scatter<TEXT, false>), dim3(1), dim3(RS_THREADS), kin, vin, txt, kout, vout, n, shift,
+                                   ntiles, os);
+}
+
+// byte histogram of the text (per-wave LDS tables, sixteen bytes per thread and step)
+__global__ __launch_bounds__(RS_THREADS) void k_os_bytes(const uint8_t *__restrict__ T, uint32_t n, uint32_t *__restrict__ H)
+{
+    __shared__ uint32_t h[RS_WAVES][256];
+    for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const int w = threadIdx.x >> 6;
+    for (size_t i = ((size_t)blockIdx.x * RS_THREADS + threadIdx.x) * 16; i < n; i += (size_t)gridDim.x * RS_THREADS * 16) {
+        if (i + 16 <= n && (((uintptr_t)(T + i)) & 15u) == 0) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(T + i);
+            const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) atomicAdd(&h[w][(ws[q] >> (8 * b)) & 255u], 1u);
+        } else {
+            for (int k = 0; k < 16 && i + k < n; k++) atomicAdd(&h[w][T[i + k]], 1u);
+        }
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < 256; d += RS_THREADS) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; k++) t += h[k][d];
+        if (t) atomicAdd(&H[d], t);
+    }
+}
+
+// exclusive digit offsets of the seven passes: pass p sorts on byte k = 6 - p of the suffix, suffix i contributes T[i + k] (0 past the
+// end), so its histogram is the text's minus the first k bytes plus k zeros
+__global__ __launch_bounds__(256) void k_os_prefix(const uint8_t *__restrict__ T, uint32_t n, const uint32_t *__restrict__ H, uint32_t *__restrict__ gdig)
+{
+    __shared__ uint32_t sm[256 / 64 + 1];
+    const uint32_t v = threadIdx.x;
+    for (int p = 0; p < 7; p++) {
+        const uint32_t k = (uint32_t)(6 - p);
+        uint32_t c = H[v];
+        for (uint32_t j = 0; j < k && j < n; j++) c -= (T[j] == v) ? 1u : 0u;
+        if (v == 0) c += k < n ? k : n;
+        const uint32_t inc = block_incl_scan<OpSum>(c, sm, nullptr);
+        gdig[p * 256 + v] = inc - c;
+        __syncthreads();
+    }
+}
+
 template <bool TEXT>
 void launch_rs_scatter_staged(jpk_ctx *ctx, const uint64_t *kin, const uint32_t *vin, const TextSrc &txt, uint64_t *kout, uint32_t *vout, size_t n, int shift,
                               const uint32_t *tileoff, uint32_t ntiles)
@@ -304,7 +429,19 @@ size_t jpk_radix_scratch_words(size_t n)
 {
     size_t ntiles = (n + RS_TILE - 1) / RS_TILE;
     size_t table = 256 * ntiles;
-    return table + jpk_scan_scratch_words(table) + 64;
+    // the tile table (= status array A of the one-pass sort) + the scan's scratch, then status array B, the byte histogram, the digit
+    // offsets of seven passes and the tickets
+    return table + jpk_scan_scratch_words(table) + 64 + table + 256 + 7 * 256 + 64;
+}
+
+// JPK_ONESWEEP=1 selects the one-pass (decoupled look-back) form for the suffix sort's round 0.  Measured (round 4,
+// profiles/r04_onesweep_ab.txt): a pass takes 455 us against 319 (scatter) + 143 (histogram) + scans for the two-pass form -- the
+// look-back words come from the memory side and a tile waits for them while it holds a quarter of a CU's LDS -- and the default
+// bench line is the same within its noise (3.94-4.16 against 3.89-4.12 GB/s).  Off by default; kept as a tested comparator.
+static bool rs_onesweep()
+{
+    static const bool on = [] { const char *e = getenv("JPK_ONESWEEP"); return e ? atoi(e) != 0 : false; }();
+    return on;
 }
 
 // the sorted pairs end up in (*keys_out, *vals_out): the caller's buffers after an even number of passes, the alt buffers after an
@@ -372,6 +509,34 @@ int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n32, ui
     const TextSrc none = {nullptr, 0u, 0u, nullptr, nullptr};
     uint64_t *ki = keysB, *ko = keysA;        // after pass 0 the pairs are in B
     uint32_t *vi = valsB, *vo = valsA;
+    if (!blk && rs_onesweep()) {
+        // one-pass sort: byte histogram of the text -> digit offsets of all seven passes; then seven scatter launches, nothing else
+        uint32_t *statusA = scratch, *statusB = scratch + table + jpk_scan_scratch_words(table) + 64;
+        uint32_t *H = statusB + table, *gdig = H + 256, *tickets = gdig + 7 * 256;
+        JPK_HIP(hipMemsetAsync(statusA, 0, table * 4, ctx->stream));
+        JPK_HIP(hipMemsetAsync(statusB, 0, (table + 256 + 7 * 256 + 64) * 4, ctx->stream));
+        JPK_LAUNCH(ctx, PROF_RS_HIST, n, k_os_bytes, dim3(ntiles < 2048 ? (ntiles ? ntiles : 1) : 2048), dim3(RS_THREADS), T, n32, H);
+        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_os_prefix, dim3(1), dim3(256), T, n32, H, gdig);
+        for (int p = 0; p < 7; p++) {
+            const int shift = 8 * (p + 1);
+            OsArgs os;
+            os.status = (p & 1) ? statusB : statusA;
+            os.status_next = (p & 1) ? statusA : statusB;
+            os.gdig = gdig + p * 256;
+            os.ticket = tickets + p;
+            if (p == 0) {
+                launch_os_scatter<true>(ctx, nullptr, nullptr, txt, keysB, valsB, n, shift, ntiles, os);
+                continue;
+            }
+            launch_os_scatter<false>(ctx, ki, vi, none, ko, vo, n, shift, ntiles, os);
+            uint64_t *tk = ki; ki = ko; ko = tk;
+            uint32_t *tv = vi; vi = vo; vo = tv;
+        }
+        JPK_HIP(hipGetLastError());
+        *keys_out = ki;
+        *vals_out = vi;
+        return JPK_OK;
+    }
     const int npass = blk ? 8 : 7;                // group sort: one more pass, on the block number in the key's low byte
     for (int p = 0; p < npass; p++) {
         const int shift = p < 7 ? 8 * (p + 1) : 0;

@@ -75,3 +75,24 @@ def test_suffix_array_with_embedded_zero_bytes(ctx, oracle):
     dsa = torch.zeros(len(t), dtype=torch.int32, device="cuda")
     ctx.suffix_array(dt, len(t), dsa)
     assert np.array_equal(dsa.cpu().numpy(), oracle.suffix_array(t))
+
+
+def test_suffix_array_with_the_one_pass_radix_form():
+    """JPK_ONESWEEP=1 (decoupled look-back passes for round 0; off by default, kept as a comparator): same suffix arrays.  The
+    switch is read once per process, so the check runs in a child."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    body = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, jampack_amd as jam\n"
+        "from oracle.pyoracle import Oracle\n"
+        "o = Oracle()\n"
+        "for kind, n in (('text_survey', 1_000_000), ('zero', 300_000), ('random', 70_001), ('dna', 500_000), ('text', 4096 * 5 + 17), ('two', 4095)):\n"
+        "    t = jam.corpus.make(kind, n, 9)\n"
+        "    assert np.array_equal(jam.Bwt().ForwardBwt(t), o.bwt_forward(t)), (kind, n)\n"
+        "print('one-pass ok')\n") % root
+    env = dict(os.environ, JPK_ONESWEEP="1")
+    r = subprocess.run([sys.executable, "-c", body], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "one-pass ok" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
