@@ -221,8 +221,9 @@ JPK_API int jpk_dev_model_pairs(jpk_ctx *ctx, const uint16_t *d_rle, int32_t rle
  * count including it, delta < 0 removes one and returns what is left, delta == 0 reads.  jpk_debug_enc_groups: the launch groups
  * a block of `nch` chunks arriving on `device` now would get. */
 JPK_API int jpk_debug_compress_inflight(int device, int delta);
-/* HBM arena bytes stage 0 (forward BWT) / 1 (rANS encode) / 2 (inverse BWT) / 3 (rANS decode, bound) plans for one block of
- * block_bytes; jpk_ctx_reserve takes their maximum. */
+/* HBM arena bytes stage 0 (forward BWT) / 1 (rANS encode, text-like data: 0.55 RLE0 symbols per byte) / 2 (inverse BWT) /
+ * 3 (rANS decode, bound) plans for one block of block_bytes; jpk_ctx_reserve takes their maximum.  Stage 4: rANS encode of the
+ * densest data (every byte a symbol) -- what a context's arena grows to the first time such a block arrives. */
 JPK_API int64_t jpk_debug_arena_bytes(int64_t block_bytes, int stage);
 /* jpk_ans_decode calls that arrive from different threads at about the same time are merged into one batched pass on their
  * device (ans.cpp:254-264 decodes Threads chunks at a time; jampack.cpp:313 calls Decomp() from Threads OpenMP threads): the

@@ -292,7 +292,8 @@ extern "C" int jpk_ctx_reserve(jpk_ctx *ctx, int64_t max_block_bytes)
     return jpk_arena_ensure(ctx, need);
 }
 
-// host-logic probe: arena bytes stage `stage` (0 forward BWT, 1 rANS encode, 2 inverse BWT, 3 rANS decode bound) plans for one
+// host-logic probe: arena bytes stage `stage` (0 forward BWT, 1 rANS encode of text-like data, 2 inverse BWT, 3 rANS decode bound,
+// 4 rANS encode of the densest data: what the arena grows to when such a block arrives) plans for one
 // block of block_bytes -- what jpk_ctx_reserve takes the maximum of (DESIGN.md section 3 quotes these)
 extern "C" int64_t jpk_debug_arena_bytes(int64_t block_bytes, int stage)
 {
@@ -303,6 +304,7 @@ extern "C" int64_t jpk_debug_arena_bytes(int64_t block_bytes, int stage)
     case 1: return (int64_t)jpk_ans_encode_arena_bytes(mid);
     case 2: return (int64_t)jpk_inv_bwt_arena_bytes(n);
     case 3: return (int64_t)((size_t)mid * 3 + ((size_t)mid / JPK_ANS_CHUNK + 2) * 1100 + (1u << 20));
+    case 4: return (int64_t)jpk_ans_encode_arena_bytes_worst(mid);
     default: return JPK_E_ARG;
     }
 }

@@ -36,8 +36,16 @@ struct EncDims {
     const uint32_t *clen; // bytes of every chunk (null: one block, the formula below)
     const uint32_t *cblk; // block of every chunk
     uint8_t *const *bout; // output buffer of every block (device array)
+    // compact symbol layout (round 4): the arrays indexed by RLE0 symbol (class bytes, ordinals, model outputs, step records, states)
+    // give every chunk as many slots as it HAS symbols (rounded up to 256) instead of one per byte: sbase[c] = first slot of chunk c
+    // (sbase[nch] = total), lbase[c] = first record of its four rANS lanes.  null: one slot per byte, chunk c at c * stride (probes).
+    const uint32_t *sbase;
+    const uint32_t *lbase;
 };
 __device__ __forceinline__ uint32_t chunk_of(const EncDims &d, uint32_t i) { return d.cmap ? d.cmap[i] : i; }
+// slots of chunk c in the symbol-indexed arrays, its first slot, and the first record of its lanes (see EncDims::sbase)
+__device__ __forceinline__ size_t sym_stride(const EncDims &d, uint32_t c, size_t rle_stride) { return d.sbase ? (size_t)(d.sbase[c + 1] - d.sbase[c]) : rle_stride; }
+__device__ __forceinline__ size_t sym_base(const EncDims &d, uint32_t c, size_t rle_stride) { return d.sbase ? (size_t)d.sbase[c] : (size_t)c * rle_stride; }
 __device__ __forceinline__ uint32_t chunk_len(const EncDims &d, uint32_t c)
 {
     if (d.clen) return d.clen[c];
@@ -467,6 +475,7 @@ __global__ __launch_bounds__(TB) void k_cls_ord(const uint16_t *__restrict__ rle
     __syncthreads();
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const uint16_t *src = rle + (size_t)c * rle_stride;
+    const size_t sb = sym_base(d, c, rle_stride), cs = sym_stride(d, c, rle_stride);
     const uint64_t lt = lanemask_lt();
     uint32_t sy[IT], rk[IT];
 #pragma unroll
@@ -507,9 +516,9 @@ __global__ __launch_bounds__(TB) void k_cls_ord(const uint16_t *__restrict__ rle
             uint32_t s = sy[it];
             int e = sym_class(s);
             uint32_t k = cnt[w][e] + rk[it];
-            ord[(size_t)c * rle_stride + i] = k;
-            cls8[(size_t)c * rle_stride + i] = (uint8_t)(e | ((s & 1u) << 3));      // class | mantissa bit of classes 0/1
-            if (e < 2) clist[((size_t)c * 2 + e) * ((rle_stride + 3) & ~(size_t)3) + k] = i | ((s & 1u) << 31);   // compact list of the class
+            ord[sb + i] = k;
+            cls8[sb + i] = (uint8_t)(e | ((s & 1u) << 3));      // class | mantissa bit of classes 0/1
+            if (e < 2) clist[2 * sb + (size_t)e * ((cs + 3) & ~(size_t)3) + k] = i | ((s & 1u) << 31);   // compact list of the class
             else {
                 const int q = qinterval(k);
                 const uint32_t m = s - (uint32_t)class_base(e);
@@ -615,12 +624,13 @@ struct AdStream {
     const uint32_t *list;     // mantissa models: compacted (position | bit << 31) of the class
     uint32_t n;               // items
 };
-__device__ __forceinline__ AdStream ad_stream(const AdRec &r, uint32_t c, const uint8_t *cls8, const uint32_t *clist, size_t rle_stride,
+__device__ __forceinline__ AdStream ad_stream(const EncDims &d, const AdRec &r, uint32_t c, const uint8_t *cls8, const uint32_t *clist, size_t rle_stride,
                                               const uint32_t *rlen, const uint32_t *clstotal)
 {
     AdStream st;
-    st.c8 = cls8 + (size_t)c * rle_stride;
-    st.list = r.exp ? nullptr : clist + ((size_t)c * 2 + r.cls) * clist_stride(rle_stride);
+    const size_t sb = sym_base(d, c, rle_stride), cs = sym_stride(d, c, rle_stride);
+    st.c8 = cls8 + sb;
+    st.list = r.exp ? nullptr : clist + 2 * sb + (size_t)r.cls * clist_stride(cs);
     st.n = r.exp ? rlen[c] : clstotal[(size_t)c * 8 + r.cls];
     return st;
 }
@@ -722,7 +732,7 @@ __global__ __launch_bounds__(64) void k_adapt_a(EncDims d, AdArgs a)
     const uint32_t c = chunk_of(d, blockIdx.z), rec = blockIdx.y;
     const uint32_t k = blockIdx.x * 64 + threadIdx.x;
     const AdRec r(rec);
-    const AdStream st = ad_stream(r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
+    const AdStream st = ad_stream(d, r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
     const uint32_t nt = (st.n + ATILE - 1) / ATILE;
     if (k >= nt) return;
     const uint32_t t0 = k * ATILE, t1 = (t0 + ATILE < st.n) ? t0 + ATILE : st.n;
@@ -736,7 +746,7 @@ __global__ __launch_bounds__(64) void k_adapt_a(EncDims d, AdArgs a)
     const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
     if (lo == hi) {
         a.seg_flag[so] = 1u;
-        a.seg_end[so] = ad_run_write(r, st, t0, t1, lo, a.exph + ((size_t)c * 7 + (rec < 7 ? rec : 0)) * a.rle_stride, a.mantad + (size_t)c * a.rle_stride);
+        a.seg_end[so] = ad_run_write(r, st, t0, t1, lo, a.exph + 7 * sym_base(d, c, a.rle_stride) + (size_t)(rec < 7 ? rec : 0) * sym_stride(d, c, a.rle_stride), a.mantad + sym_base(d, c, a.rle_stride));
         return;
     }
     // unresolved: k_adapt_tab tabulates the 32 candidate start states lo .. lo+31 (hi - lo <= 31 after the warm-up).
@@ -766,7 +776,7 @@ __global__ __launch_bounds__(64) void k_adapt_ext(EncDims d, AdArgs a)
     const uint32_t c = chunk_of(d, blockIdx.z), rec = blockIdx.y;
     const uint32_t k = blockIdx.x * 64 + threadIdx.x;
     const AdRec r(rec);
-    const AdStream st = ad_stream(r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
+    const AdStream st = ad_stream(d, r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
     const uint32_t nt = (st.n + ATILE - 1) / ATILE;
     if (k >= nt) return;
     const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
@@ -789,7 +799,7 @@ __global__ __launch_bounds__(64) void k_adapt_tab(EncDims d, AdArgs a)
     const uint32_t k = blockIdx.x * 2 + (threadIdx.x >> 5);
     const int q = threadIdx.x & 31;
     const AdRec r(rec);
-    const AdStream st = ad_stream(r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
+    const AdStream st = ad_stream(d, r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
     const uint32_t nt = (st.n + ATILE - 1) / ATILE;
     if (k >= nt) return;
     const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
@@ -809,7 +819,7 @@ __global__ __launch_bounds__(64) void k_adapt_b(EncDims d, AdArgs a)
     if ((g >> 4) >= d.ncl || rec >= 9) return;
     const uint32_t c = chunk_of(d, g >> 4);
     const AdRec r(rec);
-    const AdStream st = ad_stream(r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
+    const AdStream st = ad_stream(d, r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
     const uint32_t nt = (st.n + ATILE - 1) / ATILE;
     int32_t x = r.init();
     for (uint32_t k = 0; k < nt; k++) {
@@ -832,7 +842,7 @@ __global__ __launch_bounds__(64) void k_adapt_c(EncDims d, AdArgs a)
     const uint32_t c = chunk_of(d, blockIdx.z), rec = blockIdx.y;
     const uint32_t k = blockIdx.x * 64 + threadIdx.x;
     const AdRec r(rec);
-    const AdStream st = ad_stream(r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
+    const AdStream st = ad_stream(d, r, c, a.cls8, a.clist, a.rle_stride, a.rlen, a.clstotal);
     const uint32_t nt = (st.n + ATILE - 1) / ATILE;
     if (k >= nt) return;
     const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
@@ -840,14 +850,14 @@ __global__ __launch_bounds__(64) void k_adapt_c(EncDims d, AdArgs a)
     if (flag == 1u) return;
     const uint32_t t0 = k * ATILE, t1 = (t0 + ATILE < st.n) ? t0 + ATILE : st.n;
     if (flag == 2u) {                                          // identity segment (exponent entries only): a constant row
-        uint16_t *hist = a.exph + ((size_t)c * 7 + rec) * a.rle_stride;
+        uint16_t *hist = a.exph + 7 * sym_base(d, c, a.rle_stride) + (size_t)rec * sym_stride(d, c, a.rle_stride);
         const uint32_t x = (uint32_t)a.seg_start[so] & 0xffffu, xx = x | (x << 16);
         uint32_t t = t0;                                       // t0 is a multiple of ATILE: 16-byte aligned in its row
         for (; t + 8 <= t1; t += 8) *reinterpret_cast<uint4 *>(hist + t) = make_uint4(xx, xx, xx, xx);
         for (; t < t1; t++) hist[t] = (uint16_t)x;
         return;
     }
-    ad_run_write(r, st, t0, t1, a.seg_start[so], a.exph + ((size_t)c * 7 + (rec < 7 ? rec : 0)) * a.rle_stride, a.mantad + (size_t)c * a.rle_stride);
+    ad_run_write(r, st, t0, t1, a.seg_start[so], a.exph + 7 * sym_base(d, c, a.rle_stride) + (size_t)(rec < 7 ? rec : 0) * sym_stride(d, c, a.rle_stride), a.mantad + sym_base(d, c, a.rle_stride));
 }
 
 // rANS records in coding order.  Pair j = 2t (exponent) / 2t+1 (mantissa) belongs to state lane j & 3; the
@@ -855,6 +865,9 @@ __global__ __launch_bounds__(64) void k_adapt_c(EncDims d, AdArgs a)
 // {low | freq << 16, Alverson reciprocal of freq}: x / freq == mulhi(x, rcp) >> (ceil(log2 freq) - 1) for x < 2^31.
 // records per state lane, a multiple of the 128-record staging tile
 __host__ __device__ __forceinline__ size_t rans_lane_stride(size_t rle_stride) { return (rle_stride / 2 + 128) & ~(size_t)127; }
+// records per lane of chunk c and the first record of its four lanes (see EncDims::sbase)
+__device__ __forceinline__ size_t lane_stride_of(const EncDims &d, uint32_t c, size_t rle_stride) { return rans_lane_stride(sym_stride(d, c, rle_stride)); }
+__device__ __forceinline__ size_t lane_base(const EncDims &d, uint32_t c, size_t rle_stride) { return d.lbase ? (size_t)d.lbase[c] : (size_t)c * 4 * rans_lane_stride(rle_stride); }
 
 // 16-byte record {xmax, rcp, bias, cmpl | shift << 20}: everything a step needs that does not depend on the state
 // is computed here, in parallel (ryg's RansEncSymbolInit, rans_byte.hpp:188-246, restated for 16-bit frequencies):
@@ -886,9 +899,9 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
     const uint32_t c = chunk_of(d, blockIdx.y);
     const uint32_t t = blockIdx.x * TB + threadIdx.x;
     const uint32_t rl = rlen[c];
-    const size_t lane_stride = rans_lane_stride(rle_stride);
-    uint4 *rc = recs + (size_t)c * 4 * lane_stride;
-    uint16_t *fq = fr16 + (size_t)c * 4 * lane_stride;     // frequency sidecar: what the emit kernels need of a record (2 of its 16 bytes)
+    const size_t lane_stride = lane_stride_of(d, c, rle_stride), lb = lane_base(d, c, rle_stride);
+    uint4 *rc = recs + lb;
+    uint16_t *fq = fr16 + lb;                              // frequency sidecar: what the emit kernels need of a record (2 of its 16 bytes)
     if (t >= rl) {
         // the chain kernel walks whole batches of 16 steps: steps past a chain's last pair get identity records
         // (xmax above every state, q * 0 + x + 0), so that it needs no bounds logic
@@ -902,15 +915,15 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
         }
         return;
     }
-    const size_t o = (size_t)c * rle_stride + t;
-    const uint32_t s = rle[o];
+    const size_t cs = sym_stride(d, c, rle_stride), o = sym_base(d, c, rle_stride) + t;
+    const uint32_t s = rle[(size_t)c * rle_stride + t];              // (the RLE0 symbols themselves keep one row of `rle_stride` per chunk)
     const int e = sym_class(s);
     const uint32_t m = s - (uint32_t)class_base(e);
     // cumulative frequencies of the exponent model before this symbol: entry e (low) and entry e + 1 (high end), from the history
     // rows of the seven adaptive entries; entry 0 is 0 and entry 8 is 65536 by definition
-    const uint16_t *hrow = exph + (size_t)c * 7 * rle_stride + t;
-    const uint32_t l0 = (e == 0) ? 0u : hrow[(size_t)(e - 1) * rle_stride];
-    const uint32_t h0 = (e == 7) ? 65536u : (uint32_t)hrow[(size_t)e * rle_stride];
+    const uint16_t *hrow = exph + 7 * sym_base(d, c, rle_stride) + t;
+    const uint32_t l0 = (e == 0) ? 0u : hrow[(size_t)(e - 1) * cs];
+    const uint32_t h0 = (e == 7) ? 65536u : (uint32_t)hrow[(size_t)e * cs];
     uint32_t l1, f1;
     if (e < 2) { const uint32_t p = mantad[o]; l1 = p & 0xffffu; f1 = p >> 16; }
     else {
@@ -1029,7 +1042,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
         return;
     }
     const int chain = t >> 4, s = t & 15;
-    const size_t lane_stride = rans_lane_stride(rle_stride);
+    const size_t lane_stride = lane_stride_of(d, c, rle_stride), lb = lane_base(d, c, rle_stride);
     const int32_t nbatch = (int32_t)((np - 1) / 4) / 16 + 1;
     const int32_t K0 = 16 * nbatch - 1 - s;                        // this lane's step index in the first batch
     uint32_t x = RANS_L;                                           // lane 15 of a row hands the start state to lane 0
@@ -1037,8 +1050,8 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
     // wave-uniform bases (SGPR pairs) and 32-bit lane offsets in bytes.  The record base sits RANS_SLACK records in front of the
     // chunk's first record, so that the offset of a prefetch past the last batch (step index down to -256) stays non-negative: those
     // loads read the slack enc_layout leaves in front of the array (or the chains of the chunk before) and nobody uses them.
-    const uint4 *rbase = recs + (size_t)c * 4 * lane_stride - RANS_SLACK;
-    uint32_t *xbase = xs + (size_t)c * 4 * lane_stride;
+    const uint4 *rbase = recs + lb - RANS_SLACK;
+    uint32_t *xbase = xs + lb;
     uint32_t roff = (uint32_t)(((size_t)chain * lane_stride + (size_t)(K0 + RANS_SLACK)) * 16u);
     uint32_t xoff = (uint32_t)(((size_t)chain * lane_stride + (size_t)K0) * 4u);
     // prologue: the first sixteen batches' records, all landed before the loop starts -- one memory latency per chunk -- so that
@@ -1117,7 +1130,7 @@ __global__ __launch_bounds__(TB) void k_emit_count(const uint32_t *__restrict__ 
     const uint32_t c = chunk_of(d, blockIdx.y), tile = blockIdx.x;
     const uint32_t np = 2 * rlen[c];
     if (tile * ETILE >= np) return;
-    const size_t lane_stride = rans_lane_stride(rle_stride), cb = (size_t)c * 4 * lane_stride;
+    const size_t lane_stride = lane_stride_of(d, c, rle_stride), cb = lane_base(d, c, rle_stride);
     uint32_t n = 0;
     uint32_t ew[ETILE / TB];
 #pragma unroll
@@ -1227,7 +1240,7 @@ __global__ __launch_bounds__(TB) void k_put_payload(const uint32_t *__restrict__
     const uint32_t c = blockIdx.y, tile = blockIdx.x;
     const uint32_t np = 2 * rlen[c];
     if (tile * ETILE >= np) return;
-    const size_t lane_stride = rans_lane_stride(rle_stride), cb = (size_t)c * 4 * lane_stride;
+    const size_t lane_stride = lane_stride_of(d, c, rle_stride), cb = lane_base(d, c, rle_stride);
     // thread t owns the 16 consecutive pairs [j0, j0 + 16) of the tile; suffix sums run from the tile's last pair backwards
     const uint32_t j0 = tile * ETILE + threadIdx.x * 16;
     uint32_t e[16];
@@ -1271,11 +1284,16 @@ struct EncBufs {
 
 enum { LAY_RANK = 1, LAY_RLE = 2, LAY_MODEL = 4, LAY_RANS = 8, LAY_PLAIN = 16 };
 
-void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what)
+// `sym_total` / `lane_total`: slots of the symbol-indexed arrays and records of the rANS lanes over all chunks (the compact layout,
+// EncDims::sbase; known once the RLE0 stage has run).  0: one slot per byte (the stand-alone probes).
+void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what, size_t sym_total = 0, size_t lane_total = 0)
 {
     const size_t tiles = (size_t)d.nch * d.tpc;
     const size_t stride = d.chunk;                 // rle symbols per chunk <= chunk bytes
-    memset(&b, 0, sizeof b);
+    const size_t nsym = sym_total ? sym_total : (size_t)d.nch * stride;
+    const size_t nlane = lane_total ? lane_total : (size_t)d.nch * 4 * rans_lane_stride(stride);
+    const EncBufs keep = b;                        // (a second call adds the model / rANS stage to the rank / RLE0 buffers of the first)
+    if (what & LAY_RANK) memset(&b, 0, sizeof b); else b = keep;
     if (what & LAY_RANK) {
         b.tilecnt = a.get<uint32_t>(tiles * 256);
         b.lastpos = a.get<int32_t>(tiles * 256);
@@ -1296,25 +1314,25 @@ void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what)
         b.cmap = a.get<uint32_t>(d.nch + 64);
         b.clscnt = a.get<uint32_t>(tiles * 8);
         b.clstotal = a.get<uint32_t>((size_t)d.nch * 8);
-        b.ord = a.get<uint32_t>((size_t)d.nch * stride);
+        b.ord = a.get<uint32_t>(nsym);
         b.qhist = a.get<uint32_t>((size_t)d.nch * 6 * NQ * QSTRIDE);
         b.qcdf = a.get<uint32_t>((size_t)d.nch * 6 * NQ * QSTRIDE);
-        b.exph = a.get<uint16_t>((size_t)d.nch * 7 * stride);
-        b.mantad = a.get<uint32_t>((size_t)d.nch * stride);
-        b.cls8 = a.get<uint8_t>((size_t)d.nch * stride + 64);
-        b.clist = a.get<uint32_t>((size_t)d.nch * 2 * ((stride + 3) & ~(size_t)3) + 64);
+        b.exph = a.get<uint16_t>(7 * nsym);
+        b.mantad = a.get<uint32_t>(nsym);
+        b.cls8 = a.get<uint8_t>(nsym + 64);
+        b.clist = a.get<uint32_t>(2 * ((nsym + 3) & ~(size_t)3) + 64);
         const size_t segs = (size_t)d.nch * 9 * d.tpc;
         b.seg_flag = a.get<uint32_t>(segs);
         b.seg_lo = a.get<int32_t>(segs);
         b.seg_end = a.get<int32_t>(segs);
         b.seg_start = a.get<int32_t>(segs);
         b.seg_tab = a.get<uint16_t>(segs * 32);
-        b.recs = a.get<uint4>((size_t)d.nch * 4 * rans_lane_stride(stride) + RANS_SLACK) + (a.planning ? 0 : RANS_SLACK);   // slack in front: k_rans_lanes' prefetches past the last batch
-        b.fr16 = a.get<uint16_t>((size_t)d.nch * 4 * rans_lane_stride(stride));
+        b.recs = a.get<uint4>(nlane + RANS_SLACK) + (a.planning ? 0 : RANS_SLACK);   // slack in front: k_rans_lanes' prefetches past the last batch
+        b.fr16 = a.get<uint16_t>(nlane);
         b.pairs = (what & LAY_PLAIN) ? a.get<uint32_t>((size_t)d.nch * stride * 2) : nullptr;
     }
     if (what & LAY_RANS) {
-        b.xs = a.get<uint32_t>((size_t)d.nch * 4 * rans_lane_stride(stride));      // state before every step, lane-major like recs
+        b.xs = a.get<uint32_t>(nlane);             // state before every step, lane-major like recs
         b.etsum = a.get<uint32_t>((size_t)d.nch * emit_tiles_per_chunk(stride));
         b.fstate = a.get<uint32_t>((size_t)d.nch * 4);
         b.csize = a.get<uint32_t>(d.nch);
@@ -1415,34 +1433,115 @@ int run_model(jpk_ctx *ctx, const uint16_t *d_rle, const uint32_t *d_rlen, const
 
 }  // namespace
 
-// arena bytes of one Ans::Encode of len bytes (jpk_ctx_reserve)
+namespace {
+size_t enc_plan_bytes(const EncDims &d, int nblk, uint32_t sym_per_byte_256);
+// Text carries ~0.42 RLE0 symbols per byte, the densest data 1.0: the arena is first sized for 0.55 and grows (the stage starts
+// over) the first time a denser block arrives.
+constexpr uint32_t ENC_PLAN_SYM_256 = 141;
+}  // namespace
+
+// arena bytes of one Ans::Encode of len bytes of text-like data (jpk_ctx_reserve)
 size_t jpk_ans_encode_arena_bytes(uint32_t len)
 {
     if (len == 0) return 0;
     const EncDims d = make_dims(len, ANS_CHUNK);
-    EncBufs b;
-    jpk_ctx dummy;
-    Arena plan(&dummy, true);
-    enc_layout(plan, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
-    return plan.need;
+    return enc_plan_bytes(d, 0, ENC_PLAN_SYM_256);
+}
+// the same for the densest input there is (every byte an RLE0 symbol): what the arena grows to when such a block arrives
+size_t jpk_ans_encode_arena_bytes_worst(uint32_t len)
+{
+    if (len == 0) return 0;
+    const EncDims d = make_dims(len, ANS_CHUNK);
+    return enc_plan_bytes(d, 0, 256);
 }
 
 namespace {
 // everything of the stage up to the chunks' output offsets, enqueued on ctx->stream (and the group streams): rank coding, RLE0,
 // models, the rANS chains, emit counts, headers, offsets.  `d` describes the chunks (one block: make_dims; a group of blocks: the
 // per-chunk tables), `inflight_n` the blocks the device is compressing right now (drives the launch grouping).
-int encode_core(jpk_ctx *ctx, const uint8_t *d_in, const EncDims &d, EncBufs &b, int inflight_n)
+// tables a group of blocks hands in (host side): the core gives them device copies inside its own arena layout
+struct GroupTabs { const uint32_t *clen, *cblk; uint8_t *const *bout; int nblk; };
+
+// slots per chunk of the compact symbol layout (EncDims::sbase): its RLE0 symbol count rounded up to 256, prefix sums, totals -> mailbox
+__global__ void k_sym_layout(EncDims d, const uint32_t *__restrict__ rlen, uint32_t *__restrict__ sbase, uint32_t *__restrict__ lbase, uint32_t *__restrict__ mail)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t so = 0, lo = 0;
+    for (uint32_t c = 0; c < d.nch; c++) {
+        sbase[c] = so; lbase[c] = lo;
+        const uint32_t cs = (rlen[c] + 255u) & ~255u;
+        so += cs;
+        lo += 4u * (uint32_t)rans_lane_stride(cs);
+    }
+    sbase[d.nch] = so; lbase[d.nch] = lo;
+    mail[12] = so; mail[13] = lo;
+}
+
+// what the stage plans for `nch` chunks when the input has `sym_per_byte_256` / 256 RLE0 symbols per byte (256 = the worst case)
+size_t enc_plan_bytes(const EncDims &d, int nblk, uint32_t sym_per_byte_256)
+{
+    EncBufs b;
+    jpk_ctx dummy;
+    Arena plan(&dummy, true);
+    enc_layout(plan, d, b, LAY_RANK | LAY_RLE);
+    plan.get<uint32_t>((size_t)d.nch + 1);
+    plan.get<uint32_t>((size_t)d.nch + 1);
+    if (nblk) { plan.get<uint32_t>(d.nch); plan.get<uint32_t>(d.nch); plan.get<uint8_t *>((size_t)nblk); }
+    const size_t worst = (size_t)d.nch * d.chunk;
+    size_t sym = worst / 256 * sym_per_byte_256 + 256 * (size_t)d.nch;
+    if (sym > worst) sym = worst;
+    enc_layout(plan, d, b, LAY_MODEL | LAY_RANS, sym, 2 * sym + 4 * 128 * (size_t)d.nch);
+    return plan.need;
+}
+int encode_core(jpk_ctx *ctx, const uint8_t *d_in, EncDims &d, EncBufs &b, int inflight_n, const GroupTabs *gt = nullptr)
 {
     hipStream_t st = ctx->stream;
     const size_t stride = d.chunk;
+    // ---- rank coding and RLE0 of every chunk, then the compact layout of everything that is indexed by RLE0 symbol ----------
+    // The symbol count of a chunk is known on the device only: one 8-byte read back (the stage's first host synchronisation) sizes
+    // the model / rANS buffers for what the block HAS -- ~33 bytes of arena per block byte on text instead of the 78 that "every
+    // byte a symbol" takes.  When the arena turns out too small it grows and the stage starts over (the first dense block of a
+    // context; jpk_ctx_reserve sizes for text).
+    JPK_TRY(jpk_arena_ensure(ctx, ctx->arena_base + enc_plan_bytes(d, gt ? gt->nblk : 0, ENC_PLAN_SYM_256)));
+    for (int attempt = 0;; attempt++) {
+        Arena real(ctx, false);
+        enc_layout(real, d, b, LAY_RANK | LAY_RLE);
+        uint32_t *sbase = real.get<uint32_t>((size_t)d.nch + 1), *lbase = real.get<uint32_t>((size_t)d.nch + 1);
+        if (gt) {
+            uint32_t *d_clen = real.get<uint32_t>(d.nch), *d_cblk = real.get<uint32_t>(d.nch);
+            uint8_t **d_bout = real.get<uint8_t *>((size_t)gt->nblk);
+            if (ctx->arena_off > ctx->arena_cap) return JPK_E_ALLOC;
+            JPK_HIP(hipMemcpyAsync(d_clen, gt->clen, sizeof(uint32_t) * d.nch, hipMemcpyHostToDevice, st));
+            JPK_HIP(hipMemcpyAsync(d_cblk, gt->cblk, sizeof(uint32_t) * d.nch, hipMemcpyHostToDevice, st));
+            JPK_HIP(hipMemcpyAsync(d_bout, gt->bout, sizeof(uint8_t *) * (size_t)gt->nblk, hipMemcpyHostToDevice, st));
+            d.clen = d_clen; d.cblk = d_cblk; d.bout = d_bout;
+        }
+        if (ctx->arena_off > ctx->arena_cap) return JPK_E_ALLOC;
+        d.sbase = nullptr; d.lbase = nullptr;
+        JPK_TRY(run_rank(ctx, d_in, d, b));
+        JPK_TRY(run_rle(ctx, b.ranks, d, b));
+        hipLaunchKernelGGL(k_sym_layout, dim3(1), dim3(64), 0, st, d, b.rlen, sbase, lbase, ctx->d_mail);
+        uint32_t mail[14];
+        JPK_TRY(jpk_read_mail(ctx, mail, 14));
+        const size_t sym_total = mail[12], lane_total = mail[13];
+        Arena rest(ctx, true);
+        EncBufs dummy = b;
+        enc_layout(rest, d, dummy, LAY_MODEL | LAY_RANS, sym_total ? sym_total : 256, lane_total ? lane_total : 512);
+        if (ctx->arena_off + rest.need > ctx->arena_cap) {
+            if (attempt) return JPK_E_ALLOC;
+            JPK_TRY(jpk_arena_ensure(ctx, ctx->arena_off + rest.need));      // frees and re-allocates: the buffers above are gone
+            continue;
+        }
+        enc_layout(real, d, b, LAY_MODEL | LAY_RANS, sym_total ? sym_total : 256, lane_total ? lane_total : 512);
+        d.sbase = sbase; d.lbase = lbase;
+        break;
+    }
     JPK_HIP(hipMemsetAsync(b.qhist, 0, (size_t)d.nch * 6 * NQ * QSTRIDE * 4, st));
     // The stage is bounded by the longest rANS chain (the densest chunk), a single wave, and several of the parallel
     // kernels in front of it are latency-bound per chunk as well.  The chunks are ordered by a density estimate and cut
     // into up to four groups, densest first, and each group runs the whole stage on its own stream: the densest
     // chains start after a quarter of the parallel work, beside the parallel stages of the other groups.
     auto pre_chain = [&](const EncDims &g) -> int {
-        JPK_TRY(run_rank(ctx, d_in, g, b));
-        JPK_TRY(run_rle(ctx, b.ranks, g, b));
         JPK_TRY(run_model(ctx, b.rle, b.rlen, g, b));
         return JPK_OK;
     };
@@ -1531,14 +1630,9 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     ctx->stats.ans_rle_symbols = 0;
     if (len == 0) return JPK_OK;
     hipStream_t st = ctx->stream;
-    const EncDims d = make_dims((uint32_t)len, ANS_CHUNK);
+    EncDims d = make_dims((uint32_t)len, ANS_CHUNK);
     EncBufs b;
-    Arena plan(ctx, true);
-    enc_layout(plan, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
-    JPK_TRY(jpk_arena_ensure(ctx, plan.need));
-    Arena real(ctx, false);
-    enc_layout(real, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
-
+    memset(&b, 0, sizeof b);
     JPK_TRY(encode_core(ctx, d_in, d, b, inflight.n));
     const size_t stride = d.chunk;
     uint32_t mail[9];
@@ -1573,15 +1667,8 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
 // block and, through the block, its output buffer; offsets restart at every block.  One host synchronisation per group.
 size_t jpk_ans_encode_group_arena_bytes(uint32_t nchunks, int nblk)
 {
-    EncDims d = make_dims(nchunks * ANS_CHUNK, ANS_CHUNK);
-    EncBufs b;
-    jpk_ctx dummy;
-    Arena plan(&dummy, true);
-    enc_layout(plan, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
-    plan.get<uint32_t>(nchunks);
-    plan.get<uint32_t>(nchunks);
-    plan.get<uint8_t *>((size_t)nblk);
-    return plan.need;
+    const EncDims d = make_dims(nchunks * ANS_CHUNK, ANS_CHUNK);
+    return enc_plan_bytes(d, nblk, ENC_PLAN_SYM_256);
 }
 
 // The arena (from ctx->arena_base on) must hold jpk_ans_encode_group_arena_bytes(); the caller has sized it.
@@ -1605,18 +1692,10 @@ int jpk_ans_encode_group_device(jpk_ctx *ctx, int nblk, const uint8_t *d_stage, 
     if (nch == 0) return JPK_OK;
     EncDims d = make_dims(nch * ANS_CHUNK, ANS_CHUNK);
     EncBufs b;
-    Arena real(ctx, false);
-    enc_layout(real, d, b, LAY_RANK | LAY_RLE | LAY_MODEL | LAY_RANS);
-    uint32_t *d_clen = real.get<uint32_t>(nch), *d_cblk = real.get<uint32_t>(nch);
-    uint8_t **d_bout = real.get<uint8_t *>((size_t)nblk);
-    if (ctx->arena_off > ctx->arena_cap) return JPK_E_ALLOC;
-    JPK_HIP(hipMemcpyAsync(d_clen, clen.data(), sizeof(uint32_t) * nch, hipMemcpyHostToDevice, st));
-    JPK_HIP(hipMemcpyAsync(d_cblk, cblk.data(), sizeof(uint32_t) * nch, hipMemcpyHostToDevice, st));
-    JPK_HIP(hipMemcpyAsync(d_bout, d_out, sizeof(uint8_t *) * (size_t)nblk, hipMemcpyHostToDevice, st));
-    d.clen = d_clen;
-    d.cblk = d_cblk;
-    d.bout = d_bout;
-    JPK_TRY(encode_core(ctx, d_stage, d, b, inflight.n));
+    memset(&b, 0, sizeof b);
+    const GroupTabs gt = {clen.data(), cblk.data(), d_out, nblk};     // (host vectors: they outlive the synchronisations below)
+    JPK_TRY(encode_core(ctx, d_stage, d, b, inflight.n, &gt));
+    uint8_t **d_bout = const_cast<uint8_t **>(d.bout);
     // sizes: header + payload of every chunk; one copy, the group's only host synchronisation before the payload is placed
     std::vector<uint32_t> hs(nch), cs(nch);
     JPK_HIP(hipMemcpyAsync(hs.data(), b.hsize, sizeof(uint32_t) * nch, hipMemcpyDeviceToHost, st));
@@ -1632,8 +1711,8 @@ int jpk_ans_encode_group_device(jpk_ctx *ctx, int nblk, const uint8_t *d_stage, 
         // blocks that fit, by pointing the others at a scratch sink inside the arena sized for the largest of them
         uint64_t worst = 0;
         for (int k = 0; k < nblk; k++) if (status[k] != JPK_OK && tot[k] > worst) worst = tot[k];
-        uint8_t *sink = real.get<uint8_t>((size_t)worst);
-        if (ctx->arena_off > ctx->arena_cap) return JPK_E_CAPACITY;            // no room for the sink: report the group as failed
+        if (ctx->arena_off + (size_t)worst + 256 > ctx->arena_cap) return JPK_E_CAPACITY;      // no room for the sink: the group as a whole is reported
+        uint8_t *sink = ctx->arena + ctx->arena_off;
         std::vector<uint8_t *> outs(d_out, d_out + nblk);
         for (int k = 0; k < nblk; k++) if (status[k] != JPK_OK) outs[k] = sink;
         JPK_HIP(hipMemcpyAsync(d_bout, outs.data(), sizeof(uint8_t *) * (size_t)nblk, hipMemcpyHostToDevice, st));

@@ -187,7 +187,8 @@ int jpk_ans_encode_group_device(jpk_ctx *ctx, int nblk, const uint8_t *d_stage, 
 size_t jpk_ans_encode_group_arena_bytes(uint32_t nchunks, int nblk);
 size_t jpk_inv_bwt_arena_bytes(uint32_t n);
 size_t jpk_fwd_bwt_arena_bytes(uint32_t n);
-size_t jpk_ans_encode_arena_bytes(uint32_t len);
+size_t jpk_ans_encode_arena_bytes(uint32_t len);          // text-like data (0.55 RLE0 symbols per byte); the arena grows for denser blocks
+size_t jpk_ans_encode_arena_bytes_worst(uint32_t len);    // every byte a symbol
 int jpk_rank_encode_device(jpk_ctx *ctx, uint8_t *d_t, int32_t *d_freq, int32_t len);
 int jpk_rank_decode_device(jpk_ctx *ctx, uint8_t *d_r, const int32_t *d_freq, int32_t len);
 int jpk_rle_encode_device(jpk_ctx *ctx, const uint8_t *d_ranks, int32_t len, uint16_t *d_rle, int32_t *rlen);

@@ -172,12 +172,13 @@ def test_reserve_follows_the_stage_layouts():
     """jpk_ctx_reserve takes the maximum of the four stages' own planning passes (DESIGN.md section 3 quotes these factors)"""
     from jampack_amd import lib
     n = 64 << 20
-    per_byte = [lib().jpk_debug_arena_bytes(n, st) / n for st in range(4)]
+    per_byte = [lib().jpk_debug_arena_bytes(n, st) / n for st in range(5)]
     assert 45 < per_byte[0] < 48          # forward BWT: radix ping-pong 24 n + ISA 4 n + active list 8 n + BWT bytes n + carried BWT bytes 3 n + run lengths 4 n + tables
-    assert 75 < per_byte[1] < 85          # rANS encode, worst case (every byte a symbol): records 32 n, states 8 n, exponent histories 14 n, ...
+    assert 40 < per_byte[1] < 47          # rANS encode sized for text (0.55 RLE0 symbols per byte at ~75 bytes per symbol + ranks n + RLE0 symbols 2 n)
     assert 9 < per_byte[2] < 11           # inverse BWT
     assert 3 <= per_byte[3] < 3.2         # rANS decode bound
-    assert lib().jpk_debug_arena_bytes(n, 4) == -1 and lib().jpk_debug_arena_bytes(-1, 0) == -1
+    assert 75 < per_byte[4] < 85          # rANS encode, densest data (every byte a symbol): records 32 n, states 8 n, exponent histories 14 n, ...
+    assert lib().jpk_debug_arena_bytes(n, 5) == -1 and lib().jpk_debug_arena_bytes(-1, 0) == -1
 
 
 def test_decoded_size_rejects_more_rle_symbols_than_bytes():

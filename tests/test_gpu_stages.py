@@ -51,3 +51,31 @@ def test_model_pairs_equal_oracle(ctx, oracle, kind, n):
     got = d_p.cpu().numpy().view(np.uint32)
     bad = np.nonzero(got != exp)[0]
     assert bad.size == 0, f"{kind} n={n}: {bad.size} mismatches, first at {bad[:6]} got {got[bad[:3]]} exp {exp[bad[:3]]}"
+
+
+def test_the_encoder_arena_grows_when_a_denser_block_arrives(oracle):
+    """Round 4: the model / rANS buffers are sized from the block's own RLE0 symbol count (one 8-byte read back), the arena first for
+    text-like data (0.55 symbols per byte).  A context that has only seen text meets random bytes (one symbol per byte): the arena
+    grows, the stage starts over, the bytes are exact; text afterwards is exact too, and so is a block whose chunks differ wildly
+    in density (zeros | random | text)."""
+    import torch
+    import jampack_amd as jam
+    c = jam.Context(0, torch.cuda.current_stream().cuda_stream)
+    try:
+        n = 3 << 20
+        mixed = np.concatenate([np.zeros(1 << 20, np.uint8), jam.corpus.make("random", (1 << 20) + 4097, 3), jam.corpus.make("text", (1 << 20) - 4097, 4)])
+        seq = [("text", jam.corpus.make("text", n, 1)), ("random", jam.corpus.make("random", n, 2)), ("text again", jam.corpus.make("text_survey", n, 5)), ("mixed", mixed)]
+        ws = []
+        for name, img in seq:
+            want = oracle.ans_encode(img.copy())
+            d_in = _dev(img)
+            cap = jam.ans_capacity(len(img))
+            d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+            m = c.ans_encode(d_in, len(img), d_out, cap)
+            got = d_out[:m].cpu().numpy()
+            assert m == len(want) and np.array_equal(got, want), name
+            ws.append(int(c.stats().workspace_bytes))
+        assert ws[1] > ws[0], "random bytes after text: the arena must have grown"
+        assert ws[0] < 60 * n, f"text needs {ws[0] / n:.1f} bytes of arena per byte: the compact layout is not in effect"
+    finally:
+        c.close()

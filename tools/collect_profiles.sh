@@ -3,7 +3,7 @@
 # Produces gpurun_out/<tag>/: PMC passes + summary, rocprofv3 kernel stats of the bench command, bench lines, worst cases.
 # (counters and traces in separate runs; the program itself after `--`)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
