@@ -298,6 +298,16 @@ def host_buffers(jam, corpus):
     out = {"blocks": nb, "block_bytes": bs}
     comp = [None] * nb
     try:
+        # un-timed: sixteen threads take a block each, so that sixteen library contexts exist with their arenas and staging buffers
+        # sized (a context's first call allocates ~6 GB; threads that end return their contexts to the library's pool, the timed
+        # threads below borrow them)
+        def warm(k):
+            jam.block_decompress(jam.block_compress(parts[k]), bs)
+        th = [threading.Thread(target=warm, args=(k,)) for k in range(16)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
         for T in (1, 8, 16):
             res = {}
             for leg in ("compress", "decompress"):
@@ -317,8 +327,6 @@ def host_buffers(jam, corpus):
                         else:
                             back[k] = jam.block_decompress(comp[k], bs)
 
-                if T == 1 and leg == "compress":
-                    jam.block_compress(parts[0])            # the first call of the process sizes an arena and loads code: not timed
                 th = [threading.Thread(target=work) for _ in range(T)]
                 t0 = time.perf_counter()
                 for t in th:
@@ -330,7 +338,6 @@ def host_buffers(jam, corpus):
                 if leg == "decompress":
                     res["round_trip_ok"] = bool(all(np.array_equal(b, p) for b, p in zip(back, parts)))
             out[f"threads_{T}"] = res
-            jam.shutdown()                                   # the threads' contexts (6 GB arenas) go back before the next T
     finally:
         jam.shutdown()
     out["note"] = ("pageable host buffers in, pageable host buffers out, every block through jpk_block_compress / jpk_block_decompress on T host threads "
@@ -343,7 +350,8 @@ def per_block_size(jam, corpus, torch, dev, device_index: int, in_flight: int):
     main.cpp:78) and SURVEY 8d names {1, 64, 256 MiB}; 8 MiB is the reference's default.  For each size, on the first 256 MiB of the
     enwik9-like text stream:
       one_at_a_time   one block per call (jpk_dev_block_compress / _decompress), the next call starts when the last one returned;
-      streamed        the blocks of a 64 / 256 / 256 / 512 MiB stream through ONE jpk_dev_blocks_compress call (`in_flight` blocks in
+      streamed        the blocks of a 256 / 256 / 256 / 512 MiB stream through ONE jpk_dev_blocks_compress call (small blocks are
+                      compressed in groups there: one suffix sort and one set of entropy grids per group) (`in_flight` blocks in
                       flight) and ONE jpk_dev_blocks_decompress call (one grid per serial kernel over all blocks);
       same_bytes      streamed output == one-at-a-time output for every block, and every round trip == the input.
     Inputs and outputs resident in HBM; wall clock around synchronised calls; each leg warmed once."""
@@ -356,7 +364,8 @@ def per_block_size(jam, corpus, torch, dev, device_index: int, in_flight: int):
         # (block MiB, blocks of the stream, blocks timed one at a time, blocks in flight of the streamed compress: a 1 MiB block is
         # one chunk = one 5 ms chain on one of 1024 SIMDs, so small blocks want many in flight -- the library admits up to 16)
         # 8 MiB is the reference's DEFAULT_BLOCKSIZE (format.hpp:20)
-        for bm, nstream, nsingle, nfl in ((1, 64, 8, 16), (8, 32, 4, 16), (64, 4, 2, in_flight), (256, 2, 1, in_flight)):
+        # (1 MiB and 8 MiB: both a 256 MiB stream, as Jampack::Compress would cut a 256 MiB file, jampack.cpp:205-224)
+        for bm, nstream, nsingle, nfl in ((1, 256, 8, 16), (8, 32, 4, 16), (64, 4, 2, in_flight), (256, 2, 1, in_flight)):
             bs = bm * MiB
             # a fresh context per size, and the previous size's worker contexts (and their streams) released first: streams are
             # dealt onto the hardware queues round robin at creation, leftovers of a finished leg should not sit beside this one

@@ -1355,6 +1355,8 @@ EncDims make_dims(uint32_t len, uint32_t chunk)
     d.clen = nullptr;
     d.cblk = nullptr;
     d.bout = nullptr;
+    d.sbase = nullptr;
+    d.lbase = nullptr;
     return d;
 }
 

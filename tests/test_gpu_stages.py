@@ -63,8 +63,10 @@ def test_the_encoder_arena_grows_when_a_denser_block_arrives(oracle):
     c = jam.Context(0, torch.cuda.current_stream().cuda_stream)
     try:
         n = 3 << 20
-        mixed = np.concatenate([np.zeros(1 << 20, np.uint8), jam.corpus.make("random", (1 << 20) + 4097, 3), jam.corpus.make("text", (1 << 20) - 4097, 4)])
-        seq = [("text", jam.corpus.make("text", n, 1)), ("random", jam.corpus.make("random", n, 2)), ("text again", jam.corpus.make("text_survey", n, 5)), ("mixed", mixed)]
+        # (images of the BWT stage, as the encoder sees them: a text block's image has ~0.4 RLE0 symbols per byte, random bytes 1.0)
+        bwt_text = oracle.bwt_forward(jam.corpus.make("text", n, 1))
+        mixed = np.concatenate([np.zeros(1 << 20, np.uint8), jam.corpus.make("random", (1 << 20) + 4097, 3), bwt_text[: (1 << 20) - 4097]])
+        seq = [("text", bwt_text), ("random", jam.corpus.make("random", n, 2)), ("text again", oracle.bwt_forward(jam.corpus.make("text_survey", n, 5))), ("mixed", mixed)]
         ws = []
         for name, img in seq:
             want = oracle.ans_encode(img.copy())
@@ -76,6 +78,6 @@ def test_the_encoder_arena_grows_when_a_denser_block_arrives(oracle):
             assert m == len(want) and np.array_equal(got, want), name
             ws.append(int(c.stats().workspace_bytes))
         assert ws[1] > ws[0], "random bytes after text: the arena must have grown"
-        assert ws[0] < 60 * n, f"text needs {ws[0] / n:.1f} bytes of arena per byte: the compact layout is not in effect"
+        assert ws[0] < 75 * n, f"text needs {ws[0] / n:.1f} bytes of arena per byte: the compact layout is not in effect"      # (4 chunks for 3 MiB + 480 B: 60 n planned, + 1/8 growth margin)
     finally:
         c.close()
