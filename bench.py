@@ -113,7 +113,9 @@ def parse():
     ap.add_argument("--limit-bytes", type=int, default=0, help="truncate the workload (debug only; marks the line invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (multi-GPU children print this anyway)")
-    ap.add_argument("--contexts", type=int, default=4, help="blocks in flight per GPU (one context + HIP stream each)")
+    # 8 since round 4: a context's arena is 3.1 GB now (6 GB before), and 8 blocks in flight measured +4.8 % over 4 (+3.2 % with 6) in
+    # twelve alternating runs on one box (profiles/r04_blocks_in_flight.txt)
+    ap.add_argument("--contexts", type=int, default=8, help="blocks in flight per GPU (one context + HIP stream each)")
     ap.add_argument("--cpu-sample-mib", type=int, default=64, help="bytes of block 0 the CPU reference is timed on")
     ap.add_argument("--no-block-sizes", action="store_true", help="skip the per_block_size extra (1 / 64 / 256 MiB blocks)")
     ap.add_argument("--master-port", type=int, default=29511)
@@ -901,6 +903,14 @@ def main():
                                             "compressed_ratio": round(sum(psz) / batch_bytes, 4),
                                             "workload": "same shape, text with a 200 000-phrase book (round 1's corpus)"}
             del p_in
+        # The extras below bring contexts of their own.  The loop's contexts (each with its stream and up to three encoder group
+        # streams) are closed first: HIP deals streams onto 32 hardware queues, a stream beyond that shares a queue, and a 12 ms
+        # chain kernel then blocks whatever sits behind it -- with the loop's twenty streams still alive the 8 MiB leg of
+        # per_block_size measured 2.8 GB/s where a fresh process measures 3.6 (tools/small_blocks.py).
+        pool.shutdown()
+        for c_ in ctxs:
+            c_.close()
+        torch.cuda.empty_cache()
         if not args.no_block_sizes and not args.limit_bytes:
             try:
                 extra["per_block_size"] = per_block_size(jam, corpus, torch, dev, local_rank, nctx)

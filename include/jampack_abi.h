@@ -188,9 +188,13 @@ JPK_API int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const uint8
 /* The compress direction of the same loop (jampack.cpp:205-224: Threads blocks read, Comp() in an OpenMP loop, written in order)
  * for blocks that sit in HBM: ForwardBwt + Ans::Encode of nblocks independent blocks in ONE call.  Compression wants several
  * blocks IN FLIGHT rather than one wide grid (the suffix sort fills the GPU by itself; the entropy stage of the other blocks
- * hides in its latency), so the library runs `in_flight` worker threads (<= 0: 4, the measured optimum on one MI355X), each with
- * a context of its own on ctx's device (kept by the library between calls, released by jpk_shutdown), that take the blocks in
- * array order.  The calling thread works too (with ctx) and returns when every block is done.  status may be NULL; otherwise
+ * hides in its latency), so the library runs `in_flight` worker threads (<= 0: 8; at most 16), each with a context of its own on
+ * ctx's device (kept by the library between calls, released by jpk_shutdown), that take the work in array order.  Blocks of up to
+ * 16 MiB -- the reference's default block is 8 MiB, its smallest 1 MiB (format.hpp:20-22) -- are compressed in GROUPS of
+ * consecutive blocks (a quarter of their total bytes, 8 .. 64 MiB, at most 256 blocks; JPK_GROUP_MIB fixes the size, JPK_GROUP=0
+ * turns grouping off): one suffix sort over the blocks of a group, one set of entropy grids over all their chunks, one host
+ * synchronisation per group; every block's bytes are those of jpk_dev_block_compress for that block.
+ * The calling thread works too (with ctx) and returns when every block is done.  status may be NULL; otherwise
  * status[b] receives block b's jpk_status (JPK_E_CAPACITY when out_cap[b] is too small, ...) and the other blocks still complete.
  * Stream order: as for every jpk_dev_* call, work already queued on ctx's stream (the producers of d_in[], readers of an earlier
  * d_out[]) is ordered in front of the batch -- the workers' streams wait for an event recorded on ctx's stream at entry -- and

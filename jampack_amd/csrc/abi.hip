@@ -27,9 +27,11 @@ int jpk_arena_ensure(jpk_ctx *ctx, size_t bytes)
     JPK_HIP(hipStreamSynchronize(ctx->stream));
     for (int g = 0; g + 1 < jpk_ctx::ENC_GROUPS; g++)
         if (ctx->aux[g]) JPK_HIP(hipStreamSynchronize(ctx->aux[g]));
+    const bool growing = ctx->arena != nullptr;
     if (ctx->arena) { JPK_HIP(hipFree(ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; }
-    // grow geometrically so that a sequence of slightly larger blocks does not re-allocate every time
-    size_t want = bytes + bytes / 8;
+    // an arena that has to GROW grows geometrically, so that a sequence of slightly larger blocks does not re-allocate every time;
+    // the first allocation (jpk_ctx_reserve, or a context's first block) takes what was asked for
+    size_t want = growing ? bytes + bytes / 8 : bytes;
     hipError_t e = hipMalloc((void **)&ctx->arena, want);
     if (e != hipSuccess) {
         want = bytes;
@@ -924,7 +926,7 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
             if (sb > max_stage) max_stage = sb;
             if (ab > max_arena) max_arena = ab;
         }
-    int nw = in_flight > 0 ? in_flight : 4;
+    int nw = in_flight > 0 ? in_flight : 8;        // (8 since round 4: +9 % over 4 in flight, profiles/r04_blocks_compress_call.txt; an arena is 3 GB now)
     if (nw > ntasks) nw = ntasks;
     if (nw > 16) nw = 16;
     uint64_t generation;

@@ -32,7 +32,7 @@ python3 $REPO/tools/rocpd_timeline.py /tmp/ke/e_results.db k_density > "$OUT/tim
 cd $REPO
 cp "$OUT/pmc_traffic.json" profiles/${TAG}_pmc_traffic.json 2>/dev/null     # bench.py reads the traffic of the dominant kernel from here
 python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/bench.json"
-python3 bench.py --workload enwik9 --contexts 4 --steps 2 --warmup 1 --no-extras 2>/dev/null | tail -1 > "$OUT/bench_enwik9like_4ctx.json"
+python3 bench.py --workload enwik9 --steps 2 --warmup 1 --no-extras 2>/dev/null | tail -1 > "$OUT/bench_enwik9like.json"
 python3 bench.py --workload silesia --block-mib 256 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_silesialike_256mib.json"
 python3 tools/worst_cases.py > "$OUT/worst_cases.txt" 2>/dev/null
 NLIST=1,4,8,16,24,32,48,64 python3 tools/dec_scaling.py batch > "$OUT/decode_batch_scaling.txt" 2>/dev/null
@@ -58,4 +58,10 @@ JPK_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --steps 4 --warmup 2 --no-extras -
 JPK_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --steps 2 --warmup 1 --no-extras --contexts 2 --workload enwik9 --limit-bytes 402653184 2>/dev/null | tail -1 > "$OUT/bench_two_ranks_one_gpu_enwik9_384mib.json"
 bash tools/pmc_sq.sh gpurun_out/$TAG/sq_fwd fwd > /dev/null 2>&1
 bash tools/pmc_sq.sh gpurun_out/$TAG/sq_enc enc > /dev/null 2>&1
+# 6. round 4: small blocks through one call (a fresh process), the interference matrix, counters in the timed loop's shape
+python3 tools/small_blocks.py 1,8,64 4,8,16 2>/dev/null | grep blocks > "$OUT/small_blocks.txt"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/hog.hip -o tools/_bin/libhog.so > /dev/null 2>&1
+python3 tools/interfere.py 4 2 2>/dev/null | grep -v amdgpu > "$OUT/interference.txt"
+bash tools/pmc_loop.sh gpurun_out/$TAG/loop > /dev/null 2>&1
+cp gpurun_out/$TAG/loop/loop_counters.txt "$OUT/loop_counters.txt" 2>/dev/null
 ls -la "$OUT"
