@@ -603,7 +603,15 @@ __global__ __launch_bounds__(64) void k_quasi_build(EncDims d, const uint32_t *_
 //   B    one lane per (chunk, recurrence) walks the segments in order composing exact states through the tables.
 //   C    the unresolved segments are run again from their now exact start state, writing the outputs.
 // Every output is produced from an exact state: the result is bit-identical to the sequential reference.
-constexpr uint32_t AD_WARM = 1280;      // multiple of 16
+// Warm-up items in front of a segment.  The interval of reachable states contracts by >= floor(width / 32) per item whatever the
+// item is (floor is superadditive), so from the full range it is <= 31 wide after 259 items: any warm-up >= 320 keeps the guarantee
+// the table of 32 candidates rests on.  Beyond that a longer warm-up only decides how many segments are already a single state
+// when the segment starts (k_adapt_ext / k_adapt_tab take the rest).  Rounds 1-3 used 1280, which is best for a block ALONE (the
+// five k_adapt_* kernels: 4.3 ms per 64 MiB block against 4.9 with 320) -- but the warm-up is pure vector work (two states per item,
+// +62 % on k_adapt_a), and with blocks in flight vector issue is what is short: the bench line prefers 320 (4.41 / 4.38 / 4.29 /
+// 4.15 GB/s for 320 / 384 / 512 / 1280 in one sequence, 4.22 / 4.13 / 4.11 for 320 / 384 / 1280 interleaved three times;
+// profiles/r04_adapt_warm.txt).  JPK_AD_WARM overrides (multiple of 64, 320..4096).
+constexpr uint32_t AD_WARM_DEFAULT = 320;
 
 struct AdRec {                          // one recurrence
     bool exp;                           // exponent model entry (true) or alphabet-2 mantissa model (false)
@@ -644,6 +652,28 @@ __device__ __forceinline__ void ad_for_each(const AdRec &r, const AdStream &st, 
     if (r.exp) {
         const uint8_t *p = st.c8;
         while (t < t1 && (t & 15u)) { f(t, (int)(p[t] & 7u)); t++; }
+        // Lanes walk segments 4 KiB apart: every load of a wave touches 64 different lines, and a lane that keeps ONE 16-byte load in
+        // flight spends its time waiting for it (the walk ran at ~30 cycles per instruction).  Round 4: a whole 64-byte line per lane
+        // and step, the next line requested before the current one is consumed (four loads in flight per lane).
+        if (t + 64 <= t1) {
+            uint4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const uint4 *>(p + t + 16 * q);
+            for (; t + 64 <= t1; t += 64) {
+                const uint32_t tn = (t + 128 <= t1) ? t + 64 : t;
+                uint4 nv[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) nv[q] = *reinterpret_cast<const uint4 *>(p + tn + 16 * q);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                    for (int k = 0; k < 16; k++) f(t + 16 * q + k, (int)((w[k >> 2] >> (8 * (k & 3))) & 7u));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = nv[q];
+            }
+        }
         if (t + 16 <= t1) {
             uint4 v = *reinterpret_cast<const uint4 *>(p + t);
             for (; t + 16 <= t1; t += 16) {
@@ -659,6 +689,26 @@ __device__ __forceinline__ void ad_for_each(const AdRec &r, const AdStream &st, 
     } else {
         const uint32_t *p = st.list;
         while (t < t1 && (t & 3u)) { const uint32_t e = p[t]; f(e & 0x7FFFFFFFu, (int)(e >> 31)); t++; }
+        if (t + 16 <= t1) {                                      // (a 64-byte line per step, the next one in flight: see above)
+            uint4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const uint4 *>(p + t + 4 * q);
+            for (; t + 16 <= t1; t += 16) {
+                const uint32_t tn = (t + 32 <= t1) ? t + 16 : t;
+                uint4 nv[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) nv[q] = *reinterpret_cast<const uint4 *>(p + tn + 4 * q);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    f(v[q].x & 0x7FFFFFFFu, (int)(v[q].x >> 31));
+                    f(v[q].y & 0x7FFFFFFFu, (int)(v[q].y >> 31));
+                    f(v[q].z & 0x7FFFFFFFu, (int)(v[q].z >> 31));
+                    f(v[q].w & 0x7FFFFFFFu, (int)(v[q].w >> 31));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = nv[q];
+            }
+        }
         if (t + 4 <= t1) {
             uint4 v = *reinterpret_cast<const uint4 *>(p + t);
             for (; t + 4 <= t1; t += 4) {
@@ -688,6 +738,33 @@ __device__ __forceinline__ int32_t ad_run_write(const AdRec &r, const AdStream &
         const uint8_t *p = st.c8;
         uint32_t t = t0;
         while (t < t1 && (t & 15u)) { hist[t] = (uint16_t)x; x = adapt_step(x, i, (int)(p[t] & 7u), 8); t++; }
+        if (t + 64 <= t1) {                                      // a 64-byte line of class bytes per step, the next one in flight (see ad_for_each)
+            uint4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const uint4 *>(p + t + 16 * q);
+            for (; t + 64 <= t1; t += 64) {
+                const uint32_t tn = (t + 128 <= t1) ? t + 64 : t;
+                uint4 nv[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) nv[q] = *reinterpret_cast<const uint4 *>(p + tn + 16 * q);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+                    uint32_t o[8];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        if (k & 1) o[k >> 1] |= (uint32_t)x << 16;
+                        else o[k >> 1] = (uint32_t)x & 0xffffu;
+                        x = adapt_step(x, i, (int)((w[k >> 2] >> (8 * (k & 3))) & 7u), 8);
+                    }
+                    uint4 *qq = reinterpret_cast<uint4 *>(hist + t + 16 * q);
+                    qq[0] = make_uint4(o[0], o[1], o[2], o[3]);
+                    qq[1] = make_uint4(o[4], o[5], o[6], o[7]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = nv[q];
+            }
+        }
         if (t + 16 <= t1) {
             uint4 v = *reinterpret_cast<const uint4 *>(p + t);
             for (; t + 16 <= t1; t += 16) {
@@ -722,6 +799,7 @@ struct AdArgs {
     const uint8_t *cls8; const uint32_t *clist; size_t rle_stride; const uint32_t *rlen; const uint32_t *clstotal;
     const uint32_t *clsbase;                // [chunk][tile][8]: symbols of every class in front of the tile (k_cls_prefix)
     uint16_t *exph; uint32_t *mantad;       // exph: [chunk][7 exponent entries][rle_stride] history of every entry
+    uint32_t warm;                          // warm-up items in front of a segment (AD_WARM_DEFAULT)
     uint32_t *seg_flag; int32_t *seg_lo, *seg_end, *seg_start; uint16_t *seg_tab;
 };
 
@@ -741,7 +819,7 @@ __global__ __launch_bounds__(64) void k_adapt_a(EncDims d, AdArgs a)
     else {
         lo = r.smin(); hi = r.smax();
         const int i = r.i, A = r.A;
-        ad_for_each(r, st, t0 - AD_WARM, t0, [&](uint32_t, int sy) { lo = adapt_step(lo, i, sy, A); hi = adapt_step(hi, i, sy, A); });
+        ad_for_each(r, st, t0 - a.warm, t0, [&](uint32_t, int sy) { lo = adapt_step(lo, i, sy, A); hi = adapt_step(hi, i, sy, A); });
     }
     const size_t so = ((size_t)c * 9 + rec) * d.tpc + k;
     if (lo == hi) {
@@ -1421,6 +1499,13 @@ int run_model(jpk_ctx *ctx, const uint16_t *d_rle, const uint32_t *d_rlen, const
     AdArgs aa;
     aa.cls8 = b.cls8; aa.clist = b.clist; aa.rle_stride = stride; aa.rlen = d_rlen; aa.clstotal = b.clstotal; aa.clsbase = b.clscnt;
     aa.exph = b.exph; aa.mantad = b.mantad;
+    static const uint32_t warm = [] {
+        const char *e = getenv("JPK_AD_WARM");
+        long v = e ? atol(e) : (long)AD_WARM_DEFAULT;
+        v = (v + 63) / 64 * 64;
+        return (uint32_t)(v < 320 ? 320 : (v > 4096 ? 4096 : v));
+    }();
+    aa.warm = warm;
     aa.seg_flag = b.seg_flag; aa.seg_lo = b.seg_lo; aa.seg_end = b.seg_end; aa.seg_start = b.seg_start; aa.seg_tab = b.seg_tab;
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_a, dim3((d.tpc + 63) / 64, 9, d.ncl), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_ext, dim3((d.tpc + 63) / 64, 9, d.ncl), dim3(64), d, aa);
