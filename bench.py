@@ -119,6 +119,7 @@ def parse():
     ap.add_argument("--cpu-sample-mib", type=int, default=64, help="bytes of block 0 the CPU reference is timed on")
     ap.add_argument("--no-block-sizes", action="store_true", help="skip the per_block_size extra (1 / 64 / 256 MiB blocks)")
     ap.add_argument("--master-port", type=int, default=29511)
+    ap.add_argument("--child-extras", action="store_true", help=argparse.SUPPRESS)     # internal: per_block_size + host_buffers in a fresh process
     return ap.parse_args()
 
 
@@ -429,8 +430,169 @@ def per_block_size(jam, corpus, torch, dev, device_index: int, in_flight: int):
     return out
 
 
+def decompress_leg(jam, torch, dev, local_rank, blocks, d_in, d_cmp, sizes, nctx, reps):
+    """rANS decode -> inverse BWT (jampack.cpp:49-50) over the batch: one context per block, one batched call per pass, and passes in
+    flight (`JPK_BENCH_DEC_PASSES`, default 8: `value`).  Every output is compared with the input.  Returns (dict, ok)."""
+    import queue
+    import threading
+    import concurrent.futures as cf
+    mb = sum(len(b) for b in blocks) / 1e6
+    nblk = len(blocks)
+    order = sorted(range(nblk), key=lambda i: -len(blocks[i]))
+    lanes = [order[k::nctx] for k in range(nctx)]
+    ctxs = [jam.Context(local_rank, None) for _ in range(nctx)]
+    pool = cf.ThreadPoolExecutor(max_workers=nctx)
+    d_dcm = [torch.empty(max(len(b), 1), dtype=torch.uint8, device=dev) for b in blocks]
+    dsz = [0] * nblk
+    ok = True
+
+    def dlane(k):
+        for i in lanes[k]:
+            dsz[i] = ctxs[k].block_decompress(d_cmp[i], sizes[i], d_dcm[i], len(blocks[i]))
+
+    def decompress_step_ctx():
+        for f in [pool.submit(dlane, k) for k in range(nctx)]:
+            f.result()
+
+    def decompress_step():
+        # all blocks of the batch in ONE call: every serial decode kernel runs a single grid over the chunks of all blocks
+        n_, st_ = ctxs[0].blocks_decompress(d_cmp, sizes, d_dcm, [len(b) for b in blocks])
+        for i in range(nblk):
+            dsz[i] = n_[i] if st_[i] == 0 else -1
+
+    decompress_step_ctx()
+    torch.cuda.synchronize()
+    tc0 = time.perf_counter()
+    for _ in range(reps):
+        decompress_step_ctx()
+    torch.cuda.synchronize()
+    tdc = (time.perf_counter() - tc0) / reps
+    decompress_step()
+    torch.cuda.synchronize()
+    td0 = time.perf_counter()
+    for _ in range(reps):
+        decompress_step()
+    torch.cuda.synchronize()
+    td = (time.perf_counter() - td0) / reps
+    ok = ok and all(dsz[i] == len(blocks[i]) and bool(torch.equal(d_dcm[i][: len(blocks[i])], d_in[i])) for i in range(nblk))
+    pool.shutdown()
+    for c_ in ctxs:
+        c_.close()
+    # the same passes in flight, as the compress loop runs them: `ndec` contexts each take whole passes (one batched call per
+    # pass) from a queue; a block is 65 serial chains, so a pass alone leaves most of the 1024 SIMDs without a chain
+    ndec = int(os.environ.get("JPK_BENCH_DEC_PASSES", "8"))
+    ndec_max = max(16, ndec)
+    dctxs = [jam.Context(local_rank, None) for _ in range(ndec_max)]
+    dbufs = [[torch.empty(max(len(b), 1), dtype=torch.uint8, device=dev) for b in blocks] for _ in range(ndec_max)]
+    dok = [True] * ndec_max
+
+    def dec_passes(npass, nthreads):
+        q_ = queue.Queue()
+        for _ in range(npass):
+            q_.put(1)
+
+        def w_(k):
+            while True:
+                try:
+                    q_.get_nowait()
+                except queue.Empty:
+                    return
+                n_, st_ = dctxs[k].blocks_decompress(d_cmp, sizes, dbufs[k], [len(b) for b in blocks])
+                dok[k] = dok[k] and all(st_[i] == 0 and n_[i] == len(blocks[i]) for i in range(nblk))
+
+        th_ = [threading.Thread(target=w_, args=(k,)) for k in range(nthreads)]
+        for t_ in th_:
+            t_.start()
+        for t_ in th_:
+            t_.join()
+
+    dec_passes(ndec_max, ndec_max)             # every context has decoded once (arenas sized)
+    torch.cuda.synchronize()
+    in_flight = {}
+    for nfl in sorted({4, ndec, 16}):
+        npass = max(2 * nfl, reps)
+        tp0 = time.perf_counter()
+        dec_passes(npass, nfl)
+        torch.cuda.synchronize()
+        in_flight[nfl] = ((time.perf_counter() - tp0) / npass, npass)
+    tdp, npass = in_flight[ndec]
+    ok = ok and all(dok) and all(bool(torch.equal(dbufs[k][i][: len(blocks[i])], d_in[i])) for k in range(ndec_max) for i in range(nblk))
+    for c_ in dctxs:
+        c_.close()
+    del dbufs
+    out = {"value": round(mb / tdp, 1), "unit": "MB/s", "ms_per_step": round(tdp * 1e3, 3), "steps": npass,
+           "how": f"passes over the batch fed through a queue to {ndec} contexts, one jpk_dev_blocks_decompress call (all blocks of "
+                  "the batch, one grid per serial kernel) per pass; every pass verified against the input",
+           "MBps_by_passes_in_flight": {str(k): round(mb / v[0], 1) for k, v in in_flight.items()},
+           "one_pass_at_a_time_MBps": round(mb / td, 1), "one_pass_at_a_time_ms": round(td * 1e3, 3),
+           "one_context_per_block_MBps": round(mb / tdc, 1)}
+    return out, bool(ok)
+
+
+def child_extras(args):
+    """`per_block_size` and `host_buffers` in a process of their own.  HIP deals streams onto the hardware queues round robin as they
+    are created and never rebalances: after the timed loop, the decompress legs and the batch calls of this bench (~60 streams created
+    and destroyed) a NEW context's stream shares a queue with one that is still alive, and everything it runs is 25-30 % slower
+    (per_block_size inside the bench process: 2.7 GB/s for the 1 MiB stream; in a fresh process on the same box: 4.5;
+    profiles/r04_fresh_process.txt).  A caller's process does not carry that history, so these two extras are measured the way a
+    caller would see them; the parent waits, idle, and merges the JSON."""
+    import torch
+    import jampack_amd as jam
+    from jampack_amd import corpus
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    out = {}
+    try:
+        # the decompress leg of the default line: the workload's blocks, compressed here first
+        data, _ = corpus.load_or_make(args.workload)
+        blocks = corpus.split_blocks(data, args.block_mib << 20)
+        d_in = [torch.from_numpy(np.ascontiguousarray(b)).to(dev) for b in blocks]
+        c0 = jam.Context(0, None)
+        d_cmp, sizes = [], []
+        for i, b in enumerate(blocks):
+            cap = jam.ans_capacity(len(b) + jam.TRAILER)
+            o = torch.empty(cap, dtype=torch.uint8, device=dev)
+            m = c0.block_compress(d_in[i], len(b), o, cap)
+            d_cmp.append(o[:m].clone()); sizes.append(m)
+        c0.close()
+        out["decompress"], out["decompress_ok"] = decompress_leg(jam, torch, dev, 0, blocks, d_in, d_cmp, sizes, max(1, args.contexts), 10)
+        out["decompress"]["process"] = "fresh child process of bench.py"
+        del d_in, d_cmp
+        torch.cuda.empty_cache()
+        jam.shutdown()
+    except Exception as ex:       # noqa: BLE001
+        out["decompress"] = {"error": repr(ex)}
+    try:
+        out["per_block_size"] = per_block_size(jam, corpus, torch, dev, 0, max(1, args.contexts))
+        out["per_block_size"]["process"] = "fresh child process of bench.py"
+    except Exception as ex:       # noqa: BLE001
+        out["per_block_size"] = {"error": repr(ex)}
+    try:
+        out["host_buffers"] = host_buffers(jam, corpus)
+        out["host_buffers"]["process"] = "fresh child process of bench.py"
+    except Exception as ex:       # noqa: BLE001
+        out["host_buffers"] = {"error": repr(ex)}
+    print("CHILD_EXTRAS " + json.dumps(out), flush=True)
+
+
+def run_child_extras(args):
+    """starts `bench.py --child-extras` and returns its dict (None if the child failed: the caller falls back to measuring in-process)"""
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child-extras", "--contexts", str(args.contexts), "--workload", args.workload,
+                            "--block-mib", str(args.block_mib)], capture_output=True, text=True, timeout=900)
+        for ln in r.stdout.splitlines():
+            if ln.startswith("CHILD_EXTRAS "):
+                return json.loads(ln[len("CHILD_EXTRAS "):])
+    except Exception:       # noqa: BLE001
+        pass
+    return None
+
+
 def main():
     args = parse()
+    if args.child_extras:
+        child_extras(args)
+        return
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(launch_children(args))
@@ -760,92 +922,22 @@ def main():
         extra["blocks_compress_call"] = {"value": round(mb / tl, 1), "unit": "MB/s", "ms_per_pass": round(tl * 1e3, 3), "passes": npl, "in_flight": nctx,
                                          "same_bytes": bool(lib_ok), "how": "one jpk_dev_blocks_compress call (C ABI) over all the blocks of 16 passes"}
         del l_out
-        # decompress leg (rANS decode -> inverse BWT, jampack.cpp:49-50) over the same batch, blocks in flight like compress
+        # decompress leg (rANS decode -> inverse BWT, jampack.cpp:49-50) over the same batch, blocks in flight like compress: measured in
+        # the fresh child process (child_extras) when there is one, here otherwise
         d_cmp = [d_out[i][: sizes[i]].clone() for i in range(len(blocks))]
-        d_dcm = [torch.empty(max(len(b), 1), dtype=torch.uint8, device=dev) for b in blocks]
-        dsz = [0] * len(blocks)
-
-        def dlane(k):
-            for i in lanes[k]:
-                dsz[i] = ctxs[k].block_decompress(d_cmp[i], sizes[i], d_dcm[i], len(blocks[i]))
-
-        def decompress_step_ctx():
-            for f in [pool.submit(dlane, k) for k in range(nctx)]:
-                f.result()
-
-        def decompress_step():
-            # all blocks of the batch in ONE call: every serial decode kernel runs a single grid over the chunks of all blocks
-            n_, st_ = ctxs[0].blocks_decompress(d_cmp, sizes, d_dcm, [len(b) for b in blocks])
-            for i in range(len(blocks)):
-                dsz[i] = n_[i] if st_[i] == 0 else -1
-
-        decompress_step_ctx()
-        torch.cuda.synchronize()
-        tc0 = time.perf_counter()
-        for _ in range(reps):
-            decompress_step_ctx()
-        torch.cuda.synchronize()
-        tdc = (time.perf_counter() - tc0) / reps
-        decompress_step()
-        torch.cuda.synchronize()
-        td0 = time.perf_counter()
-        for _ in range(reps):
-            decompress_step()
-        torch.cuda.synchronize()
-        td = (time.perf_counter() - td0) / reps
-        ok = ok and all(dsz[i] == len(blocks[i]) and bool(torch.equal(d_dcm[i][: len(blocks[i])], d_in[i])) for i in range(len(blocks)))
-        # the same passes in flight, as the compress loop runs them: `ndec` contexts each take whole passes (one batched call per
-        # pass) from a queue; a block is 65 serial chains, so a pass alone leaves most of the 1024 SIMDs without a chain
-        ndec = int(os.environ.get("JPK_BENCH_DEC_PASSES", "8"))
-        ndec_max = max(16, ndec)
-        dctxs = [jam.Context(local_rank, None) for _ in range(ndec_max)]
-        dbufs = [[torch.empty(max(len(b), 1), dtype=torch.uint8, device=dev) for b in blocks] for _ in range(ndec_max)]
-        dok = [True] * ndec_max
-
-        def dec_passes(npass, nthreads):
-            q_ = queue.Queue()
-            for _ in range(npass):
-                q_.put(1)
-
-            def w_(k):
-                while True:
-                    try:
-                        q_.get_nowait()
-                    except queue.Empty:
-                        return
-                    n_, st_ = dctxs[k].blocks_decompress(d_cmp, sizes, dbufs[k], [len(b) for b in blocks])
-                    dok[k] = dok[k] and all(st_[i] == 0 and n_[i] == len(blocks[i]) for i in range(len(blocks)))
-
-            th_ = [threading.Thread(target=w_, args=(k,)) for k in range(nthreads)]
-            for t_ in th_:
-                t_.start()
-            for t_ in th_:
-                t_.join()
-
-        dec_passes(ndec_max, ndec_max)             # every context has decoded once (arenas sized)
-        torch.cuda.synchronize()
-        in_flight = {}
-        for nfl in sorted({4, ndec, 16}):
-            npass = max(2 * nfl, reps)
-            tp0 = time.perf_counter()
-            dec_passes(npass, nfl)
-            torch.cuda.synchronize()
-            in_flight[nfl] = ((time.perf_counter() - tp0) / npass, npass)
-        tdp, npass = in_flight[ndec]
-        ok = ok and all(dok) and all(bool(torch.equal(dbufs[k][i][: len(blocks[i])], d_in[i])) for k in range(ndec_max) for i in range(len(blocks)))
-        for c_ in dctxs:
-            c_.close()
-        del dbufs
-        extra["decompress"] = {"value": round(mb / tdp, 1), "unit": "MB/s", "ms_per_step": round(tdp * 1e3, 3), "steps": npass,
-                               "how": f"passes over the batch fed through a queue to {ndec} contexts, one jpk_dev_blocks_decompress call (all blocks of "
-                                      "the batch, one grid per serial kernel) per pass; every pass verified against the input",
-                               "MBps_by_passes_in_flight": {str(k): round(mb / v[0], 1) for k, v in in_flight.items()},
-                               "one_pass_at_a_time_MBps": round(mb / td, 1), "one_pass_at_a_time_ms": round(td * 1e3, 3),
-                               "one_context_per_block_MBps": round(mb / tdc, 1),
-                               "one_block_at_a_time_MBps": round(mb / ((stage_ms["ans_decode"] + stage_ms["inverse_bwt"]) / 1e3), 1),
-                               "inverse_bwt_MBps": round(mb / (stage_ms["inverse_bwt"] / 1e3), 1)}
+        ce = None
+        if not args.no_block_sizes and not args.limit_bytes:
+            ce = run_child_extras(args)
+        if ce is not None and isinstance(ce.get("decompress"), dict) and "value" in ce["decompress"]:
+            dleg, dok_ = ce["decompress"], bool(ce.get("decompress_ok", False))
+        else:
+            dleg, dok_ = decompress_leg(jam, torch, dev, local_rank, blocks, d_in, d_cmp, sizes, nctx, reps)
+        ok = ok and dok_
+        dleg["one_block_at_a_time_MBps"] = round(mb / ((stage_ms["ans_decode"] + stage_ms["inverse_bwt"]) / 1e3), 1)
+        dleg["inverse_bwt_MBps"] = round(mb / (stage_ms["inverse_bwt"] / 1e3), 1)
+        extra["decompress"] = dleg
         extra["round_trip_ok"] = ok
-        del d_cmp, d_dcm
+        del d_cmp
         # BASELINE config 3's "120-way parallel LF-map": the reference's own GPU kernel shape (CUDAInverse<<<40,3>>>, bwt.cpp:8-19) as
         # a measured comparator beside the list-ranking inverse, on block 0
         try:
@@ -912,15 +1004,17 @@ def main():
             c_.close()
         torch.cuda.empty_cache()
         if not args.no_block_sizes and not args.limit_bytes:
-            try:
-                extra["per_block_size"] = per_block_size(jam, corpus, torch, dev, local_rank, nctx)
-            except Exception as ex:       # noqa: BLE001 -- an extra must never take the headline down
-                extra["per_block_size"] = {"error": repr(ex)}
-        if not args.no_block_sizes and not args.limit_bytes:
-            try:
-                extra["host_buffers"] = host_buffers(jam, corpus)
-            except Exception as ex:       # noqa: BLE001
-                extra["host_buffers"] = {"error": repr(ex)}
+            if ce is not None:                   # (the fresh child process has measured them: see child_extras())
+                extra.update({k: v for k, v in ce.items() if k in ("per_block_size", "host_buffers")})
+            else:
+                try:
+                    extra["per_block_size"] = per_block_size(jam, corpus, torch, dev, local_rank, nctx)
+                except Exception as ex:       # noqa: BLE001 -- an extra must never take the headline down
+                    extra["per_block_size"] = {"error": repr(ex)}
+                try:
+                    extra["host_buffers"] = host_buffers(jam, corpus)
+                except Exception as ex:       # noqa: BLE001
+                    extra["host_buffers"] = {"error": repr(ex)}
         if not args.no_cpu_baseline:
             try:
                 cb, ref_enc, n = cpu_baseline(blocks, args.cpu_sample_mib)
