@@ -246,6 +246,9 @@ JPK_API int jpk_debug_enc_groups(int device, int32_t nch);
 JPK_API int jpk_blocks_compress_multi(uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, uint8_t *d_out, int64_t out_cap,
                                       int64_t *out_off, int32_t *status);
 JPK_API int jpk_debug_multi_plan(uint64_t device_mask, int32_t ndev_visible, int32_t nblocks, int32_t *owner);
+/* host-logic probe: the work list jpk_dev_blocks_compress forms for these block lengths (groups of small blocks, large blocks alone):
+ * task t covers blocks [first[t], first[t] + count[t]); returns the number of tasks.  No device call. */
+JPK_API int jpk_debug_group_plan(int32_t nblocks, const int32_t *in_len, int32_t *first, int32_t *count);
 /* Hooks that CHANGE live state work only in a process with JPK_DEBUG_HOOKS=1 in its environment (JPK_E_ARG otherwise):
  * jpk_debug_compress_inflight with delta != 0, and jpk_debug_combiner_fail_next(n): the next n merged decode passes fail as a
  * whole before they run -- every merged request must then come back through its own thread's single-block path. */

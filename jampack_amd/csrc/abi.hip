@@ -837,6 +837,26 @@ size_t group_target_bytes(size_t small_bytes_total)
     return t;
 }
 
+struct Task { int first, count; };
+// the work list of jpk_dev_blocks_compress: every block exactly once, in order; consecutive blocks of <= GROUP_BLOCK_MAX bytes form
+// groups of at most 256 blocks and (beyond the first block) at most the target size; a larger block is a task of its own
+void plan_tasks(int nblocks, const int32_t *in_len, std::vector<Task> &tasks)
+{
+    static const bool grouping = [] { const char *e = getenv("JPK_GROUP"); return e ? atoi(e) != 0 : true; }();
+    size_t small_total = 0;
+    for (int k = 0; k < nblocks; k++) if (in_len[k] <= GROUP_BLOCK_MAX) small_total += (size_t)in_len[k];
+    const size_t target = group_target_bytes(small_total);
+    int b = 0;
+    while (b < nblocks) {
+        if (!grouping || in_len[b] > GROUP_BLOCK_MAX) { tasks.push_back(Task{b, 1}); b++; continue; }
+        int e = b;
+        size_t bytes = 0;
+        while (e < nblocks && in_len[e] <= GROUP_BLOCK_MAX && e - b < 256 && (e == b || bytes + (size_t)in_len[e] <= target)) { bytes += (size_t)in_len[e]; e++; }
+        tasks.push_back(Task{b, e - b});
+        b = e;
+    }
+}
+
 // what a group of these blocks needs: the staging buffer for the images and the arena (the larger of the two stages' layouts + the
 // encoder's capacity sink)
 void group_needs(int nb, const int32_t *in_len, size_t *stage_bytes, size_t *arena_bytes)
@@ -897,24 +917,9 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
         if (in_len[b] < 0 || out_cap[b] < 0 || !d_out[b] || (in_len[b] > 0 && !d_in[b])) return JPK_E_ARG;
     std::vector<int32_t> st_local((size_t)nblocks);
     int32_t *stp = status ? status : st_local.data();
-    // tasks: a large block, or a group of consecutive small ones (at least two, up to the target size / 256 blocks)
-    struct Task { int first, count; };
+    // tasks: a large block, or a group of consecutive small ones (up to the target size / 256 blocks)
     std::vector<Task> tasks;
-    {
-        static const bool grouping = [] { const char *e = getenv("JPK_GROUP"); return e ? atoi(e) != 0 : true; }();
-        size_t small_total = 0;
-        for (int k = 0; k < nblocks; k++) if (in_len[k] <= GROUP_BLOCK_MAX) small_total += (size_t)in_len[k];
-        const size_t target = group_target_bytes(small_total);
-        int b = 0;
-        while (b < nblocks) {
-            if (!grouping || in_len[b] > GROUP_BLOCK_MAX) { tasks.push_back(Task{b, 1}); b++; continue; }
-            int e = b;
-            size_t bytes = 0;
-            while (e < nblocks && in_len[e] <= GROUP_BLOCK_MAX && e - b < 256 && (e == b || bytes + (size_t)in_len[e] <= target)) { bytes += (size_t)in_len[e]; e++; }
-            tasks.push_back(Task{b, e - b});
-            b = e;
-        }
-    }
+    plan_tasks(nblocks, in_len, tasks);
     const int ntasks = (int)tasks.size();
     // every worker sizes its staging buffer and arena for the largest group once, before it takes its first task: which worker gets
     // which group changes from call to call, and an arena that grows in the middle of a call costs a free + malloc + synchronise
@@ -973,6 +978,18 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
     if (!status)
         for (int b = 0; b < nblocks; b++) if (stp[b] != JPK_OK) return stp[b];
     return JPK_OK;
+}
+
+// host-logic probe (no device call): the tasks jpk_dev_blocks_compress would form for these block lengths: task t covers blocks
+// [first[t], first[t] + count[t]); returns the number of tasks (at most nblocks)
+extern "C" int jpk_debug_group_plan(int32_t nblocks, const int32_t *in_len, int32_t *first, int32_t *count)
+{
+    if (nblocks < 0 || (nblocks > 0 && (!in_len || !first || !count))) return JPK_E_ARG;
+    for (int b = 0; b < nblocks; b++) if (in_len[b] < 0) return JPK_E_ARG;
+    std::vector<Task> tasks;
+    plan_tasks(nblocks, in_len, tasks);
+    for (size_t t = 0; t < tasks.size(); t++) { first[t] = tasks[t].first; count[t] = tasks[t].count; }
+    return (int)tasks.size();
 }
 
 // ---- jpk_blocks_compress_multi: the block loop of Jampack::Compress over the GPUs of one node, natively ---------------------------

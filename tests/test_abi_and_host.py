@@ -227,3 +227,41 @@ def test_multi_device_ownership_and_order():
     # no link-time dependency on RCCL: it is loaded at first use
     out = subprocess.run(["ldd", os.path.join(ROOT, "jampack_amd", "libjampack_amd.so")], capture_output=True, text=True).stdout
     assert "rccl" not in out
+
+
+def test_group_plan_covers_every_block_once_and_in_order():
+    """jpk_dev_blocks_compress' work list (host logic): small blocks (<= 16 MiB) in groups of consecutive blocks -- at most 256 blocks, at
+    most the target size beyond the first block (a quarter of the small blocks' bytes, 8..64 MiB) --, a larger block alone"""
+    from jampack_amd import lib
+    MiB = 1 << 20
+
+    def plan(lens):
+        n = len(lens)
+        L = (ctypes.c_int32 * max(n, 1))(*lens)
+        F = (ctypes.c_int32 * max(n, 1))()
+        K = (ctypes.c_int32 * max(n, 1))()
+        t = lib().jpk_debug_group_plan(n, L, F, K)
+        assert t >= 0
+        return [(F[i], K[i]) for i in range(t)]
+
+    def check(lens, tasks):
+        nxt = 0
+        for f, k in tasks:
+            assert f == nxt and k >= 1
+            nxt += k
+            if k > 1:
+                assert k <= 256 and all(lens[i] <= 16 * MiB for i in range(f, f + k))
+            if any(lens[i] > 16 * MiB for i in range(f, f + k)):
+                assert k == 1
+        assert nxt == len(lens)
+
+    assert plan([]) == []
+    for lens in ([MiB] * 256, [8 * MiB] * 32, [64 * MiB] * 4, [0, 1, 119, 120, 121, MiB - 1, MiB, 8 * MiB, 17 * MiB, 5, 3 * MiB + 61], [300] * 1000, [16 * MiB, 16 * MiB + 1] * 5):
+        t = plan(lens)
+        check(lens, t)
+    assert plan([MiB] * 256) == [(0, 64), (64, 64), (128, 64), (192, 64)]           # 256 MiB of 1 MiB blocks: four groups of 64 MiB
+    assert plan([8 * MiB] * 32) == [(8 * i, 8) for i in range(4)]
+    assert plan([MiB] * 64) == [(16 * i, 16) for i in range(4)]                       # a 64 MiB stream: a quarter each
+    assert plan([64 * MiB] * 4) == [(i, 1) for i in range(4)]                         # large blocks go alone
+    assert all(k <= 256 for _, k in plan([300] * 1000))
+    assert lib().jpk_debug_group_plan(2, (ctypes.c_int32 * 2)(5, -1), (ctypes.c_int32 * 2)(), (ctypes.c_int32 * 2)()) == -1
