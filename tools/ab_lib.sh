@@ -1,0 +1,10 @@
+#!/bin/bash
+# same-box A/B of two builds of the library on the small-block streams:  bash tools/ab_lib.sh   (tools/_bin/libjampack_amd_prev.so = the build to compare with)
+cp jampack_amd/libjampack_amd.so /tmp/new.so
+for r in 1 2; do
+  for v in prev new; do
+    if [ $v = prev ]; then cp tools/_bin/libjampack_amd_prev.so jampack_amd/libjampack_amd.so; else cp /tmp/new.so jampack_amd/libjampack_amd.so; fi
+    echo "== $v"; timeout 300 python tools/small_blocks.py 1,8 8,16 2>&1 | grep -v amdgpu | tail -2
+  done
+done
+cp /tmp/new.so jampack_amd/libjampack_amd.so
