@@ -52,6 +52,7 @@ PROFILE_ROUND = "r04"
 ALG_BYTES_PER_UNIT = {
     "k_rs_hist": (8, "sorted (key,value) pair", "hbm"),
     "k_rs_scatter": (24, "sorted (key,value) pair", "hbm"),
+    "k_sym_present/k_pack_keys": (5, "suffix x launch (1 B read; 1 B read + 8 B written)", "hbm"),
     "k_lg_hist": (4, "member of a large group x pass", "hbm"),
     "k_lg_scatter": (18, "member of a large group x pass", "hbm"),
     "k_gather_win": (16, "active suffix", "hbm-random"),

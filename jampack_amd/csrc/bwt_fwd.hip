@@ -59,6 +59,11 @@ struct SaState {
     uint32_t nrun;                         // unresolved suffixes after round 0 that start inside a run of >= 7 equal bytes
     uint32_t round_m[JPK_SA_MAX_ROUNDS];   // per round: unresolved suffixes when it starts
     uint32_t round_lc[JPK_SA_MAX_ROUNDS];  // per round: of those, members of groups > SEG_TILE
+    // round 0's key (k_key_plan): the text's bytes renumbered 0..sigma-1 in byte order, `bits` bits each, `depth` of them in 56 bits
+    uint32_t bits, depth;
+    uint64_t rep;                          // the key field of "code 1 repeated depth times": code * rep = a run of that code
+    uint32_t present[256];                 // byte value occurs in the text
+    uint8_t lut[256];                      // byte -> code
 };
 
 // one piece of a large group: the part of the group that lies inside one 1024-slot window of the active list
@@ -110,6 +115,150 @@ __device__ __forceinline__ uint32_t wg_scan(const uint32_t *in, uint32_t *out, u
     return carry;
 }
 
+// ---- round 0's keys ---------------------------------------------------------------------------------------------------
+// The key of suffix i is its first `depth` bytes, each renumbered to its rank among the byte values that OCCUR in the text (an
+// order-preserving code of `bits` = ceil(log2 sigma) bits), big-endian in the 56 key bits, zero padded past the end of the text: text
+// over 28 letters packs 11 bytes where the plain form held 7, DNA 28, and the doubling rounds start at that distance -- on the
+// enwik8-like block round 1 starts with 70 % of the suffixes instead of 93 %, round 2 with 12 % instead of 52 %.  More than 128 byte
+// values (binary data, real enwik8: 205): bits = 8, depth = 7, the keys of round 3.  Everything downstream only relies on "equal key =
+// equal first `depth` bytes" and "code 0 is the smallest"; a byte past the end packs as 0 like the smallest code, and the stable sort
+// fed in descending position puts the shorter suffix first, as before.
+__global__ __launch_bounds__(TB) void k_sym_present(const uint8_t *__restrict__ T, uint32_t n, SaState *__restrict__ st)
+{
+    __shared__ uint32_t f[256];
+    f[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t mis0 = (uint32_t)((16u - ((uintptr_t)T & 15u)) & 15u), mis = mis0 < n ? mis0 : n;
+    const uint4 *V = reinterpret_cast<const uint4 *>(T + mis);
+    const uint32_t nv = (n - mis) / 16u, tail0 = mis + nv * 16u;
+    if (blockIdx.x == 0) {                                            // the unaligned head and the tail, a few bytes
+        if (threadIdx.x < mis) f[T[threadIdx.x]] = 1u;
+        if (tail0 + threadIdx.x < n) f[T[tail0 + threadIdx.x]] = 1u;
+    }
+    for (uint32_t v = blockIdx.x * TB + threadIdx.x; v < nv; v += gridDim.x * TB) {
+        const uint4 x = V[v];
+        const uint32_t ws[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) f[(ws[q] >> (8 * b)) & 255u] = 1u;      // (plain stores of the same value: no atomics)
+    }
+    __syncthreads();
+    if (f[threadIdx.x]) st->present[threadIdx.x] = 1u;
+}
+
+// one workgroup of 256: code of every byte value, bits per code, bytes per key.  force_bits: 0 = from the alphabet, 8 = plain bytes.
+__global__ __launch_bounds__(256) void k_key_plan(SaState *__restrict__ st, int force_bits)
+{
+    __shared__ uint32_t sm[256 / 64 + 1];
+    const uint32_t here = st->present[threadIdx.x] ? 1u : 0u;
+    uint32_t sigma;
+    const uint32_t inc = block_incl_scan<OpSum>(here, sm, &sigma);
+    st->lut[threadIdx.x] = (uint8_t)(inc - here);
+    if (threadIdx.x == 0) {
+        uint32_t bits = 1;
+        while ((1u << bits) < sigma) bits++;
+        if (force_bits > 0 && (uint32_t)force_bits > bits) bits = (uint32_t)force_bits;
+        const uint32_t depth = 56u / bits;
+        uint64_t rep = 0;
+        for (uint32_t k = 0; k < depth; k++) rep |= 1ull << (56u - bits * (k + 1u));
+        st->bits = bits;
+        st->depth = depth;
+        st->rep = rep;
+    }
+}
+
+// P[j] = key of slot j = suffix n-1-j (the order round 0's radix sort is fed in), low byte = T[i-1] (0 for suffix 0) -- the suffix's
+// BWT byte rides through the sort -- or, in a group sort, the number of the suffix's block, which is the sort's last digit; a suffix
+// ends with its block there.  One tile = 4096 slots = 4096 consecutive text positions: their bytes, codes and block numbers are
+// staged in LDS (index q = position i_lo - 16 + q, so that a thread's sixteen positions are one aligned 16-byte read), every thread
+// rolls the window over its sixteen positions (one shift and one code per position), the keys are turned into slot order in LDS
+// and leave in whole lines.
+constexpr int PK_HALO = 80;                 // 16 positions in front (the byte before the tile), up to 55 + 9 behind
+constexpr int PK_KO = CT + CT / 16;         // one spare word per sixteen keys: the threads' 128-byte strides fall on different banks
+template <int B>
+__device__ __forceinline__ void pack_tile(const uint8_t *cc, const uint8_t *cr, const uint8_t *cb, uint64_t *ko, int64_t i_lo, uint32_t n,
+                                          const uint32_t *__restrict__ bend)
+{
+    constexpr int D = 56 / B;
+    constexpr int NV = (16 + D + 15) / 16;   // the codes of positions [0, 16 + D) of the thread's stretch, in 16-byte reads
+    constexpr uint64_t M56 = (1ull << 56) - 1ull;
+    const int t = threadIdx.x;
+    uint32_t cw[NV * 4], rw[4], bw[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        const uint4 x = reinterpret_cast<const uint4 *>(cc + 16 + 16 * t)[v];
+        cw[4 * v] = x.x; cw[4 * v + 1] = x.y; cw[4 * v + 2] = x.z; cw[4 * v + 3] = x.w;
+    }
+    {
+        const uint4 x = *reinterpret_cast<const uint4 *>(cr + 16 + 16 * t);
+        rw[0] = x.x; rw[1] = x.y; rw[2] = x.z; rw[3] = x.w;
+    }
+    if (bend) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(cb + 16 + 16 * t);
+        bw[0] = x.x; bw[1] = x.y; bw[2] = x.z; bw[3] = x.w;
+    }
+    const uint32_t before = cr[15 + 16 * t];                          // the byte in front of the thread's first position
+#define JPK_BYTE(A, X) (((A)[(X) >> 2] >> (((X) & 3) * 8)) & 255u)
+    uint64_t v = 0;
+#pragma unroll
+    for (int k = 0; k < D; k++) v = (v << B) | JPK_BYTE(cw, k);
+    v <<= 56 - B * D;
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const int64_t i = i_lo + 16 * t + s;
+        if (i >= 0) {
+            const uint32_t blkno = JPK_BYTE(bw, s);
+            const uint32_t left = (bend ? bend[blkno] : n) - (uint32_t)i;               // bytes left in the suffix (its own block), >= 1
+            const uint64_t vm = (left < (uint32_t)D) ? v & ~((1ull << (56u - (uint32_t)B * left)) - 1ull) : v;
+            const uint32_t prev = s ? JPK_BYTE(rw, s ? s - 1 : 0) : before;
+            const uint32_t low = bend ? blkno : (i ? prev : 0u);
+            const uint32_t x = (uint32_t)(CT - 1 - 16 * t - s);
+            ko[x + (x >> 4)] = (vm << 8) | low;
+        }
+        if (s < 15) v = ((v << B) & M56) | ((uint64_t)JPK_BYTE(cw, s + D) << (56 - B * D));
+    }
+#undef JPK_BYTE
+}
+__global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T, uint32_t n, const SaState *__restrict__ st, uint64_t *__restrict__ P,
+                                                 const uint8_t *__restrict__ blk, const uint32_t *__restrict__ bend)
+{
+    __shared__ __align__(16) uint8_t cc[CT + PK_HALO];                // codes
+    __shared__ __align__(16) uint8_t cr[CT + PK_HALO];                // bytes
+    __shared__ __align__(16) uint8_t cb[CT + PK_HALO];                // block numbers (group sort)
+    __shared__ uint64_t ko[PK_KO];
+    __shared__ uint8_t lut[256];
+    lut[threadIdx.x] = st->lut[threadIdx.x];
+    const uint32_t bits = st->bits;
+    const uint32_t ntiles = (n + CT - 1) / CT;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * CT, cnt = (n - base < (uint32_t)CT) ? n - base : (uint32_t)CT;
+        const int64_t i_lo = (int64_t)n - 1 - base - (CT - 1);        // position of the tile's LAST slot (negative in the last tile: no such slot)
+        __syncthreads();                                                // lut; the previous tile's ko has been read
+        for (int q = threadIdx.x; q < CT + PK_HALO; q += TB) {
+            const int64_t p = i_lo - 16 + q;
+            const bool in = p >= 0 && p < (int64_t)n;
+            const uint32_t raw = in ? T[p] : 0u;
+            cr[q] = (uint8_t)raw;
+            cc[q] = in ? lut[raw] : (uint8_t)0;
+            if (blk) cb[q] = in ? blk[p] : (uint8_t)0;
+        }
+        __syncthreads();
+        switch (bits) {
+        case 1: pack_tile<1>(cc, cr, cb, ko, i_lo, n, bend); break;
+        case 2: pack_tile<2>(cc, cr, cb, ko, i_lo, n, bend); break;
+        case 3: pack_tile<3>(cc, cr, cb, ko, i_lo, n, bend); break;
+        case 4: pack_tile<4>(cc, cr, cb, ko, i_lo, n, bend); break;
+        case 5: pack_tile<5>(cc, cr, cb, ko, i_lo, n, bend); break;
+        case 6: pack_tile<6>(cc, cr, cb, ko, i_lo, n, bend); break;
+        case 7: pack_tile<7>(cc, cr, cb, ko, i_lo, n, bend); break;
+        default: pack_tile<8>(cc, cr, cb, ko, i_lo, n, bend); break;
+        }
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < cnt; x += TB) P[base + x] = ko[x + (x >> 4)];
+    }
+}
+
 // ---- round 0 ---------------------------------------------------------------------------------------------------------
 // Round 0 sorts slot j = suffix n-1-j by key = first 7 bytes, big-endian in bits 63..8, zero padded past the end of the text
 // (radix.hip builds the keys from the text in its first pass).  The LSD sort is stable, so suffixes that tie on the padded
@@ -120,11 +269,12 @@ __device__ __forceinline__ uint32_t wg_scan(const uint32_t *in, uint32_t *out, u
 // Group sort (bend != null: several blocks sorted as one text, the key's low byte = block number, see radix.hip): the whole key
 // takes part in the comparison, and a suffix is "short" when fewer than 7 bytes are left in ITS block.
 __device__ __forceinline__ uint32_t r0_end(uint64_t key, uint32_t n, const uint32_t *__restrict__ bend) { return bend ? bend[(uint32_t)key & 255u] : n; }
-__device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t j, uint32_t n, const uint32_t *__restrict__ bend)
+__device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t j, uint32_t n, const uint32_t *__restrict__ bend,
+                                        uint32_t D)
 {
     if (j == 0) return true;
     const uint64_t a = keys[j], b = keys[j - 1];
-    return ((a ^ b) >> (bend ? 0 : 8)) != 0ull || sa[j] + 7u > r0_end(a, n, bend) || sa[j - 1] + 7u > r0_end(b, n, bend);   // bits 7..0 carry T[sa-1], not key
+    return ((a ^ b) >> (bend ? 0 : 8)) != 0ull || sa[j] + D > r0_end(a, n, bend) || sa[j - 1] + D > r0_end(b, n, bend);   // bits 7..0 carry T[sa-1], not key
 }
 
 // head words of one 4096-slot tile: HE[word] = heads | slots past the end (so that "the next slot is a head" is one shift),
@@ -133,7 +283,7 @@ __device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const
 // comes from the neighbouring lane (DPP wave shift; lane 0: lane 63 of the row before, the wave's first row: one extra load),
 // and "the suffix in front is shorter than 7 bytes" is the shifted ballot of the row's own "short" bits.
 __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n, uint32_t base, uint64_t *HE,
-                                              uint64_t (&kj)[CT_ITEMS], uint32_t (&sj)[CT_ITEMS], const uint32_t *__restrict__ bend)
+                                              uint64_t (&kj)[CT_ITEMS], uint32_t (&sj)[CT_ITEMS], const uint32_t *__restrict__ bend, uint32_t D)
 {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const uint32_t j0 = base + w * (64 * CT_ITEMS);
@@ -148,7 +298,7 @@ __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys,
     const uint64_t kb = keys[jb];
     const uint32_t sb = sa[jb];
     uint32_t plo = (uint32_t)kb, phi = (uint32_t)(kb >> 32);
-    uint64_t carry_short = (j0 && sb + 7u > r0_end(kb, n, bend)) ? 1ull : 0ull;
+    uint64_t carry_short = (j0 && sb + D > r0_end(kb, n, bend)) ? 1ull : 0ull;
     const int low_shift = bend ? 0 : 8;                                              // bits 7..0 carry T[sa-1], not key -- or the block number, which is key
 #pragma unroll
     for (int k = 0; k < CT_ITEMS; k++) {
@@ -157,7 +307,7 @@ __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys,
         const uint32_t qlo = (uint32_t)__builtin_amdgcn_update_dpp((int)plo, (int)lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
         const uint32_t qhi = (uint32_t)__builtin_amdgcn_update_dpp((int)phi, (int)hi, 0x138, 0xf, 0xf, false);
         const bool differs = (((lo ^ qlo) >> low_shift) | (hi ^ qhi)) != 0u;
-        const uint64_t S = __ballot(sj[k] + 7u > r0_end(kj[k], n, bend));            // a suffix with fewer than 7 bytes is a group of its own
+        const uint64_t S = __ballot(sj[k] + D > r0_end(kj[k], n, bend));             // a suffix with fewer than `depth` bytes is a group of its own
         const uint64_t b = __ballot(differs || j >= n || j == 0) | S | (S << 1) | carry_short;
         if (l == 0) HE[w * CT_ITEMS + k] = b;
         carry_short = S >> 63;
@@ -166,7 +316,7 @@ __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys,
     }
     if (threadIdx.x == 0) {
         const uint32_t jn = base + CT;
-        HE[64] = (jn >= n || r0_head(keys, sa, jn, n, bend)) ? 1ull : 0ull;
+        HE[64] = (jn >= n || r0_head(keys, sa, jn, n, bend, D)) ? 1ull : 0ull;
     }
 }
 __device__ __forceinline__ uint64_t valid_word(uint32_t word_base, uint32_t n)
@@ -178,16 +328,18 @@ __device__ __forceinline__ uint64_t valid_word(uint32_t word_base, uint32_t n)
 
 // per tile: 1 + position of its last head (0: none), number of suffixes that stay unresolved
 __global__ __launch_bounds__(TB) void k_r0_count(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n,
-                                                uint32_t *__restrict__ tLast, uint32_t *__restrict__ tSurv, const uint32_t *__restrict__ bend)
+                                                uint32_t *__restrict__ tLast, uint32_t *__restrict__ tSurv, const uint32_t *__restrict__ bend,
+                                                const SaState *__restrict__ st)
 {
     __shared__ uint64_t HE[65];
     const uint32_t ntiles = (n + CT - 1) / CT;
+    const uint32_t D = st->depth;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * CT;
         __syncthreads();
         uint64_t kj[CT_ITEMS];
         uint32_t sj[CT_ITEMS];
-        r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend);
+        r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend, D);
         __syncthreads();
         if (threadIdx.x < 64) {
             const int l = threadIdx.x;
@@ -234,12 +386,14 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
     __shared__ uint32_t SW[64];            // output position of the first survivor of word l
     const uint32_t ntiles = (n + CT - 1) / CT;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const uint32_t D = st->depth, code_shift = 56u - st->bits;
+    const uint64_t rep = st->rep;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * CT;
         __syncthreads();
         uint64_t kj[CT_ITEMS];
         uint32_t sj[CT_ITEMS];
-        r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend);
+        r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend, D);
         __syncthreads();
         const uint32_t carry = tCarry[tile];
         if (threadIdx.x < 64) {
@@ -274,9 +428,9 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                     if (SA) SA[j] = s;
                 } else {
                     const uint32_t pos = SW[word] + (uint32_t)__popcll(sv & mask_below(l));
-                    // seven equal bytes (a survivor has all seven: short suffixes are groups of their own): a run member
+                    // `depth` equal bytes (a survivor has all of them: short suffixes are groups of their own): a run member
                     const uint64_t k7 = kj[k] >> 8;
-                    const bool inrun = k7 == (k7 >> 48) * 0x01010101010101ull;
+                    const bool inrun = k7 == (k7 >> code_shift) * rep;
                     nrun += inrun ? 1u : 0u;
                     a_sa[pos] = s;
                     a_grp[pos] = grp | (inrun ? RUNF : 0u);
@@ -284,7 +438,7 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                 }
             }
         }
-        if (__ballot(nrun != 0)) {                                   // (rare: text has few runs of seven)
+        if (__ballot(nrun != 0)) {                                   // (rare: text has few runs that long)
             nrun = wave_sum(nrun);
             if (l == 0) atomicAdd(&st->nrun, nrun);
         }
@@ -366,14 +520,14 @@ __global__ __launch_bounds__(TB) void k_run_fill(const uint8_t *__restrict__ T, 
 // (A = c^a x.., B = c^b y.. with a < b differ at offset a: x against c), ties = same kind and length, decided by the suffix behind
 // the run.  The invariant of prefix doubling -- at the start of the round with distance h every group shares its first h bytes,
 // so every rank read at distance h resolves h more -- must hold for them too:
-//   round 1 (h = 7, the group is everything that starts with c^7): the ordinary key2 = rank7(s + 7) + 1 already places the members
-//     with fewer than 14 equal bytes; those with 14 or more all read the rank G of their own group there.  They get
-//     G + 1 + (L for the first kind, 2n - L for the second), keys above G + 1 move up by 2n: one key, every group 14-ordered.
-//   later rounds: a group of run members with L >= 14 has one kind and one run length, so it may compare at distance max(h, L)
+//   round 1 (h = D, round 0's depth; the group is everything that starts with c^D): the ordinary key2 = rankD(s + D) + 1 already places
+//     the members with fewer than 2D equal bytes; those with 2D or more all read the rank G of their own group there.  They get
+//     G + 1 + (L for the first kind, 2n - L for the second), keys above G + 1 move up by 2n: one key, every group 2D-ordered.
+//   later rounds: a group of run members with L >= 2D has one kind and one run length, so it may compare at distance max(h, L)
 //     -- the rank of the suffix behind the run, whatever the run's length: it shares L >= that many bytes (L > h) or is h-ordered
 //     like everybody else, and gains >= h either way.  An all-zero block is sorted after round 1.
 __global__ __launch_bounds__(TB) void k_gather_win(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const SaState *__restrict__ st,
-                                                  int par, uint32_t n, uint32_t h, const uint32_t *__restrict__ ISA, uint32_t *__restrict__ k2,
+                                                  int par, uint32_t n, int hshift, const uint32_t *__restrict__ ISA, uint32_t *__restrict__ k2,
                                                   uint32_t *__restrict__ FH, uint32_t *__restrict__ LH,
                                                   const uint8_t *__restrict__ T, const uint32_t *__restrict__ RL, int first_round,
                                                   const uint8_t *__restrict__ a_blk, const uint32_t *__restrict__ bend)
@@ -382,6 +536,10 @@ __global__ __launch_bounds__(TB) void k_gather_win(const uint32_t *__restrict__ 
     const uint32_t m = st->m[par];
     const uint32_t nwin = (m + SEG_TILE - 1) / SEG_TILE;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    // the round's distance: round 0 resolved `depth` bytes (k_key_plan), every round doubles it
+    const uint32_t D = st->depth;
+    const uint64_t h64 = (uint64_t)D << hshift;
+    const uint32_t h = (hshift < 32 && h64 < n) ? (uint32_t)h64 : n;
     for (uint32_t win = blockIdx.x; win < nwin; win += gridDim.x) {
         const uint32_t base = win * SEG_TILE;
         __syncthreads();
@@ -413,24 +571,24 @@ __global__ __launch_bounds__(TB) void k_gather_win(const uint32_t *__restrict__ 
             kv[k] = (s2 < lim[k]) ? kv[k] + 1u : 0u;
             anyrun |= (gj[k] & RUNF) != 0u;
         }
-        if (__ballot(anyrun)) {                                      // wave-uniform and rare: text has few runs of seven equal bytes
+        if (__ballot(anyrun)) {                                      // wave-uniform and rare: text has few runs of `depth` equal bytes
 #pragma unroll
             for (int k = 0; k < WIN_ITEMS; k++) {
                 const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l;
                 if (j < m && (gj[k] & RUNF)) {
-                    const uint32_t G1 = (gj[k] & ~(RUNF | DONE)) + 1u;  // key2 of "the suffix 7 further is still in my group": 14 equal bytes
+                    const uint32_t G1 = (gj[k] & ~(RUNF | DONE)) + 1u;  // key2 of "the suffix D further is still in my group": 2D equal bytes
                     if (first_round) {
-                        // every key keeps its place relative to the group's own rank; the members with >= 14 equal bytes, which
+                        // every key keeps its place relative to the group's own rank; the members with >= 2D equal bytes, which
                         // all tie there, are spread over the 2n values behind it by (kind, run length)
                         if (kv[k] == G1) {
                             const uint32_t L = RL[s[k]];
                             const uint64_t e = (uint64_t)s[k] + L;  // first position behind the run
                             const bool down = e >= lim[k] || T[e] < T[s[k]];
-                            kv[k] = G1 + (down ? L : 2u * n - L);    // L in [14, n]: the kinds cannot collide (2n - L >= n >= L, equal only for L = n: one suffix)
+                            kv[k] = G1 + (down ? L : 2u * n - L);    // L in [2D, n]: the kinds cannot collide (2n - L >= n >= L, equal only for L = n: one suffix)
                         } else if (kv[k] > G1) kv[k] += 2u * n;
                     } else {
                         const uint32_t L = RL[s[k]];
-                        if (L >= 14u && L > h) {                     // (a descendant of a c^7 group with a shorter run is an ordinary suffix)
+                        if (L >= 2u * D && L > h) {                  // (a descendant of a c^D group with a shorter run is an ordinary suffix)
                             const uint64_t e = (uint64_t)s[k] + L;
                             kv[k] = e < lim[k] ? ISA[e] + 1u : 0u;
                         }
@@ -1339,6 +1497,13 @@ void launch_lg_pass(jpk_ctx *ctx, SaBufs &b, const uint32_t *kin, const uint32_t
     JPK_LAUNCH(ctx, PROF_LG_SCATTER, 0, (k_lg_scatter<DB>), dim3(gp), dim3(TB), kin, vin, pin, kout, vout, pout, b.pieces, b.state, shift, b.table);
 }
 
+// JPK_KEY_BITS=8 keeps round 0's keys at one byte per symbol whatever the alphabet (the comparator of the packed keys; 0 = from the alphabet)
+int key_force_bits()
+{
+    static const int v = [] { const char *e = getenv("JPK_KEY_BITS"); const int x = e ? atoi(e) : 0; return x < 0 ? 0 : (x > 8 ? 8 : x); }();
+    return v;
+}
+
 // builds the BWT-in-SA-order bytes (b.bwt), the complete inverse suffix array (b.ISA) and, if b.SA is set, the suffix array
 int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
 {
@@ -1354,11 +1519,14 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     constexpr unsigned CAP = 1u << 20;
     constexpr unsigned CAP_SEG = 1u << 20;
 
-    // round 0: sort by the first 7 bytes (7 passes; ties keep descending text position)
+    // round 0: sort by the first `depth` bytes, packed into 56 bits (7 passes; ties keep descending text position)
     JPK_HIP(hipMemsetAsync(b.state, 0, sizeof(SaState), st));
     uint64_t *ks = b.keysA;
     uint32_t *vs = b.valsA;
-    JPK_TRY(jpk_radix_sort_suffix_keys7(ctx, T, n, b.keysA, b.valsA, b.keysB, b.valsB, b.scratch, &ks, &vs, b.blk, b.bend));
+    JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_sym_present, dim3(cap_grid(n, 16 * TB * 4, 4096)), dim3(TB), T, n, b.state);
+    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_key_plan, dim3(1), dim3(256), b.state, key_force_bits());
+    JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_pack_keys, dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend);
+    JPK_TRY(jpk_radix_sort_slot_keys(ctx, n, b.keysA, b.valsA, b.keysB, b.valsB, b.scratch, &ks, &vs, b.blk != nullptr));
     ctx->stats.sa_sorted_elems += n;
     // The sorted pairs sit in (ks, vs).  The other pair of radix buffers is free from here on, the pair that holds the result
     // once k_r0_finish has read it: the doubling rounds live in them.
@@ -1371,7 +1539,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     b.sa_alt = reinterpret_cast<uint32_t *>(ks) + n;
 
     const unsigned g_ct = cap_grid(n, CT, CAP);
-    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_count, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.bend);
+    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_count, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.bend, b.state);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_r0_scan, dim3(1), dim3(WG1), b.tA, b.tB, n, b.state);
     JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev, b.state, b.bend);
     ctx->stats.sa_rounds = 1;
@@ -1383,23 +1551,35 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     const int kbits = jpk_bits_for(3u * n);        // key2 <= n (a rank + 1); round 1 spreads the keys of groups of run members up to 3n; group rank < n
     int lg_pass = 0;
     const int lg_db = lg_digit_bits(n, &lg_pass);
-    // The host learns the number of unresolved suffixes one round late: round r is enqueued with the grid bound of round r-2's
-    // result while the GPU is still busy with round r-1.  A round that starts with m == 0 is a handful of empty launches.
-    uint32_t *h_m = ctx->h_mail + 16;              // pinned: h_m[r & 1] receives the count round r leaves behind
-    JPK_HIP(hipMemcpyAsync(&h_m[0], &b.state->m[1], 4, hipMemcpyDeviceToHost, st));
+    // Rounds 1 and 2 (the long ones: milliseconds each) are enqueued without waiting: the host learns the number of unresolved
+    // suffixes one round late and enqueues round r with the grid bound of round r-2's result while the GPU is busy with round r-1.
+    // From round 3 on the rounds are short and mostly empty, and what costs is their ~45 dependent launches each (a launch that has
+    // nothing to do still waits its turn behind the other blocks' kernels: 90-190 us apiece in the timed loop): the host waits for
+    // the previous round's counts first -- a few microseconds while other blocks keep the GPU busy -- and then enqueues exactly what is
+    // needed: nothing when no suffix is unresolved (round 4: the trailing empty round is gone), no large-group passes (23 launches) once
+    // a round has had no group above 1024 (groups only split: the count of their members never grows).
+    uint32_t *h_m = ctx->h_mail + 16;              // pinned: h_m[4 * (r & 1) ..] receives {m[0], m[1], npieces, lc} as round r leaves them
+    JPK_HIP(hipMemcpyAsync(&h_m[0], &b.state->m[0], 16, hipMemcpyDeviceToHost, st));
     JPK_HIP(hipEventRecord(ctx->ev_sa[0], st));
     uint32_t bound = n;                            // upper bound of the active count of the round being enqueued
-    uint64_t h = 7;
+    bool large_possible = true;                    // a group above 1024 members may still exist
     for (int round = 1;; round++) {
         const int par = round & 1;
+        if (round >= 3) {
+            JPK_HIP(hipEventSynchronize(ctx->ev_sa[par ^ 1]));
+            const uint32_t m_now = h_m[4 * (par ^ 1) + par];        // round r-1 wrote m[(r-1 & 1) ^ 1] = m[par]
+            if (m_now == 0) break;                                    // nothing left: no empty round
+            bound = m_now;
+            if (h_m[4 * (par ^ 1) + 3] == 0) large_possible = false; // lc of round r-1
+            ctx->stats.sa_rounds = round + 1;
+        }
         const unsigned g_win = cap_grid(bound, SEG_TILE, CAP);
         const unsigned g_seg = cap_grid(bound, SEG_TILE, CAP_SEG);
         const unsigned g_cmp = cap_grid(bound, CT, CAP);
         const size_t pc_bound = 2 * ((size_t)bound / SEG_TILE + 1);
         const unsigned g_pc = cap_grid(pc_bound, 1, CAP);
         const unsigned g_tab = cap_grid(pc_bound << lg_db, SC_TILE, CAP);
-        const uint32_t hh = (h < n) ? (uint32_t)h : n;
-        JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, hh, b.ISA, b.k2, b.FH, b.LH, T, b.RL, round == 1 ? 1 : 0,
+        JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, round - 1, b.ISA, b.k2, b.FH, b.LH, T, b.RL, round == 1 ? 1 : 0,
                    b.a_prev, b.bend);
         const unsigned g_wm = cap_grid((size_t)bound / SEG_TILE + 1, TB, 256);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan1, dim3(1), dim3(WG1), b.FH, b.LH, b.PH, b.NH, b.state, par);
@@ -1408,7 +1588,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_pieces, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.pieces, b.state, par);
         JPK_LAUNCH(ctx, PROF_SA_SEG, 0, k_seg_round, dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, kbits, b.PH, b.a_prev, b.ISA, b.bwt, b.SA,
                    b.b_sa, b.b_grp, b.b_prev);
-        {   // large groups: lg_pass LSD passes over (key2, sa), ping-pong between (k2, a_sa) and (k2alt, sa_alt)
+        if (large_possible) {   // large groups: lg_pass LSD passes over (key2, sa), ping-pong between (k2, a_sa) and (k2alt, sa_alt)
             uint32_t *kin = b.k2, *vin = b.a_sa, *kout = b.k2alt, *vout = b.sa_alt;
             uint8_t *pin = b.a_prev, *pout = b.p_alt;
             for (int p = 0; p < lg_pass; p++) {
@@ -1433,16 +1613,17 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_cmp_scan, dim3(1), dim3(WG1), b.tA, b.state, par, round);
         JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_cmp_scatter, dim3(g_cmp), dim3(TB), b.b_sa, b.b_grp, b.b_prev, b.state, par, b.tA, b.a_sa, b.a_grp, b.a_prev);
         JPK_HIP(hipGetLastError());
-        JPK_HIP(hipMemcpyAsync(&h_m[par], &b.state->m[par ^ 1], 4, hipMemcpyDeviceToHost, st));
+        JPK_HIP(hipMemcpyAsync(&h_m[4 * par], &b.state->m[0], 16, hipMemcpyDeviceToHost, st));
         JPK_HIP(hipEventRecord(ctx->ev_sa[par], st));
-        // what the PREVIOUS round (or round 0) left behind: known without draining the queue
-        JPK_HIP(hipEventSynchronize(ctx->ev_sa[par ^ 1]));
-        const uint32_t m_start = h_m[par ^ 1];      // = the active count this round started with
-        if (m_start == 0) break;                    // this round was empty: done
-        ctx->stats.sa_rounds = round + 1;
-        bound = m_start;
-        h <<= 1;
-        if (round >= 2 * JPK_SA_MAX_ROUNDS) return JPK_E_DEVICE;     // cannot happen: h doubles, every suffix is unique once h >= n
+        if (round < 3) {
+            // what the PREVIOUS round (or round 0) left behind: known without draining the queue
+            JPK_HIP(hipEventSynchronize(ctx->ev_sa[par ^ 1]));
+            const uint32_t m_start = h_m[4 * (par ^ 1) + par];      // = the active count this round started with (round r-1 wrote m[par])
+            if (m_start == 0) break;                // this round was empty: done
+            ctx->stats.sa_rounds = round + 1;
+            bound = m_start;
+        }
+        if (round >= 2 * JPK_SA_MAX_ROUNDS) return JPK_E_DEVICE;     // cannot happen: the distance doubles, every suffix is unique once it is >= n
     }
     // statistics: one small copy, read by sa_collect_stats() after the caller has synchronised the stream
     JPK_HIP(hipMemcpyAsync(ctx->h_mail + 32, b.state->round_m, sizeof(uint32_t) * 2 * JPK_SA_MAX_ROUNDS, hipMemcpyDeviceToHost, st));

@@ -34,7 +34,7 @@ enum JpkProfId {
     PROF_RS_HIST = 0, PROF_RS_SCATTER, PROF_SCAN, PROF_SA_KEYS, PROF_SA_SEG, PROF_SA_RERANK, PROF_BWT_GATHER,
     PROF_INV_HIST, PROF_INV_BUILD, PROF_INV_WALK, PROF_INV_RANK, PROF_INV_COPY,
     PROF_ENC_HIST, PROF_ENC_MTF, PROF_ENC_RLE, PROF_ENC_CLASS, PROF_ENC_ADAPTIVE, PROF_ENC_PAIRS, PROF_ENC_RANS, PROF_ENC_EMIT,
-    PROF_DEC_HEADERS, PROF_DEC_RANS, PROF_DEC_RLE, PROF_DEC_RANK, PROF_CHECKSUM, PROF_LG_HIST, PROF_LG_SCATTER, PROF_COUNT
+    PROF_DEC_HEADERS, PROF_DEC_RANS, PROF_DEC_RLE, PROF_DEC_RANK, PROF_CHECKSUM, PROF_LG_HIST, PROF_LG_SCATTER, PROF_SA_PACK, PROF_COUNT
 };
 struct JpkProfPending { hipEvent_t a, b; int id; uint64_t units; };
 
@@ -140,8 +140,8 @@ int jpk_radix_sort_pairs_u64(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint6
                              const int *shifts, int nshifts, uint32_t *scratch);
 int jpk_radix_sort_pairs_u64_nocopy(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint64_t *keys_alt, uint32_t *vals_alt, size_t n,
                                     const int *shifts, int nshifts, uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out);
-int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n, uint64_t *keysA, uint32_t *valsA, uint64_t *keysB, uint32_t *valsB,
-                                uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out, const uint8_t *blk = nullptr, const uint32_t *bend = nullptr);
+int jpk_radix_sort_slot_keys(jpk_ctx *ctx, uint32_t n, uint64_t *keysA, uint32_t *valsA, uint64_t *keysB, uint32_t *valsB,
+                             uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out, bool group);
 // Heavy-phase gate (experiment, off by default -- see gate_on() in abi.hip for the numbers): the GPU-saturating phases of the
 // blocks in flight on one device -- the suffix sort and the wide kernels of the entropy stage in front of the rANS chains --
 // run one block after the other on the GPU, in the order the blocks arrive here, while the chains (a few waves that run for

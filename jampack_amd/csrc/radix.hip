@@ -19,66 +19,27 @@ constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
 
-// Pass 0 of the suffix sort reads its (key, value) pairs straight from the text: slot j holds suffix i = n-1-j, key = the
-// first 7 bytes of the suffix, big-endian in bits 63..8, zero padded past the end (bwt_fwd.hip, round 0); bits 7..0 = T[i-1].  Three aligned dword
-// loads per slot (neighbouring lanes share them), a funnel shift and a byte swap; nothing beyond the dword that holds
-// T[n-1] is touched.
-struct TextSrc {
-    const uint32_t *tb;      // T rounded down to a dword boundary
-    uint32_t off;            // T - tb (0..3)
-    uint32_t n;
-    // group sort (several blocks in one text, jpk_fwd_bwt_group_device): the block of every position and where each block ends -- a
-    // suffix stops at the end of ITS block, and the key's low byte carries the block number (the last, most significant digit)
-    const uint8_t *blk;      // null: one block
-    const uint32_t *bend;
-};
-__device__ __forceinline__ uint64_t text_key7(const TextSrc &t, uint32_t i)
-{
-    const uint32_t a = i + t.off, wi = a >> 2, sh = (a & 3u) * 8u;
-    const uint32_t lastw = (t.n - 1u + t.off) >> 2;
-    const uint32_t w0 = t.tb[wi], w1 = t.tb[wi + 1 < lastw ? wi + 1 : lastw], w2 = t.tb[wi + 2 < lastw ? wi + 2 : lastw];
-    const uint64_t lo = ((uint64_t)w1 << 32) | w0;
-    uint64_t v = sh ? (lo >> sh) | ((uint64_t)w2 << (64u - sh)) : lo;            // bytes i .. i+7, little endian
-    if (t.blk) {                                                                    // (uniform branch)
-        const uint32_t b = t.blk[i];
-        const uint32_t left = t.bend[b] - i;                                        // bytes left in the suffix's own block, >= 1
-        v &= (left < 8u) ? (1ull << (8u * left)) - 1ull : ~0ull;
-        return (__builtin_bswap64(v) & ~0xFFull) | b;                               // low byte: the block number, the sort's last digit
-    }
-    const uint32_t left = t.n - i;                                                  // >= 1
-    v &= (left < 8u) ? (1ull << (8u * left)) - 1ull : ~0ull;
-    // The low byte of the key is never a sort digit (7 passes, bits 8..63): it carries T[i-1] (0 for suffix 0), the BWT byte of
-    // the suffix, so that no kernel has to gather it from the text once the suffix's SA position is known.
-    uint32_t prev = (uint32_t)reinterpret_cast<const uint8_t *>(t.tb)[a - (i ? 1u : 0u)];        // (no branch around the load)
-    prev = i ? prev : 0u;
-    return (__builtin_bswap64(v) & ~0xFFull) | prev;
-}
-
+// Pass 0 of the suffix sort (SLOTS): the values are implicit -- slot j holds suffix n-1-j, its key comes from the packed key array
+// (bwt_fwd.hip k_pack_keys) -- so no value array is read.
 // The sixteen pairs of a thread, all loads issued back to back: no branch around a load (slots past the end re-read the last
 // pair and are zeroed afterwards).  With the loads inside `valid ? .. : 0` the compiler put an s_waitcnt vmcnt(0) behind every
 // one of them -- a full memory latency per 64 elements instead of per tile.
-template <bool TEXT>
-__device__ __forceinline__ void rs_load_tile(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, const TextSrc &txt, size_t n, size_t base,
+template <bool SLOTS>
+__device__ __forceinline__ void rs_load_tile(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, size_t n, size_t base,
                                              uint64_t (&key)[RS_ITEMS], uint32_t (&val)[RS_ITEMS])
 {
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++) {
         const size_t i = base + (size_t)it * 64, ic = i < n ? i : n - 1;
-        if (TEXT) {
-            val[it] = (uint32_t)(n - 1 - ic);
-            key[it] = text_key7(txt, val[it]);
-        } else {
-            key[it] = kin[ic];
-            val[it] = vin[ic];
-        }
+        key[it] = kin[ic];
+        val[it] = SLOTS ? (uint32_t)(n - 1 - ic) : vin[ic];
     }
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++)
         if (base + (size_t)it * 64 >= n) { key[it] = 0; val[it] = 0; }
 }
 
-template <bool TEXT>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *__restrict__ keys, TextSrc txt, size_t n, int shift,
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *__restrict__ keys, size_t n, int shift,
                                                        uint32_t *__restrict__ tilehist, uint32_t ntiles)
 {
     __shared__ uint32_t h[RS_WAVES][256];
@@ -94,7 +55,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *__restri
     // and ONE of them adds their number to the wave's counter -- plain LDS read-modify-write, one lane per address.  Text digits
     // are skewed (a tenth of the lanes of a wave hit the same bin): the atomic form spent 92 % of its LDS cycles in same-address
     // conflicts and cost about as much as the whole scatter pass.
-    if (!TEXT && (shift & 7) == 0 && (size_t)(blockIdx.x + 1) * RS_TILE <= n) {
+    if ((shift & 7) == 0 && (size_t)(blockIdx.x + 1) * RS_TILE <= n) {
         // a whole tile of keys and a digit that is a byte of the key (every pass of the suffix sort): the digit is loaded as that
         // byte from a wave-uniform base with the item offset in the instruction -- no clamp, no 64-bit shift, no validity masks
         const uint8_t *bp = reinterpret_cast<const uint8_t *>(keys + (size_t)blockIdx.x * RS_TILE + (size_t)w * (64 * RS_ITEMS)) + (shift >> 3);
@@ -110,12 +71,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *__restri
 #pragma unroll
         for (int it = 0; it < RS_ITEMS; it++) {
             const size_t i = base + (size_t)it * 64, ic = i < n ? i : n - 1;
-            if (TEXT) {                                    // digit of byte (56 - shift) / 8 of the suffix: one text byte
-                const uint32_t i0 = (uint32_t)(n - 1 - ic), pos = i0 + (uint32_t)((56 - shift) >> 3);
-                dig[it] = reinterpret_cast<const uint8_t *>(txt.tb)[(pos < txt.n ? pos : txt.n - 1u) + txt.off];
-                const uint32_t lim = txt.blk ? txt.bend[txt.blk[i0]] : txt.n;          // the suffix ends with its block
-                if (pos >= lim) dig[it] = 0u;
-            } else dig[it] = (uint32_t)(keys[ic] >> shift) & 255u;
+            dig[it] = (uint32_t)(keys[ic] >> shift) & 255u;
         }
 #pragma unroll
         for (int it = 0; it < RS_ITEMS; it++) {
@@ -133,8 +89,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *__restri
     }
 }
 
-template <bool TEXT>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, TextSrc txt,
+template <bool SLOTS>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                           uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n, int shift,
                                                           const uint32_t *__restrict__ tileoff, uint32_t ntiles)
 {
@@ -149,7 +105,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *__res
     uint32_t val[RS_ITEMS];
     uint32_t rnk[RS_ITEMS];
     const uint64_t lt = lanemask_lt();
-    rs_load_tile<TEXT>(kin, vin, txt, n, base, key, val);
+    rs_load_tile<SLOTS>(kin, vin, n, base, key, val);
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++) {
         size_t i = base + (size_t)it * 64;
@@ -203,8 +159,8 @@ struct OsArgs {
 };
 constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_PFX = 2u << 30, OS_MASK = (1u << 30) - 1u;
 
-template <bool TEXT, bool FULL, bool LOOKBACK = false>
-__device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, const TextSrc &txt,
+template <bool SLOTS, bool FULL, bool LOOKBACK = false>
+__device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                        uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n, int shift,
                                                        const uint32_t *__restrict__ tileoff, uint32_t ntiles, uint32_t tile, uint32_t (*cnt)[256],
                                                        uint32_t *gbase, uint64_t *stage, uint32_t *sm, const OsArgs *os = nullptr)
@@ -217,12 +173,16 @@ __device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restric
     uint32_t val[RS_ITEMS];
     uint32_t rnk[RS_ITEMS];
     const uint64_t lt = lanemask_lt();
-    if (FULL && !TEXT) {
+    if (FULL) {
         const uint64_t *kw = kin + tbase + (size_t)w * (64 * RS_ITEMS);      // wave-uniform
         const uint32_t *vw = vin + tbase + (size_t)w * (64 * RS_ITEMS);
+        const uint32_t v0 = (uint32_t)(n - 1 - (tbase + (size_t)w * (64 * RS_ITEMS)));   // SLOTS: slot j holds suffix n-1-j
 #pragma unroll
-        for (int it = 0; it < RS_ITEMS; it++) { key[it] = kw[(uint32_t)(it * 64 + l)]; val[it] = vw[(uint32_t)(it * 64 + l)]; }
-    } else rs_load_tile<TEXT>(kin, vin, txt, n, base, key, val);
+        for (int it = 0; it < RS_ITEMS; it++) {
+            key[it] = kw[(uint32_t)(it * 64 + l)];
+            val[it] = SLOTS ? v0 - (uint32_t)(it * 64 + l) : vw[(uint32_t)(it * 64 + l)];
+        }
+    } else rs_load_tile<SLOTS>(kin, vin, n, base, key, val);
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++) {
         const bool valid = FULL || base + (size_t)it * 64 < n;
@@ -319,8 +279,8 @@ __device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restric
 }
 
 // two launches per pass: the full tiles (no bounds logic) and, if n is not a multiple of the tile, the last tile alone
-template <bool TEXT, bool FULL>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter_staged(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, TextSrc txt,
+template <bool SLOTS, bool FULL>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter_staged(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                                  uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n, int shift,
                                                                  const uint32_t *__restrict__ tileoff, uint32_t ntiles, uint32_t tile0)
 {
@@ -330,13 +290,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter_staged(const uint64_t
     __shared__ uint32_t sm[RS_THREADS / 64 + 1];
     for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
-    rs_scatter_staged_tile<TEXT, FULL>(kin, vin, txt, kout, vout, n, shift, tileoff, ntiles, tile0 + blockIdx.x, cnt, gbase, stage, sm);
+    rs_scatter_staged_tile<SLOTS, FULL>(kin, vin, kout, vout, n, shift, tileoff, ntiles, tile0 + blockIdx.x, cnt, gbase, stage, sm);
 }
 
 // (two launches per pass, like the two-pass form: the full tiles -- no bounds logic, a third of the registers -- and then the last,
 // partial tile alone; it takes the next ticket and finds every prefix published)
-template <bool TEXT, bool FULL>
-__global__ __launch_bounds__(RS_THREADS) void k_os_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, TextSrc txt,
+template <bool SLOTS, bool FULL>
+__global__ __launch_bounds__(RS_THREADS) void k_os_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                           uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n, int shift, uint32_t ntiles, OsArgs os)
 {
     __shared__ uint32_t cnt[RS_WAVES][256];
@@ -348,71 +308,52 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_scatter(const uint64_t *__res
     for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
     const uint32_t tile = s_tile;
-    rs_scatter_staged_tile<TEXT, FULL, true>(kin, vin, txt, kout, vout, n, shift, nullptr, ntiles, tile, cnt, gbase, stage, sm, &os);
+    rs_scatter_staged_tile<SLOTS, FULL, true>(kin, vin, kout, vout, n, shift, nullptr, ntiles, tile, cnt, gbase, stage, sm, &os);
 }
-template <bool TEXT>
-void launch_os_scatter(jpk_ctx *ctx, const uint64_t *kin, const uint32_t *vin, const TextSrc &txt, uint64_t *kout, uint32_t *vout, size_t n, int shift, uint32_t ntiles,
+template <bool SLOTS>
+void launch_os_scatter(jpk_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, size_t n, int shift, uint32_t ntiles,
                        const OsArgs &os)
 {
     const uint32_t nfull = (uint32_t)(n / RS_TILE);
-    if (nfull) JPK_LAUNCH(ctx, PROF_RS_SCATTER, (size_t)nfull * RS_TILE, (k_os_scatter<TEXT, true>), dim3(nfull), dim3(RS_THREADS), kin, vin, txt, kout, vout, n, shift, ntiles, os);
-    if (nfull < ntiles) JPK_LAUNCH(ctx, PROF_RS_SCATTER, n - (size_t)nfull * RS_TILE, (k_os_scatter<TEXT, false>), dim3(1), dim3(RS_THREADS), kin, vin, txt, kout, vout, n, shift,
+    if (nfull) JPK_LAUNCH(ctx, PROF_RS_SCATTER, (size_t)nfull * RS_TILE, (k_os_scatter<SLOTS, true>), dim3(nfull), dim3(RS_THREADS), kin, vin, kout, vout, n, shift, ntiles, os);
+    if (nfull < ntiles) JPK_LAUNCH(ctx, PROF_RS_SCATTER, n - (size_t)nfull * RS_TILE, (k_os_scatter<SLOTS, false>), dim3(1), dim3(RS_THREADS), kin, vin, kout, vout, n, shift,
                                    ntiles, os);
 }
 
-// byte histogram of the text (per-wave LDS tables, sixteen bytes per thread and step)
-__global__ __launch_bounds__(RS_THREADS) void k_os_bytes(const uint8_t *__restrict__ T, uint32_t n, uint32_t *__restrict__ H)
+// digit histograms of all seven passes from one read of the packed keys, then their exclusive offsets (one-pass form only)
+__global__ __launch_bounds__(RS_THREADS) void k_os_digits(const uint64_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ H)
 {
-    __shared__ uint32_t h[RS_WAVES][256];
-    for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&h[0][0])[i] = 0;
+    __shared__ uint32_t h[7][256];
+    for (int i = threadIdx.x; i < 7 * 256; i += RS_THREADS) (&h[0][0])[i] = 0;
     __syncthreads();
-    const int w = threadIdx.x >> 6;
-    for (size_t i = ((size_t)blockIdx.x * RS_THREADS + threadIdx.x) * 16; i < n; i += (size_t)gridDim.x * RS_THREADS * 16) {
-        if (i + 16 <= n && (((uintptr_t)(T + i)) & 15u) == 0) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(T + i);
-            const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+    for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * RS_THREADS) {
+        const uint64_t k = keys[i];
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-#pragma unroll
-                for (int b = 0; b < 4; b++) atomicAdd(&h[w][(ws[q] >> (8 * b)) & 255u], 1u);
-        } else {
-            for (int k = 0; k < 16 && i + k < n; k++) atomicAdd(&h[w][T[i + k]], 1u);
-        }
+        for (int p = 0; p < 7; p++) atomicAdd(&h[p][(uint32_t)(k >> (8 * (p + 1))) & 255u], 1u);
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < 256; d += RS_THREADS) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int k = 0; k < RS_WAVES; k++) t += h[k][d];
-        if (t) atomicAdd(&H[d], t);
-    }
+    for (int i = threadIdx.x; i < 7 * 256; i += RS_THREADS)
+        if ((&h[0][0])[i]) atomicAdd(&H[i], (&h[0][0])[i]);
 }
-
-// exclusive digit offsets of the seven passes: pass p sorts on byte k = 6 - p of the suffix, suffix i contributes T[i + k] (0 past the
-// end), so its histogram is the text's minus the first k bytes plus k zeros
-__global__ __launch_bounds__(256) void k_os_prefix(const uint8_t *__restrict__ T, uint32_t n, const uint32_t *__restrict__ H, uint32_t *__restrict__ gdig)
+__global__ __launch_bounds__(256) void k_os_prefix(const uint32_t *__restrict__ H, uint32_t *__restrict__ gdig)
 {
     __shared__ uint32_t sm[256 / 64 + 1];
-    const uint32_t v = threadIdx.x;
     for (int p = 0; p < 7; p++) {
-        const uint32_t k = (uint32_t)(6 - p);
-        uint32_t c = H[v];
-        for (uint32_t j = 0; j < k && j < n; j++) c -= (T[j] == v) ? 1u : 0u;
-        if (v == 0) c += k < n ? k : n;
+        const uint32_t c = H[p * 256 + threadIdx.x];
         const uint32_t inc = block_incl_scan<OpSum>(c, sm, nullptr);
-        gdig[p * 256 + v] = inc - c;
+        gdig[p * 256 + threadIdx.x] = inc - c;
         __syncthreads();
     }
 }
 
-template <bool TEXT>
-void launch_rs_scatter_staged(jpk_ctx *ctx, const uint64_t *kin, const uint32_t *vin, const TextSrc &txt, uint64_t *kout, uint32_t *vout, size_t n, int shift,
+template <bool SLOTS>
+void launch_rs_scatter_staged(jpk_ctx *ctx, const uint64_t *kin, const uint32_t *vin, uint64_t *kout, uint32_t *vout, size_t n, int shift,
                               const uint32_t *tileoff, uint32_t ntiles)
 {
     const uint32_t nfull = (uint32_t)(n / RS_TILE);
-    if (nfull) JPK_LAUNCH(ctx, PROF_RS_SCATTER, (size_t)nfull * RS_TILE, (k_rs_scatter_staged<TEXT, true>), dim3(nfull), dim3(RS_THREADS), kin, vin, txt, kout, vout, n, shift,
+    if (nfull) JPK_LAUNCH(ctx, PROF_RS_SCATTER, (size_t)nfull * RS_TILE, (k_rs_scatter_staged<SLOTS, true>), dim3(nfull), dim3(RS_THREADS), kin, vin, kout, vout, n, shift,
                           tileoff, ntiles, 0u);
-    if (nfull < ntiles) JPK_LAUNCH(ctx, PROF_RS_SCATTER, n - (size_t)nfull * RS_TILE, (k_rs_scatter_staged<TEXT, false>), dim3(1), dim3(RS_THREADS), kin, vin, txt, kout, vout, n,
+    if (nfull < ntiles) JPK_LAUNCH(ctx, PROF_RS_SCATTER, n - (size_t)nfull * RS_TILE, (k_rs_scatter_staged<SLOTS, false>), dim3(1), dim3(RS_THREADS), kin, vin, kout, vout, n,
                                    shift, tileoff, ntiles, nfull);
 }
 
@@ -429,9 +370,9 @@ size_t jpk_radix_scratch_words(size_t n)
 {
     size_t ntiles = (n + RS_TILE - 1) / RS_TILE;
     size_t table = 256 * ntiles;
-    // the tile table (= status array A of the one-pass sort) + the scan's scratch, then status array B, the byte histogram, the digit
+    // the tile table (= status array A of the one-pass sort) + the scan's scratch, then status array B, the digit histograms and
     // offsets of seven passes and the tickets
-    return table + jpk_scan_scratch_words(table) + 64 + table + 256 + 7 * 256 + 64;
+    return table + jpk_scan_scratch_words(table) + 64 + table + 7 * 256 + 7 * 256 + 64;
 }
 
 // JPK_ONESWEEP=1 selects the one-pass (decoupled look-back) form for the suffix sort's round 0.  Measured (round 4,
@@ -459,11 +400,10 @@ int jpk_radix_sort_pairs_u64_nocopy(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals
     uint64_t *ki = keys, *ko = keys_alt;
     uint32_t *vi = vals, *vo = vals_alt;
     for (int p = 0; p < nshifts; p++) {
-        const TextSrc none = {nullptr, 0u, 0u, nullptr, nullptr};
-        JPK_LAUNCH(ctx, PROF_RS_HIST, n, (k_rs_hist<false>), dim3(ntiles), dim3(RS_THREADS), ki, none, n, shifts[p], hist, ntiles);
+        JPK_LAUNCH(ctx, PROF_RS_HIST, n, k_rs_hist, dim3(ntiles), dim3(RS_THREADS), ki, n, shifts[p], hist, ntiles);
         JPK_TRY(jpk_exclusive_sum_u32(ctx, hist, hist, table, scan_scratch, nullptr));
-        if (rs_staged()) launch_rs_scatter_staged<false>(ctx, ki, vi, none, ko, vo, n, shifts[p], hist, ntiles);
-        else JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter<false>), dim3(ntiles), dim3(RS_THREADS), ki, vi, none, ko, vo, n, shifts[p], hist, ntiles);
+        if (rs_staged()) launch_rs_scatter_staged<false>(ctx, ki, vi, ko, vo, n, shifts[p], hist, ntiles);
+        else JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter<false>), dim3(ntiles), dim3(RS_THREADS), ki, vi, ko, vo, n, shifts[p], hist, ntiles);
         uint64_t *tk = ki; ki = ko; ko = tk;
         uint32_t *tv = vi; vi = vo; vo = tv;
     }
@@ -486,11 +426,11 @@ int jpk_radix_sort_pairs_u64(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint6
     return JPK_OK;
 }
 
-// Round 0 of the suffix sort (bwt_fwd.hip): all n suffixes of T by their first 7 bytes, 7 LSD passes; the first pass builds the
-// keys from the text on the fly, so no key array is written or read for it.  Result: (keysB, valsB) -- 7 passes, the first one
-// lands in B.
-int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n32, uint64_t *keysA, uint32_t *valsA, uint64_t *keysB, uint32_t *valsB,
-                                uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out, const uint8_t *blk, const uint32_t *bend)
+// Round 0 of the suffix sort (bwt_fwd.hip): slot j of keysA holds the packed key of suffix n-1-j (k_pack_keys); 7 LSD passes over
+// its 56 key bits -- 8 in a group sort, the last one on the block number in the low byte.  The first pass has no value array to read
+// (slot j = suffix n-1-j) and lands in B; keysA is overwritten by the second.  Result: (*keys_out, *vals_out).
+int jpk_radix_sort_slot_keys(jpk_ctx *ctx, uint32_t n32, uint64_t *keysA, uint32_t *valsA, uint64_t *keysB, uint32_t *valsB,
+                             uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out, bool group)
 {
     const size_t n = n32;
     *keys_out = keysB;
@@ -500,23 +440,16 @@ int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n32, ui
     const size_t table = (size_t)256 * ntiles;
     uint32_t *hist = scratch;
     uint32_t *scan_scratch = scratch + table;
-    TextSrc txt;
-    txt.off = (uint32_t)((uintptr_t)T & 3u);
-    txt.tb = reinterpret_cast<const uint32_t *>(T - txt.off);
-    txt.n = n32;
-    txt.blk = blk;
-    txt.bend = bend;
-    const TextSrc none = {nullptr, 0u, 0u, nullptr, nullptr};
     uint64_t *ki = keysB, *ko = keysA;        // after pass 0 the pairs are in B
     uint32_t *vi = valsB, *vo = valsA;
-    if (!blk && rs_onesweep()) {
-        // one-pass sort: byte histogram of the text -> digit offsets of all seven passes; then seven scatter launches, nothing else
+    if (!group && rs_onesweep()) {
+        // one-pass sort: digit histograms of the keys -> digit offsets of all seven passes; then seven scatter launches, nothing else
         uint32_t *statusA = scratch, *statusB = scratch + table + jpk_scan_scratch_words(table) + 64;
-        uint32_t *H = statusB + table, *gdig = H + 256, *tickets = gdig + 7 * 256;
+        uint32_t *H = statusB + table, *gdig = H + 7 * 256, *tickets = gdig + 7 * 256;
         JPK_HIP(hipMemsetAsync(statusA, 0, table * 4, ctx->stream));
-        JPK_HIP(hipMemsetAsync(statusB, 0, (table + 256 + 7 * 256 + 64) * 4, ctx->stream));
-        JPK_LAUNCH(ctx, PROF_RS_HIST, n, k_os_bytes, dim3(ntiles < 2048 ? (ntiles ? ntiles : 1) : 2048), dim3(RS_THREADS), T, n32, H);
-        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_os_prefix, dim3(1), dim3(256), T, n32, H, gdig);
+        JPK_HIP(hipMemsetAsync(statusB, 0, (table + 7 * 256 + 7 * 256 + 64) * 4, ctx->stream));
+        JPK_LAUNCH(ctx, PROF_RS_HIST, n, k_os_digits, dim3(ntiles < 2048 ? (ntiles ? ntiles : 1) : 2048), dim3(RS_THREADS), keysA, n32, H);
+        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_os_prefix, dim3(1), dim3(256), H, gdig);
         for (int p = 0; p < 7; p++) {
             const int shift = 8 * (p + 1);
             OsArgs os;
@@ -525,10 +458,10 @@ int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n32, ui
             os.gdig = gdig + p * 256;
             os.ticket = tickets + p;
             if (p == 0) {
-                launch_os_scatter<true>(ctx, nullptr, nullptr, txt, keysB, valsB, n, shift, ntiles, os);
+                launch_os_scatter<true>(ctx, keysA, nullptr, keysB, valsB, n, shift, ntiles, os);
                 continue;
             }
-            launch_os_scatter<false>(ctx, ki, vi, none, ko, vo, n, shift, ntiles, os);
+            launch_os_scatter<false>(ctx, ki, vi, ko, vo, n, shift, ntiles, os);
             uint64_t *tk = ki; ki = ko; ko = tk;
             uint32_t *tv = vi; vi = vo; vo = tv;
         }
@@ -537,21 +470,21 @@ int jpk_radix_sort_suffix_keys7(jpk_ctx *ctx, const uint8_t *T, uint32_t n32, ui
         *vals_out = vi;
         return JPK_OK;
     }
-    const int npass = blk ? 8 : 7;                // group sort: one more pass, on the block number in the key's low byte
+    const int npass = group ? 8 : 7;              // group sort: one more pass, on the block number in the key's low byte
     for (int p = 0; p < npass; p++) {
         const int shift = p < 7 ? 8 * (p + 1) : 0;
         if (p == 0) {
-            JPK_LAUNCH(ctx, PROF_RS_HIST, n, (k_rs_hist<true>), dim3(ntiles), dim3(RS_THREADS), (const uint64_t *)nullptr, txt, n, shift, hist, ntiles);
+            JPK_LAUNCH(ctx, PROF_RS_HIST, n, k_rs_hist, dim3(ntiles), dim3(RS_THREADS), (const uint64_t *)keysA, n, shift, hist, ntiles);
             JPK_TRY(jpk_exclusive_sum_u32(ctx, hist, hist, table, scan_scratch, nullptr));
-            if (rs_staged()) launch_rs_scatter_staged<true>(ctx, nullptr, nullptr, txt, keysB, valsB, n, shift, hist, ntiles);
-            else JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter<true>), dim3(ntiles), dim3(RS_THREADS), (const uint64_t *)nullptr, (const uint32_t *)nullptr, txt,
+            if (rs_staged()) launch_rs_scatter_staged<true>(ctx, keysA, nullptr, keysB, valsB, n, shift, hist, ntiles);
+            else JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter<true>), dim3(ntiles), dim3(RS_THREADS), (const uint64_t *)keysA, (const uint32_t *)nullptr,
                        keysB, valsB, n, shift, hist, ntiles);
             continue;
         }
-        JPK_LAUNCH(ctx, PROF_RS_HIST, n, (k_rs_hist<false>), dim3(ntiles), dim3(RS_THREADS), ki, none, n, shift, hist, ntiles);
+        JPK_LAUNCH(ctx, PROF_RS_HIST, n, k_rs_hist, dim3(ntiles), dim3(RS_THREADS), (const uint64_t *)ki, n, shift, hist, ntiles);
         JPK_TRY(jpk_exclusive_sum_u32(ctx, hist, hist, table, scan_scratch, nullptr));
-        if (rs_staged()) launch_rs_scatter_staged<false>(ctx, ki, vi, none, ko, vo, n, shift, hist, ntiles);
-        else JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter<false>), dim3(ntiles), dim3(RS_THREADS), ki, vi, none, ko, vo, n, shift, hist, ntiles);
+        if (rs_staged()) launch_rs_scatter_staged<false>(ctx, ki, vi, ko, vo, n, shift, hist, ntiles);
+        else JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter<false>), dim3(ntiles), dim3(RS_THREADS), (const uint64_t *)ki, (const uint32_t *)vi, ko, vo, n, shift, hist, ntiles);
         uint64_t *tk = ki; ki = ko; ko = tk;
         uint32_t *tv = vi; vi = vo; vo = tv;
     }
