@@ -893,9 +893,13 @@ def main():
             if i == 0:
                 st = ctx.stats()
                 nr = int(st.sa_rounds)
-                extra["sa_rounds"] = {"block_bytes": n, "rounds": nr, "active_suffixes": [int(x) for x in st.sa_round_active[:nr]],
+                dep = int(st.sa_key_depth)
+                extra["sa_rounds"] = {"block_bytes": n, "rounds": nr, "key_depth_bytes": dep, "alphabet": int(len(np.unique(blocks[i]))),
+                                      "active_suffixes": [int(x) for x in st.sa_round_active[:nr]],
                                       "in_large_groups": [int(x) for x in st.sa_round_large[:nr]],
-                                      "note": "round 0 = radix sort on the first 7 bytes of every suffix; round r >= 1 sorts the still unresolved suffixes by the rank of the suffix 7*2^(r-1) bytes further"}
+                                      "note": "round 0 = radix sort on the first key_depth_bytes bytes of every suffix (the block's byte values renumbered and "
+                                              "packed into 56 bits: 7 bytes for alphabets above 128 values, 11 for this text's); round r >= 1 sorts the still "
+                                              "unresolved suffixes by the rank of the suffix key_depth_bytes * 2^(r-1) bytes further"}
             del d_bwt, d_enc, d_dec, d_back
         mb = batch_bytes / 1e6
         extra["stages_ms"] = {k: round(v, 3) for k, v in stage_ms.items()}

@@ -54,14 +54,14 @@ typedef struct jpk_ctx jpk_ctx;
 /* per-call statistics of the last operation on a context (for bench.py / DESIGN.md accounting) */
 typedef struct jpk_stats {
     int32_t sa_rounds;            /* prefix-doubling rounds of the last forward BWT */
-    int32_t reserved0;
+    int32_t sa_key_depth;         /* bytes of every suffix that round 0's key holds (7 for alphabets above 128 byte values, up to 56) */
     int64_t sa_sorted_elems;      /* sum over rounds of active suffixes that went through a sort */
     int64_t inv_splitters;        /* walkers used by the last inverse BWT */
     int64_t inv_overflow_slots;   /* sub-lists that exceeded one scratch slot */
     int64_t workspace_bytes;      /* HBM arena currently held by the context */
     int64_t ans_chunks;           /* 1 MiB chunks in the last entropy call */
     int64_t ans_rle_symbols;      /* RLE0 symbols in the last entropy call */
-    /* per doubling round r (r = 0: the 7-byte radix round, r >= 1: h = 7 * 2^(r-1)) of the last forward BWT:
+    /* per doubling round r (r = 0: the radix round on sa_key_depth bytes, r >= 1: h = sa_key_depth * 2^(r-1)) of the last forward BWT:
      * suffixes still unresolved when the round starts / of those, members of groups too large for the LDS path */
     int32_t sa_round_active[JPK_SA_MAX_ROUNDS];
     int32_t sa_round_large[JPK_SA_MAX_ROUNDS];

@@ -27,7 +27,7 @@ class JampackError(RuntimeError):
 
 
 class Stats(C.Structure):
-    _fields_ = [("sa_rounds", C.c_int32), ("reserved0", C.c_int32), ("sa_sorted_elems", C.c_int64),
+    _fields_ = [("sa_rounds", C.c_int32), ("sa_key_depth", C.c_int32), ("sa_sorted_elems", C.c_int64),
                 ("inv_splitters", C.c_int64), ("inv_overflow_slots", C.c_int64), ("workspace_bytes", C.c_int64),
                 ("ans_chunks", C.c_int64), ("ans_rle_symbols", C.c_int64),
                 ("sa_round_active", C.c_int32 * 40), ("sa_round_large", C.c_int32 * 40),

@@ -65,6 +65,7 @@ struct SaState {
     uint32_t present[256];                 // byte value occurs in the text
     uint8_t lut[256];                      // byte -> code
 };
+static_assert(offsetof(SaState, depth) == offsetof(SaState, round_m) + sizeof(uint32_t) * (2 * JPK_SA_MAX_ROUNDS + 1), "the statistics copy takes round_m, round_lc, bits, depth in one piece");
 
 // one piece of a large group: the part of the group that lies inside one 1024-slot window of the active list
 struct Piece {
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(256) void k_key_plan(SaState *__restrict__ st, int 
 // staged in LDS (index q = position i_lo - 16 + q, so that a thread's sixteen positions are one aligned 16-byte read), every thread
 // rolls the window over its sixteen positions (one shift and one code per position), the keys are turned into slot order in LDS
 // and leave in whole lines.
+static_assert(CT == 4096, "k_pack_keys counts the tile histogram of the radix sort's first pass: CT must be radix.hip's RS_TILE");
 constexpr int PK_HALO = 80;                 // 16 positions in front (the byte before the tile), up to 55 + 9 behind
 constexpr int PK_KO = CT + CT / 16;         // one spare word per sixteen keys: the threads' 128-byte strides fall on different banks
 template <int B>
@@ -220,9 +222,12 @@ __device__ __forceinline__ void pack_tile(const uint8_t *cc, const uint8_t *cr, 
     }
 #undef JPK_BYTE
 }
+// The tile is also a tile of the radix sort's first pass (same 4096 slots): its digit histogram (key bits 15..8) is counted here, from
+// LDS, so that pass has no histogram kernel of its own (tilehist: digit-major [256][ntiles], radix.hip).
 __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T, uint32_t n, const SaState *__restrict__ st, uint64_t *__restrict__ P,
-                                                 const uint8_t *__restrict__ blk, const uint32_t *__restrict__ bend)
+                                                 const uint8_t *__restrict__ blk, const uint32_t *__restrict__ bend, uint32_t *__restrict__ tilehist)
 {
+    __shared__ uint32_t hd[WAVES][256];
     __shared__ __align__(16) uint8_t cc[CT + PK_HALO];                // codes
     __shared__ __align__(16) uint8_t cr[CT + PK_HALO];                // bytes
     __shared__ __align__(16) uint8_t cb[CT + PK_HALO];                // block numbers (group sort)
@@ -254,8 +259,29 @@ __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T,
         case 7: pack_tile<7>(cc, cr, cb, ko, i_lo, n, bend); break;
         default: pack_tile<8>(cc, cr, cb, ko, i_lo, n, bend); break;
         }
+        for (int i = threadIdx.x; i < WAVES * 256; i += TB) (&hd[0][0])[i] = 0u;
         __syncthreads();
-        for (uint32_t x = threadIdx.x; x < cnt; x += TB) P[base + x] = ko[x + (x >> 4)];
+        {
+            const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+            const uint64_t lt = mask_below(l);
+#pragma unroll
+            for (int it = 0; it < CT_ITEMS; it++) {
+                const uint32_t x = (uint32_t)(w * (64 * CT_ITEMS) + it * 64 + l);
+                const bool valid = x < cnt;
+                const uint64_t key = ko[x + (x >> 4)];
+                if (valid) P[base + x] = key;
+                const uint32_t dig = (uint32_t)(key >> 8) & 255u;
+                const uint64_t mm = match_any8(dig, valid);
+                if (valid && (mm & lt) == 0ull) hd[w][dig] += (uint32_t)__popcll(mm);      // one lane per digit value and wave: plain read-modify-write
+            }
+        }
+        __syncthreads();
+        {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int k = 0; k < WAVES; k++) sum += hd[k][threadIdx.x];
+            tilehist[(size_t)threadIdx.x * ntiles + tile] = sum;
+        }
     }
 }
 
@@ -1525,7 +1551,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     uint32_t *vs = b.valsA;
     JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_sym_present, dim3(cap_grid(n, 16 * TB * 4, 4096)), dim3(TB), T, n, b.state);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_key_plan, dim3(1), dim3(256), b.state, key_force_bits());
-    JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_pack_keys, dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend);
+    JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_pack_keys, dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.scratch);
     JPK_TRY(jpk_radix_sort_slot_keys(ctx, n, b.keysA, b.valsA, b.keysB, b.valsB, b.scratch, &ks, &vs, b.blk != nullptr));
     ctx->stats.sa_sorted_elems += n;
     // The sorted pairs sit in (ks, vs).  The other pair of radix buffers is free from here on, the pair that holds the result
@@ -1626,7 +1652,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         if (round >= 2 * JPK_SA_MAX_ROUNDS) return JPK_E_DEVICE;     // cannot happen: the distance doubles, every suffix is unique once it is >= n
     }
     // statistics: one small copy, read by sa_collect_stats() after the caller has synchronised the stream
-    JPK_HIP(hipMemcpyAsync(ctx->h_mail + 32, b.state->round_m, sizeof(uint32_t) * 2 * JPK_SA_MAX_ROUNDS, hipMemcpyDeviceToHost, st));
+    JPK_HIP(hipMemcpyAsync(ctx->h_mail + 32, b.state->round_m, sizeof(uint32_t) * (2 * JPK_SA_MAX_ROUNDS + 2), hipMemcpyDeviceToHost, st));   // + bits, depth
     ctx->sa_stats_pending = true;
     return JPK_OK;
 }
@@ -1638,6 +1664,7 @@ void jpk_sa_stats_sync(jpk_ctx *ctx)
     if (!ctx->sa_stats_pending) return;
     ctx->sa_stats_pending = false;
     const uint32_t *rm = ctx->h_mail + 32, *rl = ctx->h_mail + 32 + JPK_SA_MAX_ROUNDS;
+    ctx->stats.sa_key_depth = (int32_t)ctx->h_mail[32 + 2 * JPK_SA_MAX_ROUNDS + 1];
     for (int r = 0; r < JPK_SA_MAX_ROUNDS; r++) {
         const bool live = r < ctx->stats.sa_rounds;
         ctx->stats.sa_round_active[r] = live ? (int32_t)rm[r] : 0;

@@ -18,6 +18,7 @@ constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_ITEMS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
+static_assert(RS_TILE == 4096, "bwt_fwd.hip k_pack_keys writes the first pass's tile histogram for tiles of 4096 slots");
 
 // Pass 0 of the suffix sort (SLOTS): the values are implicit -- slot j holds suffix n-1-j, its key comes from the packed key array
 // (bwt_fwd.hip k_pack_keys) -- so no value array is read.
@@ -54,7 +55,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *__restri
     // counting by wave match instead of LDS atomics: the lanes of a wave that hold the same digit are found with eight ballots
     // and ONE of them adds their number to the wave's counter -- plain LDS read-modify-write, one lane per address.  Text digits
     // are skewed (a tenth of the lanes of a wave hit the same bin): the atomic form spent 92 % of its LDS cycles in same-address
-    // conflicts and cost about as much as the whole scatter pass.
+    // conflicts and cost about as much as the whole scatter pass.  (Round 4 tried both per row -- atomics where the row's digits are
+    // spread out, as the packed keys' are, the match where they are not: 12 % fewer vector instructions per block and the same
+    // bench line, profiles/r04_hist_rows.txt -- the kernel waits for its loads either way.)
     if ((shift & 7) == 0 && (size_t)(blockIdx.x + 1) * RS_TILE <= n) {
         // a whole tile of keys and a digit that is a byte of the key (every pass of the suffix sort): the digit is loaded as that
         // byte from a wave-uniform base with the item offset in the instruction -- no clamp, no 64-bit shift, no validity masks
@@ -428,7 +431,8 @@ int jpk_radix_sort_pairs_u64(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint6
 
 // Round 0 of the suffix sort (bwt_fwd.hip): slot j of keysA holds the packed key of suffix n-1-j (k_pack_keys); 7 LSD passes over
 // its 56 key bits -- 8 in a group sort, the last one on the block number in the low byte.  The first pass has no value array to read
-// (slot j = suffix n-1-j) and lands in B; keysA is overwritten by the second.  Result: (*keys_out, *vals_out).
+// (slot j = suffix n-1-j) and no histogram to count (k_pack_keys left the digit-major tile table of key bits 15..8 at the start of
+// `scratch`; its tiles are RS_TILE slots like ours) and lands in B; keysA is overwritten by the second.  Result: (*keys_out, *vals_out).
 int jpk_radix_sort_slot_keys(jpk_ctx *ctx, uint32_t n32, uint64_t *keysA, uint32_t *valsA, uint64_t *keysB, uint32_t *valsB,
                              uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out, bool group)
 {
@@ -474,7 +478,7 @@ int jpk_radix_sort_slot_keys(jpk_ctx *ctx, uint32_t n32, uint64_t *keysA, uint32
     for (int p = 0; p < npass; p++) {
         const int shift = p < 7 ? 8 * (p + 1) : 0;
         if (p == 0) {
-            JPK_LAUNCH(ctx, PROF_RS_HIST, n, k_rs_hist, dim3(ntiles), dim3(RS_THREADS), (const uint64_t *)keysA, n, shift, hist, ntiles);
+            // (the first pass's tile histogram was counted by k_pack_keys, whose tiles are this sort's: hist = scratch, digit-major)
             JPK_TRY(jpk_exclusive_sum_u32(ctx, hist, hist, table, scan_scratch, nullptr));
             if (rs_staged()) launch_rs_scatter_staged<true>(ctx, keysA, nullptr, keysB, valsB, n, shift, hist, ntiles);
             else JPK_LAUNCH(ctx, PROF_RS_SCATTER, n, (k_rs_scatter<true>), dim3(ntiles), dim3(RS_THREADS), (const uint64_t *)keysA, (const uint32_t *)nullptr,

@@ -24,7 +24,7 @@ python3 $REPO/tools/rocpd_stats.py /tmp/kt/kt_results.db > "$OUT/kernel_stats.tx
 # 3. stage-level traces of one 64 MiB block (per-rep numbers)
 rm -rf /tmp/kf /tmp/ke
 rocprofv3 --kernel-trace -d /tmp/kf -o f -- python3 $REPO/tools/fwd_once.py text_survey 3 > /dev/null 2>&1
-python3 $REPO/tools/rocpd_stats.py /tmp/kf/f_results.db 3 > "$OUT/kernel_stats_forward_bwt_64mib.txt" 2>&1
+python3 $REPO/tools/rocpd_stats.py /tmp/kf/f_results.db 4 > "$OUT/kernel_stats_forward_bwt_64mib.txt" 2>&1
 rocprofv3 --kernel-trace -d /tmp/ke -o e -- python3 $REPO/tools/enc_once.py text_survey > /dev/null 2>&1
 python3 $REPO/tools/rocpd_stats.py /tmp/ke/e_results.db 3 > "$OUT/kernel_stats_ans_encode_64mib.txt" 2>&1
 python3 $REPO/tools/rocpd_timeline.py /tmp/ke/e_results.db k_density > "$OUT/timeline_ans_encode_64mib.txt" 2>&1
@@ -62,6 +62,11 @@ bash tools/pmc_sq.sh gpurun_out/$TAG/sq_enc enc > /dev/null 2>&1
 python3 tools/small_blocks.py 1,8,64 4,8,16 2>/dev/null | grep blocks > "$OUT/small_blocks.txt"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/hog.hip -o tools/_bin/libhog.so > /dev/null 2>&1
 python3 tools/interfere.py 4 2 2>/dev/null | grep -v amdgpu > "$OUT/interference.txt"
+( echo "# bench.py --steps 20 --warmup 5 --no-extras, same box, alternating: round 0's keys packed by the alphabet (default) against JPK_KEY_BITS=8 (one byte per symbol: 7 bytes per key, round 3's keys)"
+  for k in 0 8 0 8 0 8; do echo -n "JPK_KEY_BITS=$k  "; JPK_KEY_BITS=$k python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*' | head -1; done
+  echo "# forward BWT of ONE 64 MiB enwik8-like block at a time, three repetitions (tools/fwd_once.py), wall clock per block"
+  for k in 0 8; do echo -n "JPK_KEY_BITS=$k  "; JPK_KEY_BITS=$k python3 tools/fwd_once.py text_survey 3 2>/dev/null | tail -1; done ) > "$OUT/packed_keys.txt"
+python3 tools/mix_stages.py 2 3,0 0,4 3,4 4,4 2>/dev/null | grep contexts > "$OUT/stage_mix.txt"
 bash tools/pmc_loop.sh gpurun_out/$TAG/loop > /dev/null 2>&1
 cp gpurun_out/$TAG/loop/loop_counters.txt "$OUT/loop_counters.txt" 2>/dev/null
 ls -la "$OUT"

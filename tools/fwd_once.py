@@ -17,8 +17,13 @@ dev = torch.device("cuda", 0)
 ctx = jam.Context(0, None)
 d_in = torch.from_numpy(t).to(dev)
 d_bwt = torch.empty(n + 480, dtype=torch.uint8, device=dev)
+import time
+ctx.bwt_forward(d_in, n, d_bwt, n + 480)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
 for _ in range(reps):
     ctx.bwt_forward(d_in, n, d_bwt, n + 480)
 torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / reps * 1e3
 s = ctx.stats()
-print("rounds", s.sa_rounds, list(s.sa_round_active)[: s.sa_rounds])
+print(f"{ms:.2f} ms per block, key depth {s.sa_key_depth} bytes, rounds {s.sa_rounds}, unresolved at the start of each {list(s.sa_round_active)[: s.sa_rounds]}")

@@ -8,7 +8,7 @@ import jampack_amd as jam
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64 << 20
 dev = torch.device("cuda", 0); st = torch.cuda.current_stream()
 ctx = jam.Context(0, st.cuda_stream)
-for kind in ("zero", "repeat", "random", "dna", "samples16", "runs"):
+for kind in ("text_survey", "text", "silesia", "zero", "repeat", "random", "dna", "two", "geometric", "samples16", "runs"):
     t = jam.corpus.make(kind, n, 3)
     d_in = torch.from_numpy(t).to(dev); cap = jam.ans_capacity(n + 480)
     d_bwt = torch.empty(n + 480, dtype=torch.uint8, device=dev); d_enc = torch.empty(cap, dtype=torch.uint8, device=dev)
@@ -24,4 +24,4 @@ for kind in ("zero", "repeat", "random", "dna", "samples16", "runs"):
         res = [e[k].elapsed_time(e[k + 1]) for k in range(4)]
     ok = bool(torch.equal(d_back, d_in))
     s = ctx.stats()
-    print(f"{kind:10s} fwd {res[0]:8.1f} ms  enc {res[1]:8.1f}  dec {res[2]:8.1f}  inv {res[3]:7.1f}  ratio {cl / n:.3f} rounds {s.sa_rounds} sorted {s.sa_sorted_elems / n:.1f}n ok={ok}")
+    print(f"{kind:10s} fwd {res[0]:8.1f} ms  enc {res[1]:8.1f}  dec {res[2]:8.1f}  inv {res[3]:7.1f}  ratio {cl / n:.3f} alphabet {len(np.unique(t)):3d} key depth {s.sa_key_depth:2d} rounds {s.sa_rounds:2d} sorted {s.sa_sorted_elems / n:.1f}n ok={ok}", flush=True)
