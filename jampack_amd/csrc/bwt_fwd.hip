@@ -2,10 +2,11 @@
 // followed by the BWT image and the 120 sampled ranks of BlockSort::Bwt::ForwardBwt (bwt.cpp:22-65).
 //
 // Suffix array = prefix doubling (Larsson-Sadakane ranks) with compaction of resolved suffixes:
-//   round 0   key = first 7 bytes (big-endian, zero padded): one LSD radix sort of all n suffixes, 7 passes (radix.hip),
-//             fed in descending text position so that a short suffix -- a proper prefix of anything it ties with on
-//             the padded bytes -- comes first: plain suffix order even when the text contains 0x00.
-//   round r   (h = 7, 14, 28, ...) unresolved suffixes only.  The active list keeps groups of equal h-rank contiguous and
+//   round 0   key = first D bytes as codes of the block's alphabet (D = 7 for more than 128 byte values, 11 for 17..32, up to 56:
+//             k_key_plan / k_pack_keys below), big-endian in 56 bits, zero padded: one LSD radix sort of all n suffixes, 7 passes
+//             (radix.hip), fed in descending text position so that a short suffix -- a proper prefix of anything it ties with on
+//             the padded bytes -- comes first: plain suffix order even when the text contains the smallest symbol.
+//   round r   (h = D, 2D, 4D, ...) unresolved suffixes only.  The active list keeps groups of equal h-rank contiguous and
 //             in SA order, so a group is sorted by key2 = rank[sa + h] + 1 (0 past the end) independently:
 //               * k_gather_win   key2 of every active suffix (the round's only random READ), head flags per 1024-slot window
 //               * groups of <= 1024 suffixes: k_seg_round -- one workgroup owns the groups that start in its window,
@@ -34,7 +35,7 @@ constexpr int WAVES = TB / 64;
 constexpr uint32_t DONE = 0x80000000u;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 // Bit 30 of a group rank in the active list (ranks are SA positions < n <= JPK_MAX_BLOCKSIZE < 2^30): the suffix starts inside a run
-// of >= 7 equal bytes.  Such suffixes do not double their way through the run (log2(run / 7) rounds, each over every member of the
+// of >= D equal bytes (D = round 0's key depth).  Such suffixes do not double their way through the run (log2(run / D) rounds, each over every member of the
 // run: an all-zero 64 MiB block took 25 rounds): round 1 sorts their group by (does the run end in a smaller or a larger byte, run
 // length) -- the complete order among suffixes that start with the same byte repeated, see k_gather_win -- and from round 2 on they
 // compare at the END of their run (distance = remaining run length, uniform inside the group by then) instead of at distance h.
@@ -56,7 +57,7 @@ struct SaState {
     uint32_t m[2];                         // unresolved suffixes: round r reads m[r & 1] and writes m[(r + 1) & 1]
     uint32_t npieces;                      // pieces of large groups in the current round
     uint32_t lc;                           // members of large groups in the current round
-    uint32_t nrun;                         // unresolved suffixes after round 0 that start inside a run of >= 7 equal bytes
+    uint32_t nrun;                         // unresolved suffixes after round 0 that start inside a run of >= depth equal bytes
     uint32_t round_m[JPK_SA_MAX_ROUNDS];   // per round: unresolved suffixes when it starts
     uint32_t round_lc[JPK_SA_MAX_ROUNDS];  // per round: of those, members of groups > SEG_TILE
     // round 0's key (k_key_plan): the text's bytes renumbered 0..sigma-1 in byte order, `bits` bits each, `depth` of them in 56 bits
@@ -286,14 +287,14 @@ __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T,
 }
 
 // ---- round 0 ---------------------------------------------------------------------------------------------------------
-// Round 0 sorts slot j = suffix n-1-j by key = first 7 bytes, big-endian in bits 63..8, zero padded past the end of the text
-// (radix.hip builds the keys from the text in its first pass).  The LSD sort is stable, so suffixes that tie on the padded
+// Round 0 sorts slot j = suffix n-1-j by key = first D bytes (as codes, see above), big-endian in bits 63..8, zero padded past the
+// end of the text (k_pack_keys built the keys).  The LSD sort is stable, so suffixes that tie on the padded
 // bytes come out in DESCENDING text position, i.e. a short suffix (a proper prefix of everything it ties with) lands in
 // front -- plain suffix order even when the text contains 0x00 -- and the low byte of the key needs no sort pass.
 
-// head of an equal-key run; a suffix with fewer than 7 bytes is always a group of its own
+// head of an equal-key run; a suffix with fewer than D bytes is always a group of its own
 // Group sort (bend != null: several blocks sorted as one text, the key's low byte = block number, see radix.hip): the whole key
-// takes part in the comparison, and a suffix is "short" when fewer than 7 bytes are left in ITS block.
+// takes part in the comparison, and a suffix is "short" when fewer than D bytes are left in ITS block.
 __device__ __forceinline__ uint32_t r0_end(uint64_t key, uint32_t n, const uint32_t *__restrict__ bend) { return bend ? bend[(uint32_t)key & 255u] : n; }
 __device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t j, uint32_t n, const uint32_t *__restrict__ bend,
                                         uint32_t D)
@@ -307,7 +308,7 @@ __device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const
 // HE[64] bit 0 = head flag of the first slot of the next tile.  Every thread loads its sixteen (key, suffix) pairs ONCE, all loads
 // in flight together (clamped indices, no branch around a load), and hands them back to the caller; the key in front of a slot
 // comes from the neighbouring lane (DPP wave shift; lane 0: lane 63 of the row before, the wave's first row: one extra load),
-// and "the suffix in front is shorter than 7 bytes" is the shifted ballot of the row's own "short" bits.
+// and "the suffix in front is shorter than D bytes" is the shifted ballot of the row's own "short" bits.
 __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n, uint32_t base, uint64_t *HE,
                                               uint64_t (&kj)[CT_ITEMS], uint32_t (&sj)[CT_ITEMS], const uint32_t *__restrict__ bend, uint32_t D)
 {
@@ -1569,7 +1570,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_r0_scan, dim3(1), dim3(WG1), b.tA, b.tB, n, b.state);
     JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev, b.state, b.bend);
     ctx->stats.sa_rounds = 1;
-    // remaining run lengths, only if round 0 left members of runs of >= 7 equal bytes behind (the kernels return at once otherwise)
+    // remaining run lengths, only if round 0 left members of runs of >= depth equal bytes behind (the kernels return at once otherwise)
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_first, dim3(cap_grid(n, CT, 4096)), dim3(TB), T, n, b.state, b.tA, b.blk);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_scan, dim3(1), dim3(WG1), b.tA, n, b.state);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_fill, dim3(cap_grid(n, CT, 4096)), dim3(TB), T, n, b.state, b.tA, b.RL, b.blk);
