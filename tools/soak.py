@@ -22,10 +22,22 @@ for i in range(N):
     k = kinds[int(rng.integers(len(kinds)))]
     r = rng.random()
     n = int(rng.integers(1, 3000)) if r < 0.15 else (int(rng.integers(3000, 1_300_000)) if r < 0.7 else int(rng.integers(1_300_000, 9_000_000)))
-    try:
-        t = jam.corpus.make(k, n, 10_000 * seed + i)
-    except Exception:
-        t = jam.corpus.make("text_survey", n, 10_000 * seed + i)
+    if rng.random() < 0.35:
+        # a phrase text over a random alphabet of 1..256 byte values (round 0's keys pack by the alphabet: every code width, real repeats)
+        sigma = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 16, 17, 28, 32, 33, 64, 65, 128, 129, 200, 256]))
+        sym = np.sort(rng.choice(256, sigma, replace=False)).astype(np.uint8)
+        book = [sym[rng.integers(0, sigma, int(rng.integers(3, 60)))] for _ in range(int(rng.integers(2, 300)))]
+        parts, have = [], 0
+        while have < n:
+            ph = book[int(rng.integers(len(book)))]
+            parts.append(ph); have += len(ph)
+        t = np.ascontiguousarray(np.concatenate(parts)[:n])
+        k = f"phrases{sigma}"
+    else:
+        try:
+            t = jam.corpus.make(k, n, 10_000 * seed + i)
+        except Exception:
+            t = jam.corpus.make("text_survey", n, 10_000 * seed + i)
     d_t = torch.from_numpy(t).to(dev)
     cap = jam.ans_capacity(len(t) + jam.TRAILER)
     d_c = torch.empty(cap, dtype=torch.uint8, device=dev)
