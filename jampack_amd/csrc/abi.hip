@@ -27,6 +27,8 @@ int jpk_arena_ensure(jpk_ctx *ctx, size_t bytes)
     JPK_HIP(hipStreamSynchronize(ctx->stream));
     for (int g = 0; g + 1 < jpk_ctx::ENC_GROUPS; g++)
         if (ctx->aux[g]) JPK_HIP(hipStreamSynchronize(ctx->aux[g]));
+    for (int k = 0; k < jpk_ctx::INV_LANES_MAX; k++)
+        if (ctx->inv_lane[k]) JPK_HIP(hipStreamSynchronize(ctx->inv_lane[k]));
     const bool growing = ctx->arena != nullptr;
     if (ctx->arena) { JPK_HIP(hipFree(ctx->arena)); ctx->arena = nullptr; ctx->arena_cap = 0; }
     // an arena that has to GROW grows geometrically, so that a sequence of slightly larger blocks does not re-allocate every time;
@@ -257,6 +259,10 @@ extern "C" void jpk_ctx_destroy(jpk_ctx *c)
     }
     for (int k = 0; k < 2; k++)
         if (c->ev_sa[k]) (void)hipEventDestroy(c->ev_sa[k]);
+    for (int k = 0; k < jpk_ctx::INV_LANES_MAX; k++) {
+        if (c->inv_lane[k]) { (void)hipStreamSynchronize(c->inv_lane[k]); (void)hipStreamDestroy(c->inv_lane[k]); }
+        if (c->ev_inv[k]) (void)hipEventDestroy(c->ev_inv[k]);
+    }
     if (c->ev_batch) (void)hipEventDestroy(c->ev_batch);
     for (auto &p : c->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
@@ -520,14 +526,26 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
     // is 20-microsecond rank-jump rounds and launch gaps), so up to three run side by side, each on its own stream with its own
     // scratch, behind one event on the decode stream.
     static const int max_lanes = [] { const char *e = getenv("JPK_INV_LANES"); const int v = e ? atoi(e) : 3; return v < 1 ? 1 : (v > jpk_ctx::ENC_GROUPS ? jpk_ctx::ENC_GROUPS : v); }();
+    // ... and up to JPK_INV_LANES_SMALL (default 12) when the batch is many SMALL blocks (<= 4 MiB): an inverse BWT of a 1 MiB block is
+    // the same ~30 dependent launches, each a sliver of the chip, and 256 of them on three lanes took 100 ms of a 245 ms call whose
+    // chains had finished after 145 (round 4: 1 070 -> 1 400 MB/s with 8 to 16 lanes; what is left is the host's launch rate, 7 700
+    // launches per call).  Blocks of 8 MiB gain nothing (nine chains per block: the chains are the call) and would pay 12 scratch areas.
+    static const int small_lanes = [] { const char *e = getenv("JPK_INV_LANES_SMALL"); const int v = e ? atoi(e) : 12; return v < 1 ? 1 : (v > jpk_ctx::INV_LANES_MAX ? jpk_ctx::INV_LANES_MAX : v); }();
     // Only a batch with many blocks gets lanes: they save the latency part of each inverse BWT (~1 ms of 2.5), nothing next to
     // the 270 ms of a small batch's chains, and every extra stream of a context lands on a hardware queue that another
     // context's chain kernels may be using (eight contexts decoding 2-block passes lost 18 % with a second stream each).
-    int lanes = nblocks < 8 ? 1 : max_lanes;
-    hipStream_t lane_stream[jpk_ctx::ENC_GROUPS] = {ctx->stream, nullptr, nullptr, nullptr};
+    const bool many_small = nblocks >= 32 && nmax <= (4u << 20);
+    int lanes = nblocks < 8 ? 1 : (many_small ? (small_lanes > max_lanes ? small_lanes : max_lanes) : max_lanes);
+    hipStream_t lane_stream[jpk_ctx::INV_LANES_MAX] = {};
+    hipEvent_t lane_event[jpk_ctx::INV_LANES_MAX] = {};
+    lane_stream[0] = ctx->stream;
     for (int k = 1; k < lanes; k++) {
-        if (!ctx->aux[k - 1] && hipStreamCreateWithFlags(&ctx->aux[k - 1], hipStreamNonBlocking) != hipSuccess) { ctx->aux[k - 1] = nullptr; lanes = k; break; }
-        lane_stream[k] = ctx->aux[k - 1];
+        hipStream_t *slot = k < jpk_ctx::ENC_GROUPS ? &ctx->aux[k - 1] : &ctx->inv_lane[k];
+        hipEvent_t *ev = k < jpk_ctx::ENC_GROUPS ? &ctx->ev_done[k] : &ctx->ev_inv[k];
+        if ((!*slot && hipStreamCreateWithFlags(slot, hipStreamNonBlocking) != hipSuccess) ||
+            (!*ev && hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess)) { lanes = k; break; }
+        lane_stream[k] = *slot;
+        lane_event[k] = *ev;
     }
     const size_t inv_one = jpk_align(jpk_inv_bwt_arena_bytes(nmax), 4096), verdict_bytes = jpk_align((size_t)nblocks * 16 + 64, 4096);
     const size_t inv_bytes = inv_one * (size_t)lanes + verdict_bytes;
@@ -574,8 +592,8 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
         }
         ctx->stream = main_stream;
         for (int k = 1; k < lanes; k++) {                      // the main stream continues behind every lane
-            JPK_HIP(hipEventRecord(ctx->ev_done[k], lane_stream[k]));
-            JPK_HIP(hipStreamWaitEvent(main_stream, ctx->ev_done[k], 0));
+            JPK_HIP(hipEventRecord(lane_event[k], lane_stream[k]));
+            JPK_HIP(hipStreamWaitEvent(main_stream, lane_event[k], 0));
         }
         restore.failed = false;
     }

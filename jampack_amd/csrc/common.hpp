@@ -46,6 +46,11 @@ struct jpk_ctx {
     static constexpr int ENC_GROUPS = 4;
     hipStream_t aux[ENC_GROUPS - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_pre[ENC_GROUPS] = {nullptr, nullptr, nullptr, nullptr}, ev_done[ENC_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+    // jpk_dev_blocks_decompress of many SMALL blocks: more inverse BWTs side by side than the three of a batch of large ones (an inverse
+    // BWT of a 1 MiB block is ~30 dependent launches, each a fraction of the chip).  Streams and events made on first use.
+    static constexpr int INV_LANES_MAX = 16;
+    hipStream_t inv_lane[INV_LANES_MAX] = {};
+    hipEvent_t ev_inv[INV_LANES_MAX] = {};
     // heavy-phase gate (abi.hip): events that mark the end of this context's GPU-saturating work -- [0] the suffix sort, [1..] the
     // wide entropy kernels of each chunk group -- and whether this context currently holds the device's gate
     static constexpr int GATE_EVENTS = 5;
