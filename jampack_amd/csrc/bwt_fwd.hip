@@ -762,13 +762,10 @@ __global__ __launch_bounds__(TB) void k_win_pieces(const uint32_t *__restrict__ 
 
 // the sort / re-rank of all groups of <= SEG_TILE elements, one window per workgroup iteration
 __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const uint32_t *__restrict__ k2g,
-                                                 const SaState *__restrict__ st, int par, int key_bits_spread, int key_bits_plain, const uint32_t *__restrict__ PH,
+                                                 const SaState *__restrict__ st, int par, int key_bits, const uint32_t *__restrict__ PH,
                                                  const uint8_t *__restrict__ a_prev, uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
                                                  uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint8_t *__restrict__ b_prev)
 {
-    // key2 is a rank + 1 <= n; only round 1 of a block that has run members spreads keys up to 3n (k_gather_win): two more key bits,
-    // which is one more LDS pass for most windows (bits of the key + bits of the window's group count, 9 per pass)
-    const int key_bits = (key_bits_spread != key_bits_plain && st->nrun != 0u) ? key_bits_spread : key_bits_plain;
     // LDS diet (30 KB, five workgroups per CU instead of three): the group ranks g[] are only needed while the group boundaries
     // are worked out and share their 8 KB with the two index permutations of the sort; the suffix numbers and the group rank of
     // the final positions are re-read from the (L2-resident) window instead of being kept; the scratch of the boundary scans
@@ -1579,7 +1576,6 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_fill, dim3(cap_grid(n, CT, 4096)), dim3(TB), T, n, b.state, b.tA, b.RL, b.blk);
 
     const int kbits = jpk_bits_for(3u * n);        // key2 <= n (a rank + 1); round 1 spreads the keys of groups of run members up to 3n; group rank < n
-    const int kbits_plain = jpk_bits_for(n);       // ... every other round, and round 1 of a block without run members
     int lg_pass = 0;
     const int lg_db = lg_digit_bits(n, &lg_pass);
     // Rounds 1 and 2 (the long ones: milliseconds each) are enqueued without waiting: the host learns the number of unresolved
@@ -1617,7 +1613,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_count, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.state, par);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan2, dim3(1), dim3(WG1), b.PC, b.state, par, round);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_pieces, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.pieces, b.state, par);
-        JPK_LAUNCH(ctx, PROF_SA_SEG, 0, k_seg_round, dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, round == 1 ? kbits : kbits_plain, kbits_plain, b.PH, b.a_prev, b.ISA, b.bwt, b.SA,
+        JPK_LAUNCH(ctx, PROF_SA_SEG, 0, k_seg_round, dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, kbits, b.PH, b.a_prev, b.ISA, b.bwt, b.SA,
                    b.b_sa, b.b_grp, b.b_prev);
         if (large_possible) {   // large groups: lg_pass LSD passes over (key2, sa), ping-pong between (k2, a_sa) and (k2alt, sa_alt)
             uint32_t *kin = b.k2, *vin = b.a_sa, *kout = b.k2alt, *vout = b.sa_alt;
