@@ -535,7 +535,10 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
     // the 270 ms of a small batch's chains, and every extra stream of a context lands on a hardware queue that another
     // context's chain kernels may be using (eight contexts decoding 2-block passes lost 18 % with a second stream each).
     const bool many_small = nblocks >= 32 && nmax <= (4u << 20);
-    int lanes = nblocks < 8 ? 1 : (many_small ? (small_lanes > max_lanes ? small_lanes : max_lanes) : max_lanes);
+    // ... or, by default, through ONE set of launches over all of them (bwt_inv.hip jpk_inv_bwt_batch_enqueue; JPK_INV_BATCH=0 keeps the lanes)
+    static const bool batch_on = [] { const char *e = getenv("JPK_INV_BATCH"); return e ? atoi(e) != 0 : true; }();
+    const bool batched = many_small && batch_on;
+    int lanes = (nblocks < 8 || batched) ? 1 : (many_small ? (small_lanes > max_lanes ? small_lanes : max_lanes) : max_lanes);
     hipStream_t lane_stream[jpk_ctx::INV_LANES_MAX] = {};
     hipEvent_t lane_event[jpk_ctx::INV_LANES_MAX] = {};
     lane_stream[0] = ctx->stream;
@@ -548,7 +551,7 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
         lane_event[k] = *ev;
     }
     const size_t inv_one = jpk_align(jpk_inv_bwt_arena_bytes(nmax), 4096), verdict_bytes = jpk_align((size_t)nblocks * 16 + 64, 4096);
-    const size_t inv_bytes = inv_one * (size_t)lanes + verdict_bytes;
+    const size_t inv_bytes = (batched ? jpk_align(jpk_inv_bwt_batch_arena_bytes(nblocks, mid_cap.data()), 4096) : inv_one * (size_t)lanes) + verdict_bytes;
     JPK_TRY(jpk_arena_ensure(ctx, inv_bytes + mid_total + bound + (1u << 20)));
     uint32_t *d_verdict = reinterpret_cast<uint32_t *>(ctx->arena + inv_bytes - verdict_bytes);
     std::vector<uint8_t *> mid((size_t)nblocks);
@@ -560,6 +563,7 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
     // the inverse BWTs are enqueued without a host round trip between them (trailer index, slot count and the head check stay
     // on the device); their verdicts come back in one copy
     std::vector<int> ran;
+    std::vector<uint8_t> host_jobs;                            // the batched inverse BWT's job table: copied from here asynchronously
     {
         struct Restore {                                       // whatever happens below, the context gets its stream and base back
             jpk_ctx *c; hipStream_t s; hipStream_t *lane; int lanes; bool failed = true;
@@ -577,11 +581,13 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
             for (int k = 1; k < lanes; k++) JPK_HIP(hipStreamWaitEvent(lane_stream[k], ctx->ev_batch, 0));
         }
         int next = 0;
+        std::vector<int> jb;                                   // blocks that go through the batched inverse BWT
         for (int b = 0; b < nblocks; b++) {
             out_len[b] = 0;
             if (stp[b] != JPK_OK) continue;
             if (mid_len[b] < JPK_TRAILER_BYTES) { stp[b] = JPK_E_CORRUPT; continue; }
             if (mid_len[b] - JPK_TRAILER_BYTES > out_cap[b]) { stp[b] = JPK_E_CAPACITY; continue; }
+            if (batched && mid_len[b] - JPK_TRAILER_BYTES >= JPK_BWT_UNITS) { jb.push_back(b); continue; }   // (a shorter image has no sorted part: two copies, below)
             const int k = next % lanes;
             ctx->stream = lane_stream[k];
             ctx->arena_base = inv_one * (size_t)k;
@@ -591,6 +597,17 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
             next++;
         }
         ctx->stream = main_stream;
+        if (!jb.empty()) {
+            std::vector<const uint8_t *> jin(jb.size());
+            std::vector<uint8_t *> jout(jb.size());
+            std::vector<int32_t> jlen(jb.size());
+            for (size_t q = 0; q < jb.size(); q++) { jin[q] = mid[jb[q]]; jout[q] = d_out[jb[q]]; jlen[q] = mid_len[jb[q]]; }
+            // (job q reports into the verdict slot of its block, jb[q])
+            ctx->arena_base = 0;
+            const int rc = jpk_inv_bwt_batch_enqueue(ctx, (int)jb.size(), jin.data(), jlen.data(), jout.data(), d_verdict, jb.data(), host_jobs);
+            if (rc != JPK_OK) { for (int b : jb) stp[b] = rc; }
+            else for (int b : jb) ran.push_back(b);
+        }
         for (int k = 1; k < lanes; k++) {                      // the main stream continues behind every lane
             JPK_HIP(hipEventRecord(lane_event[k], lane_stream[k]));
             JPK_HIP(hipStreamWaitEvent(main_stream, lane_event[k], 0));

@@ -42,9 +42,8 @@ struct InvState {
     uint32_t head_dist;     // bytes the chain from the head covers (must be n)
 };
 
-__global__ void k_inv_prep(const uint8_t *__restrict__ trailer, uint32_t n, InvState *__restrict__ st)
+__device__ __forceinline__ void inv_prep_body(const uint8_t *__restrict__ trailer, uint32_t n, InvState *__restrict__ st)
 {
-    if (threadIdx.x != 0) return;
     const uint32_t I = (uint32_t)trailer[0] | ((uint32_t)trailer[1] << 8) | ((uint32_t)trailer[2] << 16) | ((uint32_t)trailer[3] << 24);
     const bool ok = I >= 1u && I <= n;
     st->status = ok ? 0u : (uint32_t)JPK_E_CORRUPT;
@@ -52,15 +51,19 @@ __global__ void k_inv_prep(const uint8_t *__restrict__ trailer, uint32_t n, InvS
     st->novf = 0;
     st->head_dist = 0;
 }
+__global__ void k_inv_prep(const uint8_t *__restrict__ trailer, uint32_t n, InvState *__restrict__ st)
+{
+    if (threadIdx.x == 0) inv_prep_body(trailer, n, st);
+}
 
 // ---- Map build ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TB) void k_hist(const uint8_t *__restrict__ B, uint32_t n, uint32_t *__restrict__ tilehist, uint32_t ntiles)
+__device__ __forceinline__ void hist_body(const uint8_t *__restrict__ B, uint32_t n, uint32_t *__restrict__ tilehist, uint32_t ntiles, uint32_t bx)
 {
     __shared__ uint32_t h[WAVES][256];
     for (int i = threadIdx.x; i < WAVES * 256; i += TB) (&h[0][0])[i] = 0;
     __syncthreads();
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const size_t base = (size_t)blockIdx.x * TILE + (size_t)w * (64 * ITEMS) + l;
+    const size_t base = (size_t)bx * TILE + (size_t)w * (64 * ITEMS) + l;
     // loads first, all in flight (slots past the end re-read the last byte and are masked): a load inside `if (i < n)` makes the
     // compiler wait for each one in turn
     uint8_t sy[ITEMS];
@@ -79,31 +82,40 @@ __global__ __launch_bounds__(TB) void k_hist(const uint8_t *__restrict__ B, uint
     }
     __syncthreads();
     for (int d = threadIdx.x; d < 256; d += TB)
-        tilehist[(size_t)d * ntiles + blockIdx.x] = h[0][d] + h[1][d] + h[2][d] + h[3][d];
+        tilehist[(size_t)d * ntiles + bx] = h[0][d] + h[1][d] + h[2][d] + h[3][d];
+}
+__global__ __launch_bounds__(TB) void k_hist(const uint8_t *__restrict__ B, uint32_t n, uint32_t *__restrict__ tilehist, uint32_t ntiles)
+{
+    hist_body(B, n, tilehist, ntiles, blockIdx.x);
 }
 
 // cum[c] = first F-position of symbol c (= scanned table entry of tile 0), cum[256] = n
-__global__ void k_cum(const uint32_t *__restrict__ tileoff, uint32_t ntiles, uint32_t n, uint32_t *__restrict__ cum)
+// (pos_base: what the scanned table holds in front of this block's entries -- 0 for one block, the bytes of the blocks before it in a batch)
+__device__ __forceinline__ void cum_body(const uint32_t *__restrict__ tileoff, uint32_t ntiles, uint32_t n, uint32_t *__restrict__ cum, uint32_t pos_base)
 {
     uint32_t c = threadIdx.x;
-    if (c < 256) cum[c] = tileoff[(size_t)c * ntiles];
+    if (c < 256) cum[c] = tileoff[(size_t)c * ntiles] - pos_base;
     if (c == 0) cum[256] = n;
+}
+__global__ void k_cum(const uint32_t *__restrict__ tileoff, uint32_t ntiles, uint32_t n, uint32_t *__restrict__ cum)
+{
+    cum_body(tileoff, ntiles, n, cum, 0u);
 }
 
 // nxt[F-position] = (i < I ? i : i + 1) - 1     (bwt.cpp:171-174, minus one so that -1 terminates the chain)
 template <bool DEV>
-__global__ __launch_bounds__(TB) void k_build_nxt(const uint8_t *__restrict__ B, uint32_t n, uint32_t I_host, const InvState *__restrict__ st,
-                                                 const uint32_t *__restrict__ tileoff, uint32_t ntiles, int32_t *__restrict__ nxt)
+__device__ __forceinline__ void build_nxt_body(const uint8_t *__restrict__ B, uint32_t n, uint32_t I_host, const InvState *__restrict__ st,
+                                               const uint32_t *__restrict__ tileoff, uint32_t ntiles, int32_t *__restrict__ nxt, uint32_t bx, uint32_t pos_base)
 {
     __shared__ uint32_t cnt[WAVES][256];
     __shared__ uint32_t gbase[256];
     const uint32_t I = DEV ? st->I : I_host;
     if (DEV && I == 0u) return;
     for (int i = threadIdx.x; i < WAVES * 256; i += TB) (&cnt[0][0])[i] = 0;
-    for (int d = threadIdx.x; d < 256; d += TB) gbase[d] = tileoff[(size_t)d * ntiles + blockIdx.x];
+    for (int d = threadIdx.x; d < 256; d += TB) gbase[d] = tileoff[(size_t)d * ntiles + bx] - pos_base;
     __syncthreads();
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const size_t base = (size_t)blockIdx.x * TILE + (size_t)w * (64 * ITEMS) + l;
+    const size_t base = (size_t)bx * TILE + (size_t)w * (64 * ITEMS) + l;
     const uint64_t lt = lanemask_lt();
     uint8_t sym[ITEMS];
     uint16_t rnk[ITEMS];
@@ -142,6 +154,12 @@ __global__ __launch_bounds__(TB) void k_build_nxt(const uint8_t *__restrict__ B,
         }
     }
 }
+template <bool DEV>
+__global__ __launch_bounds__(TB) void k_build_nxt(const uint8_t *__restrict__ B, uint32_t n, uint32_t I_host, const InvState *__restrict__ st,
+                                                 const uint32_t *__restrict__ tileoff, uint32_t ntiles, int32_t *__restrict__ nxt)
+{
+    build_nxt_body<DEV>(B, n, I_host, st, tileoff, ntiles, nxt, blockIdx.x, 0u);
+}
 
 // ---- walk ----------------------------------------------------------------------------------------------
 // One lane per splitter (+ one for the chain head j0 = I-1).  Lane k walks from its splitter to the next
@@ -150,9 +168,9 @@ __global__ __launch_bounds__(TB) void k_build_nxt(const uint8_t *__restrict__ B,
 // freshly allocated overflow slot, so every slot holds <= CAP bytes.
 constexpr int LUT = 4096;
 
-__global__ __launch_bounds__(TB) void k_walk(const int32_t *__restrict__ nxt, const uint32_t *__restrict__ cum_g, uint32_t n, InvState *__restrict__ st,
-                                            uint32_t nsplit, uint32_t lut_shift, uint8_t *__restrict__ scratch,
-                                            uint32_t *__restrict__ slot_len, uint32_t *__restrict__ slot_next, uint32_t max_slots)
+__device__ __forceinline__ void walk_body(const int32_t *__restrict__ nxt, const uint32_t *__restrict__ cum_g, uint32_t n, InvState *__restrict__ st,
+                                          uint32_t nsplit, uint32_t lut_shift, uint8_t *__restrict__ scratch,
+                                          uint32_t *__restrict__ slot_len, uint32_t *__restrict__ slot_next, uint32_t max_slots, uint32_t bx)
 {
     __shared__ uint32_t cum[257];
     __shared__ uint8_t lut[LUT];
@@ -172,7 +190,7 @@ __global__ __launch_bounds__(TB) void k_walk(const int32_t *__restrict__ nxt, co
     }
     __syncthreads();
 
-    const uint32_t k = blockIdx.x * TB + threadIdx.x;
+    const uint32_t k = bx * TB + threadIdx.x;
     if (k > nsplit) return;
     const uint32_t j0 = I - 1;
     uint32_t j;
@@ -221,6 +239,12 @@ __global__ __launch_bounds__(TB) void k_walk(const int32_t *__restrict__ nxt, co
         j = (uint32_t)nx;
     }
 }
+__global__ __launch_bounds__(TB) void k_walk(const int32_t *__restrict__ nxt, const uint32_t *__restrict__ cum_g, uint32_t n, InvState *__restrict__ st,
+                                            uint32_t nsplit, uint32_t lut_shift, uint8_t *__restrict__ scratch,
+                                            uint32_t *__restrict__ slot_len, uint32_t *__restrict__ slot_next, uint32_t max_slots)
+{
+    walk_body(nxt, cum_g, n, st, nsplit, lut_shift, scratch, slot_len, slot_next, max_slots, blockIdx.x);
+}
 
 // ---- list ranking of the slots (Wyllie pointer jumping, ping-pong buffers) ----------------------------
 // dist[s] = bytes from the start of slot s to the end of the text.
@@ -233,34 +257,44 @@ __device__ __forceinline__ uint32_t slots_in_use(const InvState *st, uint32_t ns
     return ns < max_slots ? ns : max_slots;
 }
 
-__global__ __launch_bounds__(TB) void k_rank_init(const uint32_t *__restrict__ slot_len, const uint32_t *__restrict__ slot_next, const InvState *__restrict__ st,
-                                                 uint32_t nsplit, uint32_t max_slots, uint32_t *__restrict__ dist, uint32_t *__restrict__ link)
+__device__ __forceinline__ void rank_init_body(const uint32_t *__restrict__ slot_len, const uint32_t *__restrict__ slot_next, const InvState *__restrict__ st,
+                                               uint32_t nsplit, uint32_t max_slots, uint32_t *__restrict__ dist, uint32_t *__restrict__ link, uint32_t bx)
 {
     const uint32_t nslots = slots_in_use(st, nsplit, max_slots);
-    uint32_t s = blockIdx.x * TB + threadIdx.x;
+    uint32_t s = bx * TB + threadIdx.x;
     if (s >= nslots) return;
     dist[s] = slot_len[s];
     link[s] = slot_next[s];
 }
-__global__ __launch_bounds__(TB) void k_rank_jump(const uint32_t *__restrict__ dist_in, const uint32_t *__restrict__ link_in, const InvState *__restrict__ st,
-                                                 uint32_t nsplit, uint32_t max_slots, uint32_t *__restrict__ dist_out, uint32_t *__restrict__ link_out)
+__device__ __forceinline__ void rank_jump_body(const uint32_t *__restrict__ dist_in, const uint32_t *__restrict__ link_in, const InvState *__restrict__ st,
+                                               uint32_t nsplit, uint32_t max_slots, uint32_t *__restrict__ dist_out, uint32_t *__restrict__ link_out, uint32_t bx)
 {
     const uint32_t nslots = slots_in_use(st, nsplit, max_slots);
-    uint32_t s = blockIdx.x * TB + threadIdx.x;
+    uint32_t s = bx * TB + threadIdx.x;
     if (s >= nslots) return;
     uint32_t d = dist_in[s], l = link_in[s];
     if (l != NIL) { d += dist_in[l]; l = link_in[l]; }
     dist_out[s] = d;
     link_out[s] = l;
 }
+__global__ __launch_bounds__(TB) void k_rank_init(const uint32_t *__restrict__ slot_len, const uint32_t *__restrict__ slot_next, const InvState *__restrict__ st,
+                                                 uint32_t nsplit, uint32_t max_slots, uint32_t *__restrict__ dist, uint32_t *__restrict__ link)
+{
+    rank_init_body(slot_len, slot_next, st, nsplit, max_slots, dist, link, blockIdx.x);
+}
+__global__ __launch_bounds__(TB) void k_rank_jump(const uint32_t *__restrict__ dist_in, const uint32_t *__restrict__ link_in, const InvState *__restrict__ st,
+                                                 uint32_t nsplit, uint32_t max_slots, uint32_t *__restrict__ dist_out, uint32_t *__restrict__ link_out)
+{
+    rank_jump_body(dist_in, link_in, st, nsplit, max_slots, dist_out, link_out, blockIdx.x);
+}
 
 // one wave per 4 slots (16 lanes each): T[n - dist[s] ...] = scratch[s*CAP ... + len)
-__global__ __launch_bounds__(TB) void k_copy_out(const uint8_t *__restrict__ scratch, const uint32_t *__restrict__ slot_len,
-                                                const uint32_t *__restrict__ dist, const InvState *__restrict__ st, uint32_t nsplit, uint32_t max_slots,
-                                                uint32_t n, uint8_t *__restrict__ T)
+__device__ __forceinline__ void copy_out_body(const uint8_t *__restrict__ scratch, const uint32_t *__restrict__ slot_len,
+                                              const uint32_t *__restrict__ dist, const InvState *__restrict__ st, uint32_t nsplit, uint32_t max_slots,
+                                              uint32_t n, uint8_t *__restrict__ T, uint32_t bx)
 {
     const uint32_t nslots = slots_in_use(st, nsplit, max_slots);
-    const uint32_t gid = blockIdx.x * TB + threadIdx.x;
+    const uint32_t gid = bx * TB + threadIdx.x;
     const uint32_t s = gid >> 4, sub = gid & 15u;
     if (s >= nslots) return;
     const uint32_t len = slot_len[s];
@@ -270,6 +304,12 @@ __global__ __launch_bounds__(TB) void k_copy_out(const uint8_t *__restrict__ scr
     const uint8_t *src = scratch + (size_t)s * CAP;
     uint8_t *dst = T + (n - d);
     for (uint32_t b = sub; b < len; b += 16) dst[b] = src[b];
+}
+__global__ __launch_bounds__(TB) void k_copy_out(const uint8_t *__restrict__ scratch, const uint32_t *__restrict__ slot_len,
+                                                const uint32_t *__restrict__ dist, const InvState *__restrict__ st, uint32_t nsplit, uint32_t max_slots,
+                                                uint32_t n, uint8_t *__restrict__ T)
+{
+    copy_out_body(scratch, slot_len, dist, st, nsplit, max_slots, n, T, blockIdx.x);
 }
 
 __global__ void k_inv_tail(const uint8_t *__restrict__ B, uint32_t n, uint32_t len, uint8_t *__restrict__ T)
@@ -321,6 +361,103 @@ void inv_layout(Arena &a, size_t n, InvBufs &b, size_t &ntiles, size_t &nsplit, 
     max_slots = nsplit + 1 + n / CAP + 2;
     b.tilehist = a.get<uint32_t>(256 * ntiles);
     b.scan_scratch = a.get<uint32_t>(jpk_scan_scratch_words(256 * ntiles));
+    b.cum = a.get<uint32_t>(260);
+    b.nxt = a.get<int32_t>(n);
+    b.slot_len = a.get<uint32_t>(max_slots);
+    b.slot_next = a.get<uint32_t>(max_slots);
+    b.distA = a.get<uint32_t>(max_slots);
+    b.distB = a.get<uint32_t>(max_slots);
+    b.linkA = a.get<uint32_t>(max_slots);
+    b.linkB = a.get<uint32_t>(max_slots);
+    b.scratch = a.get<uint8_t>(max_slots * CAP);
+    b.state = a.get<InvState>(1);
+}
+
+// ---- the same kernels over MANY blocks at once (jpk_inv_bwt_batch_enqueue) ------------------------------------------------------------
+// A stream of the reference's smallest blocks is decompressed 256 blocks to a call, and an inverse BWT is ~30 launches whatever its size:
+// 7 700 launches, 40 ms of host time, for kernels that together run for 5.  Here every launch covers all blocks: blockIdx.y = the job, a
+// table of per-job pointers and sizes, grids as wide as the largest job needs (blocks beyond a job's own extent leave at once).  The tile
+// histograms of all jobs are ONE array and ONE scan; what the scan leaves in front of a job's entries is the sum of the blocks before it
+// (pos_base, known on the host).  Each job has its own InvState, so a corrupt block stops only itself.
+struct InvJob {
+    const uint8_t *B;
+    uint8_t *T;
+    uint32_t *verdict;
+    uint32_t n, len, ntiles, nsplit, max_slots, lut_shift, pos_base, pad;
+    uint32_t *tilehist, *cum, *slot_len, *slot_next, *distA, *distB, *linkA, *linkB;
+    int32_t *nxt;
+    uint8_t *scratch;
+    InvState *state;
+};
+__global__ void k_b_prep(const InvJob *__restrict__ jobs, uint32_t njobs)
+{
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < njobs) inv_prep_body(jobs[q].B + jobs[q].len, jobs[q].n, jobs[q].state);
+}
+__global__ __launch_bounds__(TB) void k_b_hist(const InvJob *__restrict__ jobs)
+{
+    const InvJob &j = jobs[blockIdx.y];
+    if (blockIdx.x >= j.ntiles) return;
+    hist_body(j.B, j.n, j.tilehist, j.ntiles, blockIdx.x);
+}
+__global__ void k_b_cum(const InvJob *__restrict__ jobs)
+{
+    const InvJob &j = jobs[blockIdx.x];
+    cum_body(j.tilehist, j.ntiles, j.n, j.cum, j.pos_base);
+}
+__global__ __launch_bounds__(TB) void k_b_build_nxt(const InvJob *__restrict__ jobs)
+{
+    const InvJob &j = jobs[blockIdx.y];
+    if (blockIdx.x >= j.ntiles) return;
+    build_nxt_body<true>(j.B, j.n, 0u, j.state, j.tilehist, j.ntiles, j.nxt, blockIdx.x, j.pos_base);
+}
+__global__ __launch_bounds__(TB) void k_b_walk(const InvJob *__restrict__ jobs)
+{
+    const InvJob &j = jobs[blockIdx.y];
+    if (blockIdx.x * TB > j.nsplit) return;
+    walk_body(j.nxt, j.cum, j.n, j.state, j.nsplit, j.lut_shift, j.scratch, j.slot_len, j.slot_next, j.max_slots, blockIdx.x);
+}
+__global__ __launch_bounds__(TB) void k_b_rank_init(const InvJob *__restrict__ jobs)
+{
+    const InvJob &j = jobs[blockIdx.y];
+    if (blockIdx.x * TB >= j.max_slots) return;
+    rank_init_body(j.slot_len, j.slot_next, j.state, j.nsplit, j.max_slots, j.distA, j.linkA, blockIdx.x);
+}
+__global__ __launch_bounds__(TB) void k_b_rank_jump(const InvJob *__restrict__ jobs, int flip)
+{
+    const InvJob &j = jobs[blockIdx.y];
+    if (blockIdx.x * TB >= j.max_slots) return;
+    if (flip) rank_jump_body(j.distB, j.linkB, j.state, j.nsplit, j.max_slots, j.distA, j.linkA, blockIdx.x);
+    else rank_jump_body(j.distA, j.linkA, j.state, j.nsplit, j.max_slots, j.distB, j.linkB, blockIdx.x);
+}
+// head check, the raw tail of the image (len % 120 bytes) and the verdict: one small workgroup per job
+__global__ void k_b_finish(const InvJob *__restrict__ jobs, int final_in_b)
+{
+    const InvJob &j = jobs[blockIdx.x];
+    const uint32_t *dist = final_in_b ? j.distB : j.distA;
+    InvState *st = j.state;
+    if (threadIdx.x < j.len - j.n) j.T[j.n + threadIdx.x] = j.B[j.n + threadIdx.x];
+    if (threadIdx.x != 0) return;
+    if (st->I != 0u) {
+        const uint32_t d = dist[j.nsplit];
+        st->head_dist = d;
+        if (d != j.n || j.nsplit + 1u + st->novf > j.max_slots) st->status = (uint32_t)JPK_E_CORRUPT;
+    }
+    j.verdict[0] = st->status; j.verdict[1] = st->I; j.verdict[2] = st->novf; j.verdict[3] = st->head_dist;
+}
+__global__ __launch_bounds__(TB) void k_b_copy_out(const InvJob *__restrict__ jobs, int final_in_b)
+{
+    const InvJob &j = jobs[blockIdx.y];
+    if (blockIdx.x * (TB / 16) >= j.max_slots) return;
+    copy_out_body(j.scratch, j.slot_len, final_in_b ? j.distB : j.distA, j.state, j.nsplit, j.max_slots, j.n, j.T, blockIdx.x);
+}
+
+// what one job takes from the arena (everything of inv_layout but the tile table and the scan scratch, which the batch shares)
+void inv_job_layout(Arena &a, size_t n, InvBufs &b, size_t &ntiles, size_t &nsplit, size_t &max_slots)
+{
+    ntiles = (n + TILE - 1) / TILE;
+    nsplit = (n + STRIDE - 1) / STRIDE;
+    max_slots = nsplit + 1 + n / CAP + 2;
     b.cum = a.get<uint32_t>(260);
     b.nxt = a.get<int32_t>(n);
     b.slot_len = a.get<uint32_t>(max_slots);
@@ -467,5 +604,92 @@ int jpk_inv_bwt_chains120_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (chase_ms) *chase_ms = ms;
+    return JPK_OK;
+}
+
+// ---- many inverse BWTs through one set of launches ---------------------------------------------------------------------------------------
+static uint32_t inv_sorted_len(int32_t len_with_trailer) { const int32_t len = len_with_trailer - JPK_TRAILER_BYTES; return (uint32_t)(len - len % JPK_BWT_UNITS); }
+
+// arena bytes of a batch (from ctx->arena_base): the job table, the shared tile table and its scan scratch, every job's own buffers
+size_t jpk_inv_bwt_batch_arena_bytes(int njobs, const int32_t *len_with_trailer)
+{
+    jpk_ctx dummy;
+    Arena plan(&dummy, true);
+    size_t tiles = 0;
+    for (int q = 0; q < njobs; q++) {
+        const uint32_t n = inv_sorted_len(len_with_trailer[q]);
+        InvBufs b;
+        size_t ntiles, nsplit, max_slots;
+        inv_job_layout(plan, n ? n : 1, b, ntiles, nsplit, max_slots);
+        tiles += ntiles;
+    }
+    plan.get<InvJob>((size_t)njobs);
+    plan.get<uint32_t>(256 * tiles);
+    plan.get<uint32_t>(jpk_scan_scratch_words(256 * tiles));
+    return plan.need + (1u << 20);
+}
+
+// Enqueues the inverse BWTs of `njobs` images (each with >= 120 sorted bytes: len - 480 >= 120) on ctx->stream, no host round trip;
+// d_verdict[4 * slot ..] (slot = verdict_slot[q], or q) receives job q's {status, trailer index, overflow slots, head distance}.  The arena must already hold
+// jpk_inv_bwt_batch_arena_bytes() from ctx->arena_base on (the caller keeps other buffers in it: it may not move here).
+// `host_jobs` is the caller's: it must outlive the stream work (the table is copied from it asynchronously).
+int jpk_inv_bwt_batch_enqueue(jpk_ctx *ctx, int njobs, const uint8_t *const *d_in, const int32_t *len_with_trailer, uint8_t *const *d_out, uint32_t *d_verdict,
+                              const int *verdict_slot, std::vector<uint8_t> &host_jobs)
+{
+    if (njobs <= 0) return JPK_OK;
+    hipStream_t st = ctx->stream;
+    if (!jpk_arena_fits(ctx, ctx->arena_base + jpk_inv_bwt_batch_arena_bytes(njobs, len_with_trailer))) return JPK_E_ALLOC;
+    Arena real(ctx, false);
+    host_jobs.assign((size_t)njobs * sizeof(InvJob), 0);
+    InvJob *hj = reinterpret_cast<InvJob *>(host_jobs.data());
+    size_t tiles = 0, max_tiles = 0, max_split = 0, max_slots_all = 0;
+    uint64_t pos = 0;
+    for (int q = 0; q < njobs; q++) {
+        const int32_t len = len_with_trailer[q] - JPK_TRAILER_BYTES;
+        const uint32_t n = inv_sorted_len(len_with_trailer[q]);
+        if (len < 0 || n == 0) return JPK_E_ARG;
+        InvBufs b;
+        size_t ntiles, nsplit, max_slots;
+        inv_job_layout(real, n, b, ntiles, nsplit, max_slots);
+        InvJob &j = hj[q];
+        j.B = d_in[q]; j.T = d_out[q]; j.verdict = d_verdict + 4 * (size_t)(verdict_slot ? verdict_slot[q] : q);
+        j.n = n; j.len = (uint32_t)len; j.ntiles = (uint32_t)ntiles; j.nsplit = (uint32_t)nsplit; j.max_slots = (uint32_t)max_slots;
+        int lut_shift = 0;
+        while (((uint64_t)(n - 1) >> lut_shift) >= LUT) lut_shift++;
+        j.lut_shift = (uint32_t)lut_shift;
+        if (pos > 0xFFFFFFFFull) return JPK_E_ARG;              // (the shared scan is 32-bit: a batch of small blocks stays far below)
+        j.pos_base = (uint32_t)pos;
+        pos += n;
+        j.cum = b.cum; j.nxt = b.nxt; j.slot_len = b.slot_len; j.slot_next = b.slot_next;
+        j.distA = b.distA; j.distB = b.distB; j.linkA = b.linkA; j.linkB = b.linkB; j.scratch = b.scratch; j.state = b.state;
+        tiles += ntiles;
+        if (ntiles > max_tiles) max_tiles = ntiles;
+        if (nsplit > max_split) max_split = nsplit;
+        if (max_slots > max_slots_all) max_slots_all = max_slots;
+    }
+    if (pos > 0xFFFFFFFFull) return JPK_E_ARG;
+    InvJob *d_jobs = real.get<InvJob>((size_t)njobs);
+    uint32_t *tilehist = real.get<uint32_t>(256 * tiles);
+    uint32_t *scan_scratch = real.get<uint32_t>(jpk_scan_scratch_words(256 * tiles));
+    {
+        size_t off = 0;
+        for (int q = 0; q < njobs; q++) { hj[q].tilehist = tilehist + off; off += 256 * (size_t)hj[q].ntiles; }
+    }
+    JPK_HIP(hipMemcpyAsync(d_jobs, hj, (size_t)njobs * sizeof(InvJob), hipMemcpyHostToDevice, st));
+    const unsigned nj = (unsigned)njobs;
+    JPK_LAUNCH(ctx, PROF_INV_HIST, 0, k_b_prep, dim3(jpk_grid(nj, 64)), dim3(64), d_jobs, nj);
+    JPK_LAUNCH(ctx, PROF_INV_HIST, pos, k_b_hist, dim3((unsigned)max_tiles, nj), dim3(TB), d_jobs);
+    JPK_TRY(jpk_exclusive_sum_u32(ctx, tilehist, tilehist, 256 * tiles, scan_scratch, nullptr));
+    JPK_LAUNCH(ctx, PROF_INV_HIST, 0, k_b_cum, dim3(nj), dim3(256), d_jobs);
+    JPK_LAUNCH(ctx, PROF_INV_BUILD, pos, k_b_build_nxt, dim3((unsigned)max_tiles, nj), dim3(TB), d_jobs);
+    JPK_LAUNCH(ctx, PROF_INV_WALK, pos, k_b_walk, dim3(jpk_grid(max_split + 1, TB), nj), dim3(TB), d_jobs);
+    const unsigned g_s = jpk_grid(max_slots_all, TB);
+    JPK_LAUNCH(ctx, PROF_INV_RANK, 0, k_b_rank_init, dim3(g_s, nj), dim3(TB), d_jobs);
+    const int rounds = jpk_bits_for((uint32_t)max_slots_all) + 1;
+    for (int r = 0; r < rounds; r++) JPK_LAUNCH(ctx, PROF_INV_RANK, 0, k_b_rank_jump, dim3(g_s, nj), dim3(TB), d_jobs, r & 1);
+    const int final_in_b = rounds & 1;                        // round r reads A when r is even and leaves its result in B
+    JPK_LAUNCH(ctx, PROF_INV_COPY, pos, k_b_copy_out, dim3(jpk_grid(max_slots_all * 16, TB), nj), dim3(TB), d_jobs, final_in_b);
+    JPK_LAUNCH(ctx, PROF_INV_COPY, 0, k_b_finish, dim3(nj), dim3(128), d_jobs, final_in_b);
+    JPK_HIP(hipGetLastError());
     return JPK_OK;
 }

@@ -191,6 +191,9 @@ int jpk_ans_encode_group_device(jpk_ctx *ctx, int nblk, const uint8_t *d_stage, 
                                 const int32_t *out_cap, int32_t *out_len, int32_t *status);
 size_t jpk_ans_encode_group_arena_bytes(uint32_t nchunks, int nblk);
 size_t jpk_inv_bwt_arena_bytes(uint32_t n);
+size_t jpk_inv_bwt_batch_arena_bytes(int njobs, const int32_t *len_with_trailer);
+int jpk_inv_bwt_batch_enqueue(jpk_ctx *ctx, int njobs, const uint8_t *const *d_in, const int32_t *len_with_trailer, uint8_t *const *d_out, uint32_t *d_verdict,
+                              const int *verdict_slot, std::vector<uint8_t> &host_jobs);
 size_t jpk_fwd_bwt_arena_bytes(uint32_t n);
 size_t jpk_ans_encode_arena_bytes(uint32_t len);          // text-like data (0.55 RLE0 symbols per byte); the arena grows for denser blocks
 size_t jpk_ans_encode_arena_bytes_worst(uint32_t len);    // every byte a symbol
