@@ -537,7 +537,11 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
     const bool many_small = nblocks >= 32 && nmax <= (4u << 20);
     // ... or, by default, through ONE set of launches over all of them (bwt_inv.hip jpk_inv_bwt_batch_enqueue; JPK_INV_BATCH=0 keeps the lanes)
     static const bool batch_on = [] { const char *e = getenv("JPK_INV_BATCH"); return e ? atoi(e) != 0 : true; }();
-    const bool batched = many_small && batch_on;
+    // (in groups of consecutive blocks whose scratch fits JPK_INV_BATCH_GIB, default 8.  Batches of LARGE blocks gain nothing from it --
+    // 16 / 32 / 64 blocks of 64 MiB: 310 / 350 / 438 ms against 309 / 348 / 435 on the three lanes: their walks fill the chip -- and stay
+    // on the lanes.)
+    static const size_t batch_budget = [] { const char *e = getenv("JPK_INV_BATCH_GIB"); const long v = e ? atol(e) : 8; return (size_t)(v < 1 ? 1 : v) << 30; }();
+    const bool batched = batch_on && many_small;
     int lanes = (nblocks < 8 || batched) ? 1 : (many_small ? (small_lanes > max_lanes ? small_lanes : max_lanes) : max_lanes);
     hipStream_t lane_stream[jpk_ctx::INV_LANES_MAX] = {};
     hipEvent_t lane_event[jpk_ctx::INV_LANES_MAX] = {};
@@ -551,7 +555,26 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
         lane_event[k] = *ev;
     }
     const size_t inv_one = jpk_align(jpk_inv_bwt_arena_bytes(nmax), 4096), verdict_bytes = jpk_align((size_t)nblocks * 16 + 64, 4096);
-    const size_t inv_bytes = (batched ? jpk_align(jpk_inv_bwt_batch_arena_bytes(nblocks, mid_cap.data()), 4096) : inv_one * (size_t)lanes) + verdict_bytes;
+    // groups of consecutive blocks whose batch scratch fits the budget (many small blocks: one group)
+    std::vector<int> group_end;
+    size_t batch_bytes_max = 0;
+    if (batched) {
+        int b0 = 0;
+        while (b0 < nblocks) {
+            int e = b0 + 1;
+            size_t need = jpk_inv_bwt_batch_arena_bytes(1, mid_cap.data() + b0);
+            while (e < nblocks) {
+                const size_t more = jpk_inv_bwt_batch_arena_bytes(e + 1 - b0, mid_cap.data() + b0);
+                if (more > batch_budget) break;
+                need = more;
+                e++;
+            }
+            if (need > batch_bytes_max) batch_bytes_max = need;
+            group_end.push_back(e);
+            b0 = e;
+        }
+    }
+    const size_t inv_bytes = (batched ? jpk_align(batch_bytes_max, 4096) : inv_one * (size_t)lanes) + verdict_bytes;
     JPK_TRY(jpk_arena_ensure(ctx, inv_bytes + mid_total + bound + (1u << 20)));
     uint32_t *d_verdict = reinterpret_cast<uint32_t *>(ctx->arena + inv_bytes - verdict_bytes);
     std::vector<uint8_t *> mid((size_t)nblocks);
@@ -563,7 +586,7 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
     // the inverse BWTs are enqueued without a host round trip between them (trailer index, slot count and the head check stay
     // on the device); their verdicts come back in one copy
     std::vector<int> ran;
-    std::vector<uint8_t> host_jobs;                            // the batched inverse BWT's job table: copied from here asynchronously
+    std::vector<std::vector<uint8_t>> host_jobs;               // the batched inverse BWTs' job tables: copied from here asynchronously
     {
         struct Restore {                                       // whatever happens below, the context gets its stream and base back
             jpk_ctx *c; hipStream_t s; hipStream_t *lane; int lanes; bool failed = true;
@@ -597,16 +620,22 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
             next++;
         }
         ctx->stream = main_stream;
-        if (!jb.empty()) {
-            std::vector<const uint8_t *> jin(jb.size());
-            std::vector<uint8_t *> jout(jb.size());
-            std::vector<int32_t> jlen(jb.size());
-            for (size_t q = 0; q < jb.size(); q++) { jin[q] = mid[jb[q]]; jout[q] = d_out[jb[q]]; jlen[q] = mid_len[jb[q]]; }
-            // (job q reports into the verdict slot of its block, jb[q])
+        // one batch per group, one after the other on the main stream (they share the scratch at the start of the arena)
+        size_t jq = 0;
+        for (size_t g = 0; g < group_end.size() && jq < jb.size(); g++) {
+            std::vector<int> part;
+            while (jq < jb.size() && jb[jq] < group_end[g]) part.push_back(jb[jq++]);
+            if (part.empty()) continue;
+            std::vector<const uint8_t *> jin(part.size());
+            std::vector<uint8_t *> jout(part.size());
+            std::vector<int32_t> jlen(part.size());
+            for (size_t q = 0; q < part.size(); q++) { jin[q] = mid[part[q]]; jout[q] = d_out[part[q]]; jlen[q] = mid_len[part[q]]; }
+            // (job q reports into the verdict slot of its block, part[q])
             ctx->arena_base = 0;
-            const int rc = jpk_inv_bwt_batch_enqueue(ctx, (int)jb.size(), jin.data(), jlen.data(), jout.data(), d_verdict, jb.data(), host_jobs);
-            if (rc != JPK_OK) { for (int b : jb) stp[b] = rc; }
-            else for (int b : jb) ran.push_back(b);
+            host_jobs.emplace_back();
+            const int rc = jpk_inv_bwt_batch_enqueue(ctx, (int)part.size(), jin.data(), jlen.data(), jout.data(), d_verdict, part.data(), host_jobs.back());
+            if (rc != JPK_OK) { for (int b : part) stp[b] = rc; }
+            else for (int b : part) ran.push_back(b);
         }
         for (int k = 1; k < lanes; k++) {                      // the main stream continues behind every lane
             JPK_HIP(hipEventRecord(lane_event[k], lane_stream[k]));
