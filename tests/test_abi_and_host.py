@@ -265,3 +265,22 @@ def test_group_plan_covers_every_block_once_and_in_order():
     assert plan([64 * MiB] * 4) == [(i, 1) for i in range(4)]                         # large blocks go alone
     assert all(k <= 256 for _, k in plan([300] * 1000))
     assert lib().jpk_debug_group_plan(2, (ctypes.c_int32 * 2)(5, -1), (ctypes.c_int32 * 2)(), (ctypes.c_int32 * 2)()) == -1
+
+
+def test_stats_struct_layout_matches_the_header(tmp_path):
+    """jpk_stats as the C compiler lays it out from include/jampack_abi.h against the ctypes mirror (jampack_amd/_lib.py): size and the
+    offset of every field -- the bench reads the rounds, the key depth of round 0 and the arena size through it"""
+    import subprocess
+    from jampack_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fields = [f[0] for f in _lib.Stats._fields_]
+    src = tmp_path / "layout.c"
+    body = "".join(f'    printf("{f} %zu\\n", offsetof(jpk_stats, {f}));\n' for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "jampack_abi.h"\nint main(void)\n{\n    printf("sizeof %zu\\n", sizeof(jpk_stats));\n' + body + "    return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    assert int(out["sizeof"]) == ctypes.sizeof(_lib.Stats)
+    for f in fields:
+        assert int(out[f]) == getattr(_lib.Stats, f).offset, f
+    assert "sa_key_depth" in fields
