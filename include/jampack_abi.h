@@ -179,7 +179,10 @@ JPK_API int jpk_dev_jam_block_read(jpk_ctx *ctx, const uint8_t *d_in, int32_t in
  * order) for blocks that already sit in HBM: Ans::Decode (+ InverseBwt) of nblocks independent blocks in ONE pass -- every
  * serial entropy kernel runs a single grid over the 1 MiB chunks of all blocks, which is what fills the GPU (one block is 65
  * chains on 1024 SIMDs).  Arrays of nblocks device pointers / sizes (the arrays themselves are host memory).  status may be
- * NULL; otherwise status[b] receives block b's jpk_status and a corrupt block does not stop the others. */
+ * NULL; otherwise status[b] receives block b's jpk_status and a corrupt block does not stop the others.
+ * jpk_dev_blocks_decompress: the inverse BWTs follow on up to three streams of the context; a batch of many small blocks (>= 32 blocks
+ * of <= 4 MiB, a stream of the reference's smallest block size, format.hpp:22) runs them through one set of launches over all blocks
+ * and needs scratch for all of them at once (about 10 bytes per block byte of the context's arena). */
 JPK_API int jpk_dev_blocks_ans_decode(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out,
                               const int32_t *out_cap, int32_t *out_len, int32_t *status);
 JPK_API int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out,
