@@ -223,8 +223,9 @@ __device__ __forceinline__ void pack_tile(const uint8_t *cc, const uint8_t *cr, 
     }
 #undef JPK_BYTE
 }
-// The tile is also a tile of the radix sort's first pass (same 4096 slots): its digit histogram (key bits 15..8) is counted here, from
-// LDS, so that pass has no histogram kernel of its own (tilehist: digit-major [256][ntiles], radix.hip).
+// The tile is also a tile of the radix sort's first pass (same 4096 slots): for the two-pass form of the sort its digit histogram (key
+// bits 15..8) is counted here, from LDS, so that pass has no histogram kernel of its own (tilehist: digit-major [256][ntiles], radix.hip;
+// null for the one-pass form).
 __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T, uint32_t n, const SaState *__restrict__ st, uint64_t *__restrict__ P,
                                                  const uint8_t *__restrict__ blk, const uint32_t *__restrict__ bend, uint32_t *__restrict__ tilehist)
 {
@@ -271,13 +272,15 @@ __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T,
                 const bool valid = x < cnt;
                 const uint64_t key = ko[x + (x >> 4)];
                 if (valid) P[base + x] = key;
-                const uint32_t dig = (uint32_t)(key >> 8) & 255u;
-                const uint64_t mm = match_any8(dig, valid);
-                if (valid && (mm & lt) == 0ull) hd[w][dig] += (uint32_t)__popcll(mm);      // one lane per digit value and wave: plain read-modify-write
+                if (tilehist) {                                    // (uniform; the one-pass radix form counts for itself)
+                    const uint32_t dig = (uint32_t)(key >> 8) & 255u;
+                    const uint64_t mm = match_any8(dig, valid);
+                    if (valid && (mm & lt) == 0ull) hd[w][dig] += (uint32_t)__popcll(mm);      // one lane per digit value and wave: plain read-modify-write
+                }
             }
         }
         __syncthreads();
-        {
+        if (tilehist) {
             uint32_t sum = 0;
 #pragma unroll
             for (int k = 0; k < WAVES; k++) sum += hd[k][threadIdx.x];
@@ -1552,7 +1555,8 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     uint32_t *vs = b.valsA;
     JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_sym_present, dim3(cap_grid(n, 16 * TB * 4, 4096)), dim3(TB), T, n, b.state);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_key_plan, dim3(1), dim3(256), b.state, key_force_bits());
-    JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_pack_keys, dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.scratch);
+    JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_pack_keys, dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend,
+               jpk_radix_onesweep() ? (uint32_t *)nullptr : b.scratch);
     JPK_TRY(jpk_radix_sort_slot_keys(ctx, n, b.keysA, b.valsA, b.keysB, b.valsB, b.scratch, &ks, &vs, b.blk != nullptr));
     ctx->stats.sa_sorted_elems += n;
     // The sorted pairs sit in (ks, vs).  The other pair of radix buffers is free from here on, the pair that holds the result

@@ -323,25 +323,29 @@ void launch_os_scatter(jpk_ctx *ctx, const uint64_t *kin, const uint32_t *vin, u
                                    ntiles, os);
 }
 
-// digit histograms of all seven passes from one read of the packed keys, then their exclusive offsets (one-pass form only)
-__global__ __launch_bounds__(RS_THREADS) void k_os_digits(const uint64_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ H)
+// digit histograms of all passes (seven; eight in a group sort: the last one on the key's low byte) from one read of the packed keys,
+// then their exclusive offsets (one-pass form only).  (Counting them inside k_pack_keys, where the keys sit in LDS anyway, was slower:
+// 0.51 ms for the fused kernel against 0.28 + 0.20.)
+constexpr int OS_PASSES = 8;
+__global__ __launch_bounds__(RS_THREADS) void k_os_digits(const uint64_t *__restrict__ keys, uint32_t n, uint32_t *__restrict__ H, int npass)
 {
-    __shared__ uint32_t h[7][256];
-    for (int i = threadIdx.x; i < 7 * 256; i += RS_THREADS) (&h[0][0])[i] = 0;
+    __shared__ uint32_t h[OS_PASSES][256];
+    for (int i = threadIdx.x; i < OS_PASSES * 256; i += RS_THREADS) (&h[0][0])[i] = 0;
     __syncthreads();
     for (size_t i = (size_t)blockIdx.x * RS_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * RS_THREADS) {
         const uint64_t k = keys[i];
 #pragma unroll
         for (int p = 0; p < 7; p++) atomicAdd(&h[p][(uint32_t)(k >> (8 * (p + 1))) & 255u], 1u);
+        if (npass > 7) atomicAdd(&h[7][(uint32_t)k & 255u], 1u);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 7 * 256; i += RS_THREADS)
+    for (int i = threadIdx.x; i < npass * 256; i += RS_THREADS)
         if ((&h[0][0])[i]) atomicAdd(&H[i], (&h[0][0])[i]);
 }
-__global__ __launch_bounds__(256) void k_os_prefix(const uint32_t *__restrict__ H, uint32_t *__restrict__ gdig)
+__global__ __launch_bounds__(256) void k_os_prefix(const uint32_t *__restrict__ H, uint32_t *__restrict__ gdig, int npass)
 {
     __shared__ uint32_t sm[256 / 64 + 1];
-    for (int p = 0; p < 7; p++) {
+    for (int p = 0; p < npass; p++) {
         const uint32_t c = H[p * 256 + threadIdx.x];
         const uint32_t inc = block_incl_scan<OpSum>(c, sm, nullptr);
         gdig[p * 256 + threadIdx.x] = inc - c;
@@ -375,18 +379,21 @@ size_t jpk_radix_scratch_words(size_t n)
     size_t table = 256 * ntiles;
     // the tile table (= status array A of the one-pass sort) + the scan's scratch, then status array B, the digit histograms and
     // offsets of seven passes and the tickets
-    return table + jpk_scan_scratch_words(table) + 64 + table + 7 * 256 + 7 * 256 + 64;
+    return table + jpk_scan_scratch_words(table) + 64 + table + OS_PASSES * 256 + OS_PASSES * 256 + 64;
 }
 
-// JPK_ONESWEEP=1 selects the one-pass (decoupled look-back) form for the suffix sort's round 0.  Measured (round 4,
-// profiles/r04_onesweep_ab.txt): a pass takes 455 us against 319 (scatter) + 143 (histogram) + scans for the two-pass form -- the
-// look-back words come from the memory side and a tile waits for them while it holds a quarter of a CU's LDS -- and the default
-// bench line is the same within its noise (3.94-4.16 against 3.89-4.12 GB/s).  Off by default; kept as a tested comparator.
+// The one-pass (decoupled look-back) form of the suffix sort's round 0; JPK_ONESWEEP=0 selects the two-pass form (histogram + scan + scatter
+// per pass).  With round 3's 7-byte text keys the two were the same (profiles/r04_onesweep_ab.txt: a one-pass pass took 455 us against 319 +
+// 143 + scans -- the look-back words come from the memory side and a tile waits for them while it holds a quarter of a CU's LDS).  The
+// packed keys (bwt_fwd.hip k_pack_keys) changed the balance: their digits are spread over all 256 bins, the two-pass scatter writes
+// shorter runs (377 us) and the histogram costs what it cost: forward BWT of a 64 MiB block 10.3 -> 9.95 ms, bench line +3.5 % in five
+// alternations out of five, groups of 1 MiB blocks +8 %, of 8 MiB blocks +2..10 % (profiles/r04_onesweep_packed.txt).  Default since then.
 static bool rs_onesweep()
 {
-    static const bool on = [] { const char *e = getenv("JPK_ONESWEEP"); return e ? atoi(e) != 0 : false; }();
+    static const bool on = [] { const char *e = getenv("JPK_ONESWEEP"); return e ? atoi(e) != 0 : true; }();
     return on;
 }
+bool jpk_radix_onesweep() { return rs_onesweep(); }
 
 // the sorted pairs end up in (*keys_out, *vals_out): the caller's buffers after an even number of passes, the alt buffers after an
 // odd number -- no copy back
@@ -446,16 +453,17 @@ int jpk_radix_sort_slot_keys(jpk_ctx *ctx, uint32_t n32, uint64_t *keysA, uint32
     uint32_t *scan_scratch = scratch + table;
     uint64_t *ki = keysB, *ko = keysA;        // after pass 0 the pairs are in B
     uint32_t *vi = valsB, *vo = valsA;
-    if (!group && rs_onesweep()) {
-        // one-pass sort: digit histograms of the keys -> digit offsets of all seven passes; then seven scatter launches, nothing else
+    const int npass = group ? 8 : 7;              // group sort: one more pass, on the block number in the key's low byte
+    if (rs_onesweep()) {
+        // one-pass sort: digit histograms of the keys -> digit offsets of all passes; then one scatter launch per pass, nothing else
         uint32_t *statusA = scratch, *statusB = scratch + table + jpk_scan_scratch_words(table) + 64;
-        uint32_t *H = statusB + table, *gdig = H + 7 * 256, *tickets = gdig + 7 * 256;
+        uint32_t *H = statusB + table, *gdig = H + OS_PASSES * 256, *tickets = gdig + OS_PASSES * 256;
         JPK_HIP(hipMemsetAsync(statusA, 0, table * 4, ctx->stream));
-        JPK_HIP(hipMemsetAsync(statusB, 0, (table + 7 * 256 + 7 * 256 + 64) * 4, ctx->stream));
-        JPK_LAUNCH(ctx, PROF_RS_HIST, n, k_os_digits, dim3(ntiles < 2048 ? (ntiles ? ntiles : 1) : 2048), dim3(RS_THREADS), keysA, n32, H);
-        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_os_prefix, dim3(1), dim3(256), H, gdig);
-        for (int p = 0; p < 7; p++) {
-            const int shift = 8 * (p + 1);
+        JPK_HIP(hipMemsetAsync(statusB, 0, (table + OS_PASSES * 256 + OS_PASSES * 256 + 64) * 4, ctx->stream));
+        JPK_LAUNCH(ctx, PROF_RS_HIST, n, k_os_digits, dim3(ntiles < 2048 ? (ntiles ? ntiles : 1) : 2048), dim3(RS_THREADS), keysA, n32, H, npass);
+        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_os_prefix, dim3(1), dim3(256), H, gdig, npass);
+        for (int p = 0; p < npass; p++) {
+            const int shift = p < 7 ? 8 * (p + 1) : 0;
             OsArgs os;
             os.status = (p & 1) ? statusB : statusA;
             os.status_next = (p & 1) ? statusA : statusB;
@@ -474,7 +482,6 @@ int jpk_radix_sort_slot_keys(jpk_ctx *ctx, uint32_t n32, uint64_t *keysA, uint32
         *vals_out = vi;
         return JPK_OK;
     }
-    const int npass = group ? 8 : 7;              // group sort: one more pass, on the block number in the key's low byte
     for (int p = 0; p < npass; p++) {
         const int shift = p < 7 ? 8 * (p + 1) : 0;
         if (p == 0) {

@@ -77,22 +77,34 @@ def test_suffix_array_with_embedded_zero_bytes(ctx, oracle):
     assert np.array_equal(dsa.cpu().numpy(), oracle.suffix_array(t))
 
 
-def test_suffix_array_with_the_one_pass_radix_form():
-    """JPK_ONESWEEP=1 (decoupled look-back passes for round 0; off by default, kept as a comparator): same suffix arrays.  The
-    switch is read once per process, so the check runs in a child."""
+@pytest.mark.parametrize("onesweep", ["0", "1"])
+def test_forward_bwt_with_either_radix_form(onesweep):
+    """round 0's radix passes: the one-pass form (decoupled look-back; the default since the packed keys) and the two-pass form
+    (JPK_ONESWEEP=0: histogram + scan + scatter per pass) give the reference's images, single blocks and grouped small blocks (eight
+    passes).  The switch is read once per process, so each form runs in a child."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     body = (
         "import sys; sys.path.insert(0, %r)\n"
-        "import numpy as np, jampack_amd as jam\n"
+        "import numpy as np, torch, jampack_amd as jam\n"
         "from oracle.pyoracle import Oracle\n"
         "o = Oracle()\n"
-        "for kind, n in (('text_survey', 1_000_000), ('zero', 300_000), ('random', 70_001), ('dna', 500_000), ('text', 4096 * 5 + 17), ('two', 4095)):\n"
+        "for kind, n in (('text_survey', 1_000_000), ('zero', 300_000), ('random', 70_001), ('dna', 500_000), ('text', 4096 * 5 + 17), ('two', 4095), ('runs', 200_000)):\n"
         "    t = jam.corpus.make(kind, n, 9)\n"
         "    assert np.array_equal(jam.Bwt().ForwardBwt(t), o.bwt_forward(t)), (kind, n)\n"
-        "print('one-pass ok')\n") % root
-    env = dict(os.environ, JPK_ONESWEEP="1")
+        "dev = torch.device('cuda', 0); ctx = jam.Context(0, None)\n"
+        "blocks = [jam.corpus.make(['text_survey', 'dna', 'zero', 'random', 'runs'][i %% 5], 50_000 + 33_333 * i, i) for i in range(12)]\n"
+        "d_in = [torch.from_numpy(b).to(dev) for b in blocks]\n"
+        "caps = [jam.ans_capacity(len(b) + jam.TRAILER) for b in blocks]\n"
+        "d_out = [torch.empty(c, dtype=torch.uint8, device=dev) for c in caps]\n"
+        "n, st = ctx.blocks_compress(d_in, [len(b) for b in blocks], d_out, caps, 2)\n"
+        "assert st == [0] * 12\n"
+        "for i, b in enumerate(blocks):\n"
+        "    want = o.ans_encode(o.bwt_forward(b))\n"
+        "    assert n[i] == len(want) and np.array_equal(d_out[i][: n[i]].cpu().numpy(), want), i\n"
+        "print('radix form ok')\n") % root
+    env = dict(os.environ, JPK_ONESWEEP=onesweep)
     r = subprocess.run([sys.executable, "-c", body], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "one-pass ok" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "radix form ok" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
