@@ -215,9 +215,10 @@ __device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restric
             else {
                 __hip_atomic_store(row + d, OS_FLAG_AGG | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // The walk is latency: every word comes from the memory side (~1.5 us), and with ~1000 tiles resident a tile finds
-                // aggregates, not prefixes, for a long way back.  Eight rows are requested at once and consumed in order; the walk
-                // stops at the first prefix, an unpublished word is polled alone.
-                constexpr int LB = 8;
+                // aggregates, not prefixes, for a long way back.  Four rows are requested at once and consumed in order; the walk
+                // stops at the first prefix, an unpublished word is polled alone.  (Forward BWT of a 64 MiB block with 1 / 2 / 3 / 4 / 8 / 16 /
+                // 32 rows at once: 10.05 / 9.88 / 10.00 / 9.86 / 10.03 / 10.35 / 10.49 ms.)
+                constexpr int LB = 4;
                 uint32_t back = 1;                                           // rows behind `tile` of the next word to consume
                 bool done = false;
                 while (!done) {
