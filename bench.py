@@ -50,8 +50,8 @@ PROFILE_ROUND = "r04"
 # actually limited by ("hbm": streaming traffic; "hbm-random": 4-byte gathers/scatters, ~55 G accesses/s whatever the bytes;
 # "lds": barrier-separated LDS sort passes; "issue": instruction issue of single waves walking serial chains)
 ALG_BYTES_PER_UNIT = {
-    "k_rs_hist": (8, "sorted (key,value) pair", "hbm"),
-    "k_rs_scatter": (24, "sorted (key,value) pair", "hbm"),
+    "k_rs_hist/k_os_digits": (8, "sorted (key,value) pair", "hbm"),
+    "k_rs_scatter/k_os_scatter": (24, "sorted (key,value) pair", "hbm"),
     "k_sym_present/k_pack_keys": (5, "suffix x launch (1 B read; 1 B read + 8 B written)", "hbm"),
     "k_lg_hist": (4, "member of a large group x pass", "hbm"),
     "k_lg_scatter": (18, "member of a large group x pass", "hbm"),

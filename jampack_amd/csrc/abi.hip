@@ -156,7 +156,7 @@ void jpk_prof_resolve(jpk_ctx *ctx)
     ctx->prof_pending.clear();
 }
 static const char *const PROF_NAMES[PROF_COUNT] = {
-    "k_rs_hist", "k_rs_scatter", "k_scan_*/k_tab_*/k_win_*", "k_gather_win", "k_seg_round", "k_r0_*/k_lg_finish/k_cmp_*", "k_bwt_image",
+    "k_rs_hist/k_os_digits", "k_rs_scatter/k_os_scatter", "k_scan_*/k_tab_*/k_win_*", "k_gather_win", "k_seg_round", "k_r0_*/k_lg_finish/k_cmp_*", "k_bwt_image",
     "k_hist", "k_build_nxt", "k_walk", "k_rank_jump", "k_copy_out",
     "k_enc_hist/k_enc_prep", "k_enc_mtf", "k_rle_*", "k_cls_*/k_quasi_build", "k_adaptive", "k_pairs", "k_rans_lanes", "k_emit_*/k_put_*",
     "k_dec_headers", "k_dec_rans", "k_dec_rle", "k_dec_rank", "k_chk_*", "k_lg_hist", "k_lg_scatter", "k_sym_present/k_pack_keys"};

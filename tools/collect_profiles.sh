@@ -10,6 +10,9 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 export JAMPACK_CORPUS_CACHE=/tmp/jpk_corpus
 cd /tmp
+# 0. the bench line first, on the untouched box: after the counter-collection passes below the host-buffer extras of a bench run on the
+#    same box were 10-20x slow on two of three boxes (SDMA copies; GPU-resident figures unaffected) -- profiles/r04_bench_after_rocprof_passes.json
+( cd $REPO && python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/bench.json" )
 # 1. PMC passes (separate, counters only) of one compress step of the default workload
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
@@ -30,8 +33,7 @@ python3 $REPO/tools/rocpd_stats.py /tmp/ke/e_results.db 3 > "$OUT/kernel_stats_a
 python3 $REPO/tools/rocpd_timeline.py /tmp/ke/e_results.db k_density > "$OUT/timeline_ans_encode_64mib.txt" 2>&1
 # 4. the bench lines
 cd $REPO
-cp "$OUT/pmc_traffic.json" profiles/${TAG}_pmc_traffic.json 2>/dev/null     # bench.py reads the traffic of the dominant kernel from here
-python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > "$OUT/bench.json"
+cp "$OUT/pmc_traffic.json" profiles/${TAG}_pmc_traffic.json 2>/dev/null     # bench.py reads the traffic of the dominant kernel from here (step 0 used the file of the collection before)
 python3 bench.py --workload enwik9 --steps 2 --warmup 1 --no-extras 2>/dev/null | tail -1 > "$OUT/bench_enwik9like.json"
 python3 bench.py --workload silesia --block-mib 256 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/bench_silesialike_256mib.json"
 python3 tools/worst_cases.py > "$OUT/worst_cases.txt" 2>/dev/null
