@@ -70,6 +70,10 @@ typedef struct jpk_stats {
     int64_t enc_chain_cycles;
     int64_t enc_chain_ns;
     int64_t enc_chain_steps;
+    /* bit r set: round r of the last forward BWT was a pair round (the induction step over long repeats, bwt_fwd.hip k_pair_*: it
+     * resolves whole groups from the order of their successors and leaves the doubling distance alone) instead of a doubling round;
+     * r >= 1 then stands for the r-th round after round 0, h = sa_key_depth * 2^(doubling rounds before it) */
+    int64_t sa_pair_rounds;
 } jpk_stats;
 
 /* ---- contexts ------------------------------------------------------------------------------------------ */

@@ -1425,6 +1425,291 @@ __global__ __launch_bounds__(TB) void k_cmp_scatter(const uint32_t *__restrict__
     }
 }
 
+// ---- the pair rule: long repeats do not double their way out (round 5) --------------------------------------------------------
+// A repeat T[u .. u+L) == T[v .. v+L) leaves L groups {u+q, v+q} that doubling resolves only once its distance exceeds L - q:
+// log2(L) rounds over all of them (a 1 MiB segment repeated: 24 rounds; divsufsort.cpp:1427-1520 has no such cliff -- it induces the
+// order of most suffixes from their successors).  This is that induction step on the active list, between two doubling rounds.
+// Members of a group sit in DESCENDING text position (round 0 is a stable sort fed in descending position, every later sort is
+// stable).  For a member s that is not the first of its group let P[s] = s' - s, s' = the member in front of it; P = 0 elsewhere.
+// s and s + P[s] are in one group, so they share their first byte, so  order(s, s + p) = order(s + 1, s + 1 + p).  Along a maximal
+// stretch of positions [a, x] with one non-zero P = p the argument repeats: every pair (y, y + p) of the stretch is ordered like
+// (x + 1, x + 1 + p), and THAT pair is decided now if the two suffixes lie in different groups (their ranks compare) or x + 1 + p is
+// the end of the text / block (the empty suffix is the smaller one).  A group all of whose neighbouring pairs carry the same decided
+// verdict is totally ordered by position: its members are finished with ranks G, G + 1, ...; every other group stays exactly as it
+// was (the doubling distance does not change).  p = 1 is the run rule's case.  tests/pair_rule_model.py states the same in Python and
+// tests/test_pair_rule_model.py checks it against a brute-force suffix sort on repeat-heavy texts.
+//   k_pair_dist    P[s] (random 4-byte store per member), FH / LH of every window
+//   k_pair_first / k_pair_scan / k_pair_fill   first stretch end at or after every position (the k_run_* scheme on P instead of T),
+//                  verdict of that end -> V[y] for every y with P[y] != 0   (1: the lower position is smaller, 2: the higher, 0: open)
+//   k_pair_mark    VL[j] = verdict of list slot j (0xFF for a group's first member); BAD[G] = 1 for a group with an open or a
+//                  dissenting pair (G = the group's rank: the list is in rank order, so these accesses walk BAD upwards)
+//   k_pair_finish  members of the other groups: rank -> ISA, BWT byte, DONE; everything to the b-list; compaction follows as in a round
+constexpr uint8_t PV_HEAD = 0xFF;
+__global__ __launch_bounds__(TB) void k_pair_dist(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const SaState *__restrict__ st, int par,
+                                                 uint32_t *__restrict__ P, uint32_t *__restrict__ FH, uint32_t *__restrict__ LH)
+{
+    __shared__ uint64_t H[16];
+    const uint32_t m = st->m[par];
+    const uint32_t nwin = (m + SEG_TILE - 1) / SEG_TILE;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (uint32_t win = blockIdx.x; win < nwin; win += gridDim.x) {
+        const uint32_t base = win * SEG_TILE;
+        __syncthreads();
+        uint32_t s[WIN_ITEMS], sp[WIN_ITEMS], gj[WIN_ITEMS], gp[WIN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l, jc = j < m ? j : m - 1, jp = jc ? jc - 1 : 0;
+            s[k] = a_sa[jc];
+            sp[k] = a_sa[jp];
+            gj[k] = a_grp[jc];
+            gp[k] = a_grp[jp];
+        }
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l;
+            bool head = false;
+            if (j < m) {
+                head = (j == 0) || (gj[k] != gp[k]);
+                if (!head) P[s[k]] = sp[k] - s[k];
+            }
+            const uint64_t b = __ballot(head);
+            if (l == 0) H[w * WIN_ITEMS + k] = b;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint64_t hv = (l < 16) ? H[l] : 0ull;
+            uint32_t first = hv ? base + l * 64 + (uint32_t)__builtin_ctzll(hv) + 1u : NONE;
+            uint32_t last = hv ? base + l * 64 + top_bit(hv) + 1u : 0u;
+            first = wave_incl_min(first);
+            last = wave_incl_max(last);
+            if (l == 63) { FH[win] = (first == NONE) ? 0u : first; LH[win] = last; }
+        }
+    }
+}
+
+// P has n + 1 entries, P[n] = 0: position x ends a stretch when P[x] != P[x + 1]
+__global__ __launch_bounds__(TB) void k_pair_first(const uint32_t *__restrict__ P, uint32_t n, uint32_t *__restrict__ tFirst)
+{
+    __shared__ uint32_t sm[TB / 64 + 1];
+    const uint32_t ntiles = (n + CT - 1) / CT;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * CT;
+        uint32_t pa[CT_ITEMS], pb[CT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < CT_ITEMS; k++) {
+            const uint32_t i = base + k * TB + threadIdx.x, ic = i < n ? i : n - 1;
+            pa[k] = P[ic];
+            pb[k] = P[ic + 1];
+        }
+        uint32_t first = NONE;
+#pragma unroll
+        for (int k = CT_ITEMS - 1; k >= 0; k--) {
+            const uint32_t i = base + k * TB + threadIdx.x;
+            if (i < n && pa[k] != pb[k]) first = i;
+        }
+        uint32_t tot;
+        block_incl_scan<OpMin>(first, sm, &tot);
+        if (threadIdx.x == 0) tFirst[tile] = tot;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(WG1) void k_pair_scan(uint32_t *__restrict__ tFirst, uint32_t n)
+{
+    __shared__ uint32_t sm[WG1 / 64 + 1];
+    wg_scan<OpMin, true, true>(tFirst, tFirst, (n + CT - 1) / CT, NONE, sm);      // first stretch end in any LATER tile
+}
+// verdict of the stretch that ends at x with distance p: the pair (x + 1, x + 1 + p)
+__device__ __forceinline__ uint32_t pair_verdict(uint32_t x, uint32_t p, const uint32_t *__restrict__ ISA, uint32_t n, const uint8_t *__restrict__ blk,
+                                                 const uint32_t *__restrict__ bend)
+{
+    const uint32_t lim = bend ? bend[blk[x]] : n;
+    const uint64_t b = (uint64_t)x + 1u + p;                     // x + p is a member's position (< lim), so b <= lim
+    if (b >= lim) return 2u;
+    const uint32_t ra = ISA[x + 1u], rb = ISA[b];
+    return ra == rb ? 0u : (ra < rb ? 1u : 2u);
+}
+__global__ __launch_bounds__(TB) void k_pair_fill(const uint32_t *__restrict__ P, uint32_t n, const uint32_t *__restrict__ tAfter, const uint32_t *__restrict__ ISA,
+                                                 uint8_t *__restrict__ V, const uint8_t *__restrict__ blk, const uint32_t *__restrict__ bend)
+{
+    __shared__ uint32_t sm[TB / 64 + 1];
+    __shared__ uint32_t rv[TB];
+    const uint32_t ntiles = (n + CT - 1) / CT;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * CT, p0 = base + threadIdx.x * CT_ITEMS;        // blocked: sixteen consecutive positions per thread
+        uint32_t pv[CT_ITEMS + 1];
+#pragma unroll
+        for (int k = 0; k <= CT_ITEMS; k++) { const uint32_t i = p0 + k; pv[k] = P[i < n ? i : n]; }
+        uint32_t bits = 0, first = NONE, any = 0;
+#pragma unroll
+        for (int k = CT_ITEMS - 1; k >= 0; k--) {
+            const uint32_t i = p0 + k;
+            if (i < n) {
+                any |= pv[k];
+                if (pv[k] != pv[k + 1]) { bits |= 1u << k; first = i; }
+            }
+        }
+        __syncthreads();                                                              // rv of the previous tile has been read
+        rv[TB - 1 - threadIdx.x] = first;
+        __syncthreads();
+        const uint32_t rinc = block_incl_scan<OpMin>(rv[threadIdx.x], sm, nullptr);   // index u: min over the threads >= TB - 1 - u
+        __syncthreads();
+        rv[threadIdx.x] = rinc;
+        __syncthreads();
+        uint32_t nb = (threadIdx.x == TB - 1) ? NONE : rv[TB - 2 - threadIdx.x];
+        if (nb == NONE) nb = tAfter[tile];
+        if (!any) continue;                                                           // (nothing of mine is a member; the barriers above are behind us)
+        uint32_t vnb = NONE;                                                          // verdict of the stretch end nb: not computed yet
+#pragma unroll
+        for (int k = CT_ITEMS - 1; k >= 0; k--) {
+            const uint32_t i = p0 + k;
+            if (i < n) {
+                const uint32_t p = pv[k];
+                if (bits & (1u << k)) { nb = i; vnb = p ? pair_verdict(i, p, ISA, n, blk, bend) : 0u; }
+                if (p) {
+                    if (vnb == NONE) vnb = pair_verdict(nb, p, ISA, n, blk, bend);   // the stretch runs on into a later thread: P[nb] == p
+                    V[i] = (uint8_t)vnb;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_pair_mark(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const SaState *__restrict__ st, int par,
+                                                 const uint8_t *__restrict__ V, uint8_t *__restrict__ VL, uint8_t *__restrict__ BAD)
+{
+    __shared__ uint8_t cs[SEG_TILE + 1];       // cs[q + 1] = code of local slot q (verdict, PV_HEAD for a group's first member); cs[0]: the slot in front of the window
+    const uint32_t m = st->m[par];
+    const uint32_t nwin = (m + SEG_TILE - 1) / SEG_TILE;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (uint32_t win = blockIdx.x; win < nwin; win += gridDim.x) {
+        const uint32_t base = win * SEG_TILE;
+        __syncthreads();
+        uint32_t s[WIN_ITEMS], gj[WIN_ITEMS], gp[WIN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l, jc = j < m ? j : m - 1;
+            s[k] = a_sa[jc];
+            gj[k] = a_grp[jc];
+            gp[k] = a_grp[jc ? jc - 1 : 0];
+        }
+        uint8_t c[WIN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l;
+            const bool head = (j == 0) || (gj[k] != gp[k]);
+            c[k] = PV_HEAD;
+            if (j < m && !head) c[k] = V[s[k]];
+        }
+        if (threadIdx.x == 0) {
+            uint8_t c0 = PV_HEAD;
+            if (base >= 2u && a_grp[base - 1] == a_grp[base - 2]) c0 = V[a_sa[base - 1]];
+            cs[0] = c0;
+        }
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const uint32_t q = w * (64 * WIN_ITEMS) + k * 64 + l;
+            cs[q + 1] = c[k];
+            if (base + q < m) VL[base + q] = c[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const uint32_t q = w * (64 * WIN_ITEMS) + k * 64 + l;
+            if (base + q < m && c[k] != PV_HEAD) {
+                const uint8_t pc = cs[q];
+                if (c[k] == 0 || (pc != PV_HEAD && pc != c[k])) BAD[gj[k] & ~(RUNF | DONE)] = 1;      // (same value from every writer)
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_pair_finish(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const uint8_t *__restrict__ a_prev,
+                                                   const SaState *__restrict__ st, int par, const uint32_t *__restrict__ PH, const uint32_t *__restrict__ NH,
+                                                   const uint8_t *__restrict__ VL, const uint8_t *__restrict__ BAD,
+                                                   uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
+                                                   uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint8_t *__restrict__ b_prev)
+{
+    __shared__ uint64_t H[16];
+    __shared__ uint32_t LHW[16];               // 1 + last head position at or before the end of word l (carry included)
+    __shared__ uint32_t NHW[16];               // first head position in a word AFTER word l (the next window's included)
+    const uint32_t m = st->m[par];
+    const uint32_t nwin = (m + SEG_TILE - 1) / SEG_TILE;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    for (uint32_t win = blockIdx.x; win < nwin; win += gridDim.x) {
+        const uint32_t base = win * SEG_TILE;
+        __syncthreads();
+        uint32_t s[WIN_ITEMS], gj[WIN_ITEMS], gp[WIN_ITEMS];
+        uint8_t pv[WIN_ITEMS], cj[WIN_ITEMS], cn[WIN_ITEMS], bad[WIN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l, jc = j < m ? j : m - 1;
+            s[k] = a_sa[jc];
+            gj[k] = a_grp[jc];
+            gp[k] = a_grp[jc ? jc - 1 : 0];
+            pv[k] = a_prev[jc];
+            cj[k] = VL[jc];
+            cn[k] = VL[jc + 1 < m ? jc + 1 : jc];
+        }
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) bad[k] = BAD[gj[k] & ~(RUNF | DONE)];
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const uint32_t j = base + w * (64 * WIN_ITEMS) + k * 64 + l;
+            const bool head = j < m && ((j == 0) || (gj[k] != gp[k]));
+            const uint64_t b = __ballot(head);
+            if (l == 0) H[w * WIN_ITEMS + k] = b;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint64_t hv = (l < 16) ? H[l] : 0ull;
+            const uint32_t carry = win ? PH[win - 1] : 0u;
+            uint32_t last = hv ? base + l * 64 + top_bit(hv) + 1u : 0u;
+            last = wave_incl_max(last);
+            if (l < 16) LHW[l] = last > carry ? last : carry;
+            // first head in the words after l: inclusive min-scan over the words in reverse order, shifted by one
+            const int rl = 15 - l;                                                  // lane l holds word 15 - l
+            const uint64_t hr = (l < 16) ? H[rl] : 0ull;
+            uint32_t firstr = hr ? base + rl * 64 + (uint32_t)__builtin_ctzll(hr) : NONE;
+            firstr = wave_incl_min(firstr);                                          // lane l: min over words >= 15 - l
+            const uint32_t after = NH[win];
+            const uint32_t prevlane = __shfl_up(firstr, 1, 64);                      // word x = 15 - l wants the min over words > x = lane l - 1's value
+            if (l < 16) {
+                uint32_t v = (l == 0) ? NONE : prevlane;
+                if (v == NONE) v = after;
+                NHW[rl] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) {
+            const int word = w * WIN_ITEMS + k;
+            const uint32_t j = base + word * 64 + l;
+            if (j < m) {
+                const uint64_t hv = H[word];
+                const bool head = (hv >> l) & 1ull;
+                const uint32_t G = gj[k] & ~(RUNF | DONE);
+                uint32_t out_g = gj[k];
+                if (!bad[k]) {
+                    const uint64_t le = hv & mask_upto(l);
+                    const uint32_t gs = le ? base + word * 64 + top_bit(le) : (word ? LHW[word - 1] : (win ? PH[win - 1] : 0u)) - 1u;
+                    const uint64_t gt = (l < 63) ? (hv >> (l + 1)) : 0ull;
+                    uint32_t ge = gt ? j + 1u + (uint32_t)__builtin_ctzll(gt) : NHW[word];
+                    if (ge > m) ge = m;
+                    const uint8_t v = head ? cn[k] : cj[k];              // a group has at least two members: the slot behind a head is its pair
+                    const uint32_t r = (v == 2) ? G + (j - gs) : G + (ge - 1u - j);
+                    if (r != G) ISA[s[k]] = r;
+                    bwt[r] = pv[k];
+                    if (SA) SA[r] = s[k];
+                    out_g = r | DONE;
+                }
+                b_sa[j] = s[k];
+                b_grp[j] = out_g;
+                b_prev[j] = pv[k];
+            }
+        }
+    }
+}
+
 // ---- BWT image (bwt.cpp:44-61) -------------------------------------------------------------------------------------
 // bwt_sa[i] = T[SA[i] - 1] was emitted when suffix SA[i] was resolved; the image drops the row of suffix 0 (index idx = ISA[0])
 // and starts with T[n-1]
@@ -1534,12 +1819,40 @@ int key_force_bits()
     return v;
 }
 
+// JPK_PAIR_SHIFT: a round from the third on is a pair round (k_pair_*) when at least n >> shift suffixes are unresolved (default 6);
+// negative = never (the comparator: plain prefix doubling)
+int pair_rule_shift()
+{
+    static const int v = [] { const char *e = getenv("JPK_PAIR_SHIFT"); const int x = e ? atoi(e) : 6; return x > 31 ? 31 : x; }();
+    return v;
+}
+// JPK_PAIR_MIN: ... and at least this many (default 4096; the tests lower it so that tiny inputs take the path);
+// JPK_PAIR_GAP: rounds from one pair round to the next (default 3 = two doubling rounds in between, at least 2)
+uint32_t pair_rule_min()
+{
+    static const uint32_t v = [] { const char *e = getenv("JPK_PAIR_MIN"); const long x = e ? atol(e) : 4096L; return (uint32_t)(x < 2 ? 2 : x); }();
+    return v;
+}
+// JPK_PAIR_RATIO: ... and the previous round left at least this percentage of ITS list unresolved (default 75: text halves its list
+// every round and never takes the path; a block of repeats keeps its list) -- 0 = whatever the previous round did
+uint32_t pair_rule_ratio()
+{
+    static const uint32_t v = [] { const char *e = getenv("JPK_PAIR_RATIO"); const int x = e ? atoi(e) : 75; return (uint32_t)(x < 0 ? 0 : (x > 100 ? 100 : x)); }();
+    return v;
+}
+int pair_rule_gap()
+{
+    static const int v = [] { const char *e = getenv("JPK_PAIR_GAP"); const int x = e ? atoi(e) : 3; return x < 2 ? 2 : x; }();
+    return v;
+}
+
 // builds the BWT-in-SA-order bytes (b.bwt), the complete inverse suffix array (b.ISA) and, if b.SA is set, the suffix array
 int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
 {
     hipStream_t st = ctx->stream;
     ctx->stats.sa_rounds = 0;
     ctx->stats.sa_sorted_elems = 0;
+    ctx->stats.sa_pair_rounds = 0;
     memset(ctx->stats.sa_round_active, 0, sizeof ctx->stats.sa_round_active);
     memset(ctx->stats.sa_round_large, 0, sizeof ctx->stats.sa_round_large);
     // One workgroup per tile / window / piece of the host's (one round old) upper bound; the surplus workgroups of a shrunken
@@ -1594,15 +1907,27 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     JPK_HIP(hipEventRecord(ctx->ev_sa[0], st));
     uint32_t bound = n;                            // upper bound of the active count of the round being enqueued
     bool large_possible = true;                    // a group above 1024 members may still exist
+    // The pair rule (k_pair_*): from round 3 on -- the host knows the exact count there -- a round whose list is still a sizeable share
+    // of the block is a pair round instead of a doubling round; the doubling distance stays where it was.  Two doubling rounds lie
+    // between two pair rounds (a group with dissenting pairs has to split before the rule can say more about it).
+    int hshift = 0;                                // the next doubling round compares at distance depth << hshift
+    int last_pair = -8;
+    bool prev_pair = false;
+    uint32_t m_prev = n;                           // the list the previous round started with
+    uint64_t pair_mask = 0;
     for (int round = 1;; round++) {
         const int par = round & 1;
+        bool pair = false;
         if (round >= 3) {
             JPK_HIP(hipEventSynchronize(ctx->ev_sa[par ^ 1]));
             const uint32_t m_now = h_m[4 * (par ^ 1) + par];        // round r-1 wrote m[(r-1 & 1) ^ 1] = m[par]
             if (m_now == 0) break;                                    // nothing left: no empty round
             bound = m_now;
-            if (h_m[4 * (par ^ 1) + 3] == 0) large_possible = false; // lc of round r-1
+            if (!prev_pair && h_m[4 * (par ^ 1) + 3] == 0) large_possible = false; // lc of round r-1 (a pair round does not count large groups)
             ctx->stats.sa_rounds = round + 1;
+            pair = pair_rule_shift() >= 0 && round - last_pair >= pair_rule_gap() && m_now >= pair_rule_min() && m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift()) &&
+                   (uint64_t)m_now * 100u >= (uint64_t)m_prev * pair_rule_ratio();
+            m_prev = m_now;
         }
         const unsigned g_win = cap_grid(bound, SEG_TILE, CAP);
         const unsigned g_seg = cap_grid(bound, SEG_TILE, CAP_SEG);
@@ -1610,8 +1935,28 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         const size_t pc_bound = 2 * ((size_t)bound / SEG_TILE + 1);
         const unsigned g_pc = cap_grid(pc_bound, 1, CAP);
         const unsigned g_tab = cap_grid(pc_bound << lg_db, SC_TILE, CAP);
-        JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, round - 1, b.ISA, b.k2, b.FH, b.LH, T, b.RL, round == 1 ? 1 : 0,
+        prev_pair = pair;
+        if (pair) {
+            // P lives in the sorted suffix numbers of round 0 (read for the last time by k_r0_finish), V | BAD | VL in the key2 buffer
+            // (no gather in this round)
+            uint32_t *P = vs;
+            uint8_t *V = reinterpret_cast<uint8_t *>(b.k2), *BAD = V + n, *VL = V + 2 * (size_t)n;
+            last_pair = round;
+            if (round < 64) pair_mask |= 1ull << round;
+            JPK_HIP(hipMemsetAsync(P, 0, sizeof(uint32_t) * ((size_t)n + 1), st));
+            JPK_HIP(hipMemsetAsync(BAD, 0, n, st));
+            JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_pair_dist, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, P, b.FH, b.LH);
+            JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan1, dim3(1), dim3(WG1), b.FH, b.LH, b.PH, b.NH, b.state, par);
+            JPK_LAUNCH(ctx, PROF_SCAN, 0, k_pair_first, dim3(cap_grid(n, CT, 4096)), dim3(TB), P, n, b.tB);
+            JPK_LAUNCH(ctx, PROF_SCAN, 0, k_pair_scan, dim3(1), dim3(WG1), b.tB, n);
+            JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_pair_fill, dim3(cap_grid(n, CT, CAP)), dim3(TB), P, n, b.tB, b.ISA, V, b.blk, b.bend);
+            JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_pair_mark, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, V, VL, BAD);
+            JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_pair_finish, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.a_prev, b.state, par, b.PH, b.NH, VL, BAD, b.ISA, b.bwt, b.SA,
+                       b.b_sa, b.b_grp, b.b_prev);
+        } else {
+        JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, hshift, b.ISA, b.k2, b.FH, b.LH, T, b.RL, round == 1 ? 1 : 0,
                    b.a_prev, b.bend);
+        hshift++;
         const unsigned g_wm = cap_grid((size_t)bound / SEG_TILE + 1, TB, 256);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan1, dim3(1), dim3(WG1), b.FH, b.LH, b.PH, b.NH, b.state, par);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_count, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.state, par);
@@ -1640,6 +1985,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_lg_finish, dim3(g_pc), dim3(TB), kin, vin, pin, b.a_grp, b.pieces, b.state, b.pLast, b.ISA, b.bwt, b.SA, b.b_sa,
                        b.b_grp, b.b_prev);
         }
+        }
         JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_cmp_count, dim3(g_cmp), dim3(TB), b.b_grp, b.state, par, b.tA);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_cmp_scan, dim3(1), dim3(WG1), b.tA, b.state, par, round);
         JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_cmp_scatter, dim3(g_cmp), dim3(TB), b.b_sa, b.b_grp, b.b_prev, b.state, par, b.tA, b.a_sa, b.a_grp, b.a_prev);
@@ -1653,9 +1999,11 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             if (m_start == 0) break;                // this round was empty: done
             ctx->stats.sa_rounds = round + 1;
             bound = m_start;
+            m_prev = m_start;
         }
         if (round >= 2 * JPK_SA_MAX_ROUNDS) return JPK_E_DEVICE;     // cannot happen: the distance doubles, every suffix is unique once it is >= n
     }
+    ctx->stats.sa_pair_rounds = (int64_t)pair_mask;
     // statistics: one small copy, read by sa_collect_stats() after the caller has synchronised the stream
     JPK_HIP(hipMemcpyAsync(ctx->h_mail + 32, b.state->round_m, sizeof(uint32_t) * (2 * JPK_SA_MAX_ROUNDS + 2), hipMemcpyDeviceToHost, st));   // + bits, depth
     ctx->sa_stats_pending = true;

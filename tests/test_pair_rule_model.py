@@ -1,0 +1,67 @@
+"""The pair rule of the suffix sort (bwt_fwd.hip k_pair_*; divsufsort.cpp:1427-1520 induces where prefix doubling would double) as a
+Python model (tests/pair_rule_model.py) against a brute-force suffix sort on repeat-heavy texts: periods, two and many copies of
+segments at arbitrary distances, runs, nested periods, Fibonacci words, copies with a few edits -- with the rule applied in front of
+different rounds and after different first-key depths.  CPU only."""
+import random
+
+from pair_rule_model import suffix_array
+
+
+def _brute(t):
+    return sorted(range(len(t)), key=lambda i: bytes(t[i:]))
+
+
+def _gen(rng):
+    kind = rng.randrange(8)
+    sigma = rng.choice([1, 2, 2, 3, 4, 8, 26])
+    rb = lambda k: bytes(rng.randrange(sigma) for _ in range(k))
+    n = rng.randrange(1, 400)
+    if kind == 0:
+        return rb(n)
+    if kind == 1:                                        # one period, a short tail
+        p = rng.randrange(1, 40)
+        return (rb(p) * (n // p + 1))[:n] + rb(rng.randrange(5))
+    if kind == 2:                                        # two copies at a distance
+        seg = rb(rng.randrange(1, 150))
+        return rb(rng.randrange(30)) + seg + rb(rng.randrange(60)) + seg + rb(rng.randrange(30))
+    if kind == 3:                                        # several copies of several segments
+        segs = [rb(rng.randrange(1, 60)) for _ in range(3)]
+        return b"".join(rng.choice(segs) for _ in range(rng.randrange(2, 12)))
+    if kind == 4:                                        # runs
+        return b"".join(bytes([rng.randrange(sigma)]) * rng.randrange(1, 50) for _ in range(rng.randrange(1, 12)))
+    if kind == 5:                                        # nested periods
+        a = rb(rng.randrange(1, 6))
+        b = a * rng.randrange(1, 6) + rb(rng.randrange(1, 4))
+        return (b * rng.randrange(1, 12))[:500]
+    if kind == 6:                                        # Fibonacci word
+        x, y = bytes([0]), bytes([1])
+        while len(y) < n:
+            x, y = y, y + x
+        return y[:n]
+    segs = [rb(rng.randrange(1, 30)) for _ in range(2)]  # copies with a few edits
+    s = bytearray(b"".join(rng.choice(segs) for _ in range(rng.randrange(2, 20))))
+    for _ in range(rng.randrange(3)):
+        if s:
+            s[rng.randrange(len(s))] = rng.randrange(sigma)
+    return bytes(s)
+
+
+def test_pair_rule_keeps_the_suffix_order_on_repeat_heavy_texts():
+    rng = random.Random(5)
+    for it in range(900):
+        t = _gen(rng)
+        d0 = rng.choice([1, 2, 3, 7])
+        pr = rng.choice([(2,), (2, 3), (3, 6, 9), (3, 7, 11), tuple(range(2, 100, 2))])
+        sa, _ = suffix_array(t, d0, pr)
+        assert sa == _brute(t), (it, t, d0, pr)
+
+
+def test_pair_rule_removes_the_rounds_of_a_long_repeat():
+    rng = random.Random(1)
+    rb = lambda k: bytes(rng.randrange(26) for _ in range(k))
+    seg = rb(300)
+    for t in (rb(500) + seg * 8 + rb(500), rb(500) + seg + rb(700) + seg + rb(100)):
+        sa0, r0 = suffix_array(t, 2, ())
+        sa1, r1 = suffix_array(t, 2, (3,))
+        assert sa0 == sa1 == _brute(t)
+        assert r0 >= 9 and r1 <= 4, (r0, r1)

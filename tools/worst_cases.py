@@ -24,4 +24,4 @@ for kind in ("text_survey", "text", "silesia", "zero", "repeat", "random", "dna"
         res = [e[k].elapsed_time(e[k + 1]) for k in range(4)]
     ok = bool(torch.equal(d_back, d_in))
     s = ctx.stats()
-    print(f"{kind:10s} fwd {res[0]:8.1f} ms  enc {res[1]:8.1f}  dec {res[2]:8.1f}  inv {res[3]:7.1f}  ratio {cl / n:.3f} alphabet {len(np.unique(t)):3d} key depth {s.sa_key_depth:2d} rounds {s.sa_rounds:2d} sorted {s.sa_sorted_elems / n:.1f}n ok={ok}", flush=True)
+    print(f"{kind:10s} fwd {res[0]:8.1f} ms  enc {res[1]:8.1f}  dec {res[2]:8.1f}  inv {res[3]:7.1f}  ratio {cl / n:.3f} alphabet {len(np.unique(t)):3d} key depth {s.sa_key_depth:2d} rounds {s.sa_rounds:2d} (pair rounds {[r for r in range(64) if (s.sa_pair_rounds >> r) & 1]}) sorted {s.sa_sorted_elems / n:.1f}n ok={ok} active/n {[round(x / n, 3) for x in s.sa_round_active[:min(s.sa_rounds, 12)]]}", flush=True)
