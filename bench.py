@@ -44,7 +44,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
 
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 # algorithmic HBM bytes per processed unit of every timed kernel class, and what the class is
 # actually limited by ("hbm": streaming traffic; "hbm-random": 4-byte gathers/scatters, ~55 G accesses/s whatever the bytes;
@@ -78,7 +78,7 @@ def pmc_traffic(kernel_class: str, passes: float, launches: int):
     half-count of wide coalesced loads, MI355X_MICROARCH.md section HBM).  The encoder's launch shape follows the blocks in
     flight, so the file's bytes per PASS over the workload are scaled to the `launches` that `passes` passes took here.
     None if no PMC summary is committed."""
-    for rnd in (PROFILE_ROUND, "r03", "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if os.path.exists(path):
             break
@@ -828,30 +828,42 @@ def main():
         rows1 = prof_rows([ctx.profile_table()])
         ctx.profile_enable(0)
         if rows:
-            d0 = rows[0]
+            # Fixed keys: `roofline` = the rANS chain class (one launch per block in the loop, the serial floor of the
+            # encode stage), `roofline_wide` = the radix scatter (the widest machine-filling class) -- not max() over totals that tie
+            # within a few per cent from run to run (round 4's driver line named the scatter, its profiles the chain: a 10x swing of
+            # `frac` from a tie-break).  `largest_total_time_class` says which class led this time.
+            d0 = next((r for r in rows if r["kernel"] == "k_rans_lanes"), rows[0])
             traffic, pmc_file = pmc_traffic(d0["kernel"], 4, d0["launches"])
             extra_["roofline"] = {"bound": "hbm" if d0["limited_by"].startswith("hbm") else d0["limited_by"], "achieved": d0["achieved"], "peak": 8000.0, "unit": "GB/s",
                                  "frac": d0["frac"], "traffic": traffic,
                                  "kernel": d0["kernel"], "limited_by": d0["limited_by"], "avg_launch_us": d0["avg_launch_us"], "launches": d0["launches"],
                                  "alg_bytes_per_launch": round(d0["alg_bytes_per_unit"] * d0["units"] / d0["launches"]),
-                                 "note": f"dominant kernel class by total time over 4 passes of the timed loop ({nctx} blocks in flight: one chain launch per block, stretched by the other blocks' kernels); achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream); traffic = PMC bytes per launch of the same command from profiles/{pmc_file}; peak = HBM spec; limited_by says what the class is really bound by (DESIGN.md section 4)"}
+                                 "largest_total_time_class": rows[0]["kernel"],
+                                 "whole_path": {"bytes_per_byte": 14.2, "achieved": round(14.2 * job_bytes / 1e9 / (ms_per_step / 1e3), 2),
+                                                "frac": round(14.2 * job_bytes / 1e9 / (ms_per_step / 1e3) / 8000.0, 5),
+                                                "note": "SURVEY 8d: 14.2 algorithmic bytes per block byte over the timed loop's ms_per_step"},
+                                 "note": f"the rANS chain class (fixed key), over 4 passes of the timed loop ({nctx} blocks in flight: one chain launch per block, stretched by the other blocks' kernels); achieved = algorithmic bytes per launch / mean launch time (HIP events on the launch stream); traffic = PMC bytes per launch of the same command from profiles/{pmc_file}; peak = HBM spec; limited_by says what the class is really bound by (DESIGN.md section 4): a chain is 65 waves on a serial recurrence, its HBM fraction says nothing about the machine -- roofline_wide is the machine-filling class"}
             extra_["roofline_kernels"] = rows[:8]
-            # the same for the dominant kernel among those that FILL the machine (the chain above is 65 waves on 1024 SIMDs: its
-            # launches are long, its share of the chip is 6 %): what a reader who wants "the kernel that costs the most GPU" looks for
-            wide = next((r for r in rows if r["limited_by"] != "issue"), None)
+            # the same for the radix scatter, the dominant class among those whose grids FILL the machine (the chain above is 65 waves
+            # on 1024 SIMDs: its launches are long, its share of the chip is 6 %)
+            wide = next((r for r in rows if r["kernel"] == "k_rs_scatter/k_os_scatter"), None) or next((r for r in rows if r["limited_by"] != "issue"), None)
             if wide:
                 wt, wf = pmc_traffic(wide["kernel"], 4, wide["launches"])
                 extra_["roofline_wide"] = {"kernel": wide["kernel"], "bound": "hbm" if wide["limited_by"].startswith("hbm") else wide["limited_by"],
                                           "achieved": wide["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": wide["frac"], "traffic": wt,
                                           "avg_launch_us": wide["avg_launch_us"], "launches": wide["launches"],
                                           "alg_bytes_per_launch": round(wide["alg_bytes_per_unit"] * wide["units"] / wide["launches"]),
-                                          "note": "largest total time among the kernel classes whose grids fill the chip, same 4 passes of the timed loop, same accounting"}
+                                          "note": "the radix scatter class (fixed key): the widest machine-filling class, same 4 passes of the timed loop, same accounting"}
             one = next((r for r in rows1 if r["kernel"] == d0["kernel"]), None)
             if one:
                 extra_["roofline"]["one_block_at_a_time"] = {"avg_launch_us": one["avg_launch_us"], "launches": one["launches"], "achieved": one["achieved"], "frac": one["frac"],
                                                             "traffic": pmc_traffic(d0["kernel"], 1, one["launches"])[0],
                                                             "alg_bytes_per_launch": round(one["alg_bytes_per_unit"] * one["units"] / one["launches"]),
                                                             "note": "a block alone cuts its chains into four graded launches"}
+            onew = next((r for r in rows1 if wide and r["kernel"] == wide["kernel"]), None)
+            if onew:
+                extra_["roofline_wide"]["one_block_at_a_time"] = {"avg_launch_us": onew["avg_launch_us"], "launches": onew["launches"], "achieved": onew["achieved"],
+                                                                 "frac": onew["frac"]}
         return extra_
 
     if rank == 0 and world > 1 and not args.no_extras and blocks:
@@ -1000,6 +1012,27 @@ def main():
                                             "compressed_ratio": round(sum(psz) / batch_bytes, 4),
                                             "workload": "same shape, text with a 200 000-phrase book (round 1's corpus)"}
             del p_in
+            # ... and on a text with enwik8's BYTE ALPHABET: the headline text has 28 distinct bytes, which lets round 0 of
+            # the suffix sort key on 11 bytes; real enwik8 has 205 (capitals, digits, punctuation, markup, UTF-8 pairs: order-0 entropy
+            # 5.1 bits) and gets the 7-byte keys of any block above 128 byte values.  Same shape, same word model, wide spelling.
+            wdata, _ = corpus.load_or_make("enwik8-wide")
+            wblocks = corpus.split_blocks(wdata, bs)
+            w_in = [torch.from_numpy(np.ascontiguousarray(b)).to(dev) for b in wblocks]
+            wsz = [0] * len(wblocks)
+            hist = np.bincount(wdata, minlength=256).astype(np.float64)
+            pr = hist[hist > 0] / hist.sum()
+            run_steps(2, w_in, wsz, gather=False)
+            torch.cuda.synchronize()
+            tw0 = time.perf_counter()
+            run_steps(6, w_in, wsz, gather=False)
+            torch.cuda.synchronize()
+            tw = (time.perf_counter() - tw0) / 6
+            extra["wide_alphabet_variant"] = {"value": round(batch_bytes / 1e6 / tw, 1), "unit": "MB/s", "ms_per_step": round(tw * 1e3, 3), "steps": 6,
+                                              "compressed_ratio": round(sum(wsz) / batch_bytes, 4), "alphabet": int((hist > 0).sum()),
+                                              "order0_entropy_bits": round(float(-(pr * np.log2(pr)).sum()), 3),
+                                              "workload": "same shape and word model over an enwik8-like byte alphabet (capitals, digits, punctuation, markup, "
+                                                          "UTF-8 pairs): the suffix sort's first key holds 7 bytes here, 11 on the headline text"}
+            del w_in, wdata
         # The extras below bring contexts of their own.  The loop's contexts (each with its stream and up to three encoder group
         # streams) are closed first: HIP deals streams onto 32 hardware queues, a stream beyond that shares a queue, and a 12 ms
         # chain kernel then blocks whatever sits behind it -- with the loop's twenty streams still alive the 8 MiB leg of

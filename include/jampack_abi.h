@@ -199,8 +199,11 @@ JPK_API int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const uint8
  * ctx's device (kept by the library between calls, released by jpk_shutdown), that take the work in array order.  Blocks of up to
  * 16 MiB -- the reference's default block is 8 MiB, its smallest 1 MiB (format.hpp:20-22) -- are compressed in GROUPS of
  * consecutive blocks (a quarter of their total bytes, 8 .. 64 MiB, at most 256 blocks; JPK_GROUP_MIB fixes the size, JPK_GROUP=0
- * turns grouping off): one suffix sort over the blocks of a group, one set of entropy grids over all their chunks, one host
- * synchronisation per group; every block's bytes are those of jpk_dev_block_compress for that block.
+ * turns grouping off): one suffix sort over the blocks of a group, one set of entropy grids over all their chunks, and a handful of
+ * host synchronisations per group instead of one per block -- the suffix sort's per-round counts from its third round on, the symbol
+ * layout, the chunk sizes and the end of the emit kernels (one more when a block does not fit its buffer); every block's bytes are those
+ * of jpk_dev_block_compress for that block.  A group that fails as a whole (its arena, a device error) is retried block by block through
+ * the single-block path on the same context; a block whose out_cap is too small reports JPK_E_CAPACITY alone.
  * The calling thread works too (with ctx) and returns when every block is done.  status may be NULL; otherwise
  * status[b] receives block b's jpk_status (JPK_E_CAPACITY when out_cap[b] is too small, ...) and the other blocks still complete.
  * Stream order: as for every jpk_dev_* call, work already queued on ctx's stream (the producers of d_in[], readers of an earlier
@@ -242,16 +245,27 @@ JPK_API int64_t jpk_debug_arena_bytes(int64_t block_bytes, int stage);
  * in microseconds, default 300; negative: never merge> in the environment. */
 JPK_API int jpk_debug_combiner_last_batch(int device);
 JPK_API int jpk_debug_enc_groups(int device, int32_t nch);
-/* The block loop of Jampack::Compress (jampack.cpp:205-224) over the GPUs of one node, natively: block b is compressed on the
- * (b mod G)-th device of `device_mask` (bit d = device d, 0 = every visible gfx950 device; one worker thread and context per
- * device; `in[b]` are HOST buffers), and the compressed blocks are gathered in block order into `d_out`, a buffer of out_cap bytes
- * on the FIRST device of the mask: block b occupies [out_off[b], out_off[b + 1]) (out_off has nblocks + 1 entries).  The gather is
- * one ncclSend / ncclRecv pair of exactly the block's bytes per block of a non-root device, grouped, over a single-process RCCL
- * communicator (ncclCommInitAll) that the library loads at first use and keeps until jpk_shutdown; the root's own blocks are
- * device-to-device copies (JPK_MULTI_FORCE_RCCL=1: through RCCL as well).  status[b] (nullable) receives every block's status.
+/* The block loops of Jampack::Compress / Jampack::Decompress (jampack.cpp:205-224, 286-317) over the GPUs of one node, natively:
+ * block b runs on the (b mod G)-th device of `device_mask` (bit d = device d, 0 = every visible gfx950 device; one worker thread per
+ * device; `in[b]` are HOST buffers, copied into a per-device slab the library keeps between calls), THROUGH THE LIBRARY'S BATCH ENTRY
+ * on that device -- jpk_dev_blocks_compress with `in_flight` blocks in flight (<= 0: its default, 8) and small blocks in groups, or
+ * jpk_dev_blocks_decompress (one pass over the chunks of all the device's blocks) -- and the results are gathered in block order into
+ * `d_out`, a buffer of out_cap bytes on the FIRST device of the mask: block b occupies [out_off[b], out_off[b + 1]) (out_off has
+ * nblocks + 1 entries).  Decompress: in_len[b] = compressed bytes, raw_len[b] = the block's decompressed size (the frame header's
+ * BlockSize or what jpk_ans_decoded_size reports minus the trailer); the gather moves raw_len[b] bytes per block.
+ * The gather is one ncclSend / ncclRecv pair of exactly the block's bytes per block of a non-root device, grouped, over a
+ * single-process RCCL communicator (ncclCommInitAll) that the library loads at first use and keeps until jpk_shutdown; the root's
+ * own blocks are device-to-device copies (JPK_MULTI_FORCE_RCCL=1: through RCCL as well).  status[b] (nullable) receives every
+ * block's status; a block that was never reached (its device failed early) reports an error, never JPK_OK.
+ * ONE CALL AT A TIME: the communicators and the slabs are the process's; concurrent callers (and jpk_shutdown) queue on one mutex.
+ * The caller's current HIP device is restored on return.
  * jpk_debug_multi_plan: the ownership rule alone, for `ndev_visible` devices (no device call). */
 JPK_API int jpk_blocks_compress_multi(uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, uint8_t *d_out, int64_t out_cap,
                                       int64_t *out_off, int32_t *status);
+JPK_API int jpk_blocks_compress_multi_ex(uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, uint8_t *d_out, int64_t out_cap,
+                                         int64_t *out_off, int32_t *status, int32_t in_flight);
+JPK_API int jpk_blocks_decompress_multi(uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, const int32_t *raw_len, uint8_t *d_out,
+                                        int64_t out_cap, int64_t *out_off, int32_t *status);
 JPK_API int jpk_debug_multi_plan(uint64_t device_mask, int32_t ndev_visible, int32_t nblocks, int32_t *owner);
 /* host-logic probe: the work list jpk_dev_blocks_compress forms for these block lengths (groups of small blocks, large blocks alone):
  * task t covers blocks [first[t], first[t] + count[t]); returns the number of tasks.  No device call. */
@@ -260,6 +274,9 @@ JPK_API int jpk_debug_group_plan(int32_t nblocks, const int32_t *in_len, int32_t
  * jpk_debug_compress_inflight with delta != 0, and jpk_debug_combiner_fail_next(n): the next n merged decode passes fail as a
  * whole before they run -- every merged request must then come back through its own thread's single-block path. */
 JPK_API int jpk_debug_combiner_fail_next(int n);
+/* (JPK_DEBUG_HOOKS=1 only) the next n groups of jpk_dev_blocks_compress fail as a whole before they run: their blocks must come back
+ * through the single-block path with the same bytes */
+JPK_API int jpk_debug_group_fail_next(int n);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,9 @@ import os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")   # see abi.hip: more than two blocks in flight need more HW queues
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libjampack_amd.so")
+# JPK_LIB=<path>: another build of the library for THIS process (tools/ab_*.sh alternate two builds on one box without touching the
+# product file in place)
+LIB_PATH = os.environ.get("JPK_LIB") or os.path.join(HERE, "libjampack_amd.so")
 
 TRAILER = 480
 CHUNK = 1 << 20
@@ -99,6 +101,9 @@ _SIGS = {
     "jpk_debug_combiner_last_batch": (C.c_int, [C.c_int]),
     "jpk_debug_combiner_fail_next": (C.c_int, [C.c_int]),
     "jpk_blocks_compress_multi": (C.c_int, [C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "jpk_blocks_compress_multi_ex": (C.c_int, [C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]),
+    "jpk_blocks_decompress_multi": (C.c_int, [C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "jpk_debug_group_fail_next": (C.c_int, [C.c_int]),
     "jpk_debug_multi_plan": (C.c_int, [C.c_uint64, C.c_int32, C.c_int32, C.c_void_p]),
     "jpk_debug_group_plan": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
 }

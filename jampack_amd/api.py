@@ -411,9 +411,10 @@ def multi_plan(device_mask: int, ndev_visible: int, nblocks: int):
     return g, list(own)[:nblocks]
 
 
-def blocks_compress_multi(blocks, d_out, out_cap: int, device_mask: int = 0):
-    """jpk_blocks_compress_multi: host blocks -> compressed blocks gathered in block order into `d_out` (a device buffer on the first
-    device of the mask; anything with data_ptr() or an int address).  Returns (offsets [nblocks + 1], status [nblocks])."""
+def blocks_compress_multi(blocks, d_out, out_cap: int, device_mask: int = 0, in_flight: int = 0):
+    """jpk_blocks_compress_multi(_ex): host blocks -> compressed blocks gathered in block order into `d_out` (a device buffer on the first
+    device of the mask; anything with data_ptr() or an int address), `in_flight` blocks in flight per device (0: the library's default).
+    Returns (offsets [nblocks + 1], status [nblocks])."""
     arrs = [_np_u8(b) for b in blocks]
     n = len(arrs)
     P, I = C.c_void_p * max(n, 1), C.c_int32 * max(n, 1)
@@ -421,5 +422,20 @@ def blocks_compress_multi(blocks, d_out, out_cap: int, device_mask: int = 0):
     lens = I(*[len(a) for a in arrs])
     off = (C.c_int64 * (n + 1))()
     st = I()
-    _chk(lib().jpk_blocks_compress_multi(device_mask, n, ins, lens, _dptr(d_out), out_cap, off, st), "jpk_blocks_compress_multi")
+    _chk(lib().jpk_blocks_compress_multi_ex(device_mask, n, ins, lens, _dptr(d_out), out_cap, off, st, in_flight), "jpk_blocks_compress_multi")
+    return list(off), list(st)[:n]
+
+
+def blocks_decompress_multi(comp_blocks, raw_lens, d_out, out_cap: int, device_mask: int = 0):
+    """jpk_blocks_decompress_multi: host compressed blocks (+ the decompressed size of each) -> the blocks' bytes gathered in block order
+    into `d_out` on the first device of the mask.  Returns (offsets [nblocks + 1], status [nblocks])."""
+    arrs = [_np_u8(b) for b in comp_blocks]
+    n = len(arrs)
+    P, I = C.c_void_p * max(n, 1), C.c_int32 * max(n, 1)
+    ins = P(*[a.ctypes.data if len(a) else None for a in arrs])
+    lens = I(*[len(a) for a in arrs])
+    raw = I(*[int(x) for x in raw_lens])
+    off = (C.c_int64 * (n + 1))()
+    st = I()
+    _chk(lib().jpk_blocks_decompress_multi(device_mask, n, ins, lens, raw, _dptr(d_out), out_cap, off, st), "jpk_blocks_decompress_multi")
     return list(off), list(st)[:n]

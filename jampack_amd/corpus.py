@@ -149,6 +149,107 @@ def text_survey(nbytes: int, seed: int, start: int = 0) -> np.ndarray:
     return out
 
 
+# ---- "wide" text: the survey text model with an enwik8-like BYTE ALPHABET ------------------------------------------------------
+# SURVEY 8d's text model has 28 distinct bytes (lower-case letters, space, newline); real enwik8 has 205 (capitals, digits,
+# punctuation, wiki / XML markup, UTF-8 lead and continuation bytes) at an order-0 entropy of 5.08 bits.  The suffix sort's first key
+# depends on the alphabet (bwt_fwd.hip k_key_plan: 11 bytes for 28 values, 7 above 128), so the bench line carries this variant beside
+# the headline: same vocabulary size, same Zipf word choice, same page scheme, but words come capitalised / upper-case / as numbers /
+# with accented letters / in two- and three-byte scripts, and the separator is drawn from a table of punctuation and markup.
+_Q3 = b"'" * 3
+_WIDE_SEPS = [(b" ", 5200), (b", ", 560), (b". ", 460), (b"\n", 170), (b" (", 60), (b") ", 60), (b"; ", 30), (b": ", 80), (b" - ", 50), (b"'s ", 80),
+              (b'" ', 40), (b' "', 40), (b"]] ", 160), (b" [[", 160), (b"|", 110), (b"'' ", 50), (b" ''", 50), (b"\n\n", 60), (b"\n* ", 40), (b"\n== ", 12),
+              (b" ==\n", 12), (b"&quot;", 30), (b"&amp;", 8), (b"&lt;", 14), (b"&gt;", 14), (b" <", 14), (b"> ", 14), (b"/", 40), (b"=", 30), (b"{{", 20),
+              (b"}} ", 20), (b"#", 8), (b"%", 6), (b"+", 6), (b"_", 30), (b"! ", 8), (b"? ", 10), (b"@", 2), (b"~", 2), (b"^", 1), (b"`", 1), (b"$", 3),
+              (b"\\", 1), (b"\t", 4), (b"]", 6), (b"[", 6), (b"}", 2), (b"{", 2), (b"*", 6), (_Q3, 25), (b"-", 60), (b".", 40), (b",", 10), (b":", 30),
+              (b"</", 10), (b"/>", 6), (b"\xe2\x80\x93", 12), (b"\xe2\x80\x94 ", 8), (b"\xc2\xa0", 6), (b"\xc2\xb0", 2), (b"\xe2\x80\x99", 6)]
+
+
+@functools.lru_cache(maxsize=2)
+def _wide_tables(seed: int):
+    """piece pool of the wide text: pieces 0..nw-1 = the vocabulary's words in their wide spelling, nw.. = the separators;
+    returns (pool bytes, piece start, piece length, word Zipf cdf, separator cdf, nw)"""
+    letters, vstart, vlen = _vocab(seed)
+    nw = len(vlen)
+    h = splitmix64(seed ^ 0x71DE, 0, nw)
+    kind = (h % np.uint64(1000)).astype(np.int64)
+    kind[:40] = 999                                         # the most frequent words stay plain lower case
+    r1 = ((h >> np.uint64(16)) % np.uint64(1 << 20)).astype(np.int64)
+    pieces = []
+    for k in range(nw):
+        w = letters[vstart[k]: vstart[k] + vlen[k]]
+        kd, r = int(kind[k]), int(r1[k])
+        if kd < 150:                                        # Capitalised
+            b = bytes([w[0] - 32]) + w[1:].tobytes()
+        elif kd < 175:                                      # UPPER CASE
+            b = (w - 32).astype(np.uint8).tobytes()
+        elif kd < 260:                                      # a number of 1..4 digits; four digits are years
+            nd = 1 + r % 4
+            b = bytes(48 + ((r >> (3 * i)) % 10) for i in range(nd))
+            if nd == 4:
+                b = (b"19" if r & 1 else b"20") + b[2:]
+        elif kd < 300:                                      # one accented letter (two-byte UTF-8, lead 0xC3..0xC5)
+            i = r % len(w)
+            b = w[:i].tobytes() + bytes([0xC3 + (r >> 8) % 3, 0x80 + (r >> 10) % 64]) + w[i + 1:].tobytes()
+        elif kd < 320:                                      # a word in a two-byte script (leads 0xC6..0xDF: Greek, Cyrillic, Hebrew, Arabic, ...)
+            lead = 0xC6 + (r >> 4) % 26
+            b = b"".join(bytes([lead, 0x80 + (int(c) * 7 + r) % 64]) for c in w[: 2 + r % 5])
+        elif kd < 335:                                      # a word in a three-byte script (leads 0xE0..0xEF)
+            lead = 0xE0 + (r >> 3) % 16
+            b = b"".join(bytes([lead, 0x80 + (int(c) * 5 + r) % 64, 0x80 + (int(c) * 11 + (r >> 7)) % 64]) for c in w[: 1 + r % 3])
+        elif kd < 350:                                      # mixed case identifier with a digit
+            b = bytes([w[0] - 32]) + w[1:].tobytes() + bytes([48 + r % 10])
+        else:
+            b = w.tobytes()
+        pieces.append(b)
+    sep_w = np.array([w for _, w in _WIDE_SEPS], dtype=np.float64)
+    for sb, _ in _WIDE_SEPS:
+        pieces.append(sb)
+    plen = np.array([len(b) for b in pieces], dtype=np.int64)
+    pstart = np.concatenate(([0], np.cumsum(plen)))[:-1]
+    pool = np.frombuffer(b"".join(pieces), dtype=np.uint8).copy()
+    pz = np.arange(1, nw + 1, dtype=np.float64) ** -1.05
+    return pool, pstart, plen, np.cumsum(pz / pz.sum()), np.cumsum(sep_w / sep_w.sum()), nw
+
+
+def _wide_page(seed: int, page: int) -> np.ndarray:
+    pool, pstart, plen, zcdf, scdf, nw = _wide_tables(seed)
+    words = SURVEY_PAGE // 5
+    pseed = (seed * 0x9E3779B1 + 0x77 + page * 0x632BE5AB) & 0xFFFFFFFFFFFFFFFF
+    wid = np.minimum(np.searchsorted(zcdf, _uniform(pseed, 0, words)), nw - 1)
+    sid = nw + np.minimum(np.searchsorted(scdf, _uniform(pseed ^ 0x5E9, 0, words)), len(scdf) - 1)
+    ids = np.empty(2 * words, dtype=np.int64)
+    ids[0::2] = wid
+    ids[1::2] = sid
+    ln = plen[ids]
+    ends = np.cumsum(ln)
+    npieces = int(np.searchsorted(ends, SURVEY_PAGE)) + 1
+    ids, ln, ends = ids[:npieces], ln[:npieces], ends[:npieces]
+    tot = int(ends[-1])
+    src = np.arange(tot, dtype=np.int64) - np.repeat(ends - ln, ln) + np.repeat(pstart[ids], ln)
+    seg = pool[src]
+    # a sentence starts with a capital: a lower-case letter behind ". " or a newline
+    low = (seg >= 97) & (seg <= 122)
+    after = np.zeros(tot, dtype=bool)
+    after[2:] = ((seg[:-2] == 46) & (seg[1:-1] == 32))
+    after[1:] |= seg[:-1] == 10
+    seg = np.where(low & after, seg - 32, seg).astype(np.uint8)
+    return seg[:SURVEY_PAGE]
+
+
+def text_wide(nbytes: int, seed: int, start: int = 0) -> np.ndarray:
+    """the survey text model over an enwik8-like byte alphabet (about 200 distinct bytes, order-0 entropy about 5 bits)"""
+    if nbytes <= 0:
+        return np.zeros(0, dtype=np.uint8)
+    out = np.empty(nbytes, dtype=np.uint8)
+    p0, p1 = start // SURVEY_PAGE, (start + nbytes - 1) // SURVEY_PAGE
+    for p in range(p0, p1 + 1):
+        page = _wide_page(seed, p)
+        lo = max(start, p * SURVEY_PAGE)
+        hi = min(start + nbytes, (p + 1) * SURVEY_PAGE)
+        out[lo - start: hi - start] = page[lo - p * SURVEY_PAGE: hi - p * SURVEY_PAGE]
+    return out
+
+
 def random_bytes(nbytes: int, seed: int) -> np.ndarray:
     n8 = (nbytes + 7) // 8
     return splitmix64(seed, 0, n8).view(np.uint8)[:nbytes].copy()
@@ -215,6 +316,8 @@ def make(kind: str, nbytes: int, seed: int) -> np.ndarray:
         return text(nbytes, seed)
     if kind == "text_survey":
         return text_survey(nbytes, seed)
+    if kind == "text_wide":
+        return text_wide(nbytes, seed)
     if kind == "random":
         return random_bytes(nbytes, seed)
     if kind == "dna":
@@ -238,7 +341,7 @@ def make(kind: str, nbytes: int, seed: int) -> np.ndarray:
     raise ValueError(f"unknown corpus kind {kind!r}")
 
 
-KINDS = ("text", "text_survey", "random", "dna", "two", "zero", "geometric", "samples16", "runs", "repeat", "repeat4k", "silesia")
+KINDS = ("text", "text_survey", "text_wide", "random", "dna", "two", "zero", "geometric", "samples16", "runs", "repeat", "repeat4k", "silesia")
 
 # name -> (kind, bytes, seed, real file under JAMPACK_CORPUS_DIR).  The enwik workloads use the SURVEY 8d text model
 # (ratio ~20 %, as enwik8's ~21 %); the *-phrase variants add a 200 000-phrase book (deeper repeats, ratio ~10 %) and are
@@ -248,6 +351,7 @@ WORKLOADS = {
     "enwik8": ("text_survey", 100_000_000, 8, "enwik8"),
     "enwik9": ("text_survey", 1_000_000_000, 9, "enwik9"),
     "enwik8-phrase": ("text", 100_000_000, 8, None),
+    "enwik8-wide": ("text_wide", 100_000_000, 8, None),
     "silesia": ("silesia", 211_938_580, 5, "silesia.tar"),
 }
 
@@ -274,6 +378,8 @@ def load_or_make(name: str, limit: int | None = None, seed_offset: int = 0, star
         return np.fromfile(cpath, dtype=np.uint8), "synthetic"
     if kind == "text_survey":
         out = text_survey(count, seed + seed_offset, start)
+    elif kind == "text_wide":
+        out = text_wide(count, seed + seed_offset, start)
     else:
         out = make(kind, nbytes, seed + seed_offset)[start:start + count]
     if cpath:

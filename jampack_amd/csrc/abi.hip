@@ -561,12 +561,18 @@ extern "C" int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const ui
     if (batched) {
         int b0 = 0;
         while (b0 < nblocks) {
+            // (extended block by block: a job adds its own bytes and tiles, the tables follow from the totals; at most 65 535 jobs --
+            // the batch launches use blockIdx.y = the job)
             int e = b0 + 1;
-            size_t need = jpk_inv_bwt_batch_arena_bytes(1, mid_cap.data() + b0);
-            while (e < nblocks) {
-                const size_t more = jpk_inv_bwt_batch_arena_bytes(e + 1 - b0, mid_cap.data() + b0);
+            size_t job_bytes = 0, tiles = 0;
+            jpk_inv_bwt_batch_plan_add(mid_cap[(size_t)b0], &job_bytes, &tiles);
+            size_t need = jpk_inv_bwt_batch_plan_total(1, job_bytes, tiles);
+            while (e < nblocks && e - b0 < JPK_INV_BATCH_MAX_JOBS) {
+                size_t jb2 = job_bytes, t2 = tiles;
+                jpk_inv_bwt_batch_plan_add(mid_cap[(size_t)e], &jb2, &t2);
+                const size_t more = jpk_inv_bwt_batch_plan_total(e + 1 - b0, jb2, t2);
                 if (more > batch_budget) break;
-                need = more;
+                need = more; job_bytes = jb2; tiles = t2;
                 e++;
             }
             if (need > batch_bytes_max) batch_bytes_max = need;
@@ -885,7 +891,7 @@ namespace {
 // Small blocks -- the reference's default block is 8 MiB, its smallest 1 MiB (format.hpp:20-22), and Jampack::Compress feeds
 // `Threads` of them at a time (jampack.cpp:205-224) -- are compressed in GROUPS: one suffix sort over the blocks of a group
 // (jpk_fwd_bwt_group_device), one set of entropy grids over all their chunks (jpk_ans_encode_group_device), one host
-// synchronisation per group instead of ~200 launches and a synchronisation per block.  Bytes per block are those of
+// synchronisation per stage boundary of a group (four in all, below) instead of ~200 launches and a synchronisation per block.  Bytes per block are those of
 // jpk_dev_block_compress.
 constexpr int32_t GROUP_BLOCK_MAX = 16 << 20;       // blocks up to this size are grouped
 // Bytes per group: large groups amortise best (a 256 MiB stream of 1 MiB blocks: 4.6 GB/s in groups of 64 MiB, 4.2 in groups of
@@ -936,9 +942,14 @@ void group_needs(int nb, const int32_t *in_len, size_t *stage_bytes, size_t *are
     *arena_bytes = (a_sort > a_enc ? a_sort : a_enc) + (size_t)GROUP_BLOCK_MAX + (1u << 20);
 }
 
+// test hook (JPK_DEBUG_HOOKS=1 only): the next `n` groups fail as a whole before they run, as if their arena could not be had --
+// every block of such a group must then come back through the single-block path with the same bytes
+std::atomic<int> g_group_fail_next{0};
+
 int group_compress(jpk_ctx *c, int nb, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out, const int32_t *out_cap, int32_t *out_len,
                    int32_t *status)
 {
+    if (g_group_fail_next.load() > 0 && g_group_fail_next.fetch_sub(1) > 0) return JPK_E_ALLOC;
     std::vector<uint32_t> first((size_t)nb);
     std::vector<int32_t> mid((size_t)nb);
     uint64_t nlen_total = 0;
@@ -1022,8 +1033,11 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
                 continue;
             }
             const int rc = group_compress(c, nb, d_in + b, in_len + b, d_out + b, out_cap + b, out_len + b, stp + b);
-            if (rc != JPK_OK)                                   // the group as a whole failed (allocation, device): every block says so
-                for (int j = b; j < b + nb; j++) { out_len[j] = 0; stp[j] = rc; }
+            if (rc != JPK_OK)                                   // the group as a whole failed (its ~46 B/byte arena or staging buffer, a device error):
+                for (int j = b; j < b + nb; j++) {              // every block goes through the single-block path on this context (~50 B/byte of ITS size), as before grouping
+                    out_len[j] = 0;
+                    stp[j] = jpk_dev_block_compress(c, d_in[j], in_len[j], d_out[j], out_cap[j], &out_len[j]);
+                }
         }
     };
     // workers 1 .. nw-1 on contexts of their own; a worker that cannot get one (or a thread that cannot be started) leaves its
@@ -1041,6 +1055,13 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
     for (jpk_ctx *c : held) batch_ctx_release(ctx->device, c, generation);
     if (!status)
         for (int b = 0; b < nblocks; b++) if (stp[b] != JPK_OK) return stp[b];
+    return JPK_OK;
+}
+
+extern "C" int jpk_debug_group_fail_next(int n)
+{
+    if (!debug_hooks_on() || n < 0) return JPK_E_ARG;
+    g_group_fail_next.store(n);
     return JPK_OK;
 }
 
@@ -1122,14 +1143,56 @@ extern "C" int jpk_debug_multi_plan(uint64_t device_mask, int32_t ndev_visible, 
     return (int)dv.size();
 }
 
-extern "C" int jpk_blocks_compress_multi(uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, uint8_t *d_out, int64_t out_cap,
-                                         int64_t *out_off, int32_t *status)
+// Shared body of the two multi-device entries.  ONE call at a time per process: RCCL communicators are not safe for concurrent use
+// from several threads, the per-device slabs below are shared, and jpk_shutdown must not destroy either under a running call -- the
+// whole call (and jpk_shutdown) holds multi_call_mu(); concurrent callers queue.
+namespace {
+std::mutex &multi_call_mu() { static std::mutex m; return m; }
+// per device: one input slab and one output slab, kept between calls (grown when a larger call arrives), freed by jpk_shutdown
+struct MultiSlab { uint8_t *in = nullptr, *out = nullptr; size_t in_cap = 0, out_cap = 0; };
+MultiSlab *multi_slabs() { static MultiSlab v[64]; return v; }
+int slab_ensure(uint8_t **p, size_t *cap, size_t bytes)
 {
-    if (nblocks < 0 || out_cap < 0 || !out_off || (nblocks > 0 && (!in || !in_len || !d_out))) return JPK_E_ARG;
+    if (*cap >= bytes && *p) return JPK_OK;
+    if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+    const size_t want = jpk_align(bytes + bytes / 8 + 4096, 1 << 20);
+    if (hipMalloc((void **)p, want) != hipSuccess) { *p = nullptr; (void)hipGetLastError(); return JPK_E_ALLOC; }
+    *cap = want;
+    return JPK_OK;
+}
+void multi_slabs_free()
+{
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (int d = 0; d < 64; d++) {
+        MultiSlab &m = multi_slabs()[d];
+        if (!m.in && !m.out) continue;
+        if (hipSetDevice(d) == hipSuccess) { if (m.in) (void)hipFree(m.in); if (m.out) (void)hipFree(m.out); }
+        m = MultiSlab();
+    }
+    if (have) (void)hipSetDevice(cur);
+}
+struct DeviceRestore {
+    int dev = -1;
+    DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+size_t multi_comp_cap(int32_t len) { return (size_t)((int64_t)(len + JPK_TRAILER_BYTES) * 5 / 4) + 4096 + 1400 * ((size_t)(len + JPK_TRAILER_BYTES) / JPK_ANS_CHUNK + 1); }
+
+// compress: in[b] host blocks of in_len[b] bytes -> compressed blocks; decompress: in[b] host compressed blocks, raw_len[b] = the
+// block's decompressed size.  Either way block b runs on devices[b mod G] through the library's batch entry on that device
+// (jpk_dev_blocks_compress with `in_flight` blocks in flight and grouped small blocks / jpk_dev_blocks_decompress: one pass over the
+// chunks of all its blocks), and the results are gathered in block order on the first device.
+int multi_run(bool compress, uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, const int32_t *raw_len, uint8_t *d_out, int64_t out_cap,
+              int64_t *out_off, int32_t *status, int32_t in_flight)
+{
+    if (nblocks < 0 || out_cap < 0 || !out_off || (nblocks > 0 && (!in || !in_len || !d_out || (!compress && !raw_len)))) return JPK_E_ARG;
     out_off[0] = 0;
     if (nblocks == 0) return JPK_OK;
     for (int b = 0; b < nblocks; b++)
-        if (in_len[b] < 0 || (in_len[b] > 0 && !in[b])) return JPK_E_ARG;
+        if (in_len[b] < 0 || (in_len[b] > 0 && !in[b]) || (!compress && raw_len[b] < 0)) return JPK_E_ARG;
+    std::lock_guard<std::mutex> call_lock(multi_call_mu());
+    DeviceRestore restore;                                   // the caller's current device comes back on every exit path
     const int ndev = jpk_device_count();
     if (ndev <= 0) return JPK_E_NODEVICE;
     std::vector<int> devs;
@@ -1143,29 +1206,50 @@ extern "C" int jpk_blocks_compress_multi(uint64_t device_mask, int32_t nblocks, 
     const int G = (int)devs.size(), root = devs[0];
     std::vector<int32_t> st_local((size_t)nblocks), olen((size_t)nblocks, 0);
     int32_t *stp = status ? status : st_local.data();
+    for (int b = 0; b < nblocks; b++) stp[b] = JPK_E_DEVICE;       // a block nobody got to says so (a device whose worker bails out early)
     uint64_t generation;
     { CtxPool &p = pool(); std::lock_guard<std::mutex> g(p.mu); generation = p.generation; }
 
-    // per device: context, one input staging buffer (largest block), one output buffer per owned block (carved from one allocation)
-    struct Dev { jpk_ctx *c = nullptr; uint8_t *outs = nullptr; std::vector<int> blocks; std::vector<size_t> off; int rc = JPK_OK; };
+    struct Dev { jpk_ctx *c = nullptr; MultiSlab *slab = nullptr; std::vector<int> blocks; std::vector<size_t> ioff, ooff; int rc = JPK_OK; };
     std::vector<Dev> dv((size_t)G);
     for (int b = 0; b < nblocks; b++) dv[(size_t)(b % G)].blocks.push_back(b);
-    auto cap_of = [](int32_t len) { return (size_t)((int64_t)(len + JPK_TRAILER_BYTES) * 5 / 4) + 4096 + 1400 * ((size_t)(len + JPK_TRAILER_BYTES) / JPK_ANS_CHUNK + 1); };
+    auto cap_of = [&](int b) { return compress ? multi_comp_cap(in_len[b]) : (size_t)raw_len[b]; };
     auto work = [&](int g) {
         Dev &D = dv[(size_t)g];
         if (D.blocks.empty()) return;
-        if (hipSetDevice(devs[(size_t)g]) != hipSuccess) { D.rc = JPK_E_DEVICE; return; }
-        if ((D.rc = batch_ctx_acquire(devs[(size_t)g], &D.c)) != JPK_OK) return;
-        size_t total = 0, maxin = 0;
-        for (int b : D.blocks) { D.off.push_back(total); total += jpk_align(cap_of(in_len[b]), 256); if ((size_t)in_len[b] > maxin) maxin = (size_t)in_len[b]; }
-        if (hipMalloc((void **)&D.outs, total + 256) != hipSuccess) { D.outs = nullptr; D.rc = JPK_E_ALLOC; return; }
-        if ((D.rc = buf_ensure(D.c, &D.c->stage_in, &D.c->stage_in_cap, maxin + 64)) != JPK_OK) return;
-        for (size_t k = 0; k < D.blocks.size(); k++) {
-            const int b = D.blocks[k];
-            if (in_len[b] && hipMemcpyAsync(D.c->stage_in, in[b], (size_t)in_len[b], hipMemcpyHostToDevice, D.c->stream) != hipSuccess) { stp[b] = JPK_E_DEVICE; continue; }
-            const size_t cap = cap_of(in_len[b]);
-            stp[b] = jpk_dev_block_compress(D.c, D.c->stage_in, in_len[b], D.outs + D.off[k], (int32_t)(cap > 0x7fffffff ? 0x7fffffff : cap), &olen[b]);   // synchronises
+        const int dev = devs[(size_t)g];
+        if (hipSetDevice(dev) != hipSuccess) { D.rc = JPK_E_DEVICE; return; }
+        if ((D.rc = batch_ctx_acquire(dev, &D.c)) != JPK_OK) return;
+        D.slab = &multi_slabs()[dev];
+        size_t itotal = 0, ototal = 0;
+        for (int b : D.blocks) {
+            D.ioff.push_back(itotal); itotal += jpk_align((size_t)in_len[b] + 64, 256);
+            D.ooff.push_back(ototal); ototal += jpk_align(cap_of(b), 256);
         }
+        if ((D.rc = slab_ensure(&D.slab->in, &D.slab->in_cap, itotal + 256)) != JPK_OK) return;
+        if ((D.rc = slab_ensure(&D.slab->out, &D.slab->out_cap, ototal + 256)) != JPK_OK) return;
+        const size_t nb = D.blocks.size();
+        std::vector<const uint8_t *> din(nb);
+        std::vector<uint8_t *> dout(nb);
+        std::vector<int32_t> ilen(nb), ocap(nb), ol(nb, 0), stl(nb, JPK_E_DEVICE);
+        for (size_t k = 0; k < nb; k++) {
+            const int b = D.blocks[k];
+            din[k] = D.slab->in + D.ioff[k];
+            dout[k] = D.slab->out + D.ooff[k];
+            ilen[k] = in_len[b];
+            const size_t cap = cap_of(b);
+            ocap[k] = (int32_t)(cap > 0x7fffffff ? 0x7fffffff : cap);
+            if (in_len[b] && hipMemcpyAsync(D.slab->in + D.ioff[k], in[b], (size_t)in_len[b], hipMemcpyHostToDevice, D.c->stream) != hipSuccess) { D.rc = JPK_E_DEVICE; return; }
+        }
+        // (the batch entries order their work behind what is queued on the context's stream: the copies above)
+        const int rc = compress ? jpk_dev_blocks_compress(D.c, (int32_t)nb, din.data(), ilen.data(), dout.data(), ocap.data(), ol.data(), stl.data(), in_flight)
+                                : jpk_dev_blocks_decompress(D.c, (int32_t)nb, din.data(), ilen.data(), dout.data(), ocap.data(), ol.data(), stl.data());
+        for (size_t k = 0; k < nb; k++) {
+            const int b = D.blocks[k];
+            stp[b] = rc != JPK_OK && stl[k] == JPK_OK ? rc : stl[k];
+            olen[(size_t)b] = stp[b] == JPK_OK ? ol[k] : 0;
+        }
+        if (rc != JPK_OK) D.rc = rc;
     };
     {
         std::vector<std::thread> th;
@@ -1174,28 +1258,33 @@ extern "C" int jpk_blocks_compress_multi(uint64_t device_mask, int32_t nblocks, 
         for (auto &t : th) t.join();
     }
     int rc = JPK_OK;
-    for (int g = 0; g < G; g++) if (dv[(size_t)g].rc != JPK_OK) rc = dv[(size_t)g].rc;
+    for (int g = 0; g < G; g++)
+        if (dv[(size_t)g].rc != JPK_OK) {
+            rc = dv[(size_t)g].rc;
+            for (int b : dv[(size_t)g].blocks) if (stp[b] == JPK_OK) { stp[b] = rc; olen[(size_t)b] = 0; }     // a failed device: none of its blocks is reported as done
+        }
     for (int b = 0; b < nblocks && rc == JPK_OK; b++) if (stp[b] != JPK_OK) rc = stp[b];
     int64_t total = 0;
-    for (int b = 0; b < nblocks; b++) { out_off[b] = total; total += olen[b]; }
+    for (int b = 0; b < nblocks; b++) { out_off[b] = total; total += olen[(size_t)b]; }
     out_off[nblocks] = total;
     if (rc == JPK_OK && total > out_cap) rc = JPK_E_CAPACITY;
 
-    // the gather: root's own blocks are device-to-device copies; the others travel over RCCL, one send / receive pair per block
+    // the gather: root's own blocks are device-to-device copies; the others travel over RCCL, one send / receive pair per block.
+    // The communicators are used under multi_call_mu() only (this call, and jpk_shutdown destroys them under it).
     static const bool force_rccl = [] { const char *e = getenv("JPK_MULTI_FORCE_RCCL"); return e && atoi(e) != 0; }();
     const bool use_rccl = rc == JPK_OK && (G > 1 || force_rccl);
-    std::vector<jpk_nccl_comm_t> comms;              // (a copy: the cache may grow under another caller)
+    const std::vector<jpk_nccl_comm_t> *comms = nullptr;
     if (use_rccl) {
         std::lock_guard<std::mutex> lk(multi_mu());
         if (!rccl().ok) rc = JPK_E_DEVICE;
         else {
-            for (auto &m : multi_comms()) if (m.devices == devs) comms = m.comms;
-            if (comms.empty()) {
+            for (auto &m : multi_comms()) if (m.devices == devs) comms = &m.comms;
+            if (!comms) {
                 MultiComm m;
                 m.devices = devs;
                 m.comms.resize((size_t)G);
                 if (rccl().CommInitAll(m.comms.data(), G, devs.data()) != 0) rc = JPK_E_DEVICE;
-                else { multi_comms().push_back(m); comms = m.comms; }
+                else { multi_comms().push_back(m); comms = &multi_comms().back().comms; }
             }
         }
     }
@@ -1203,16 +1292,16 @@ extern "C" int jpk_blocks_compress_multi(uint64_t device_mask, int32_t nblocks, 
         if (hipSetDevice(root) != hipSuccess) rc = JPK_E_DEVICE;
         Dev &R = dv[0];
         hipStream_t rs = R.c ? R.c->stream : nullptr;
-        if (rc == JPK_OK && use_rccl && !comms.empty()) {
+        if (rc == JPK_OK && use_rccl && comms) {
             bool grouped = rccl().GroupStart() == 0;
             for (int g = 0; g < G && grouped; g++) {
                 Dev &D = dv[(size_t)g];
                 if (g == 0 && !force_rccl) continue;
                 for (size_t k = 0; k < D.blocks.size(); k++) {
                     const int b = D.blocks[k];
-                    if (olen[b] == 0) continue;
-                    if (rccl().Send(D.outs + D.off[k], (size_t)olen[b], NCCL_UINT8, 0, comms[(size_t)g], D.c->stream) != 0) rc = JPK_E_DEVICE;
-                    if (rccl().Recv(d_out + out_off[b], (size_t)olen[b], NCCL_UINT8, g, comms[0], rs) != 0) rc = JPK_E_DEVICE;
+                    if (olen[(size_t)b] == 0) continue;
+                    if (rccl().Send(D.slab->out + D.ooff[k], (size_t)olen[(size_t)b], NCCL_UINT8, 0, (*comms)[(size_t)g], D.c->stream) != 0) rc = JPK_E_DEVICE;
+                    if (rccl().Recv(d_out + out_off[b], (size_t)olen[(size_t)b], NCCL_UINT8, g, (*comms)[0], rs) != 0) rc = JPK_E_DEVICE;
                 }
             }
             if (!grouped || rccl().GroupEnd() != 0) rc = JPK_E_DEVICE;
@@ -1220,22 +1309,34 @@ extern "C" int jpk_blocks_compress_multi(uint64_t device_mask, int32_t nblocks, 
         if (rc == JPK_OK && !(use_rccl && force_rccl))
             for (size_t k = 0; k < R.blocks.size(); k++) {
                 const int b = R.blocks[k];
-                if (olen[b] && hipMemcpyAsync(d_out + out_off[b], R.outs + R.off[k], (size_t)olen[b], hipMemcpyDeviceToDevice, rs) != hipSuccess) rc = JPK_E_DEVICE;
+                if (olen[(size_t)b] && hipMemcpyAsync(d_out + out_off[b], R.slab->out + R.ooff[k], (size_t)olen[(size_t)b], hipMemcpyDeviceToDevice, rs) != hipSuccess) rc = JPK_E_DEVICE;
             }
-        // every stream that took part has finished before the per-device buffers go away
-        for (int g = 0; g < G; g++) {
-            Dev &D = dv[(size_t)g];
-            if (!D.c) continue;
-            if (hipSetDevice(devs[(size_t)g]) != hipSuccess || hipStreamSynchronize(D.c->stream) != hipSuccess) rc = rc == JPK_OK ? JPK_E_DEVICE : rc;
-        }
     }
+    // every stream that took part has finished before the slabs can be used by the next call (also on the error paths)
     for (int g = 0; g < G; g++) {
         Dev &D = dv[(size_t)g];
-        if (hipSetDevice(devs[(size_t)g]) == hipSuccess && D.outs) (void)hipFree(D.outs);
-        if (D.c) batch_ctx_release(devs[(size_t)g], D.c, generation);
+        if (!D.c) continue;
+        if (hipSetDevice(devs[(size_t)g]) != hipSuccess || hipStreamSynchronize(D.c->stream) != hipSuccess) rc = rc == JPK_OK ? JPK_E_DEVICE : rc;
+        batch_ctx_release(devs[(size_t)g], D.c, generation);
     }
-    (void)hipSetDevice(root);
     return rc;
+}
+}  // namespace
+
+extern "C" int jpk_blocks_compress_multi(uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, uint8_t *d_out, int64_t out_cap,
+                                         int64_t *out_off, int32_t *status)
+{
+    return multi_run(true, device_mask, nblocks, in, in_len, nullptr, d_out, out_cap, out_off, status, 0);
+}
+extern "C" int jpk_blocks_compress_multi_ex(uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, uint8_t *d_out, int64_t out_cap,
+                                            int64_t *out_off, int32_t *status, int32_t in_flight)
+{
+    return multi_run(true, device_mask, nblocks, in, in_len, nullptr, d_out, out_cap, out_off, status, in_flight);
+}
+extern "C" int jpk_blocks_decompress_multi(uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, const int32_t *raw_len, uint8_t *d_out,
+                                           int64_t out_cap, int64_t *out_off, int32_t *status)
+{
+    return multi_run(false, device_mask, nblocks, in, in_len, raw_len, d_out, out_cap, out_off, status, 0);
 }
 
 extern "C" int jpk_init(uint64_t device_mask)
@@ -1266,6 +1367,7 @@ extern "C" int jpk_thread_device(void)
 
 extern "C" void jpk_shutdown(void)
 {
+    std::lock_guard<std::mutex> multi_lock(multi_call_mu());    // no multi-device call is using the communicators / slabs destroyed below
     CtxPool &p = pool();
     std::lock_guard<std::mutex> g(p.mu);
     for (jpk_ctx *c : p.all) jpk_ctx_destroy(c);    // synchronises each context's streams first
@@ -1280,6 +1382,7 @@ extern "C" void jpk_shutdown(void)
             for (jpk_nccl_comm_t cm : m.comms) if (cm && rccl().ok) (void)rccl().CommDestroy(cm);
         multi_comms().clear();
     }
+    multi_slabs_free();
     p.devices.clear();
     p.generation++;
     p.next_thread = 0;

@@ -1299,7 +1299,9 @@ __global__ __launch_bounds__(TB) void k_put_headers(EncDims d, const uint8_t *__
                                                    const uint64_t *__restrict__ outoff, const uint32_t *__restrict__ fstate, uint8_t *__restrict__ out)
 {
     const uint32_t c = blockIdx.x;
-    uint8_t *o = (d.cblk ? d.bout[d.cblk[c]] : out) + outoff[c];
+    uint8_t *const ob = d.cblk ? d.bout[d.cblk[c]] : out;
+    if (!ob) return;                        // group encode: the chunk's block does not fit its buffer (reported JPK_E_CAPACITY): nothing of it is written
+    uint8_t *o = ob + outoff[c];
     const uint32_t hs = hsize[c];
     for (uint32_t i = threadIdx.x; i < hs; i += TB) o[i] = hdr[(size_t)c * HDR_MAX + i];
     if (threadIdx.x < 16) {
@@ -1318,6 +1320,8 @@ __global__ __launch_bounds__(TB) void k_put_payload(const uint32_t *__restrict__
     const uint32_t c = blockIdx.y, tile = blockIdx.x;
     const uint32_t np = 2 * rlen[c];
     if (tile * ETILE >= np) return;
+    uint8_t *const ob = d.cblk ? d.bout[d.cblk[c]] : out;
+    if (!ob) return;                        // (uniform over the workgroup; see k_put_headers)
     const size_t lane_stride = lane_stride_of(d, c, rle_stride), cb = lane_base(d, c, rle_stride);
     // thread t owns the 16 consecutive pairs [j0, j0 + 16) of the tile; suffix sums run from the tile's last pair backwards
     const uint32_t j0 = tile * ETILE + threadIdx.x * 16;
@@ -1335,7 +1339,7 @@ __global__ __launch_bounds__(TB) void k_put_payload(const uint32_t *__restrict__
     uint32_t tot;
     const uint32_t inc = block_incl_scan<OpSum>(n, sm, &tot);
     uint32_t after = tsuf[(size_t)c * etpc + tile] + (tot - inc);       // bytes of all pairs after my 16
-    uint8_t *end = (d.cblk ? d.bout[d.cblk[c]] : out) + outoff[c] + hsize[c] + csize[c];
+    uint8_t *end = ob + outoff[c] + hsize[c] + csize[c];
 #pragma unroll
     for (int k = 15; k >= 0; k--) {
         const uint32_t cnt = e[k] >> 16;
@@ -1751,7 +1755,8 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
 // ---- group encode: the images of several (small) blocks through ONE set of grids ---------------------------------------------
 // Chunks are independent (ans.cpp:136-140), so the chunks of all blocks of a group run through the same launches; a block's image
 // starts at a chunk boundary of the staging buffer `d_stage` (block b at first_chunk[b] * 1 MiB), every chunk knows its length, its
-// block and, through the block, its output buffer; offsets restart at every block.  One host synchronisation per group.
+// block and, through the block, its output buffer; offsets restart at every block.  Host synchronisations per group: the symbol layout (encode_core), the chunk sizes, the end of
+// the emit kernels, and one more when a block does not fit its buffer.
 size_t jpk_ans_encode_group_arena_bytes(uint32_t nchunks, int nblk)
 {
     const EncDims d = make_dims(nchunks * ANS_CHUNK, ANS_CHUNK);
@@ -1794,14 +1799,10 @@ int jpk_ans_encode_group_device(jpk_ctx *ctx, int nblk, const uint8_t *d_stage, 
     for (int k = 0; k < nblk; k++)
         if (tot[k] > (uint64_t)out_cap[k]) { status[k] = JPK_E_CAPACITY; all_fit = false; }
     if (!all_fit) {
-        // a block that does not fit its buffer must not be written: its chunks get a null... simplest exact behaviour: place only the
-        // blocks that fit, by pointing the others at a scratch sink inside the arena sized for the largest of them
-        uint64_t worst = 0;
-        for (int k = 0; k < nblk; k++) if (status[k] != JPK_OK && tot[k] > worst) worst = tot[k];
-        if (ctx->arena_off + (size_t)worst + 256 > ctx->arena_cap) return JPK_E_CAPACITY;      // no room for the sink: the group as a whole is reported
-        uint8_t *sink = ctx->arena + ctx->arena_off;
+        // a block that does not fit its buffer is not written at all: its entry of the output table becomes null and the two emit
+        // kernels skip its chunks; the blocks that fit are emitted as usual (no scratch sink, no whole-group failure)
         std::vector<uint8_t *> outs(d_out, d_out + nblk);
-        for (int k = 0; k < nblk; k++) if (status[k] != JPK_OK) outs[k] = sink;
+        for (int k = 0; k < nblk; k++) if (status[k] != JPK_OK) outs[k] = nullptr;
         JPK_HIP(hipMemcpyAsync(d_bout, outs.data(), sizeof(uint8_t *) * (size_t)nblk, hipMemcpyHostToDevice, st));
         JPK_HIP(hipStreamSynchronize(st));                                     // (`outs` is a local: the copy must have read it)
     }

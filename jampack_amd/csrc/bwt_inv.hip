@@ -611,22 +611,33 @@ int jpk_inv_bwt_chains120_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len_
 static uint32_t inv_sorted_len(int32_t len_with_trailer) { const int32_t len = len_with_trailer - JPK_TRAILER_BYTES; return (uint32_t)(len - len % JPK_BWT_UNITS); }
 
 // arena bytes of a batch (from ctx->arena_base): the job table, the shared tile table and its scan scratch, every job's own buffers
-size_t jpk_inv_bwt_batch_arena_bytes(int njobs, const int32_t *len_with_trailer)
+// (incrementally: a job adds its own buffers and its tiles; the tables depend on the job count and the tile total -- the group
+// planner of jpk_dev_blocks_decompress extends a group block by block without re-planning the prefix)
+void jpk_inv_bwt_batch_plan_add(int32_t len_with_trailer, size_t *job_bytes, size_t *tiles)
 {
     jpk_ctx dummy;
     Arena plan(&dummy, true);
-    size_t tiles = 0;
-    for (int q = 0; q < njobs; q++) {
-        const uint32_t n = inv_sorted_len(len_with_trailer[q]);
-        InvBufs b;
-        size_t ntiles, nsplit, max_slots;
-        inv_job_layout(plan, n ? n : 1, b, ntiles, nsplit, max_slots);
-        tiles += ntiles;
-    }
+    const uint32_t n = inv_sorted_len(len_with_trailer);
+    InvBufs b;
+    size_t ntiles, nsplit, max_slots;
+    inv_job_layout(plan, n ? n : 1, b, ntiles, nsplit, max_slots);
+    *job_bytes += plan.need;
+    *tiles += ntiles;
+}
+size_t jpk_inv_bwt_batch_plan_total(int njobs, size_t job_bytes, size_t tiles)
+{
+    jpk_ctx dummy;
+    Arena plan(&dummy, true);
     plan.get<InvJob>((size_t)njobs);
     plan.get<uint32_t>(256 * tiles);
     plan.get<uint32_t>(jpk_scan_scratch_words(256 * tiles));
-    return plan.need + (1u << 20);
+    return job_bytes + plan.need + (1u << 20);
+}
+size_t jpk_inv_bwt_batch_arena_bytes(int njobs, const int32_t *len_with_trailer)
+{
+    size_t job_bytes = 0, tiles = 0;
+    for (int q = 0; q < njobs; q++) jpk_inv_bwt_batch_plan_add(len_with_trailer[q], &job_bytes, &tiles);
+    return jpk_inv_bwt_batch_plan_total(njobs, job_bytes, tiles);
 }
 
 // Enqueues the inverse BWTs of `njobs` images (each with >= 120 sorted bytes: len - 480 >= 120) on ctx->stream, no host round trip;
@@ -637,6 +648,7 @@ int jpk_inv_bwt_batch_enqueue(jpk_ctx *ctx, int njobs, const uint8_t *const *d_i
                               const int *verdict_slot, std::vector<uint8_t> &host_jobs)
 {
     if (njobs <= 0) return JPK_OK;
+    if (njobs > JPK_INV_BATCH_MAX_JOBS) return JPK_E_ARG;      // blockIdx.y = the job: the grid's y extent is 65 535 (the caller cuts its groups there)
     hipStream_t st = ctx->stream;
     if (!jpk_arena_fits(ctx, ctx->arena_base + jpk_inv_bwt_batch_arena_bytes(njobs, len_with_trailer))) return JPK_E_ALLOC;
     Arena real(ctx, false);

@@ -193,6 +193,9 @@ int jpk_ans_encode_group_device(jpk_ctx *ctx, int nblk, const uint8_t *d_stage, 
 size_t jpk_ans_encode_group_arena_bytes(uint32_t nchunks, int nblk);
 size_t jpk_inv_bwt_arena_bytes(uint32_t n);
 size_t jpk_inv_bwt_batch_arena_bytes(int njobs, const int32_t *len_with_trailer);
+constexpr int JPK_INV_BATCH_MAX_JOBS = 65535;               // one set of launches, blockIdx.y = the job
+void jpk_inv_bwt_batch_plan_add(int32_t len_with_trailer, size_t *job_bytes, size_t *tiles);
+size_t jpk_inv_bwt_batch_plan_total(int njobs, size_t job_bytes, size_t tiles);
 int jpk_inv_bwt_batch_enqueue(jpk_ctx *ctx, int njobs, const uint8_t *const *d_in, const int32_t *len_with_trailer, uint8_t *const *d_out, uint32_t *d_verdict,
                               const int *verdict_slot, std::vector<uint8_t> &host_jobs);
 size_t jpk_fwd_bwt_arena_bytes(uint32_t n);

@@ -72,13 +72,61 @@ def test_enwik8_like_tail_block(gpu):
     _roundtrip(torch, jam, ctx, t)
 
 
-def test_silesia_like_212mb_block(gpu):
-    """config 5: one mixed block (text, 16-bit samples, random, DNA, runs, 1 MiB segment repeated) of 211 938 580 B"""
+def _same_as_reference(ref, t, d_bwt, d_enc):
+    """SHA-256 of the BWT image and of the rANS stream against the reference build on the same block (bwt.cpp:22-65, ans.cpp:113-234)"""
+    rb = ref.bwt_forward(t)
+    assert hashlib.sha256(rb.tobytes()).hexdigest() == _sha(d_bwt)
+    re_ = ref.ans_encode(rb)
+    assert len(re_) == d_enc.numel() and hashlib.sha256(re_.tobytes()).hexdigest() == _sha(d_enc)
+
+
+def test_bench_block_64mib_text_survey(gpu, ref):
+    """the bench line's own first block (workload enwik8 = SURVEY 8d's text model, 28 byte values: 11-byte keys)"""
+    torch, jam, ctx = gpu
+    t, _ = jam.corpus.load_or_make("enwik8", start=0, count=64 << 20)
+    assert len(t) == 64 << 20
+    d_bwt, d_enc = _roundtrip(torch, jam, ctx, t)
+    assert ctx.stats().sa_key_depth == 11
+    _same_as_reference(ref, t, d_bwt, d_enc)
+
+
+@pytest.mark.parametrize("kind", ["text_wide", "silesia", "samples16"])
+def test_wide_alphabet_64mib_blocks_equal_the_reference(gpu, ref, kind):
+    """the path real data takes -- more than 128 byte values: 7-byte keys, five and more rounds -- compared with the reference's BYTES at
+    full size (VERDICT r4 #3): an enwik8-like alphabet (207 values), the mixed block, 16-bit samples"""
+    torch, jam, ctx = gpu
+    t = jam.corpus.make(kind, 64 << 20, 5)
+    d_bwt, d_enc = _roundtrip(torch, jam, ctx, t)
+    s = ctx.stats()
+    assert s.sa_key_depth == 7, s.sa_key_depth
+    _same_as_reference(ref, t, d_bwt, d_enc)
+
+
+def test_silesia_like_212mb_block(gpu, ref):
+    """config 5: one mixed block (text, 16-bit samples, random, DNA, runs, 1 MiB segment repeated) of 211 938 580 B, 256 byte values:
+    the reference's bytes (15 s of host time), and the repeated segment no longer costs log2(LCP) doubling rounds (round 4: 21)"""
     torch, jam, ctx = gpu
     t = jam.corpus.make("silesia", 211_938_580, 5)
-    _roundtrip(torch, jam, ctx, t)
+    d_bwt, d_enc = _roundtrip(torch, jam, ctx, t)
     s = ctx.stats()
-    assert s.sa_rounds >= 10          # the repeated 1 MiB segment needs log2(LCP) doubling rounds
+    assert s.sa_rounds <= 12 and s.sa_pair_rounds != 0, (s.sa_rounds, bin(s.sa_pair_rounds))
+    _same_as_reference(ref, t, d_bwt, d_enc)
+
+
+def test_grouped_8mib_wide_alphabet_blocks_equal_the_reference(gpu, ref):
+    """the reference's default block size through the grouped path of jpk_dev_blocks_compress (one suffix sort per group), wide alphabet"""
+    torch, jam, ctx = gpu
+    dev = torch.device("cuda", 0)
+    data = jam.corpus.make("text_wide", 3 * (8 << 20) + 12345, 21)
+    blocks = jam.corpus.split_blocks(data, 8 << 20)
+    d_in = [torch.from_numpy(np.ascontiguousarray(b)).to(dev) for b in blocks]
+    caps = [jam.ans_capacity(len(b) + 480) for b in blocks]
+    d_out = [torch.empty(c, dtype=torch.uint8, device=dev) for c in caps]
+    n, st = ctx.blocks_compress(d_in, [len(b) for b in blocks], d_out, caps, 2)
+    assert st == [0] * len(blocks)
+    for i, b in enumerate(blocks):
+        want = ref.ans_encode(ref.bwt_forward(b))
+        assert n[i] == len(want) and hashlib.sha256(want.tobytes()).hexdigest() == _sha(d_out[i][: n[i]]), i
 
 
 def test_worst_case_blocks_16mib(gpu, oracle):

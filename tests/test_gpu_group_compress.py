@@ -100,3 +100,44 @@ def test_many_one_mib_blocks_through_one_call(gpu, oracle):
     for i in (0, 13, 39):
         want = oracle.ans_encode(oracle.bwt_forward(blocks[i]))
         assert n[i] == len(want) and np.array_equal(d_out[i][: n[i]].cpu().numpy(), want), i
+
+
+_HOOK_CHILD = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import jampack_amd as jam
+from jampack_amd._lib import lib
+dev = torch.device("cuda", 0)
+ctx = jam.Context(0, torch.cuda.current_stream().cuda_stream)
+blocks = [jam.corpus.make(k, n, 9 + i) for i, (k, n) in enumerate((("text_survey", 1 << 20), ("random", 300_000), ("dna", 2_000_001), ("zero", 70_000), ("text", 1_500_000)))]
+d_in = [torch.from_numpy(b).to(dev) for b in blocks]
+caps = [jam.ans_capacity(len(b) + 480) for b in blocks]
+def run(caps_now):
+    d_out = [torch.zeros(max(c, 1), dtype=torch.uint8, device=dev) for c in caps_now]
+    n, st = ctx.blocks_compress(d_in, [len(b) for b in blocks], d_out, caps_now, 2)
+    return n, st, [d_out[i][: n[i]].cpu().numpy() for i in range(len(blocks))], d_out
+n0, st0, ref, _ = run(caps)
+assert st0 == [0] * len(blocks)
+# 1. the whole group fails before it runs (as if its arena could not be had): every block comes back through the single-block path
+assert lib().jpk_debug_group_fail_next(1) == 0
+n1, st1, got, _ = run(caps)
+assert st1 == [0] * len(blocks) and list(n1) == list(n0) and all(np.array_equal(a, b) for a, b in zip(ref, got)), (st1, n1, n0)
+# 2. one block's buffer is too small: that block alone says JPK_E_CAPACITY, nothing is written to its buffer, the others are complete
+small = list(caps); small[2] = 1000
+n2, st2, got2, d_out2 = run(small)
+assert st2 == [0, 0, -2, 0, 0], st2
+assert int(d_out2[2].max().item()) == 0
+for i in (0, 1, 3, 4):
+    assert n2[i] == n0[i] and np.array_equal(got2[i], ref[i]), i
+print("GROUP_HOOK_OK")
+"""
+
+
+def test_a_failed_group_is_retried_block_by_block_and_a_small_buffer_fails_alone():
+    """a group-level failure used to fail every block of the group (up to 256); the decode combiner already had this fallback"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JPK_DEBUG_HOOKS="1")
+    r = subprocess.run([sys.executable, "-c", _HOOK_CHILD % root], env=env, capture_output=True, text=True, timeout=600)
+    assert "GROUP_HOOK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -1,7 +1,9 @@
-"""jpk_blocks_compress_multi on the 1-GPU box (world 1): host blocks in, compressed blocks gathered in block order on the root
-device, each equal to the single-block entry point's bytes; once with the root's own blocks copied device-to-device and once
-(subprocess, JPK_MULTI_FORCE_RCCL=1) through an RCCL send/receive to itself, which loads librccl and builds the single-process
-communicator.  No multi-GPU hardware number exists; tests/test_abi_and_host.py covers the ownership rule for 2..8 devices.  -m gpu"""
+"""jpk_blocks_compress_multi / jpk_blocks_decompress_multi on the 1-GPU box (world 1; jampack.cpp:205-224, 286-317 over the GPUs of a
+node): host blocks in, results gathered in block order on the root device, each equal to the single-block entry point's bytes; once
+with the root's own blocks copied device-to-device and once (subprocess, JPK_MULTI_FORCE_RCCL=1) through an RCCL send/receive to
+itself, which loads librccl and builds the single-process communicator.  Every device runs its blocks through the library's batch
+entries (blocks in flight, grouped small blocks): the multi entry must stay within 10 % of jpk_dev_blocks_compress on the same blocks.
+No multi-GPU hardware number exists; tests/test_abi_and_host.py covers the ownership rule for 2..8 devices.  -m gpu"""
 import os
 import subprocess
 import sys
@@ -39,8 +41,58 @@ try:
     raise SystemExit("expected a capacity error")
 except jam.JampackError as e:
     assert e.status == -2, e.status
+# the decompress direction: the compressed blocks (host) come back as the blocks' bytes, in block order, on the root
+comp = [out[off[i]: off[i + 1]].copy() for i in range(len(blocks))]
+raw = [len(b) for b in blocks]
+d_back = torch.empty(sum(raw) + 64, dtype=torch.uint8, device=dev)
+doff, dst = jam.blocks_decompress_multi(comp, raw, d_back, sum(raw) + 64, 0b1)
+assert dst == [0] * len(blocks), dst
+back = d_back.cpu().numpy()
+for i, t in enumerate(blocks):
+    assert doff[i + 1] - doff[i] == len(t) and np.array_equal(back[doff[i]: doff[i + 1]], t), i
+# a corrupt block fails alone
+bad = [c.copy() for c in comp]
+bad[0][len(bad[0]) // 2] ^= 0x55
+try:
+    jam.blocks_decompress_multi(bad, raw, d_back, sum(raw) + 64, 0b1)
+    raise SystemExit("expected an error for the corrupt block")
+except jam.JampackError as e:
+    assert e.status in (-3, -2), e.status
+# the caller's device is what it was, and a second call re-uses the slabs
+assert torch.cuda.current_device() == 0
+off2, st2 = jam.blocks_compress_multi(blocks, d_out, cap, 0b1, 4)
+assert off2 == off and st2 == st and np.array_equal(d_out.cpu().numpy()[: off[-1]], out[: off[-1]])
 jam.shutdown()
 print("multi ok")
+'''
+
+SPEED = r'''
+import sys, time
+sys.path.insert(0, %r)
+import numpy as np, torch
+import jampack_amd as jam
+dev = torch.device("cuda", 0)
+blocks = [jam.corpus.make("text_survey", 32 << 20, 70 + i) for i in range(12)]
+cap = sum(jam.ans_capacity(len(b) + 480) for b in blocks)
+d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+ctx = jam.Context(0, torch.cuda.current_stream().cuda_stream)
+d_in = [torch.from_numpy(b).to(dev) for b in blocks]
+caps = [jam.ans_capacity(len(b) + 480) for b in blocks]
+d_o = [torch.empty(c, dtype=torch.uint8, device=dev) for c in caps]
+def t_batch():
+    t0 = time.perf_counter(); n, st = ctx.blocks_compress(d_in, [len(b) for b in blocks], d_o, caps, 8); torch.cuda.synchronize(); return time.perf_counter() - t0, n
+def t_multi():
+    t0 = time.perf_counter(); off, st = jam.blocks_compress_multi(blocks, d_out, cap, 0b1, 8); torch.cuda.synchronize(); return time.perf_counter() - t0, off
+t_batch(); t_multi()
+tb = min(t_batch()[0] for _ in range(3)); n = t_batch()[1]
+tm = min(t_multi()[0] for _ in range(3)); off = t_multi()[1]
+tot = sum(len(b) for b in blocks)
+pcie = tot / 45e9                       # the multi entry also moves the blocks in from (pageable) host memory
+print("batch %%.1f ms = %%.0f MB/s, multi %%.1f ms = %%.0f MB/s (host copies ~%%.1f ms inside)" %% (tb * 1e3, tot / tb / 1e6, tm * 1e3, tot / tm / 1e6, pcie * 1e3))
+assert [off[i + 1] - off[i] for i in range(len(blocks))] == list(n)
+assert tm - pcie <= 1.10 * tb + 0.005, (tm, tb)
+jam.shutdown()
+print("speed ok")
 '''
 
 
@@ -51,3 +103,11 @@ def test_blocks_compress_multi_world1(force_rccl):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-c", BODY % ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "multi ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_multi_entry_runs_at_the_batch_entry_speed():
+    """every device drives its blocks through jpk_dev_blocks_compress (8 in flight), not one block at a time: within 10 %
+    of that entry on the same blocks once the host-to-device copies the multi entry has to make are taken out"""
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, "-c", SPEED % ROOT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "speed ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -1,10 +1,12 @@
 #!/bin/bash
 # same-box A/B of two builds of the library on the small-block streams:  bash tools/ab_lib.sh   (tools/_bin/libjampack_amd_prev.so = the build to compare with)
-cp jampack_amd/libjampack_amd.so /tmp/new.so
+# The build is chosen per process through JPK_LIB (jampack_amd/_lib.py): the product library is never replaced in place.
+set -u
+prev=tools/_bin/libjampack_amd_prev.so
+[ -f "$prev" ] || { echo "missing $prev" >&2; exit 1; }
 for r in 1 2; do
   for v in prev new; do
-    if [ $v = prev ]; then cp tools/_bin/libjampack_amd_prev.so jampack_amd/libjampack_amd.so; else cp /tmp/new.so jampack_amd/libjampack_amd.so; fi
-    echo "== $v"; timeout 300 python tools/small_blocks.py 1,8 8,16 2>&1 | grep -v amdgpu | tail -2
+    if [ $v = prev ]; then lib=$PWD/$prev; else lib=$PWD/jampack_amd/libjampack_amd.so; fi
+    echo "== $v"; JPK_LIB=$lib timeout 300 python tools/small_blocks.py 1,8 8,16 2>&1 | grep -v amdgpu | tail -2
   done
 done
-cp /tmp/new.so jampack_amd/libjampack_amd.so
