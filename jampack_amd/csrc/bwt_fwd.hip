@@ -65,6 +65,17 @@ struct SaState {
     uint64_t rep;                          // the key field of "code 1 repeated depth times": code * rep = a run of that code
     uint32_t present[256];                 // byte value occurs in the text
     uint8_t lut[256];                      // byte -> code
+    // variable-length keys (vmode, round 5): an order-preserving PREFIX code of the block's bytes -- weight-balanced on a sampled
+    // histogram -- instead of the fixed-width one: a key holds as many symbols as fit its 56 bits (about 56 / H0: ten for enwik8's 205
+    // byte values where the fixed code holds seven) and every group of tied suffixes carries its own depth (GD, see build_sa)
+    uint32_t vmode;
+    uint32_t tag_shift, tag_max;           // a key's depth rides in the sorted value's bits from tag_shift up: at most tag_max (26 and 63 up to 2^26 bytes)
+    uint32_t cnt[256];                     // sampled byte counts (k_sym_present: every sixteenth 16-byte vector)
+    uint32_t vcode[256];                   // code of byte b, right-justified in vlen[b] bits
+    uint8_t vlen[256];
+    uint8_t vrun_d[256];                   // symbols of a run of byte b that one key holds: 56 / vlen[b]
+    uint16_t vtop[256];                    // the byte whose code (of at most 8 bits) starts these 8 bits, 0xFFFF: none
+    uint64_t vrunkey[256];                 // the 56-bit key of a run of byte b
 };
 static_assert(offsetof(SaState, depth) == offsetof(SaState, round_m) + sizeof(uint32_t) * (2 * JPK_SA_MAX_ROUNDS + 1), "the statistics copy takes round_m, round_lc, bits, depth in one piece");
 
@@ -128,7 +139,9 @@ __device__ __forceinline__ uint32_t wg_scan(const uint32_t *in, uint32_t *out, u
 __global__ __launch_bounds__(TB) void k_sym_present(const uint8_t *__restrict__ T, uint32_t n, SaState *__restrict__ st)
 {
     __shared__ uint32_t f[256];
+    __shared__ uint32_t c[256];           // sampled counts: every sixteenth vector (the variable-length code is built from them)
     f[threadIdx.x] = 0u;
+    c[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t mis0 = (uint32_t)((16u - ((uintptr_t)T & 15u)) & 15u), mis = mis0 < n ? mis0 : n;
     const uint4 *V = reinterpret_cast<const uint4 *>(T + mis);
@@ -144,19 +157,35 @@ __global__ __launch_bounds__(TB) void k_sym_present(const uint8_t *__restrict__ 
         for (int q = 0; q < 4; q++)
 #pragma unroll
             for (int b = 0; b < 4; b++) f[(ws[q] >> (8 * b)) & 255u] = 1u;      // (plain stores of the same value: no atomics)
+        if ((v & 15u) == 0u) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) atomicAdd(&c[(ws[q] >> (8 * b)) & 255u], 1u);
+        }
     }
     __syncthreads();
     if (f[threadIdx.x]) st->present[threadIdx.x] = 1u;
+    if (c[threadIdx.x]) atomicAdd(&st->cnt[threadIdx.x], c[threadIdx.x]);
 }
 
 // one workgroup of 256: code of every byte value, bits per code, bytes per key.  force_bits: 0 = from the alphabet, 8 = plain bytes.
-__global__ __launch_bounds__(256) void k_key_plan(SaState *__restrict__ st, int force_bits)
+// want_var: build the variable-length code as well (vmode): thread b walks the weight-balanced splitting of the occurring bytes from
+// the root to its own leaf -- at every node the byte range [l, r) is cut where the sampled weight is halved, left = 0, right = 1 -- which
+// is an alphabetic (order-preserving) prefix code with an average length below H0 + 2 (5.3 bits on an enwik8-like alphabet whose
+// H0 is 5.05; Hu-Tucker's optimum is 5.2).  A code longer than 28 bits (it cannot happen with sampled weights + 1) drops to the
+// fixed-width code.
+__global__ __launch_bounds__(256) void k_key_plan(SaState *__restrict__ st, int force_bits, int want_var, int tag_shift)
 {
     __shared__ uint32_t sm[256 / 64 + 1];
+    __shared__ uint32_t cpre[257];             // exclusive prefix of the weights of the occurring bytes, in byte order
+    __shared__ uint32_t lcode[256];
+    __shared__ uint8_t llen[256];
     const uint32_t here = st->present[threadIdx.x] ? 1u : 0u;
     uint32_t sigma;
     const uint32_t inc = block_incl_scan<OpSum>(here, sm, &sigma);
-    st->lut[threadIdx.x] = (uint8_t)(inc - here);
+    const uint32_t idx = inc - here;
+    st->lut[threadIdx.x] = (uint8_t)idx;
     if (threadIdx.x == 0) {
         uint32_t bits = 1;
         while ((1u << bits) < sigma) bits++;
@@ -167,6 +196,77 @@ __global__ __launch_bounds__(256) void k_key_plan(SaState *__restrict__ st, int 
         st->bits = bits;
         st->depth = depth;
         st->rep = rep;
+    }
+    if (!want_var || force_bits > 0) return;          // (uniform)
+    const uint32_t w = here ? st->cnt[threadIdx.x] + 1u : 0u;
+    uint32_t wtot;
+    const uint32_t winc = block_incl_scan<OpSum>(w, sm, &wtot);
+    if (here) cpre[idx] = winc - w;
+    if (threadIdx.x == 0) cpre[sigma] = wtot;
+    __syncthreads();
+    uint32_t code = 0, len = 0;
+    if (here) {
+        uint32_t l = 0, r = sigma;
+        while (r - l > 1u) {
+            const uint64_t tgt2 = (uint64_t)cpre[l] + cpre[r];            // twice the weight at which [l, r) is halved
+            uint32_t lo = l + 1u, hi = r - 1u;                            // the cut m lies in [l + 1, r - 1]: first index with 2 cpre[m] >= tgt2
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (2ull * cpre[mid] >= tgt2) hi = mid; else lo = mid + 1u;
+            }
+            uint32_t m = lo;
+            if (m - 1u > l) {
+                const uint64_t a = 2ull * cpre[m], b = 2ull * cpre[m - 1u];
+                const uint64_t da = a > tgt2 ? a - tgt2 : tgt2 - a, db = b > tgt2 ? b - tgt2 : tgt2 - b;
+                if (db < da) m--;
+            }
+            if (idx < m) { r = m; code <<= 1; } else { l = m; code = (code << 1) | 1u; }
+            len++;
+            if (len > 30u) break;
+        }
+        if (len == 0u) len = 1u;                                          // one byte value: the code is "0"
+    }
+    lcode[threadIdx.x] = code;
+    llen[threadIdx.x] = (uint8_t)len;
+    uint32_t maxlen;
+    block_incl_scan<OpMax>(len, sm, &maxlen);
+    uint32_t wl;                                                          // sum of weight x length: the average code length
+    // (32-bit: weights are sampled, at most n / 16 + 256 in all, lengths <= 30 -- below 2^32 for blocks of 2^26 bytes)
+    block_incl_scan<OpSum>(w * len, sm, &wl);
+    __syncthreads();
+    if (maxlen > 28u) return;                                             // vmode stays 0: the fixed-width code
+    {   // ... and when the code does not buy at least 3/4 of a symbol per key over the fixed width (near-uniform alphabets: random bytes,
+        // DNA, 16-bit samples -- a balanced code of a flat histogram IS the fixed code, a slightly skewed one can even be longer)
+        uint32_t fb = 1;
+        while ((1u << fb) < sigma) fb++;
+        const uint32_t fixed_d = 56u / fb;
+        if (224ull * wtot < (uint64_t)wl * (4u * fixed_d + 3u)) return;
+    }
+    st->vcode[threadIdx.x] = code;
+    st->vlen[threadIdx.x] = (uint8_t)len;
+    if (here) {
+        const uint32_t d = 56u / len;
+        uint64_t k = 0;
+        for (uint32_t i = 0; i < d; i++) k = (k << len) | code;
+        const uint32_t left = 56u - d * len;                              // bits behind the last whole symbol: the start of one more
+        k = (k << left) | (left ? (uint64_t)(code >> (len - left)) : 0ull);
+        st->vrun_d[threadIdx.x] = (uint8_t)d;
+        st->vrunkey[threadIdx.x] = k;
+    }
+    {   // the byte whose code, of at most 8 bits, starts the 8 bits `threadIdx.x`
+        uint32_t hit = 0xFFFFu;
+        for (uint32_t b = 0; b < 256u; b++) {
+            const uint32_t lb = llen[b];
+            if (lb && lb <= 8u && st->present[b] && (threadIdx.x >> (8u - lb)) == lcode[b]) hit = b;
+        }
+        st->vtop[threadIdx.x] = (uint16_t)hit;
+    }
+    if (threadIdx.x == 0) {
+        st->vmode = 1u;
+        st->tag_shift = (uint32_t)tag_shift;
+        st->tag_max = (tag_shift <= 26) ? 63u : ((1u << (32 - tag_shift)) - 1u);
+        const uint32_t avg_d = wl ? (uint32_t)((56ull * wtot) / wl) : 56u;   // symbols an average key holds (the statistics' key depth)
+        st->depth = avg_d ? avg_d : 1u;
     }
 }
 
@@ -223,13 +323,58 @@ __device__ __forceinline__ void pack_tile(const uint8_t *cc, const uint8_t *cr, 
     }
 #undef JPK_BYTE
 }
+// Variable-length keys (vmode): the same tile, every byte as its prefix code.  A thread builds the key of its LAST position from
+// scratch -- whole symbols while they fit the 56 bits, then the leading bits of one more -- and rolls backwards over its other
+// fifteen: key(i) = code(T[i]) in front of key(i + 1) shifted right by its length, and the count of WHOLE symbols in the key (its
+// depth) follows with an end pointer that only moves backwards.  Symbols past the end of the text are zero bits and do not count: a
+// suffix whose depth reaches the end is shorter than anything it ties with and becomes a group of its own (k_r0_*).  dk[x] = depth of
+// slot x (< 64: rides in bits 26..31 of the slot's value through the radix sort).
+__device__ __forceinline__ void pack_tile_var(const uint8_t *cr, const uint32_t *lcode, const uint8_t *llen, uint64_t *ko, uint8_t *dk, int64_t i_lo, uint32_t n,
+                                              uint32_t tag_max)
+{
+    constexpr uint64_t M56 = (1ull << 56) - 1ull;
+    const int t = threadIdx.x;
+    const int q15 = 16 + 16 * t + 15;                                  // staging index of the thread's last position (index q = position i_lo - 16 + q)
+    uint64_t acc = 0;
+    uint32_t used = 0;                                                 // bits of the whole symbols [q, e) of the current key
+    int e = q15;
+    {
+        const int64_t p15 = i_lo + 16 * t + 15;
+        if (p15 >= 0) {
+            for (;;) {
+                if (i_lo - 16 + e >= (int64_t)n) break;                // the text ends: zero bits from here on
+                const uint32_t b = cr[e], l = llen[b], c = lcode[b];
+                if (used + l <= 56u) { acc |= (uint64_t)c << (56u - used - l); used += l; e++; if (used == 56u) break; }
+                else { acc |= (uint64_t)c >> (l - (56u - used)); break; }
+            }
+        }
+    }
+#pragma unroll 1
+    for (int s = 15; s >= 0; s--) {
+        const int64_t i = i_lo + 16 * t + s;
+        if (i < 0) break;                                              // (the last tile: positions in front of the text)
+        const int q = 16 + 16 * t + s;
+        if (s < 15) {
+            const uint32_t b = cr[q], l = llen[b], c = lcode[b];
+            acc = (((uint64_t)c << (56u - l)) | (acc >> l)) & M56;
+            used += l;
+            while (used > 56u) { e--; used -= llen[cr[e]]; }
+        }
+        const uint32_t prev = i ? cr[q - 1] : 0u;
+        const uint32_t x = (uint32_t)(CT - 1 - 16 * t - s);
+        ko[x + (x >> 4)] = (acc << 8) | prev;
+        const uint32_t d = (uint32_t)(e - q);
+        dk[x] = (uint8_t)(d < tag_max ? d : tag_max);        // (a clamped depth is still a number of symbols the key's group shares)
+    }
+}
 // The tile is also a tile of the radix sort's first pass (same 4096 slots): for the two-pass form of the sort its digit histogram (key
 // bits 15..8) is counted here, from LDS, so that pass has no histogram kernel of its own (tilehist: digit-major [256][ntiles], radix.hip;
 // null for the one-pass form).
 __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T, uint32_t n, const SaState *__restrict__ st, uint64_t *__restrict__ P,
-                                                 const uint8_t *__restrict__ blk, const uint32_t *__restrict__ bend, uint32_t *__restrict__ tilehist)
+                                                 const uint8_t *__restrict__ blk, const uint32_t *__restrict__ bend, uint32_t *__restrict__ tilehist,
+                                                 uint8_t *__restrict__ D0)
 {
-    __shared__ uint32_t hd[WAVES][256];
+    __shared__ uint32_t hd[WAVES][256];                               // (vmode: [0] = the codes, [1] = their lengths; the slots' depths go where the fixed codes go)
     __shared__ __align__(16) uint8_t cc[CT + PK_HALO];                // codes
     __shared__ __align__(16) uint8_t cr[CT + PK_HALO];                // bytes
     __shared__ __align__(16) uint8_t cb[CT + PK_HALO];                // block numbers (group sort)
@@ -237,6 +382,10 @@ __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T,
     __shared__ uint8_t lut[256];
     lut[threadIdx.x] = st->lut[threadIdx.x];
     const uint32_t bits = st->bits;
+    const bool vmode = D0 && st->vmode;                                // (uniform; only the single-block sort with the one-pass radix asks for it)
+    uint32_t *const lcode = &hd[0][0];
+    uint8_t *const llen = reinterpret_cast<uint8_t *>(&hd[1][0]), *const dk = cc;
+    if (vmode) { lcode[threadIdx.x] = st->vcode[threadIdx.x]; llen[threadIdx.x] = st->vlen[threadIdx.x]; }
     const uint32_t ntiles = (n + CT - 1) / CT;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * CT, cnt = (n - base < (uint32_t)CT) ? n - base : (uint32_t)CT;
@@ -247,10 +396,21 @@ __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T,
             const bool in = p >= 0 && p < (int64_t)n;
             const uint32_t raw = in ? T[p] : 0u;
             cr[q] = (uint8_t)raw;
-            cc[q] = in ? lut[raw] : (uint8_t)0;
+            if (!vmode) cc[q] = in ? lut[raw] : (uint8_t)0;
             if (blk) cb[q] = in ? blk[p] : (uint8_t)0;
         }
         __syncthreads();
+        if (vmode) {
+            pack_tile_var(cr, lcode, llen, ko, dk, i_lo, n, st->tag_max);
+            __syncthreads();
+            const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll
+            for (int it = 0; it < CT_ITEMS; it++) {
+                const uint32_t x = (uint32_t)(w * (64 * CT_ITEMS) + it * 64 + l);
+                if (x < cnt) { P[base + x] = ko[x + (x >> 4)]; D0[base + x] = dk[x]; }
+            }
+            continue;
+        }
         switch (bits) {
         case 1: pack_tile<1>(cc, cr, cb, ko, i_lo, n, bend); break;
         case 2: pack_tile<2>(cc, cr, cb, ko, i_lo, n, bend); break;
@@ -299,12 +459,19 @@ __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T,
 // Group sort (bend != null: several blocks sorted as one text, the key's low byte = block number, see radix.hip): the whole key
 // takes part in the comparison, and a suffix is "short" when fewer than D bytes are left in ITS block.
 __device__ __forceinline__ uint32_t r0_end(uint64_t key, uint32_t n, const uint32_t *__restrict__ bend) { return bend ? bend[(uint32_t)key & 255u] : n; }
+// vmode (variable-length keys): the sorted value carries the key's depth in its upper bits (from SaState::tag_shift up) and a
+// suffix is "short" (a group of its own) when its depth reaches the end of the text: every symbol it has is in the key
+// (in vmode the parameter D of the helpers below is the tag shift, not a depth)
+__device__ __forceinline__ bool r0_short(uint32_t v, uint64_t key, uint32_t n, const uint32_t *__restrict__ bend, uint32_t D, bool vmode)
+{
+    return vmode ? (v & ((1u << D) - 1u)) + (v >> D) >= n : v + D > r0_end(key, n, bend);
+}
 __device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t j, uint32_t n, const uint32_t *__restrict__ bend,
-                                        uint32_t D)
+                                        uint32_t D, bool vmode)
 {
     if (j == 0) return true;
     const uint64_t a = keys[j], b = keys[j - 1];
-    return ((a ^ b) >> (bend ? 0 : 8)) != 0ull || sa[j] + D > r0_end(a, n, bend) || sa[j - 1] + D > r0_end(b, n, bend);   // bits 7..0 carry T[sa-1], not key
+    return ((a ^ b) >> (bend ? 0 : 8)) != 0ull || r0_short(sa[j], a, n, bend, D, vmode) || r0_short(sa[j - 1], b, n, bend, D, vmode);   // bits 7..0 carry T[sa-1], not key
 }
 
 // head words of one 4096-slot tile: HE[word] = heads | slots past the end (so that "the next slot is a head" is one shift),
@@ -312,8 +479,9 @@ __device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const
 // in flight together (clamped indices, no branch around a load), and hands them back to the caller; the key in front of a slot
 // comes from the neighbouring lane (DPP wave shift; lane 0: lane 63 of the row before, the wave's first row: one extra load),
 // and "the suffix in front is shorter than D bytes" is the shifted ballot of the row's own "short" bits.
+// (vmode: sj[] comes back WITH the depth tag in its upper bits)
 __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n, uint32_t base, uint64_t *HE,
-                                              uint64_t (&kj)[CT_ITEMS], uint32_t (&sj)[CT_ITEMS], const uint32_t *__restrict__ bend, uint32_t D)
+                                              uint64_t (&kj)[CT_ITEMS], uint32_t (&sj)[CT_ITEMS], const uint32_t *__restrict__ bend, uint32_t D, bool vmode)
 {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const uint32_t j0 = base + w * (64 * CT_ITEMS);
@@ -328,7 +496,7 @@ __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys,
     const uint64_t kb = keys[jb];
     const uint32_t sb = sa[jb];
     uint32_t plo = (uint32_t)kb, phi = (uint32_t)(kb >> 32);
-    uint64_t carry_short = (j0 && sb + D > r0_end(kb, n, bend)) ? 1ull : 0ull;
+    uint64_t carry_short = (j0 && r0_short(sb, kb, n, bend, D, vmode)) ? 1ull : 0ull;
     const int low_shift = bend ? 0 : 8;                                              // bits 7..0 carry T[sa-1], not key -- or the block number, which is key
 #pragma unroll
     for (int k = 0; k < CT_ITEMS; k++) {
@@ -337,7 +505,7 @@ __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys,
         const uint32_t qlo = (uint32_t)__builtin_amdgcn_update_dpp((int)plo, (int)lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
         const uint32_t qhi = (uint32_t)__builtin_amdgcn_update_dpp((int)phi, (int)hi, 0x138, 0xf, 0xf, false);
         const bool differs = (((lo ^ qlo) >> low_shift) | (hi ^ qhi)) != 0u;
-        const uint64_t S = __ballot(sj[k] + D > r0_end(kj[k], n, bend));             // a suffix with fewer than `depth` bytes is a group of its own
+        const uint64_t S = __ballot(r0_short(sj[k], kj[k], n, bend, D, vmode));      // a suffix with fewer than `depth` bytes is a group of its own
         const uint64_t b = __ballot(differs || j >= n || j == 0) | S | (S << 1) | carry_short;
         if (l == 0) HE[w * CT_ITEMS + k] = b;
         carry_short = S >> 63;
@@ -346,7 +514,7 @@ __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys,
     }
     if (threadIdx.x == 0) {
         const uint32_t jn = base + CT;
-        HE[64] = (jn >= n || r0_head(keys, sa, jn, n, bend, D)) ? 1ull : 0ull;
+        HE[64] = (jn >= n || r0_head(keys, sa, jn, n, bend, D, vmode)) ? 1ull : 0ull;
     }
 }
 __device__ __forceinline__ uint64_t valid_word(uint32_t word_base, uint32_t n)
@@ -363,13 +531,14 @@ __global__ __launch_bounds__(TB) void k_r0_count(const uint64_t *__restrict__ ke
 {
     __shared__ uint64_t HE[65];
     const uint32_t ntiles = (n + CT - 1) / CT;
-    const uint32_t D = st->depth;
+    const bool vmode = st->vmode != 0u;
+    const uint32_t D = vmode ? st->tag_shift : st->depth;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * CT;
         __syncthreads();
         uint64_t kj[CT_ITEMS];
         uint32_t sj[CT_ITEMS];
-        r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend, D);
+        r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend, D, vmode);
         __syncthreads();
         if (threadIdx.x < 64) {
             const int l = threadIdx.x;
@@ -408,22 +577,36 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                                                  const uint32_t *__restrict__ tCarry, const uint32_t *__restrict__ tOff,
                                                  uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
                                                  uint32_t *__restrict__ a_sa, uint32_t *__restrict__ a_grp, uint8_t *__restrict__ a_prev, SaState *__restrict__ st,
-                                                 const uint32_t *__restrict__ bend)
+                                                 const uint32_t *__restrict__ bend, uint32_t *__restrict__ GD)
 {
     __shared__ uint64_t HE[65];
+    __shared__ uint64_t runkey[256];       // vmode: the key of a run of byte b, and the byte whose code starts a key's first 8 bits
+    __shared__ uint64_t runsorted[256];    // ... and the run keys of the occurring bytes in byte order = ascending (codes above 8 bits: binary search)
+    __shared__ uint16_t vtop[256];
+    __shared__ uint32_t s_sigma;
     __shared__ uint64_t SV[64];            // survivor bits per word
     __shared__ uint32_t LHW[64];           // 1 + last head position at or before the end of word l (carry included)
     __shared__ uint32_t SW[64];            // output position of the first survivor of word l
     const uint32_t ntiles = (n + CT - 1) / CT;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const uint32_t D = st->depth, code_shift = 56u - st->bits;
+    const bool vmode = st->vmode != 0u;
+    const uint32_t D = vmode ? st->tag_shift : st->depth, code_shift = 56u - st->bits;
     const uint64_t rep = st->rep;
+    const uint32_t TAGM = vmode ? (1u << D) - 1u : 0xFFFFFFFFu;
+    if (vmode) {
+        runkey[threadIdx.x] = st->vrunkey[threadIdx.x];
+        vtop[threadIdx.x] = st->vtop[threadIdx.x];
+        runsorted[threadIdx.x] = ~0ull;
+        __syncthreads();
+        if (st->present[threadIdx.x]) runsorted[st->lut[threadIdx.x]] = runkey[threadIdx.x];     // lut = the byte's index among the occurring ones
+        if (threadIdx.x == 255) s_sigma = (uint32_t)st->lut[255] + (st->present[255] ? 1u : 0u);
+    }
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * CT;
         __syncthreads();
         uint64_t kj[CT_ITEMS];
         uint32_t sj[CT_ITEMS];
-        r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend, D);
+        r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend, D, vmode);
         __syncthreads();
         const uint32_t carry = tCarry[tile];
         if (threadIdx.x < 64) {
@@ -449,7 +632,7 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                 const uint64_t hv = HE[word] & valid_word(base + word * 64, n);
                 const uint64_t le = hv & mask_upto(l);
                 const uint32_t grp = le ? base + word * 64 + top_bit(le) : (word ? LHW[word - 1] : carry) - 1u;
-                const uint32_t s = sj[k];                           // (loaded once, by r0_tile_heads)
+                const uint32_t s = sj[k] & TAGM;                    // (loaded once, by r0_tile_heads)
                 const uint8_t pv = (uint8_t)kj[k];                  // T[s - 1], carried in the key's low byte since pass 0 (group sort: the block number)
                 ISA[s] = grp;
                 const uint64_t sv = SV[word];
@@ -460,7 +643,19 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                     const uint32_t pos = SW[word] + (uint32_t)__popcll(sv & mask_below(l));
                     // `depth` equal bytes (a survivor has all of them: short suffixes are groups of their own): a run member
                     const uint64_t k7 = kj[k] >> 8;
-                    const bool inrun = k7 == (k7 >> code_shift) * rep;
+                    bool inrun;
+                    if (vmode) {
+                        // the key of a run is a function of its byte; the byte is the one whose code starts the key: a table on the
+                        // key's first 8 bits for codes up to 8 bits, a binary search over the (ascending) run keys for the rare longer ones
+                        const uint32_t c = vtop[(uint32_t)(k7 >> 48)];
+                        if (c != 0xFFFFu) inrun = k7 == runkey[c];
+                        else {
+                            uint32_t lo = 0, hi = s_sigma;
+                            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (runsorted[mid] < k7) lo = mid + 1u; else hi = mid; }
+                            inrun = lo < s_sigma && runsorted[lo] == k7;
+                        }
+                        GD[grp] = sj[k] >> D;                    // the group's depth (every member writes the same value)
+                    } else inrun = k7 == (k7 >> code_shift) * rep;
                     nrun += inrun ? 1u : 0u;
                     a_sa[pos] = s;
                     a_grp[pos] = grp | (inrun ? RUNF : 0u);
@@ -560,10 +755,15 @@ __global__ __launch_bounds__(TB) void k_gather_win(const uint32_t *__restrict__ 
                                                   int par, uint32_t n, int hshift, const uint32_t *__restrict__ ISA, uint32_t *__restrict__ k2,
                                                   uint32_t *__restrict__ FH, uint32_t *__restrict__ LH,
                                                   const uint8_t *__restrict__ T, const uint32_t *__restrict__ RL, int first_round,
-                                                  const uint8_t *__restrict__ a_blk, const uint32_t *__restrict__ bend)
+                                                  const uint8_t *__restrict__ a_blk, const uint32_t *__restrict__ bend, const uint32_t *__restrict__ GDr)
 {
     __shared__ uint64_t H[16];
     const uint32_t m = st->m[par];
+    // vmode (variable-length keys; GDr = the depth of every unresolved group by its rank): a group compares at ITS OWN depth -- the
+    // symbols its members are known to share -- instead of the round's common distance.  The run rule needs no later-round case then:
+    // round 1 gives the members it spreads by (kind, run length) the depth L (k_seg_round / k_lg_finish), so they read the suffix
+    // behind their run like everybody reads the suffix behind its depth.
+    const bool vmode = GDr != nullptr && st->vmode != 0u;
     const uint32_t nwin = (m + SEG_TILE - 1) / SEG_TILE;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     // the round's distance: round 0 resolved `depth` bytes (k_key_plan), every round doubles it
@@ -594,9 +794,12 @@ __global__ __launch_bounds__(TB) void k_gather_win(const uint32_t *__restrict__ 
                 lim[k] = bend[a_blk[j < m ? j : m - 1]];
             }
         }
+        uint32_t hk[WIN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < WIN_ITEMS; k++) hk[k] = vmode ? GDr[gj[k] & ~(RUNF | DONE)] : h;      // (vmode: ascending ranks along the list, neighbours share the word)
 #pragma unroll
         for (int k = 0; k < WIN_ITEMS; k++) {
-            const uint64_t s2 = (uint64_t)s[k] + h;
+            const uint64_t s2 = (uint64_t)s[k] + hk[k];
             kv[k] = ISA[s2 < lim[k] ? s2 : 0];
             kv[k] = (s2 < lim[k]) ? kv[k] + 1u : 0u;
             anyrun |= (gj[k] & RUNF) != 0u;
@@ -616,7 +819,7 @@ __global__ __launch_bounds__(TB) void k_gather_win(const uint32_t *__restrict__ 
                             const bool down = e >= lim[k] || T[e] < T[s[k]];
                             kv[k] = G1 + (down ? L : 2u * n - L);    // L in [2D, n]: the kinds cannot collide (2n - L >= n >= L, equal only for L = n: one suffix)
                         } else if (kv[k] > G1) kv[k] += 2u * n;
-                    } else {
+                    } else if (!vmode) {
                         const uint32_t L = RL[s[k]];
                         if (L >= 2u * D && L > h) {                  // (a descendant of a c^D group with a shorter run is an ordinary suffix)
                             const uint64_t e = (uint64_t)s[k] + L;
@@ -763,11 +966,32 @@ __global__ __launch_bounds__(TB) void k_win_pieces(const uint32_t *__restrict__ 
     }
 }
 
+// vmode: the symbols the members of a NEW group share = the old group's depth + the depth of the group their common key2 names (they all
+// read the same rank at the old depth: Larsson-Sadakane's invariant per group instead of per round).  Exceptions, round 1 only, in a
+// group of run members (RUNF): k_gather_win spread the members with >= 2 d equal bytes over G + 1 + (L | 2n - L) -- such a group shares
+// its run, depth L -- and moved the ordinary keys above G + 1 up by 2n.  (A group of one needs no depth; key2 = 0 is always alone.)
+__device__ __forceinline__ uint32_t new_group_depth(const uint32_t *__restrict__ GDr, uint32_t G, bool runf, uint32_t key2, bool first_round, uint32_t n)
+{
+    const uint32_t own = GDr[G];
+    uint32_t tr = key2 - 1u;
+    if (first_round && runf) {
+        const uint32_t G1 = G + 1u;
+        if (key2 > G1 && key2 - G1 <= 2u * n) {
+            const uint32_t x = key2 - G1;
+            return x <= n ? x : 2u * n - x;
+        }
+        if (key2 > G1) tr -= 2u * n;
+    }
+    const uint64_t d = (uint64_t)own + GDr[tr];
+    return d > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)d;
+}
+
 // the sort / re-rank of all groups of <= SEG_TILE elements, one window per workgroup iteration
 __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const uint32_t *__restrict__ k2g,
                                                  const SaState *__restrict__ st, int par, int key_bits, const uint32_t *__restrict__ PH,
                                                  const uint8_t *__restrict__ a_prev, uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
-                                                 uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint8_t *__restrict__ b_prev)
+                                                 uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint8_t *__restrict__ b_prev,
+                                                 const uint32_t *__restrict__ GDr, uint32_t *__restrict__ GDw, int first_round, uint32_t n)
 {
     // LDS diet (30 KB, five workgroups per CU instead of three): the group ranks g[] are only needed while the group boundaries
     // are worked out and share their 8 KB with the two index permutations of the sort; the suffix numbers and the group rank of
@@ -1032,6 +1256,7 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
                 const bool single = nh[k] && next_head;
                 const uint32_t s = sv[k];
                 const uint8_t pv = pvv[k];
+                if (GDw && nh[k] && !single) GDw[run] = new_group_depth(GDr, og[k], rf[k] != 0u, k2[src[q]], first_round != 0, n);   // vmode: the depth of the new group
                 if (run != og[k]) ISA[s] = run;                     // the sub-group that sorts first keeps the old group's rank: no store
                 if (single) {
                     bwt[ap[k]] = pv;
@@ -1211,7 +1436,8 @@ __global__ __launch_bounds__(TB) void k_lg_finish(const uint32_t *__restrict__ k
                                                  const uint32_t *__restrict__ a_grp,
                                                  const Piece *__restrict__ pieces, const SaState *__restrict__ st, const uint32_t *__restrict__ pCarry,
                                                  uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
-                                                 uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint8_t *__restrict__ b_prev)
+                                                 uint32_t *__restrict__ b_sa, uint32_t *__restrict__ b_grp, uint8_t *__restrict__ b_prev,
+                                                 const uint32_t *__restrict__ GDr, uint32_t *__restrict__ GDw, int first_round, uint32_t n)
 {
     __shared__ uint64_t H[17];
     __shared__ uint32_t LHW[16];
@@ -1258,6 +1484,7 @@ __global__ __launch_bounds__(TB) void k_lg_finish(const uint32_t *__restrict__ k
                 const bool single = head && nh;
                 const uint32_t s = sl[k];
                 const uint8_t pv = pl[k];
+                if (GDw && head && !single) GDw[rank] = new_group_depth(GDr, G, rf != 0u, key[j], first_round != 0, n);   // vmode: the depth of the new group
                 if (hp != q.gs) ISA[s] = rank;                      // the first sub-group keeps the old group's rank
                 if (single) {
                     const uint32_t ap = G + (j - q.gs);
@@ -1434,7 +1661,8 @@ __global__ __launch_bounds__(TB) void k_cmp_scatter(const uint32_t *__restrict__
 // s and s + P[s] are in one group, so they share their first byte, so  order(s, s + p) = order(s + 1, s + 1 + p).  Along a maximal
 // stretch of positions [a, x] with one non-zero P = p the argument repeats: every pair (y, y + p) of the stretch is ordered like
 // (x + 1, x + 1 + p), and THAT pair is decided now if the two suffixes lie in different groups (their ranks compare) or x + 1 + p is
-// the end of the text / block (the empty suffix is the smaller one).  A group all of whose neighbouring pairs carry the same decided
+// the end of the text / block (the empty suffix is the smaller one), or -- in a second pass over the stretches -- if they lie in one group
+// and the neighbouring pairs between them all carry one verdict.  A group all of whose neighbouring pairs carry the same decided
 // verdict is totally ordered by position: its members are finished with ranks G, G + 1, ...; every other group stays exactly as it
 // was (the doubling distance does not change).  p = 1 is the run rule's case.  tests/pair_rule_model.py states the same in Python and
 // tests/test_pair_rule_model.py checks it against a brute-force suffix sort on repeat-heavy texts.
@@ -1445,6 +1673,7 @@ __global__ __launch_bounds__(TB) void k_cmp_scatter(const uint32_t *__restrict__
 //                  dissenting pair (G = the group's rank: the list is in rank order, so these accesses walk BAD upwards)
 //   k_pair_finish  members of the other groups: rank -> ISA, BWT byte, DONE; everything to the b-list; compaction follows as in a round
 constexpr uint8_t PV_HEAD = 0xFF;
+constexpr uint32_t PREP = 0x80000000u;      // P[z]: the stretch was carried THROUGH z by k_pair_repair (z's own neighbour is nearer): distances are < 2^30
 __global__ __launch_bounds__(TB) void k_pair_dist(const uint32_t *__restrict__ a_sa, const uint32_t *__restrict__ a_grp, const SaState *__restrict__ st, int par,
                                                  uint32_t *__restrict__ P, uint32_t *__restrict__ FH, uint32_t *__restrict__ LH)
 {
@@ -1487,7 +1716,34 @@ __global__ __launch_bounds__(TB) void k_pair_dist(const uint32_t *__restrict__ a
     }
 }
 
-// P has n + 1 entries, P[n] = 0: position x ends a stretch when P[x] != P[x + 1]
+// A group that mixes two repeats cuts the stretches of BOTH: its members' neighbours are nearer than the repeats' distance p, so the
+// positions of an inner repeat (a phrase that occurs twice inside a segment that is itself repeated) end every stretch that reaches them
+// in an open pair -- and a segment with a thousand inner repeats has a thousand stretch pieces, all but the last open.  But the
+// induction only needs T[z] = T[z + p], and z and z + p ARE in one group there: the thread of a stretch end walks on through such
+// positions and writes p (with PREP) over their own distance until the stretch's own distance returns, the two suffixes part, or
+// the text ends.  The walk reads consecutive ranks (z and z + p advance together).  A position that was walked through gives up its own
+// pair (V = 0: its group, a mixed one, waits for the doubling rounds); two walks over the same position may overwrite each other: either
+// value is a true same-group distance.
+constexpr int PAIR_WALK_MAX = 2048;
+__global__ __launch_bounds__(TB) void k_pair_repair(uint32_t *P, uint32_t n, const uint32_t *__restrict__ ISA, const uint8_t *__restrict__ blk,
+                                                   const uint32_t *__restrict__ bend)
+{
+    for (uint32_t x = blockIdx.x * TB + threadIdx.x; x + 1u < n; x += gridDim.x * TB) {
+        const uint32_t p = P[x];
+        if (p == 0u || (p & PREP)) continue;
+        if ((P[x + 1u] & ~PREP) == p) continue;                   // not a stretch end
+        const uint32_t lim = bend ? bend[blk[x]] : n;
+        uint32_t z = x + 1u;
+        for (int step = 0; step < PAIR_WALK_MAX; step++, z++) {
+            if ((uint64_t)z + p >= lim) break;                    // the pair behind the stretch reaches the end of the text: decided there
+            if ((P[z] & ~PREP) == p) break;                       // the stretch's own distance again: it runs on by itself
+            if (ISA[z] != ISA[z + p]) break;                      // the two suffixes part: decided by their ranks
+            P[z] = p | PREP;
+        }
+    }
+}
+
+// P has n + 1 entries, P[n] = 0: position x ends a stretch when P[x] != P[x + 1] (distances compared without PREP)
 __global__ __launch_bounds__(TB) void k_pair_first(const uint32_t *__restrict__ P, uint32_t n, uint32_t *__restrict__ tFirst)
 {
     __shared__ uint32_t sm[TB / 64 + 1];
@@ -1498,8 +1754,8 @@ __global__ __launch_bounds__(TB) void k_pair_first(const uint32_t *__restrict__ 
 #pragma unroll
         for (int k = 0; k < CT_ITEMS; k++) {
             const uint32_t i = base + k * TB + threadIdx.x, ic = i < n ? i : n - 1;
-            pa[k] = P[ic];
-            pb[k] = P[ic + 1];
+            pa[k] = P[ic] & ~PREP;
+            pb[k] = P[ic + 1] & ~PREP;
         }
         uint32_t first = NONE;
 #pragma unroll
@@ -1518,18 +1774,32 @@ __global__ __launch_bounds__(WG1) void k_pair_scan(uint32_t *__restrict__ tFirst
     __shared__ uint32_t sm[WG1 / 64 + 1];
     wg_scan<OpMin, true, true>(tFirst, tFirst, (n + CT - 1) / CT, NONE, sm);      // first stretch end in any LATER tile
 }
-// verdict of the stretch that ends at x with distance p: the pair (x + 1, x + 1 + p)
+// verdict of the stretch that ends at x with distance p: the pair (x + 1, x + 1 + p).  When the two lie in ONE group with other
+// members between them (x + 1 belongs to a group that mixes two repeats: its neighbour is nearer than p), the pair is decided by the
+// chain of neighbouring pairs from x + 1 up to x + 1 + p if all of them carry one verdict already (`chain`: V holds the verdicts of an
+// earlier pass over the stretches; a value only ever changes from open to decided, so reading it while this pass writes is safe).
 __device__ __forceinline__ uint32_t pair_verdict(uint32_t x, uint32_t p, const uint32_t *__restrict__ ISA, uint32_t n, const uint8_t *__restrict__ blk,
-                                                 const uint32_t *__restrict__ bend)
+                                                 const uint32_t *__restrict__ bend, const uint32_t *__restrict__ P, const uint8_t *V, bool chain)
 {
     const uint32_t lim = bend ? bend[blk[x]] : n;
     const uint64_t b = (uint64_t)x + 1u + p;                     // x + p is a member's position (< lim), so b <= lim
     if (b >= lim) return 2u;
     const uint32_t ra = ISA[x + 1u], rb = ISA[b];
-    return ra == rb ? 0u : (ra < rb ? 1u : 2u);
+    if (ra != rb) return ra < rb ? 1u : 2u;
+    if (!chain) return 0u;
+    uint32_t z = x + 1u, v = 0u;
+    for (int step = 0; step < 8 && z < (uint32_t)b; step++) {
+        const uint32_t pz = P[z];
+        if (pz == 0u || (pz & PREP)) return 0u;                  // (the first member of its group, or a carried-through position: the chain does not reach b)
+        const uint32_t vz = V[z];
+        if (vz == 0u || (v && vz != v)) return 0u;
+        v = vz;
+        z += pz;
+    }
+    return z == (uint32_t)b ? v : 0u;
 }
 __global__ __launch_bounds__(TB) void k_pair_fill(const uint32_t *__restrict__ P, uint32_t n, const uint32_t *__restrict__ tAfter, const uint32_t *__restrict__ ISA,
-                                                 uint8_t *__restrict__ V, const uint8_t *__restrict__ blk, const uint32_t *__restrict__ bend)
+                                                 uint8_t *V, const uint8_t *__restrict__ blk, const uint32_t *__restrict__ bend, int chain)
 {
     __shared__ uint32_t sm[TB / 64 + 1];
     __shared__ uint32_t rv[TB];
@@ -1539,15 +1809,18 @@ __global__ __launch_bounds__(TB) void k_pair_fill(const uint32_t *__restrict__ P
         uint32_t pv[CT_ITEMS + 1];
 #pragma unroll
         for (int k = 0; k <= CT_ITEMS; k++) { const uint32_t i = p0 + k; pv[k] = P[i < n ? i : n]; }
-        uint32_t bits = 0, first = NONE, any = 0;
+        uint32_t bits = 0, first = NONE, any = 0, rep = 0;
 #pragma unroll
         for (int k = CT_ITEMS - 1; k >= 0; k--) {
             const uint32_t i = p0 + k;
             if (i < n) {
                 any |= pv[k];
-                if (pv[k] != pv[k + 1]) { bits |= 1u << k; first = i; }
+                if (pv[k] & PREP) rep |= 1u << k;
+                if ((pv[k] & ~PREP) != (pv[k + 1] & ~PREP)) { bits |= 1u << k; first = i; }
             }
         }
+#pragma unroll
+        for (int k = 0; k <= CT_ITEMS; k++) pv[k] &= ~PREP;
         __syncthreads();                                                              // rv of the previous tile has been read
         rv[TB - 1 - threadIdx.x] = first;
         __syncthreads();
@@ -1564,10 +1837,10 @@ __global__ __launch_bounds__(TB) void k_pair_fill(const uint32_t *__restrict__ P
             const uint32_t i = p0 + k;
             if (i < n) {
                 const uint32_t p = pv[k];
-                if (bits & (1u << k)) { nb = i; vnb = p ? pair_verdict(i, p, ISA, n, blk, bend) : 0u; }
+                if (bits & (1u << k)) { nb = i; vnb = p ? pair_verdict(i, p, ISA, n, blk, bend, P, V, chain != 0) : 0u; }
                 if (p) {
-                    if (vnb == NONE) vnb = pair_verdict(nb, p, ISA, n, blk, bend);   // the stretch runs on into a later thread: P[nb] == p
-                    V[i] = (uint8_t)vnb;
+                    if (vnb == NONE) vnb = pair_verdict(nb, p, ISA, n, blk, bend, P, V, chain != 0);   // the stretch runs on into a later thread: P[nb] == p
+                    V[i] = (rep & (1u << k)) ? (uint8_t)0 : (uint8_t)vnb;      // a position the stretch was carried through: ITS pair stays open
                 }
             }
         }
@@ -1744,6 +2017,8 @@ struct SaBufs {
     uint8_t *bwt;
     uint8_t *a_prev, *b_prev, *p_alt;      // T[sa - 1] of every active suffix: travels with (sa, rank) through the rounds
     uint32_t *RL;                          // remaining run length per text position (written only when round 0 leaves run members behind)
+    uint32_t *GD[2] = {nullptr, nullptr};  // variable-length keys: depth of every unresolved group by its rank, read side / write side of a round
+    uint8_t *D0 = nullptr;                 // ... and the depth of every slot's key (rides through the radix sort in the value's upper bits)
     const uint8_t *blk = nullptr;          // group sort: block number of every text position, and where every block ends (device)
     const uint32_t *bend = nullptr;
     Piece *pieces;
@@ -1761,7 +2036,25 @@ int lg_digit_bits(uint32_t n, int *npass)
     return db;                                     // 4..8
 }
 
-void sa_layout(Arena &a, size_t n, SaBufs &b)
+// JPK_KEY_BITS=8 keeps round 0's keys at one byte per symbol whatever the alphabet (the comparator of the packed keys; 0 = from the alphabet)
+int key_force_bits()
+{
+    static const int v = [] { const char *e = getenv("JPK_KEY_BITS"); const int x = e ? atoi(e) : 0; return x < 0 ? 0 : (x > 8 ? 8 : x); }();
+    return v;
+}
+
+// JPK_VARKEYS=0: fixed-width keys whatever the block (the comparator of the variable-length keys)
+bool var_keys_on()
+{
+    static const bool v = [] { const char *e = getenv("JPK_VARKEYS"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
+// variable-length keys: single-block sorts of at most 2^28 bytes (the key's depth rides in the spare bits of the 32-bit suffix number:
+// six up to 2^26 bytes, five up to 2^27, four -- depths clamped at 15 -- up to 2^28), the one-pass radix form, no forced code width
+bool var_keys_eligible(size_t n, bool group) { return !group && n <= ((size_t)1 << 28) && var_keys_on() && jpk_radix_onesweep() && key_force_bits() == 0; }
+int var_tag_shift(size_t n) { int s = 26; while (((size_t)1 << s) < n) s++; return s; }
+
+void sa_layout(Arena &a, size_t n, SaBufs &b, bool var)
 {
     const size_t nwin = n / SEG_TILE + 2, ntile = n / CT + 2;
     memset(&b, 0, sizeof b);
@@ -1777,6 +2070,11 @@ void sa_layout(Arena &a, size_t n, SaBufs &b)
     b.b_prev = a.get<uint8_t>(n);
     b.p_alt = a.get<uint8_t>(n);
     b.RL = a.get<uint32_t>(n);
+    if (var) {
+        b.GD[0] = a.get<uint32_t>(n);
+        b.GD[1] = a.get<uint32_t>(n);
+        b.D0 = a.get<uint8_t>(n);
+    }
     const size_t nbmax = 256;
     b.table = a.get<uint32_t>(nbmax * 2 * nwin);
     b.partial = a.get<uint32_t>(nbmax * 2 * nwin / SC_TILE + 64);
@@ -1812,13 +2110,6 @@ void launch_lg_pass(jpk_ctx *ctx, SaBufs &b, const uint32_t *kin, const uint32_t
     JPK_LAUNCH(ctx, PROF_LG_SCATTER, 0, (k_lg_scatter<DB>), dim3(gp), dim3(TB), kin, vin, pin, kout, vout, pout, b.pieces, b.state, shift, b.table);
 }
 
-// JPK_KEY_BITS=8 keeps round 0's keys at one byte per symbol whatever the alphabet (the comparator of the packed keys; 0 = from the alphabet)
-int key_force_bits()
-{
-    static const int v = [] { const char *e = getenv("JPK_KEY_BITS"); const int x = e ? atoi(e) : 0; return x < 0 ? 0 : (x > 8 ? 8 : x); }();
-    return v;
-}
-
 // JPK_PAIR_SHIFT: a round from the third on is a pair round (k_pair_*) when at least n >> shift suffixes are unresolved (default 6);
 // negative = never (the comparator: plain prefix doubling)
 int pair_rule_shift()
@@ -1833,11 +2124,24 @@ uint32_t pair_rule_min()
     static const uint32_t v = [] { const char *e = getenv("JPK_PAIR_MIN"); const long x = e ? atol(e) : 4096L; return (uint32_t)(x < 2 ? 2 : x); }();
     return v;
 }
-// JPK_PAIR_RATIO: ... and the previous round left at least this percentage of ITS list unresolved (default 75: text halves its list
+// JPK_PAIR_RATIO: ... and the previous round left at least this percentage of ITS list unresolved (default 60: text halves its list
 // every round and never takes the path; a block of repeats keeps its list) -- 0 = whatever the previous round did
 uint32_t pair_rule_ratio()
 {
-    static const uint32_t v = [] { const char *e = getenv("JPK_PAIR_RATIO"); const int x = e ? atoi(e) : 75; return (uint32_t)(x < 0 ? 0 : (x > 100 ? 100 : x)); }();
+    static const uint32_t v = [] { const char *e = getenv("JPK_PAIR_RATIO"); const int x = e ? atoi(e) : 60; return (uint32_t)(x < 0 ? 0 : (x > 100 ? 100 : x)); }();
+    return v;
+}
+// JPK_PAIR_ITERS: passes of k_pair_fill per pair round (default 1; 2..4: later passes decide an end pair inside one group by the chain
+// of its neighbouring pairs -- built for groups that mix two repeats, where k_pair_repair turned out to be what helps; kept as an option)
+int pair_rule_iters()
+{
+    static const int v = [] { const char *e = getenv("JPK_PAIR_ITERS"); const int x = e ? atoi(e) : 1; return x < 1 ? 1 : (x > 4 ? 4 : x); }();
+    return v;
+}
+// JPK_PAIR_REPAIR=0: stretches end at every position whose own neighbour is nearer (the comparator of k_pair_repair)
+bool pair_rule_repair()
+{
+    static const bool v = [] { const char *e = getenv("JPK_PAIR_REPAIR"); return e ? atoi(e) != 0 : true; }();
     return v;
 }
 int pair_rule_gap()
@@ -1867,10 +2171,12 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     uint64_t *ks = b.keysA;
     uint32_t *vs = b.valsA;
     JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_sym_present, dim3(cap_grid(n, 16 * TB * 4, 4096)), dim3(TB), T, n, b.state);
-    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_key_plan, dim3(1), dim3(256), b.state, key_force_bits());
+    const bool var = b.D0 != nullptr;               // (sa_layout: var_keys_eligible)
+    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_key_plan, dim3(1), dim3(256), b.state, key_force_bits(), var ? 1 : 0, var_tag_shift(n));
+    if (var) JPK_HIP(hipMemsetAsync(b.D0, 0, n, st));      // (a plan that falls back to the fixed code leaves no depths: tag 0 everywhere)
     JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_pack_keys, dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend,
-               jpk_radix_onesweep() ? (uint32_t *)nullptr : b.scratch);
-    JPK_TRY(jpk_radix_sort_slot_keys(ctx, n, b.keysA, b.valsA, b.keysB, b.valsB, b.scratch, &ks, &vs, b.blk != nullptr));
+               jpk_radix_onesweep() ? (uint32_t *)nullptr : b.scratch, b.D0);
+    JPK_TRY(jpk_radix_sort_slot_keys(ctx, n, b.keysA, b.valsA, b.keysB, b.valsB, b.scratch, &ks, &vs, b.blk != nullptr, b.D0, var_tag_shift(n)));
     ctx->stats.sa_sorted_elems += n;
     // The sorted pairs sit in (ks, vs).  The other pair of radix buffers is free from here on, the pair that holds the result
     // once k_r0_finish has read it: the doubling rounds live in them.
@@ -1885,7 +2191,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     const unsigned g_ct = cap_grid(n, CT, CAP);
     JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_count, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.bend, b.state);
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_r0_scan, dim3(1), dim3(WG1), b.tA, b.tB, n, b.state);
-    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev, b.state, b.bend);
+    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev, b.state, b.bend, b.GD[0]);
     ctx->stats.sa_rounds = 1;
     // remaining run lengths, only if round 0 left members of runs of >= depth equal bytes behind (the kernels return at once otherwise)
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_first, dim3(cap_grid(n, CT, 4096)), dim3(TB), T, n, b.state, b.tA, b.blk);
@@ -1911,6 +2217,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     // of the block is a pair round instead of a doubling round; the doubling distance stays where it was.  Two doubling rounds lie
     // between two pair rounds (a group with dissenting pairs has to split before the rule can say more about it).
     int hshift = 0;                                // the next doubling round compares at distance depth << hshift
+    int gd = 0;                                    // variable-length keys: GD[gd] holds the groups' depths, the next doubling round writes GD[gd ^ 1]
     int last_pair = -8;
     bool prev_pair = false;
     uint32_t m_prev = n;                           // the list the previous round started with
@@ -1947,23 +2254,28 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             JPK_HIP(hipMemsetAsync(BAD, 0, n, st));
             JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_pair_dist, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, P, b.FH, b.LH);
             JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan1, dim3(1), dim3(WG1), b.FH, b.LH, b.PH, b.NH, b.state, par);
+            if (pair_rule_repair()) JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_pair_repair, dim3(cap_grid(n, TB * 4, 8192)), dim3(TB), P, n, b.ISA, b.blk, b.bend);
             JPK_LAUNCH(ctx, PROF_SCAN, 0, k_pair_first, dim3(cap_grid(n, CT, 4096)), dim3(TB), P, n, b.tB);
             JPK_LAUNCH(ctx, PROF_SCAN, 0, k_pair_scan, dim3(1), dim3(WG1), b.tB, n);
-            JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_pair_fill, dim3(cap_grid(n, CT, CAP)), dim3(TB), P, n, b.tB, b.ISA, V, b.blk, b.bend);
+            for (int it = 0; it < pair_rule_iters(); it++)     // later passes decide stretches that end in a group mixing two repeats (pair_verdict)
+                JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_pair_fill, dim3(cap_grid(n, CT, CAP)), dim3(TB), P, n, b.tB, b.ISA, V, b.blk, b.bend, it);
             JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_pair_mark, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, V, VL, BAD);
             JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_pair_finish, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.a_prev, b.state, par, b.PH, b.NH, VL, BAD, b.ISA, b.bwt, b.SA,
                        b.b_sa, b.b_grp, b.b_prev);
         } else {
+        const uint32_t *gdr = var ? b.GD[gd] : nullptr;
+        uint32_t *gdw = var ? b.GD[gd ^ 1] : nullptr;
         JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, hshift, b.ISA, b.k2, b.FH, b.LH, T, b.RL, round == 1 ? 1 : 0,
-                   b.a_prev, b.bend);
+                   b.a_prev, b.bend, gdr);
         hshift++;
+        gd ^= 1;
         const unsigned g_wm = cap_grid((size_t)bound / SEG_TILE + 1, TB, 256);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan1, dim3(1), dim3(WG1), b.FH, b.LH, b.PH, b.NH, b.state, par);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_count, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.state, par);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan2, dim3(1), dim3(WG1), b.PC, b.state, par, round);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_pieces, dim3(g_wm), dim3(TB), b.FH, b.LH, b.PH, b.NH, b.PC, b.pieces, b.state, par);
         JPK_LAUNCH(ctx, PROF_SA_SEG, 0, k_seg_round, dim3(g_seg), dim3(TB), b.a_sa, b.a_grp, b.k2, b.state, par, kbits, b.PH, b.a_prev, b.ISA, b.bwt, b.SA,
-                   b.b_sa, b.b_grp, b.b_prev);
+                   b.b_sa, b.b_grp, b.b_prev, gdr, gdw, round == 1 ? 1 : 0, n);
         if (large_possible) {   // large groups: lg_pass LSD passes over (key2, sa), ping-pong between (k2, a_sa) and (k2alt, sa_alt)
             uint32_t *kin = b.k2, *vin = b.a_sa, *kout = b.k2alt, *vout = b.sa_alt;
             uint8_t *pin = b.a_prev, *pout = b.p_alt;
@@ -1983,7 +2295,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_lg_heads, dim3(g_pc), dim3(TB), kin, b.pieces, b.state, b.pLast);
             JPK_LAUNCH(ctx, PROF_SCAN, 0, k_lg_scan, dim3(1), dim3(WG1), b.pLast, b.state);
             JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_lg_finish, dim3(g_pc), dim3(TB), kin, vin, pin, b.a_grp, b.pieces, b.state, b.pLast, b.ISA, b.bwt, b.SA, b.b_sa,
-                       b.b_grp, b.b_prev);
+                       b.b_grp, b.b_prev, gdr, gdw, round == 1 ? 1 : 0, n);
         }
         }
         JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_cmp_count, dim3(g_cmp), dim3(TB), b.b_grp, b.state, par, b.tA);
@@ -2039,7 +2351,7 @@ size_t jpk_fwd_bwt_arena_bytes(uint32_t n)
     SaBufs b;
     jpk_ctx dummy;
     Arena plan(&dummy, true);
-    sa_layout(plan, n ? n : 1, b);
+    sa_layout(plan, n ? n : 1, b, var_keys_eligible(n ? n : 1, false));
     return plan.need;
 }
 
@@ -2048,10 +2360,10 @@ int jpk_suffix_array_device(jpk_ctx *ctx, const uint8_t *d_t, int32_t n, int32_t
     if (n <= 0) return JPK_OK;
     SaBufs b;
     Arena plan(ctx, true);
-    sa_layout(plan, (size_t)n, b);
+    sa_layout(plan, (size_t)n, b, var_keys_eligible((size_t)n, false));
     JPK_TRY(jpk_arena_ensure(ctx, plan.need));
     Arena real(ctx, false);
-    sa_layout(real, (size_t)n, b);
+    sa_layout(real, (size_t)n, b, var_keys_eligible((size_t)n, false));
     b.SA = reinterpret_cast<uint32_t *>(d_sa);
     return build_sa(ctx, d_t, (uint32_t)n, b);
 }
@@ -2110,7 +2422,7 @@ size_t jpk_fwd_bwt_group_arena_bytes(uint32_t total_nlen, int nblk)
     SaBufs b;
     jpk_ctx dummy;
     Arena plan(&dummy, true);
-    sa_layout(plan, total_nlen ? total_nlen : 1, b);
+    sa_layout(plan, total_nlen ? total_nlen : 1, b, false);
     plan.get<uint8_t>(total_nlen);            // common text
     plan.get<uint8_t>(total_nlen);            // block number per position
     plan.get<uint32_t>(total_nlen);           // suffix array (the BWT bytes are gathered through it)
@@ -2145,7 +2457,7 @@ int jpk_fwd_bwt_group_device(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in,
     const JpkCompressInflight inflight(ctx->device);
     SaBufs sb;
     Arena real(ctx, false);
-    sa_layout(real, N ? N : 1, sb);
+    sa_layout(real, N ? N : 1, sb, false);
     uint8_t *C = real.get<uint8_t>(N);
     uint8_t *blk = real.get<uint8_t>(N);
     uint32_t *SA = real.get<uint32_t>(N);
@@ -2178,10 +2490,10 @@ int jpk_fwd_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *
     }
     SaBufs b;
     Arena plan(ctx, true);
-    sa_layout(plan, (size_t)nlen, b);
+    sa_layout(plan, (size_t)nlen, b, var_keys_eligible((size_t)nlen, false));
     JPK_TRY(jpk_arena_ensure(ctx, plan.need));
     Arena real(ctx, false);
-    sa_layout(real, (size_t)nlen, b);
+    sa_layout(real, (size_t)nlen, b, var_keys_eligible((size_t)nlen, false));
     // heavy-phase gate: a caller that goes on to the entropy stage (jpk_dev_block_compress) already holds it and releases it
     // there; a stand-alone forward BWT holds it for the sort only
     const bool outer = ctx->gate_held;

@@ -27,13 +27,21 @@ static_assert(RS_TILE == 4096, "bwt_fwd.hip k_pack_keys writes the first pass's 
 // one of them -- a full memory latency per 64 elements instead of per tile.
 template <bool SLOTS>
 __device__ __forceinline__ void rs_load_tile(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, size_t n, size_t base,
-                                             uint64_t (&key)[RS_ITEMS], uint32_t (&val)[RS_ITEMS])
+                                             uint64_t (&key)[RS_ITEMS], uint32_t (&val)[RS_ITEMS], int tag_shift = 26)
 {
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++) {
         const size_t i = base + (size_t)it * 64, ic = i < n ? i : n - 1;
         key[it] = kin[ic];
         val[it] = SLOTS ? (uint32_t)(n - 1 - ic) : vin[ic];
+    }
+    if (SLOTS && vin) {                                 // (uniform) slot tags: see jpk_radix_sort_slot_keys
+        const uint8_t *tag = reinterpret_cast<const uint8_t *>(vin);
+        uint32_t tg[RS_ITEMS];
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; it++) { const size_t i = base + (size_t)it * 64; tg[it] = tag[i < n ? i : n - 1]; }
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; it++) val[it] |= tg[it] << tag_shift;
     }
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++)
@@ -159,6 +167,7 @@ struct OsArgs {
     uint32_t *status_next;     // ... of the next pass: zeroed row by row
     const uint32_t *gdig;      // [256] exclusive global offsets of this pass's digit
     uint32_t *ticket;          // tile numbers of this pass
+    int tag_shift;             // pass 0 with slot tags: the tag goes into the value's bits from here up
 };
 constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_PFX = 2u << 30, OS_MASK = (1u << 30) - 1u;
 
@@ -185,7 +194,15 @@ __device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restric
             key[it] = kw[(uint32_t)(it * 64 + l)];
             val[it] = SLOTS ? v0 - (uint32_t)(it * 64 + l) : vw[(uint32_t)(it * 64 + l)];
         }
-    } else rs_load_tile<SLOTS>(kin, vin, n, base, key, val);
+        if (SLOTS && vin) {                             // (uniform) slot tags: see jpk_radix_sort_slot_keys
+            const uint8_t *tw = reinterpret_cast<const uint8_t *>(vin) + tbase + (size_t)w * (64 * RS_ITEMS);
+            uint32_t tg[RS_ITEMS];
+#pragma unroll
+            for (int it = 0; it < RS_ITEMS; it++) tg[it] = tw[(uint32_t)(it * 64 + l)];
+#pragma unroll
+            for (int it = 0; it < RS_ITEMS; it++) val[it] |= tg[it] << (os ? os->tag_shift : 26);
+        }
+    } else rs_load_tile<SLOTS>(kin, vin, n, base, key, val, os ? os->tag_shift : 26);
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++) {
         const bool valid = FULL || base + (size_t)it * 64 < n;
@@ -441,9 +458,12 @@ int jpk_radix_sort_pairs_u64(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint6
 // its 56 key bits -- 8 in a group sort, the last one on the block number in the low byte.  The first pass has no value array to read
 // (slot j = suffix n-1-j) and no histogram to count (k_pack_keys left the digit-major tile table of key bits 15..8 at the start of
 // `scratch`; its tiles are RS_TILE slots like ours) and lands in B; keysA is overwritten by the second.  Result: (*keys_out, *vals_out).
+// `slot_tag` (one-pass form only; may be null): a byte per slot that rides in the bits of the slot's value from `tag_shift` up through the
+// sort (the suffix sort's variable-length keys carry the number of symbols a key holds there); n <= 2^tag_shift, tag < 2^(32 - tag_shift).
 int jpk_radix_sort_slot_keys(jpk_ctx *ctx, uint32_t n32, uint64_t *keysA, uint32_t *valsA, uint64_t *keysB, uint32_t *valsB,
-                             uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out, bool group)
+                             uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out, bool group, const uint8_t *slot_tag, int tag_shift)
 {
+    if (slot_tag && (!rs_onesweep() || tag_shift < 1 || tag_shift > 31 || (uint64_t)n32 > (1ull << tag_shift))) return JPK_E_ARG;
     const size_t n = n32;
     *keys_out = keysB;
     *vals_out = valsB;
@@ -470,8 +490,9 @@ int jpk_radix_sort_slot_keys(jpk_ctx *ctx, uint32_t n32, uint64_t *keysA, uint32
             os.status_next = (p & 1) ? statusA : statusB;
             os.gdig = gdig + p * 256;
             os.ticket = tickets + p;
+            os.tag_shift = tag_shift;
             if (p == 0) {
-                launch_os_scatter<true>(ctx, keysA, nullptr, keysB, valsB, n, shift, ntiles, os);
+                launch_os_scatter<true>(ctx, keysA, reinterpret_cast<const uint32_t *>(slot_tag), keysB, valsB, n, shift, ntiles, os);
                 continue;
             }
             launch_os_scatter<false>(ctx, ki, vi, ko, vo, n, shift, ntiles, os);

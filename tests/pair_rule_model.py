@@ -12,6 +12,11 @@ induction step, applied to the active list between two doubling rounds:
   * along a maximal stretch of positions [a, x] with the same non-zero P = p the argument repeats: every pair (y, y + p) of the
     stretch is ordered like (x + 1, x + 1 + p).  That pair is decided NOW if the two suffixes lie in different groups (compare
     their ranks) or if x + 1 + p is the end of the text (the empty suffix is the smaller one); otherwise the stretch stays open.
+  * a second pass over the stretches also decides an end pair that lies in ONE group with other members between its two suffixes (a
+    group that mixes two repeats): by the chain of neighbouring pairs between them, if all carry one verdict of the first pass.
+  * repair: the induction only needs T[z] = T[z + p]; where a group mixes two repeats its members' neighbours are nearer than p and
+    would end every stretch in an open pair, so a stretch is carried THROUGH such positions while z and z + p stay in one group (they
+    give up their own pair: their verdict stays open and their group waits for the doubling rounds).
   * a group all of whose neighbouring pairs carry the same decided verdict is totally ordered by position: its members become
     singletons with ranks G, G+1, ...; every other group is left exactly as it was (the doubling distance does not change).
 
@@ -31,29 +36,60 @@ def _groups(lst):
     return out
 
 
-def pair_round(t, n, active, isa, sa_out):
+def pair_round(t, n, active, isa, sa_out, iters=2, repair=True):
     """one application of the pair rule: resolves the groups it can, returns the new active list"""
     P = [0] * (n + 1)
     for b, e in _groups(active):
         for j in range(b + 1, e):
             assert active[j - 1][0] > active[j][0], "members of a group are kept in descending position"
             P[active[j][0]] = active[j - 1][0] - active[j][0]
-    # verdict of the stretch that ends at x (P[x] != P[x+1]): 1 = the lower position is the smaller suffix, 2 = the higher, 0 = open
+    # repair: a stretch is carried THROUGH positions whose own neighbour is nearer (members of a group that mixes two repeats) as long as
+    # z and z + p stay in one group; such a position gives up its own pair (its verdict stays open)
+    carried = [False] * (n + 1)
+    if repair:
+        ends = [x for x in range(n - 1) if P[x] and P[x + 1] != P[x]]
+        for x in ends:
+            p = P[x]
+            if carried[x]:
+                continue
+            z = x + 1
+            while z + p < n and P[z] != p and isa[z] == isa[z + p]:
+                P[z] = p
+                carried[z] = True
+                z += 1
+    # verdict of the stretch that ends at x (P[x] != P[x+1]): 1 = the lower position is the smaller suffix, 2 = the higher, 0 = open.
+    # Passes after the first also decide a stretch whose end pair lies in ONE group with other members between the two: by the chain of
+    # neighbouring pairs from x + 1 up to x + 1 + p, if all of them carry one verdict of the pass before.
     V = [0] * (n + 1)
-    nxt = 0
-    for y in range(n - 1, -1, -1):
-        p = P[y]
-        if p == 0:
-            continue
-        if P[y + 1] != p:                               # y ends its stretch
-            a, b2 = y + 1, y + 1 + p
-            if b2 >= n:
-                nxt = 2                                  # the suffix at b2 is empty: smaller
-            elif isa[a] != isa[b2]:
-                nxt = 1 if isa[a] < isa[b2] else 2
-            else:
-                nxt = 0
-        V[y] = nxt
+    for it in range(iters):
+        Vn = [0] * (n + 1)
+        nxt = 0
+        for y in range(n - 1, -1, -1):
+            p = P[y]
+            if p == 0:
+                continue
+            if P[y + 1] != p:                               # y ends its stretch
+                a, b2 = y + 1, y + 1 + p
+                if b2 >= n:
+                    nxt = 2                                  # the suffix at b2 is empty: smaller
+                elif isa[a] != isa[b2]:
+                    nxt = 1 if isa[a] < isa[b2] else 2
+                else:
+                    nxt = 0
+                    if it > 0:
+                        z, v, ok = a, 0, True
+                        for _ in range(8):
+                            if z >= b2:
+                                break
+                            if P[z] == 0 or carried[z] or V[z] == 0 or (v and V[z] != v):
+                                ok = False
+                                break
+                            v = V[z]
+                            z += P[z]
+                        if ok and z == b2:
+                            nxt = v
+            Vn[y] = 0 if carried[y] else nxt
+        V = Vn
     out = []
     for b, e in _groups(active):
         G = active[b][1]

@@ -86,7 +86,7 @@ def test_bench_block_64mib_text_survey(gpu, ref):
     t, _ = jam.corpus.load_or_make("enwik8", start=0, count=64 << 20)
     assert len(t) == 64 << 20
     d_bwt, d_enc = _roundtrip(torch, jam, ctx, t)
-    assert ctx.stats().sa_key_depth == 11
+    assert ctx.stats().sa_key_depth >= 11          # 11 bytes with the fixed 5-bit code of its 28 byte values, 12 on average with the variable-length code
     _same_as_reference(ref, t, d_bwt, d_enc)
 
 
@@ -98,7 +98,7 @@ def test_wide_alphabet_64mib_blocks_equal_the_reference(gpu, ref, kind):
     t = jam.corpus.make(kind, 64 << 20, 5)
     d_bwt, d_enc = _roundtrip(torch, jam, ctx, t)
     s = ctx.stats()
-    assert s.sa_key_depth == 7, s.sa_key_depth
+    assert 7 <= s.sa_key_depth <= 11, s.sa_key_depth      # 7 bytes with the fixed 8-bit code; the variable-length code holds about 56 / H0 symbols
     _same_as_reference(ref, t, d_bwt, d_enc)
 
 

@@ -4,6 +4,9 @@ segments at arbitrary distances, runs, nested periods, Fibonacci words, copies w
 different rounds and after different first-key depths.  CPU only."""
 import random
 
+import functools
+
+import pair_rule_model
 from pair_rule_model import suffix_array
 
 
@@ -54,6 +57,33 @@ def test_pair_rule_keeps_the_suffix_order_on_repeat_heavy_texts():
         pr = rng.choice([(2,), (2, 3), (3, 6, 9), (3, 7, 11), tuple(range(2, 100, 2))])
         sa, _ = suffix_array(t, d0, pr)
         assert sa == _brute(t), (it, t, d0, pr)
+
+
+def test_every_variant_of_the_rule_keeps_the_suffix_order():
+    """stretches carried through mixed groups or not (k_pair_repair), one or two passes over the stretches (the chained verdict)"""
+    rng = random.Random(9)
+    orig = pair_rule_model.pair_round
+    try:
+        for rep, iters in ((False, 1), (False, 2), (True, 1), (True, 3)):
+            pair_rule_model.pair_round = functools.partial(orig, repair=rep, iters=iters)
+            for it in range(250):
+                t = _gen(rng)
+                sa, _ = suffix_array(t, rng.choice([1, 2, 3]), rng.choice([(2,), (3, 6, 9), tuple(range(2, 100, 2))]))
+                assert sa == _brute(t), (rep, iters, it, t)
+    finally:
+        pair_rule_model.pair_round = orig
+
+
+def test_a_segment_with_inner_repeats_repeated():
+    """the case k_pair_repair exists for: a phrase that occurs twice inside a segment that is itself repeated -- groups that mix two repeats"""
+    rng = random.Random(3)
+    rb = lambda k: bytes(rng.randrange(26) for _ in range(k))
+    for copies in (2, 3, 6):
+        phrase = rb(40)
+        seg = rb(100) + phrase + rb(120) + phrase + rb(80)
+        t = rb(200) + seg * copies + rb(100)
+        sa, _ = suffix_array(t, 2, (3, 6, 9))
+        assert sa == _brute(t), copies
 
 
 def test_pair_rule_removes_the_rounds_of_a_long_repeat():
