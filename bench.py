@@ -433,7 +433,7 @@ def per_block_size(jam, corpus, torch, dev, device_index: int, in_flight: int):
 
 def decompress_leg(jam, torch, dev, local_rank, blocks, d_in, d_cmp, sizes, nctx, reps):
     """rANS decode -> inverse BWT (jampack.cpp:49-50) over the batch: one context per block, one batched call per pass, and passes in
-    flight (`JPK_BENCH_DEC_PASSES`, default 8: `value`).  Every output is compared with the input.  Returns (dict, ok)."""
+    flight (`JPK_BENCH_DEC_PASSES`, default 16: `value`; 4 and 8 are reported beside it).  Every output is compared with the input.  Returns (dict, ok)."""
     import queue
     import threading
     import concurrent.futures as cf
@@ -481,7 +481,7 @@ def decompress_leg(jam, torch, dev, local_rank, blocks, d_in, d_cmp, sizes, nctx
         c_.close()
     # the same passes in flight, as the compress loop runs them: `ndec` contexts each take whole passes (one batched call per
     # pass) from a queue; a block is 65 serial chains, so a pass alone leaves most of the 1024 SIMDs without a chain
-    ndec = int(os.environ.get("JPK_BENCH_DEC_PASSES", "8"))
+    ndec = int(os.environ.get("JPK_BENCH_DEC_PASSES", "16"))   # (8 until round 4: a pass is 130 serial chains on 1024 SIMDs, sixteen of them still leave every chain a SIMD of its own)
     ndec_max = max(16, ndec)
     dctxs = [jam.Context(local_rank, None) for _ in range(ndec_max)]
     dbufs = [[torch.empty(max(len(b), 1), dtype=torch.uint8, device=dev) for b in blocks] for _ in range(ndec_max)]
@@ -510,7 +510,7 @@ def decompress_leg(jam, torch, dev, local_rank, blocks, d_in, d_cmp, sizes, nctx
     dec_passes(ndec_max, ndec_max)             # every context has decoded once (arenas sized)
     torch.cuda.synchronize()
     in_flight = {}
-    for nfl in sorted({4, ndec, 16}):
+    for nfl in sorted({4, 8, ndec, 16}):
         npass = max(2 * nfl, reps)
         tp0 = time.perf_counter()
         dec_passes(npass, nfl)
@@ -909,9 +909,12 @@ def main():
                 extra["sa_rounds"] = {"block_bytes": n, "rounds": nr, "key_depth_bytes": dep, "alphabet": int(len(np.unique(blocks[i]))),
                                       "active_suffixes": [int(x) for x in st.sa_round_active[:nr]],
                                       "in_large_groups": [int(x) for x in st.sa_round_large[:nr]],
-                                      "note": "round 0 = radix sort on the first key_depth_bytes bytes of every suffix (the block's byte values renumbered and "
-                                              "packed into 56 bits: 7 bytes for alphabets above 128 values, 11 for this text's); round r >= 1 sorts the still "
-                                              "unresolved suffixes by the rank of the suffix key_depth_bytes * 2^(r-1) bytes further"}
+                                      "pair_rounds": [r for r in range(min(nr, 64)) if (int(st.sa_pair_rounds) >> r) & 1],
+                                      "note": "round 0 = radix sort on the first key_depth_bytes symbols of every suffix on average (an order-preserving "
+                                              "prefix code of the block's byte values, as many symbols as fit 56 bits: about 56 / H0 -- the fixed-width "
+                                              "code of round 4 held 11 bytes of this text, 7 of any block above 128 byte values); round r >= 1 sorts the "
+                                              "still unresolved suffixes, every group at its own depth, by the rank of the suffix that many symbols "
+                                              "further; pair_rounds = rounds that resolved long repeats by induction from their successors instead"}
             del d_bwt, d_enc, d_dec, d_back
         mb = batch_bytes / 1e6
         extra["stages_ms"] = {k: round(v, 3) for k, v in stage_ms.items()}

@@ -654,7 +654,7 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (runsorted[mid] < k7) lo = mid + 1u; else hi = mid; }
                             inrun = lo < s_sigma && runsorted[lo] == k7;
                         }
-                        GD[grp] = sj[k] >> D;                    // the group's depth (every member writes the same value)
+                        if ((HE[word] >> l) & 1ull) GD[grp] = sj[k] >> D;      // the group's depth, written by its first member
                     } else inrun = k7 == (k7 >> code_shift) * rep;
                     nrun += inrun ? 1u : 0u;
                     a_sa[pos] = s;
@@ -1722,8 +1722,9 @@ __global__ __launch_bounds__(TB) void k_pair_dist(const uint32_t *__restrict__ a
 // induction only needs T[z] = T[z + p], and z and z + p ARE in one group there: the thread of a stretch end walks on through such
 // positions and writes p (with PREP) over their own distance until the stretch's own distance returns, the two suffixes part, or
 // the text ends.  The walk reads consecutive ranks (z and z + p advance together).  A position that was walked through gives up its own
-// pair (V = 0: its group, a mixed one, waits for the doubling rounds); two walks over the same position may overwrite each other: either
-// value is a true same-group distance.
+// pair (V = 0: its group, a mixed one, waits for the doubling rounds).  Inner repeats start walks of their own through the same positions:
+// the largest distance wins (atomicMax; PREP is the top bit, so any carried distance beats a position's own) -- the outer repeat's
+// stretch is the long one.  Any winner is a true same-group distance.
 constexpr int PAIR_WALK_MAX = 2048;
 __global__ __launch_bounds__(TB) void k_pair_repair(uint32_t *P, uint32_t n, const uint32_t *__restrict__ ISA, const uint8_t *__restrict__ blk,
                                                    const uint32_t *__restrict__ bend)
@@ -1738,7 +1739,7 @@ __global__ __launch_bounds__(TB) void k_pair_repair(uint32_t *P, uint32_t n, con
             if ((uint64_t)z + p >= lim) break;                    // the pair behind the stretch reaches the end of the text: decided there
             if ((P[z] & ~PREP) == p) break;                       // the stretch's own distance again: it runs on by itself
             if (ISA[z] != ISA[z + p]) break;                      // the two suffixes part: decided by their ranks
-            P[z] = p | PREP;
+            atomicMax(&P[z], p | PREP);                            // the LARGEST distance carried through z wins: the outer repeat, not an inner one
         }
     }
 }
@@ -2073,7 +2074,7 @@ void sa_layout(Arena &a, size_t n, SaBufs &b, bool var)
     if (var) {
         b.GD[0] = a.get<uint32_t>(n);
         b.GD[1] = a.get<uint32_t>(n);
-        b.D0 = a.get<uint8_t>(n);
+        b.D0 = b.bwt;                         // (the slots' depths are read by the radix sort's first pass; the BWT bytes arrive from k_r0_finish on)
     }
     const size_t nbmax = 256;
     b.table = a.get<uint32_t>(nbmax * 2 * nwin);
@@ -2171,7 +2172,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     uint64_t *ks = b.keysA;
     uint32_t *vs = b.valsA;
     JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_sym_present, dim3(cap_grid(n, 16 * TB * 4, 4096)), dim3(TB), T, n, b.state);
-    const bool var = b.D0 != nullptr;               // (sa_layout: var_keys_eligible)
+    const bool var = b.GD[0] != nullptr;            // (sa_layout: var_keys_eligible)
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_key_plan, dim3(1), dim3(256), b.state, key_force_bits(), var ? 1 : 0, var_tag_shift(n));
     if (var) JPK_HIP(hipMemsetAsync(b.D0, 0, n, st));      // (a plan that falls back to the fixed code leaves no depths: tag 0 everywhere)
     JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_pack_keys, dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend,

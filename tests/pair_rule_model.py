@@ -47,16 +47,20 @@ def pair_round(t, n, active, isa, sa_out, iters=2, repair=True):
     # z and z + p stay in one group; such a position gives up its own pair (its verdict stays open)
     carried = [False] * (n + 1)
     if repair:
-        ends = [x for x in range(n - 1) if P[x] and P[x + 1] != P[x]]
-        for x in ends:
-            p = P[x]
-            if carried[x]:
+        P0 = list(P)
+        best = [0] * (n + 1)
+        for x in range(n - 1):
+            p = P0[x]
+            if p == 0 or P0[x + 1] == p:
                 continue
             z = x + 1
-            while z + p < n and P[z] != p and isa[z] == isa[z + p]:
-                P[z] = p
-                carried[z] = True
+            while z + p < n and P0[z] != p and isa[z] == isa[z + p]:
+                best[z] = max(best[z], p)                   # the largest distance carried through z wins (the outer repeat, not an inner one)
                 z += 1
+        for z in range(n):
+            if best[z]:
+                P[z] = best[z]
+                carried[z] = True
     # verdict of the stretch that ends at x (P[x] != P[x+1]): 1 = the lower position is the smaller suffix, 2 = the higher, 0 = open.
     # Passes after the first also decide a stretch whose end pair lies in ONE group with other members between the two: by the chain of
     # neighbouring pairs from x + 1 up to x + 1 + p, if all of them carry one verdict of the pass before.
