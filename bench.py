@@ -109,7 +109,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="enwik8", choices=["enwik6", "enwik8", "enwik8-phrase", "enwik9", "silesia"])
+    ap.add_argument("--workload", default="enwik8", choices=["enwik6", "enwik8", "enwik8-phrase", "enwik8-wide", "enwik9", "silesia"])
     ap.add_argument("--block-mib", type=int, default=64)
     ap.add_argument("--limit-bytes", type=int, default=0, help="truncate the workload (debug only; marks the line invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -771,6 +771,49 @@ def main():
     value = job_bytes / 1e6 / (dt / args.steps)
 
     extra = {}
+    if rank == 0 and world == 1 and not args.no_extras and blocks:
+        # the workload variants first: the same loop, the same contexts, right behind the timed steps (before the extras that create contexts
+        # and streams of their own: a later leg of this process measures 5-10 % lower, see child_extras)
+        if args.workload == "enwik8" and not args.limit_bytes:
+            # the same step on the phrase-book text (deeper repeats, ratio ~10 %): round 1's headline corpus, kept for comparison
+            pdata, _ = corpus.load_or_make("enwik8-phrase")
+            pblocks = corpus.split_blocks(pdata, bs)
+            p_in = [torch.from_numpy(np.ascontiguousarray(b)).to(dev) for b in pblocks]
+            psz = [0] * len(pblocks)
+
+            run_steps(3, p_in, psz, gather=False)
+            torch.cuda.synchronize()
+            tp0 = time.perf_counter()
+            run_steps(10, p_in, psz, gather=False)
+            torch.cuda.synchronize()
+            tp = (time.perf_counter() - tp0) / 10
+            extra["phrase_book_variant"] = {"value": round(batch_bytes / 1e6 / tp, 1), "unit": "MB/s", "ms_per_step": round(tp * 1e3, 3), "steps": 10,
+                                            "compressed_ratio": round(sum(psz) / batch_bytes, 4),
+                                            "workload": "same shape, text with a 200 000-phrase book (round 1's corpus)"}
+            del p_in
+            # ... and on a text with enwik8's BYTE ALPHABET (VERDICT r4 #2): the headline text has 28 distinct bytes, which lets round 0 of
+            # the suffix sort key on 11 bytes; real enwik8 has 205 (capitals, digits, punctuation, markup, UTF-8 pairs: order-0 entropy
+            # 5.1 bits) and gets the 7-byte keys of any block above 128 byte values.  Same shape, same word model, wide spelling.
+            wdata, _ = corpus.load_or_make("enwik8-wide")
+            wblocks = corpus.split_blocks(wdata, bs)
+            w_in = [torch.from_numpy(np.ascontiguousarray(b)).to(dev) for b in wblocks]
+            wsz = [0] * len(wblocks)
+            hist = np.bincount(wdata, minlength=256).astype(np.float64)
+            pr = hist[hist > 0] / hist.sum()
+            run_steps(3, w_in, wsz, gather=False)
+            torch.cuda.synchronize()
+            tw0 = time.perf_counter()
+            run_steps(12, w_in, wsz, gather=False)
+            torch.cuda.synchronize()
+            tw = (time.perf_counter() - tw0) / 12
+            extra["wide_alphabet_variant"] = {"value": round(batch_bytes / 1e6 / tw, 1), "unit": "MB/s", "ms_per_step": round(tw * 1e3, 3), "steps": 12,
+                                              "compressed_ratio": round(sum(wsz) / batch_bytes, 4), "alphabet": int((hist > 0).sum()),
+                                              "order0_entropy_bits": round(float(-(pr * np.log2(pr)).sum()), 3),
+                                              "workload": "same shape and word model over an enwik8-like byte alphabet (capitals, digits, punctuation, markup, "
+                                                          "UTF-8 pairs): a fixed-width code holds 7 of its bytes per sort key (11 of the headline text's), the variable-length code about 10 (12)"}
+            del w_in, wdata
+            run_steps(1, gather=False)          # the variants wrote the loop's output buffers: the workload's own blocks again (sizes, d_out)
+            torch.cuda.synchronize()
     if use_dist:
         backend = dist.get_backend()
         extra["collective"] = {"backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend), "ranks": dist.get_world_size(),
@@ -998,44 +1041,6 @@ def main():
         extra["compress_alg"] = {"bytes_per_byte": round(14.0 + c, 2), "achieved_GBps": round((14.0 + c) * batch_bytes / 1e9 / (ms_per_step / 1e3), 2),
                                  "frac": round((14.0 + c) * batch_bytes / 1e9 / (ms_per_step / 1e3) / 8000.0, 5), "one_block_at_a_time_ms": round(comp_ms, 3)}
         # per-kernel HIP-event timing (events recorded by the library on the launch stream) of one more compress pass
-        if args.workload == "enwik8" and not args.limit_bytes:
-            # the same step on the phrase-book text (deeper repeats, ratio ~10 %): round 1's headline corpus, kept for comparison
-            pdata, _ = corpus.load_or_make("enwik8-phrase")
-            pblocks = corpus.split_blocks(pdata, bs)
-            p_in = [torch.from_numpy(np.ascontiguousarray(b)).to(dev) for b in pblocks]
-            psz = [0] * len(pblocks)
-
-            run_steps(2, p_in, psz, gather=False)
-            torch.cuda.synchronize()
-            tp0 = time.perf_counter()
-            run_steps(6, p_in, psz, gather=False)
-            torch.cuda.synchronize()
-            tp = (time.perf_counter() - tp0) / 6
-            extra["phrase_book_variant"] = {"value": round(batch_bytes / 1e6 / tp, 1), "unit": "MB/s", "ms_per_step": round(tp * 1e3, 3), "steps": 6,
-                                            "compressed_ratio": round(sum(psz) / batch_bytes, 4),
-                                            "workload": "same shape, text with a 200 000-phrase book (round 1's corpus)"}
-            del p_in
-            # ... and on a text with enwik8's BYTE ALPHABET (VERDICT r4 #2): the headline text has 28 distinct bytes, which lets round 0 of
-            # the suffix sort key on 11 bytes; real enwik8 has 205 (capitals, digits, punctuation, markup, UTF-8 pairs: order-0 entropy
-            # 5.1 bits) and gets the 7-byte keys of any block above 128 byte values.  Same shape, same word model, wide spelling.
-            wdata, _ = corpus.load_or_make("enwik8-wide")
-            wblocks = corpus.split_blocks(wdata, bs)
-            w_in = [torch.from_numpy(np.ascontiguousarray(b)).to(dev) for b in wblocks]
-            wsz = [0] * len(wblocks)
-            hist = np.bincount(wdata, minlength=256).astype(np.float64)
-            pr = hist[hist > 0] / hist.sum()
-            run_steps(2, w_in, wsz, gather=False)
-            torch.cuda.synchronize()
-            tw0 = time.perf_counter()
-            run_steps(6, w_in, wsz, gather=False)
-            torch.cuda.synchronize()
-            tw = (time.perf_counter() - tw0) / 6
-            extra["wide_alphabet_variant"] = {"value": round(batch_bytes / 1e6 / tw, 1), "unit": "MB/s", "ms_per_step": round(tw * 1e3, 3), "steps": 6,
-                                              "compressed_ratio": round(sum(wsz) / batch_bytes, 4), "alphabet": int((hist > 0).sum()),
-                                              "order0_entropy_bits": round(float(-(pr * np.log2(pr)).sum()), 3),
-                                              "workload": "same shape and word model over an enwik8-like byte alphabet (capitals, digits, punctuation, markup, "
-                                                          "UTF-8 pairs): the suffix sort's first key holds 7 bytes here, 11 on the headline text"}
-            del w_in, wdata
         # The extras below bring contexts of their own.  The loop's contexts (each with its stream and up to three encoder group
         # streams) are closed first: HIP deals streams onto 32 hardware queues, a stream beyond that shares a queue, and a 12 ms
         # chain kernel then blocks whatever sits behind it -- with the loop's twenty streams still alive the 8 MiB leg of

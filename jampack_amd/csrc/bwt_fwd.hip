@@ -329,8 +329,8 @@ __device__ __forceinline__ void pack_tile(const uint8_t *cc, const uint8_t *cr, 
 // depth) follows with an end pointer that only moves backwards.  Symbols past the end of the text are zero bits and do not count: a
 // suffix whose depth reaches the end is shorter than anything it ties with and becomes a group of its own (k_r0_*).  dk[x] = depth of
 // slot x (< 64: rides in bits 26..31 of the slot's value through the radix sort).
-__device__ __forceinline__ void pack_tile_var(const uint8_t *cr, const uint32_t *lcode, const uint8_t *llen, uint64_t *ko, uint8_t *dk, int64_t i_lo, uint32_t n,
-                                              uint32_t tag_max)
+__device__ __forceinline__ void pack_tile_var(const uint8_t *cr, const uint8_t *cb, const uint32_t *lcode, const uint8_t *llen, uint64_t *ko, uint8_t *dk, int64_t i_lo,
+                                              uint32_t n, uint32_t tag_max, const uint32_t *__restrict__ bend)
 {
     constexpr uint64_t M56 = (1ull << 56) - 1ull;
     const int t = threadIdx.x;
@@ -338,31 +338,39 @@ __device__ __forceinline__ void pack_tile_var(const uint8_t *cr, const uint32_t 
     uint64_t acc = 0;
     uint32_t used = 0;                                                 // bits of the whole symbols [q, e) of the current key
     int e = q15;
+    // the key of position p from scratch: whole symbols while they fit and the suffix lasts (group sort: its own block), then the leading
+    // bits of one more
+    auto scratch = [&](int q, uint32_t lim) {
+        acc = 0; used = 0; e = q;
+        for (;;) {
+            if (i_lo - 16 + e >= (int64_t)lim) break;                  // the text (the block) ends: zero bits from here on
+            const uint32_t b = cr[e], l = llen[b], c = lcode[b];
+            if (used + l <= 56u) { acc |= (uint64_t)c << (56u - used - l); used += l; e++; if (used == 56u) break; }
+            else { acc |= (uint64_t)c >> (l - (56u - used)); break; }
+        }
+    };
     {
         const int64_t p15 = i_lo + 16 * t + 15;
-        if (p15 >= 0) {
-            for (;;) {
-                if (i_lo - 16 + e >= (int64_t)n) break;                // the text ends: zero bits from here on
-                const uint32_t b = cr[e], l = llen[b], c = lcode[b];
-                if (used + l <= 56u) { acc |= (uint64_t)c << (56u - used - l); used += l; e++; if (used == 56u) break; }
-                else { acc |= (uint64_t)c >> (l - (56u - used)); break; }
-            }
-        }
+        if (p15 >= 0) scratch(q15, bend ? bend[cb[q15]] : n);
     }
 #pragma unroll 1
     for (int s = 15; s >= 0; s--) {
         const int64_t i = i_lo + 16 * t + s;
         if (i < 0) break;                                              // (the last tile: positions in front of the text)
         const int q = 16 + 16 * t + s;
+        const uint32_t blkno = bend ? cb[q] : 0u;
         if (s < 15) {
-            const uint32_t b = cr[q], l = llen[b], c = lcode[b];
-            acc = (((uint64_t)c << (56u - l)) | (acc >> l)) & M56;
-            used += l;
-            while (used > 56u) { e--; used -= llen[cr[e]]; }
+            if (bend && cb[q + 1] != blkno) scratch(q, bend[blkno]);   // the last position of its block: nothing of the next block is in its key
+            else {
+                const uint32_t b = cr[q], l = llen[b], c = lcode[b];
+                acc = (((uint64_t)c << (56u - l)) | (acc >> l)) & M56;
+                used += l;
+                while (used > 56u) { e--; used -= llen[cr[e]]; }
+            }
         }
-        const uint32_t prev = i ? cr[q - 1] : 0u;
+        const uint32_t low = bend ? blkno : (i ? cr[q - 1] : 0u);     // T[i - 1] rides in the low byte -- the block number in a group sort (the sort's last digit)
         const uint32_t x = (uint32_t)(CT - 1 - 16 * t - s);
-        ko[x + (x >> 4)] = (acc << 8) | prev;
+        ko[x + (x >> 4)] = (acc << 8) | low;
         const uint32_t d = (uint32_t)(e - q);
         dk[x] = (uint8_t)(d < tag_max ? d : tag_max);        // (a clamped depth is still a number of symbols the key's group shares)
     }
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T,
         }
         __syncthreads();
         if (vmode) {
-            pack_tile_var(cr, lcode, llen, ko, dk, i_lo, n, st->tag_max);
+            pack_tile_var(cr, cb, lcode, llen, ko, dk, i_lo, n, st->tag_max, bend);
             __syncthreads();
             const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
 #pragma unroll
@@ -464,7 +472,7 @@ __device__ __forceinline__ uint32_t r0_end(uint64_t key, uint32_t n, const uint3
 // (in vmode the parameter D of the helpers below is the tag shift, not a depth)
 __device__ __forceinline__ bool r0_short(uint32_t v, uint64_t key, uint32_t n, const uint32_t *__restrict__ bend, uint32_t D, bool vmode)
 {
-    return vmode ? (v & ((1u << D) - 1u)) + (v >> D) >= n : v + D > r0_end(key, n, bend);
+    return vmode ? (v & ((1u << D) - 1u)) + (v >> D) >= r0_end(key, n, bend) : v + D > r0_end(key, n, bend);
 }
 __device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t j, uint32_t n, const uint32_t *__restrict__ bend,
                                         uint32_t D, bool vmode)
@@ -1126,6 +1134,7 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
                 }
             }
         }
+        uint32_t kmax = 0;                         // the window's largest key2: the sort only needs passes over the bits it has
         {
             uint32_t kl[SEG_ITEMS];
 #pragma unroll
@@ -1135,25 +1144,35 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
                 const uint32_t q = tid + k * TB;
                 if (q < no) {
                     k2[q] = kl[k];
+                    kmax |= kl[k];
                     idxA[q] = (uint16_t)q;    // g[] is dead from here on (last read: the classification above)
                 }
             }
         }
+        {
+            uint32_t kall;
+            block_incl_scan<OpMax>(kmax, sm, &kall);                  // (an OR would do; the maximum of the ORs has the same top bit)
+            kmax = kall;
+        }
         __syncthreads();
+        // key2 <= n needs 27 bits on a 64 MiB block, the host's bound (3 n: round 1 spreads run members) 28 -- and with ten bits of group
+        // number that is a fifth 9-bit pass which the window's own largest key usually does not need
+        const int key_bits_w = kmax ? 32 - __clz((int)kmax) : 1;
+        const int kbw = key_bits_w < key_bits ? key_bits_w : key_bits;
         const uint32_t ngroups = (uint32_t)lgid[no - 1] + 1u;
 
-        // ---- LSD radix sort of the index permutation by the composite key (lgid << key_bits) | key2, 9 bits per pass ----
+        // ---- LSD radix sort of the index permutation by the composite key (lgid << kbw) | key2, 9 bits per pass ----
         uint16_t *src = idxA, *dst = idxB;
         const int w = tid >> 6, l = tid & 63;
         const uint64_t lt = lanemask_lt();
         const int gbits = (ngroups > 1u) ? 32 - __clz((int)(ngroups - 1u)) : 0;
-        const int npass = (key_bits + gbits + SEG_DBITS - 1) / SEG_DBITS;
+        const int npass = (kbw + gbits + SEG_DBITS - 1) / SEG_DBITS;
         // each wave ranks a contiguous quarter of the owned range: only ceil(no / 256) iterations of 64 are live
         const int nit = (int)((no + TB - 1) / TB);
         const uint32_t wspan = (uint32_t)nit * 64u;
         for (int pass = 0; pass < npass; pass++) {
             const int shift = SEG_DBITS * pass;
-            const int part = (shift + SEG_DBITS <= key_bits) ? 0 : (shift >= key_bits ? 2 : 1);   // digit from key2 / both / group id
+            const int part = (shift + SEG_DBITS <= kbw) ? 0 : (shift >= kbw ? 2 : 1);   // digit from key2 / both / group id
             for (int i = tid; i < (TB / 64) * SEG_DIGITS / 2; i += TB) reinterpret_cast<uint32_t *>(&cnt[0][0])[i] = 0;
             __syncthreads();
             uint32_t rk[SEG_ITEMS], dg[SEG_ITEMS];
@@ -1165,8 +1184,8 @@ __global__ __launch_bounds__(TB) void k_seg_round(const uint32_t *__restrict__ a
                 const uint32_t id = valid ? src[q] : 0u;
                 uint32_t d;
                 if (part == 0) d = k2[id] >> shift;
-                else if (part == 2) d = (uint32_t)lgid[id] >> (shift - key_bits);
-                else d = (k2[id] >> shift) | ((uint32_t)lgid[id] << (key_bits - shift));
+                else if (part == 2) d = (uint32_t)lgid[id] >> (shift - kbw);
+                else d = (k2[id] >> shift) | ((uint32_t)lgid[id] << (kbw - shift));
                 d = valid ? (d & (uint32_t)(SEG_DIGITS - 1)) : 0u;
                 dg[it] = d | (id << SEG_DBITS);
                 const uint64_t mm = match_any<SEG_DBITS>(d, valid);
@@ -2050,9 +2069,9 @@ bool var_keys_on()
     static const bool v = [] { const char *e = getenv("JPK_VARKEYS"); return e ? atoi(e) != 0 : true; }();
     return v;
 }
-// variable-length keys: single-block sorts of at most 2^28 bytes (the key's depth rides in the spare bits of the 32-bit suffix number:
+// variable-length keys: sorts (one block, or a group of small ones) of at most 2^28 bytes (the key's depth rides in the spare bits of the 32-bit suffix number:
 // six up to 2^26 bytes, five up to 2^27, four -- depths clamped at 15 -- up to 2^28), the one-pass radix form, no forced code width
-bool var_keys_eligible(size_t n, bool group) { return !group && n <= ((size_t)1 << 28) && var_keys_on() && jpk_radix_onesweep() && key_force_bits() == 0; }
+bool var_keys_eligible(size_t n, bool group) { (void)group; return n <= ((size_t)1 << 28) && var_keys_on() && jpk_radix_onesweep() && key_force_bits() == 0; }
 int var_tag_shift(size_t n) { int s = 26; while (((size_t)1 << s) < n) s++; return s; }
 
 void sa_layout(Arena &a, size_t n, SaBufs &b, bool var)
@@ -2423,7 +2442,7 @@ size_t jpk_fwd_bwt_group_arena_bytes(uint32_t total_nlen, int nblk)
     SaBufs b;
     jpk_ctx dummy;
     Arena plan(&dummy, true);
-    sa_layout(plan, total_nlen ? total_nlen : 1, b, false);
+    sa_layout(plan, total_nlen ? total_nlen : 1, b, var_keys_eligible(total_nlen ? total_nlen : 1, true));
     plan.get<uint8_t>(total_nlen);            // common text
     plan.get<uint8_t>(total_nlen);            // block number per position
     plan.get<uint32_t>(total_nlen);           // suffix array (the BWT bytes are gathered through it)
@@ -2458,7 +2477,7 @@ int jpk_fwd_bwt_group_device(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in,
     const JpkCompressInflight inflight(ctx->device);
     SaBufs sb;
     Arena real(ctx, false);
-    sa_layout(real, N ? N : 1, sb, false);
+    sa_layout(real, N ? N : 1, sb, var_keys_eligible(N ? N : 1, true));
     uint8_t *C = real.get<uint8_t>(N);
     uint8_t *blk = real.get<uint8_t>(N);
     uint32_t *SA = real.get<uint32_t>(N);

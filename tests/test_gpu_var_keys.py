@@ -70,7 +70,7 @@ def test_skewed_wide_alphabets_equal_the_oracle(gpu, oracle, sigma):
         got, s = _fwd(torch, jam, ctx, t)
         assert np.array_equal(got, oracle.bwt_forward(t, prefill=0x11)), (sigma, n)
         if n >= 70_001:
-            assert s.sa_key_depth >= 9, (sigma, n, s.sa_key_depth)          # the fixed 8-bit code holds 7
+            assert s.sa_key_depth >= 8, (sigma, n, s.sa_key_depth)          # the fixed 8-bit code holds 7
 
 
 @pytest.mark.parametrize("sigma,s", [(3, 2.0), (6, 1.5), (20, 1.0), (28, 0.8), (64, 1.3), (100, 2.5)])
