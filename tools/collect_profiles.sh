@@ -3,7 +3,7 @@
 # Produces gpurun_out/<tag>/: PMC passes + summary, rocprofv3 kernel stats of the bench command, bench lines, worst cases.
 # (counters and traces in separate runs; the program itself after `--`)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -44,7 +44,10 @@ ls -la "$OUT"
 python3 tools/block_sizes.py 1,8,64,128 2>/dev/null > "$OUT/block_sizes.txt"
 python3 tools/batch_compress.py 2>/dev/null | grep "in flight" > "$OUT/blocks_compress_call.txt"
 # 5. round 3: the floor of the suffix sort, the drop-in block loop with 16 threads, the N > 1 code path on one GPU, SQ counters
-tools/_bin/sa_floor > "$OUT/sa_floor.txt" 2>&1
+( echo "# headline block (text_survey, variable-length keys: round counts of tools/fwd_once.py)"; tools/_bin/sa_floor 67108800 41245987 5028889 321
+  echo "# the same block with round 4's fixed-width keys (11 bytes)"; tools/_bin/sa_floor 67108800 47350511 8839248 3530
+  echo "# wide-alphabet block (text_wide, variable-length keys)"; tools/_bin/sa_floor 67108800 38943552 4138392 3586
+  echo "# the same block with fixed-width keys (7 bytes)"; tools/_bin/sa_floor 67108800 56766712 23323321 420103 ) > "$OUT/sa_floor.txt" 2>&1
 python3 - <<'PY'
 import sys
 sys.path.insert(0, ".")
@@ -59,16 +62,27 @@ make -C jampack_amd/csrc/shim > /dev/null
 JPK_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --steps 4 --warmup 2 --no-extras --contexts 2 2>/dev/null | tail -1 > "$OUT/bench_two_ranks_one_gpu.json"
 JPK_BENCH_ONE_GPU=1 python3 bench.py --gpus 2 --steps 2 --warmup 1 --no-extras --contexts 2 --workload enwik9 --limit-bytes 402653184 2>/dev/null | tail -1 > "$OUT/bench_two_ranks_one_gpu_enwik9_384mib.json"
 bash tools/pmc_sq.sh gpurun_out/$TAG/sq_fwd fwd > /dev/null 2>&1
-bash tools/pmc_sq.sh gpurun_out/$TAG/sq_enc enc > /dev/null 2>&1
-# 6. round 4: small blocks through one call (a fresh process), the interference matrix, counters in the timed loop's shape
+bash tools/pmc_sq.sh gpurun_out/$TAG/sq_dec dec > /dev/null 2>&1
+python3 tools/dec_once.py text_survey 2 2>/dev/null | tail -1 > "$OUT/decode_once.txt"
+tools/_bin/issuetest > "$OUT/issuetest.txt" 2>&1
+# 6. round 4: small blocks through one call (a fresh process)
 python3 tools/small_blocks.py 1,8,64 4,8,16 2>/dev/null | grep blocks > "$OUT/small_blocks.txt"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/hog.hip -o tools/_bin/libhog.so > /dev/null 2>&1
-python3 tools/interfere.py 4 2 2>/dev/null | grep -v amdgpu > "$OUT/interference.txt"
-( echo "# bench.py --steps 20 --warmup 5 --no-extras, same box, alternating: round 0's keys packed by the alphabet (default) against JPK_KEY_BITS=8 (one byte per symbol: 7 bytes per key, round 3's keys)"
-  for k in 0 8 0 8 0 8; do echo -n "JPK_KEY_BITS=$k  "; JPK_KEY_BITS=$k python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*' | head -1; done
-  echo "# forward BWT of ONE 64 MiB enwik8-like block at a time, three repetitions (tools/fwd_once.py), wall clock per block"
-  for k in 0 8; do echo -n "JPK_KEY_BITS=$k  "; JPK_KEY_BITS=$k python3 tools/fwd_once.py text_survey 3 2>/dev/null | tail -1; done ) > "$OUT/packed_keys.txt"
-python3 tools/mix_stages.py 2 3,0 0,4 3,4 4,4 2>/dev/null | grep contexts > "$OUT/stage_mix.txt"
-bash tools/pmc_loop.sh gpurun_out/$TAG/loop > /dev/null 2>&1
-cp gpurun_out/$TAG/loop/loop_counters.txt "$OUT/loop_counters.txt" 2>/dev/null
+# 7. round 5: variable-length keys against the fixed-width ones, the pair rule against plain doubling (same box, alternating)
+( echo "# bench.py --steps 12 --warmup 3 --no-extras, same box, alternating: variable-length keys (default) against JPK_VARKEYS=0 (round 4's alphabet-packed fixed-width keys)"
+  for i in 1 2 3; do for v in 1 0; do
+    echo -n "headline (28 byte values) JPK_VARKEYS=$v  "; JPK_VARKEYS=$v python3 bench.py --steps 12 --warmup 3 --no-extras --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*' | head -1
+    echo -n "wide (207 byte values)    JPK_VARKEYS=$v  "; JPK_VARKEYS=$v python3 bench.py --workload enwik8-wide --steps 12 --warmup 3 --no-extras --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*' | head -1
+  done; done
+  echo "# forward BWT of ONE 64 MiB block at a time (tools/fwd_once.py), wall clock per block"
+  for k in text_survey text_wide; do for v in 1 0; do echo -n "$k JPK_VARKEYS=$v  "; JPK_VARKEYS=$v python3 tools/fwd_once.py $k 3 2>/dev/null | tail -1; done; done ) > "$OUT/var_keys.txt"
+( echo "# the pair rule (k_pair_*) against plain prefix doubling (JPK_PAIR_SHIFT=-1) and without the repair walk (JPK_PAIR_REPAIR=0): forward BWT of one 64 MiB block"
+  for k in repeat silesia runs text; do
+    echo -n "$k default            "; python3 tools/fwd_once.py $k 3 2>/dev/null | tail -1
+    echo -n "$k JPK_PAIR_REPAIR=0  "; JPK_PAIR_REPAIR=0 python3 tools/fwd_once.py $k 3 2>/dev/null | tail -1
+    echo -n "$k JPK_PAIR_SHIFT=-1  "; JPK_PAIR_SHIFT=-1 python3 tools/fwd_once.py $k 3 2>/dev/null | tail -1
+  done
+  echo "# config 5: bench.py --workload silesia --block-mib 256 --steps 4 --warmup 1 --no-extras"
+  for e in "" "JPK_PAIR_SHIFT=-1" "JPK_VARKEYS=0" "JPK_PAIR_SHIFT=-1 JPK_VARKEYS=0"; do echo -n "silesia-like 212 MB [$e]  "; env $e python3 bench.py --workload silesia --block-mib 256 --steps 4 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | grep -o '"value": [0-9.]*' | head -1; done ) > "$OUT/pair_rule.txt"
+rm -rf /tmp/kfw
+( cd /tmp; rocprofv3 --kernel-trace -d /tmp/kfw -o f -- python3 $REPO/tools/fwd_once.py text_wide 3 > /dev/null 2>&1; python3 $REPO/tools/rocpd_stats.py /tmp/kfw/f_results.db 4 > "$OUT/kernel_stats_forward_bwt_64mib_wide.txt" 2>&1 )
 ls -la "$OUT"

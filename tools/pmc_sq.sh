@@ -5,7 +5,7 @@ set -u
 REPO=$PWD
 OUT=$REPO/${1:-gpurun_out/pmc_sq}
 WHAT=${2:-fwd}
-if [ "$WHAT" = enc ]; then PROG="$REPO/tools/enc_once.py text_survey"; else PROG="$REPO/tools/fwd_once.py text_survey 1"; fi
+if [ "$WHAT" = enc ]; then PROG="$REPO/tools/enc_once.py text_survey"; elif [ "$WHAT" = dec ]; then PROG="$REPO/tools/dec_once.py text_survey 1"; else PROG="$REPO/tools/fwd_once.py text_survey 1"; fi
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
