@@ -58,6 +58,7 @@ struct SaState {
     uint32_t npieces;                      // pieces of large groups in the current round
     uint32_t lc;                           // members of large groups in the current round
     uint32_t nrun;                         // unresolved suffixes after round 0 that start inside a run of >= depth equal bytes
+    uint32_t pair_steps;                   // k_pair_repair: positions walked so far in this pair round (its work is capped at 8 n)
     uint32_t round_m[JPK_SA_MAX_ROUNDS];   // per round: unresolved suffixes when it starts
     uint32_t round_lc[JPK_SA_MAX_ROUNDS];  // per round: of those, members of groups > SEG_TILE
     // round 0's key (k_key_plan): the text's bytes renumbered 0..sigma-1 in byte order, `bits` bits each, `depth` of them in 56 bits
@@ -1746,8 +1747,9 @@ __global__ __launch_bounds__(TB) void k_pair_dist(const uint32_t *__restrict__ a
 // stretch is the long one.  Any winner is a true same-group distance.
 constexpr int PAIR_WALK_MAX = 2048;
 __global__ __launch_bounds__(TB) void k_pair_repair(uint32_t *P, uint32_t n, const uint32_t *__restrict__ ISA, const uint8_t *__restrict__ blk,
-                                                   const uint32_t *__restrict__ bend)
+                                                   const uint32_t *__restrict__ bend, SaState *__restrict__ st)
 {
+    const uint32_t budget = (n < 0x1E000000u) ? 8u * n : 0xF0000000u;
     for (uint32_t x = blockIdx.x * TB + threadIdx.x; x + 1u < n; x += gridDim.x * TB) {
         const uint32_t p = P[x];
         if (p == 0u || (p & PREP)) continue;
@@ -1755,6 +1757,9 @@ __global__ __launch_bounds__(TB) void k_pair_repair(uint32_t *P, uint32_t n, con
         const uint32_t lim = bend ? bend[blk[x]] : n;
         uint32_t z = x + 1u;
         for (int step = 0; step < PAIR_WALK_MAX; step++, z++) {
+            // (all walks of a pair round together stay below 8 n positions: an input built to make every position a stretch end with a long
+            // walk behind it costs a bounded pass, and the stretches it leaves cut wait for the doubling rounds)
+            if ((step & 31) == 31 && atomicAdd(&st->pair_steps, 32u) > budget) break;
             if ((uint64_t)z + p >= lim) break;                    // the pair behind the stretch reaches the end of the text: decided there
             if ((P[z] & ~PREP) == p) break;                       // the stretch's own distance again: it runs on by itself
             if (ISA[z] != ISA[z + p]) break;                      // the two suffixes part: decided by their ranks
@@ -2272,9 +2277,10 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             if (round < 64) pair_mask |= 1ull << round;
             JPK_HIP(hipMemsetAsync(P, 0, sizeof(uint32_t) * ((size_t)n + 1), st));
             JPK_HIP(hipMemsetAsync(BAD, 0, n, st));
+            JPK_HIP(hipMemsetAsync(&b.state->pair_steps, 0, sizeof(uint32_t), st));
             JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_pair_dist, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, P, b.FH, b.LH);
             JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan1, dim3(1), dim3(WG1), b.FH, b.LH, b.PH, b.NH, b.state, par);
-            if (pair_rule_repair()) JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_pair_repair, dim3(cap_grid(n, TB * 4, 8192)), dim3(TB), P, n, b.ISA, b.blk, b.bend);
+            if (pair_rule_repair()) JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_pair_repair, dim3(cap_grid(n, TB * 4, 8192)), dim3(TB), P, n, b.ISA, b.blk, b.bend, b.state);
             JPK_LAUNCH(ctx, PROF_SCAN, 0, k_pair_first, dim3(cap_grid(n, CT, 4096)), dim3(TB), P, n, b.tB);
             JPK_LAUNCH(ctx, PROF_SCAN, 0, k_pair_scan, dim3(1), dim3(WG1), b.tB, n);
             for (int it = 0; it < pair_rule_iters(); it++)     // later passes decide stretches that end in a group mixing two repeats (pair_verdict)
