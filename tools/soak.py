@@ -5,15 +5,16 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import jampack_amd as jam
-from oracle.pyoracle import Oracle
+from oracle.pyoracle import Oracle, Ref
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 o = Oracle()
+ref = Ref() if Ref.available() else None          # the real reference (oracle/_ref): every block is compared with it, whatever its size
 dev = torch.device("cuda", 0)
 ctx = jam.Context(0, None)
-kinds = ["text_survey", "text", "random", "runs", "geometric", "dna", "silesia", "zero", "two", "samples16", "repeat"]
+kinds = ["text_survey", "text", "text_wide", "random", "runs", "geometric", "dna", "silesia", "zero", "two", "samples16", "repeat", "repeat4k"]
 kinds = [k for k in kinds if k in jam.corpus.KINDS] if hasattr(jam.corpus, "KINDS") else kinds
 t0 = time.time()
 blocks, comp = [], []
@@ -47,6 +48,10 @@ for i in range(N):
         want = o.ans_encode(o.bwt_forward(t))
         assert np.array_equal(c.cpu().numpy(), want), (i, k, n)
         checked += 1
+    elif ref is not None and len(t) >= 120:
+        want = ref.ans_encode(ref.bwt_forward(t))
+        assert np.array_equal(c.cpu().numpy(), want), (i, k, n, "reference")
+        checked += 1
     blocks.append(t); comp.append(c)
 outs = [torch.empty(max(len(t), 1), dtype=torch.uint8, device=dev) for t in blocks]
 for lo in range(0, N, 64):
@@ -67,4 +72,4 @@ for rep, nfl in enumerate((6, 3)):
     for j in range(N):
         assert st[j] == 0 and n_[j] == comp[j].numel() and torch.equal(d_outs[j][: n_[j]], comp[j]), (rep, j)
     del d_ins, d_outs
-print(f"soak ok: {N} blocks, {sum(len(b) for b in blocks) / 1e6:.0f} MB, {checked} compared with the oracle byte for byte, {time.time() - t0:.0f} s")
+print(f"soak ok: {N} blocks, {sum(len(b) for b in blocks) / 1e6:.0f} MB, {checked} compared with the oracle or the reference build byte for byte, {time.time() - t0:.0f} s")
