@@ -174,7 +174,7 @@ __global__ __launch_bounds__(TB) void k_sym_present(const uint8_t *__restrict__ 
 // want_var: build the variable-length code as well (vmode): thread b walks the weight-balanced splitting of the occurring bytes from
 // the root to its own leaf -- at every node the byte range [l, r) is cut where the sampled weight is halved, left = 0, right = 1 -- which
 // is an alphabetic (order-preserving) prefix code with an average length below H0 + 2 (5.3 bits on an enwik8-like alphabet whose
-// H0 is 5.05; Hu-Tucker's optimum is 5.2).  A code longer than 28 bits (it cannot happen with sampled weights + 1) drops to the
+// H0 is 5.05; Hu-Tucker's optimum is 5.2).  A code longer than 27 bits (it cannot happen with sampled weights + 1) drops to the
 // fixed-width code.
 __global__ __launch_bounds__(256) void k_key_plan(SaState *__restrict__ st, int force_bits, int want_var, int tag_shift)
 {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_key_plan(SaState *__restrict__ st, int 
     // (32-bit: weights are sampled, at most n / 16 + 256 in all, lengths <= 30 -- below 2^32 for blocks of 2^26 bytes)
     block_incl_scan<OpSum>(w * len, sm, &wl);
     __syncthreads();
-    if (maxlen > 28u) return;                                             // vmode stays 0: the fixed-width code
+    if (maxlen > 27u) return;                                             // vmode stays 0: the fixed-width code (k_pack_keys_var keeps code | length << 27 in one word)
     {   // ... and when the code does not buy at least 3/4 of a symbol per key over the fixed width (near-uniform alphabets: random bytes,
         // DNA, 16-bit samples -- a balanced code of a flat histogram IS the fixed code, a slightly skewed one can even be longer)
         uint32_t fb = 1;
@@ -330,52 +330,91 @@ __device__ __forceinline__ void pack_tile(const uint8_t *cc, const uint8_t *cr, 
 // depth) follows with an end pointer that only moves backwards.  Symbols past the end of the text are zero bits and do not count: a
 // suffix whose depth reaches the end is shorter than anything it ties with and becomes a group of its own (k_r0_*).  dk[x] = depth of
 // slot x (< 64: rides in bits 26..31 of the slot's value through the radix sort).
-__device__ __forceinline__ void pack_tile_var(const uint8_t *cr, const uint8_t *cb, const uint32_t *lcode, const uint8_t *llen, uint64_t *ko, uint8_t *dk, int64_t i_lo,
-                                              uint32_t n, uint32_t tag_max, const uint32_t *__restrict__ bend)
+// A kernel of its own (second half of round 5).  The first version rolled every thread over SIXTEEN consecutive positions inside
+// k_pack_keys -- a serial chain of sixteen steps with two dependent LDS lookups each, and the keys had to be turned into slot order
+// through 35 KB of LDS (three workgroups per CU: 0.44 ms alone, five times that among the blocks in flight, which compete for the CUs'
+// LDS); every position from scratch (sixteen independent byte loads and table lookups, the accumulation in registers, keys straight out
+// in slot order, 10 KB of LDS) turned out bound by its ~260 vector instructions per position instead: 0.46-0.53 ms.  This form sits between:
+// a thread builds the key of the LAST of FOUR consecutive positions from scratch and rolls backwards over the other three,
+// key(i) = code(T[i]) in front of key(i + 1) shifted right by its length; its four keys are four consecutive slots and leave as two
+// 16-byte stores, its four depths as one word.  Depth = the WHOLE symbols in the key: an end pointer that only moves backwards.
+__global__ __launch_bounds__(TB) void k_pack_keys_var(const uint8_t *__restrict__ T, uint32_t n, const SaState *__restrict__ st, uint64_t *__restrict__ P,
+                                                     const uint8_t *__restrict__ blk, const uint32_t *__restrict__ bend, uint8_t *__restrict__ D0)
 {
+    if (!st->vmode) return;                                           // (the plan kept the fixed-width code: k_pack_keys does the tiles)
+    __shared__ __align__(16) uint8_t cr[CT + PK_HALO];                // bytes: index q = position i_lo - 16 + q
+    __shared__ __align__(16) uint8_t cb[CT + PK_HALO];                // block numbers (group sort)
+    __shared__ uint32_t lcl[256];                                      // code | length << 27: one lookup per symbol (k_key_plan keeps codes below 28 bits)
     constexpr uint64_t M56 = (1ull << 56) - 1ull;
+    constexpr int R = 4;                                               // consecutive positions per thread and step
+    lcl[threadIdx.x] = st->vcode[threadIdx.x] | ((uint32_t)st->vlen[threadIdx.x] << 27);
+    const uint32_t tag_max = st->tag_max;
+    const uint32_t ntiles = (n + CT - 1) / CT;
     const int t = threadIdx.x;
-    const int q15 = 16 + 16 * t + 15;                                  // staging index of the thread's last position (index q = position i_lo - 16 + q)
-    uint64_t acc = 0;
-    uint32_t used = 0;                                                 // bits of the whole symbols [q, e) of the current key
-    int e = q15;
-    // the key of position p from scratch: whole symbols while they fit and the suffix lasts (group sort: its own block), then the leading
-    // bits of one more
-    auto scratch = [&](int q, uint32_t lim) {
-        acc = 0; used = 0; e = q;
-        for (;;) {
-            if (i_lo - 16 + e >= (int64_t)lim) break;                  // the text (the block) ends: zero bits from here on
-            const uint32_t b = cr[e], l = llen[b], c = lcode[b];
-            if (used + l <= 56u) { acc |= (uint64_t)c << (56u - used - l); used += l; e++; if (used == 56u) break; }
-            else { acc |= (uint64_t)c >> (l - (56u - used)); break; }
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * CT, cnt = (n - base < (uint32_t)CT) ? n - base : (uint32_t)CT;
+        const int64_t i_lo = (int64_t)n - 1 - base - (CT - 1);        // position of the tile's LAST slot (negative in the last tile: no such slot)
+        __syncthreads();                                                // the table; the previous tile's bytes have been read
+        for (int q = threadIdx.x; q < CT + PK_HALO; q += TB) {
+            const int64_t p = i_lo - 16 + q;
+            const bool in = p >= 0 && p < (int64_t)n;
+            cr[q] = in ? T[p] : (uint8_t)0;
+            if (blk) cb[q] = in ? blk[p] : (uint8_t)0;
         }
-    };
-    {
-        const int64_t p15 = i_lo + 16 * t + 15;
-        if (p15 >= 0) scratch(q15, bend ? bend[cb[q15]] : n);
-    }
+        __syncthreads();
 #pragma unroll 1
-    for (int s = 15; s >= 0; s--) {
-        const int64_t i = i_lo + 16 * t + s;
-        if (i < 0) break;                                              // (the last tile: positions in front of the text)
-        const int q = 16 + 16 * t + s;
-        const uint32_t blkno = bend ? cb[q] : 0u;
-        if (s < 15) {
-            if (bend && cb[q + 1] != blkno) scratch(q, bend[blkno]);   // the last position of its block: nothing of the next block is in its key
-            else {
-                const uint32_t b = cr[q], l = llen[b], c = lcode[b];
-                acc = (((uint64_t)c << (56u - l)) | (acc >> l)) & M56;
-                used += l;
-                while (used > 56u) { e--; used -= llen[cr[e]]; }
+        for (int it = 0; it < CT / (TB * R); it++) {
+            const uint32_t x0 = (uint32_t)((it * TB + t) * R);         // my four slots x0 .. x0 + 3 = positions i_hi, i_hi - 1, ..
+            if (x0 >= cnt) continue;
+            const int q_hi = 16 + (CT - 1) - (int)x0;                  // staging index of slot x0's position
+            uint64_t acc = 0, key[R];
+            uint32_t used = 0, dep = 0;
+            int e = q_hi;
+            // the key of a position from scratch: whole symbols while they fit the 56 bits and the suffix lasts (group sort: its own
+            // block), then the leading bits of one more
+            auto scratch = [&](int q) {
+                const int64_t lim = bend ? (int64_t)bend[cb[q]] : (int64_t)n;
+                acc = 0; used = 0; e = q;
+                for (;;) {
+                    if (i_lo - 16 + e >= lim) break;                    // zero bits from here on
+                    const uint32_t en = lcl[cr[e]], l = en >> 27, c = en & 0x7FFFFFFu;
+                    if (used + l <= 56u) { acc |= (uint64_t)c << (56u - used - l); used += l; e++; if (used == 56u) break; }
+                    else { acc |= (uint64_t)c >> (l - (56u - used)); break; }
+                }
+            };
+            scratch(q_hi);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const int q = q_hi - j;
+                const int64_t i = i_lo - 16 + q;
+                if (j && i >= 0) {
+                    if (bend && cb[q + 1] != cb[q]) scratch(q);        // the last position of its block: nothing of the next block is in its key
+                    else {
+                        const uint32_t en = lcl[cr[q]], l = en >> 27, c = en & 0x7FFFFFFu;
+                        acc = (((uint64_t)c << (56u - l)) | (acc >> l)) & M56;
+                        used += l;
+                        while (used > 56u) { e--; used -= lcl[cr[e]] >> 27; }
+                    }
+                }
+                const uint32_t low = bend ? cb[q] : (i > 0 ? cr[q - 1] : 0u);   // T[i - 1] rides in the low byte -- the block number in a group sort (the sort's last digit)
+                key[j] = (acc << 8) | low;
+                const uint32_t d = (uint32_t)(e - q);
+                dep |= (d < tag_max ? d : tag_max) << (8 * j);         // (a clamped depth is still a number of symbols the key's group shares)
+            }
+            if (x0 + R <= cnt) {
+                uint4 *o = reinterpret_cast<uint4 *>(P + base + x0);
+                o[0] = make_uint4((uint32_t)key[0], (uint32_t)(key[0] >> 32), (uint32_t)key[1], (uint32_t)(key[1] >> 32));
+                o[1] = make_uint4((uint32_t)key[2], (uint32_t)(key[2] >> 32), (uint32_t)key[3], (uint32_t)(key[3] >> 32));
+                *reinterpret_cast<uint32_t *>(D0 + base + x0) = dep;
+            } else {
+#pragma unroll
+                for (int j = 0; j < R; j++)
+                    if (x0 + j < cnt) { P[base + x0 + j] = key[j]; D0[base + x0 + j] = (uint8_t)(dep >> (8 * j)); }
             }
         }
-        const uint32_t low = bend ? blkno : (i ? cr[q - 1] : 0u);     // T[i - 1] rides in the low byte -- the block number in a group sort (the sort's last digit)
-        const uint32_t x = (uint32_t)(CT - 1 - 16 * t - s);
-        ko[x + (x >> 4)] = (acc << 8) | low;
-        const uint32_t d = (uint32_t)(e - q);
-        dk[x] = (uint8_t)(d < tag_max ? d : tag_max);        // (a clamped depth is still a number of symbols the key's group shares)
     }
 }
+
 // The tile is also a tile of the radix sort's first pass (same 4096 slots): for the two-pass form of the sort its digit histogram (key
 // bits 15..8) is counted here, from LDS, so that pass has no histogram kernel of its own (tilehist: digit-major [256][ntiles], radix.hip;
 // null for the one-pass form).
@@ -383,7 +422,7 @@ __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T,
                                                  const uint8_t *__restrict__ blk, const uint32_t *__restrict__ bend, uint32_t *__restrict__ tilehist,
                                                  uint8_t *__restrict__ D0)
 {
-    __shared__ uint32_t hd[WAVES][256];                               // (vmode: [0] = the codes, [1] = their lengths; the slots' depths go where the fixed codes go)
+    __shared__ uint32_t hd[WAVES][256];
     __shared__ __align__(16) uint8_t cc[CT + PK_HALO];                // codes
     __shared__ __align__(16) uint8_t cr[CT + PK_HALO];                // bytes
     __shared__ __align__(16) uint8_t cb[CT + PK_HALO];                // block numbers (group sort)
@@ -391,10 +430,7 @@ __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T,
     __shared__ uint8_t lut[256];
     lut[threadIdx.x] = st->lut[threadIdx.x];
     const uint32_t bits = st->bits;
-    const bool vmode = D0 && st->vmode;                                // (uniform; only the single-block sort with the one-pass radix asks for it)
-    uint32_t *const lcode = &hd[0][0];
-    uint8_t *const llen = reinterpret_cast<uint8_t *>(&hd[1][0]), *const dk = cc;
-    if (vmode) { lcode[threadIdx.x] = st->vcode[threadIdx.x]; llen[threadIdx.x] = st->vlen[threadIdx.x]; }
+    if (D0 && st->vmode) return;                                       // (uniform) variable-length keys: k_pack_keys_var does the tiles
     const uint32_t ntiles = (n + CT - 1) / CT;
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * CT, cnt = (n - base < (uint32_t)CT) ? n - base : (uint32_t)CT;
@@ -405,21 +441,10 @@ __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T,
             const bool in = p >= 0 && p < (int64_t)n;
             const uint32_t raw = in ? T[p] : 0u;
             cr[q] = (uint8_t)raw;
-            if (!vmode) cc[q] = in ? lut[raw] : (uint8_t)0;
+            cc[q] = in ? lut[raw] : (uint8_t)0;
             if (blk) cb[q] = in ? blk[p] : (uint8_t)0;
         }
         __syncthreads();
-        if (vmode) {
-            pack_tile_var(cr, cb, lcode, llen, ko, dk, i_lo, n, st->tag_max, bend);
-            __syncthreads();
-            const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-#pragma unroll
-            for (int it = 0; it < CT_ITEMS; it++) {
-                const uint32_t x = (uint32_t)(w * (64 * CT_ITEMS) + it * 64 + l);
-                if (x < cnt) { P[base + x] = ko[x + (x >> 4)]; D0[base + x] = dk[x]; }
-            }
-            continue;
-        }
         switch (bits) {
         case 1: pack_tile<1>(cc, cr, cb, ko, i_lo, n, bend); break;
         case 2: pack_tile<2>(cc, cr, cb, ko, i_lo, n, bend); break;
@@ -2201,6 +2226,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     if (var) JPK_HIP(hipMemsetAsync(b.D0, 0, n, st));      // (a plan that falls back to the fixed code leaves no depths: tag 0 everywhere)
     JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_pack_keys, dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend,
                jpk_radix_onesweep() ? (uint32_t *)nullptr : b.scratch, b.D0);
+    if (var) JPK_LAUNCH(ctx, PROF_SA_PACK, 0, k_pack_keys_var, dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.D0);
     JPK_TRY(jpk_radix_sort_slot_keys(ctx, n, b.keysA, b.valsA, b.keysB, b.valsB, b.scratch, &ks, &vs, b.blk != nullptr, b.D0, var_tag_shift(n)));
     ctx->stats.sa_sorted_elems += n;
     // The sorted pairs sit in (ks, vs).  The other pair of radix buffers is free from here on, the pair that holds the result
