@@ -2,12 +2,16 @@
 // followed by the BWT image and the 120 sampled ranks of BlockSort::Bwt::ForwardBwt (bwt.cpp:22-65).
 //
 // Suffix array = prefix doubling (Larsson-Sadakane ranks) with compaction of resolved suffixes:
-//   round 0   key = first D bytes as codes of the block's alphabet (D = 7 for more than 128 byte values, 11 for 17..32, up to 56:
-//             k_key_plan / k_pack_keys below), big-endian in 56 bits, zero padded: one LSD radix sort of all n suffixes, 7 passes
-//             (radix.hip), fed in descending text position so that a short suffix -- a proper prefix of anything it ties with on
-//             the padded bytes -- comes first: plain suffix order even when the text contains the smallest symbol.
-//   round r   (h = D, 2D, 4D, ...) unresolved suffixes only.  The active list keeps groups of equal h-rank contiguous and
-//             in SA order, so a group is sorted by key2 = rank[sa + h] + 1 (0 past the end) independently:
+//   round 0   key = the first symbols of the suffix in an order-preserving code of the block's alphabet, big-endian in 56 bits, zero padded:
+//             a VARIABLE-LENGTH prefix code built from the block's sampled histogram (k_key_plan, k_pack_keys_var: about 56 / H0 symbols per
+//             key -- 12 for English-like text over 28 byte values, 10 over enwik8's 205 -- and every group of tied suffixes carries its own
+//             depth, GD) or, for flat histograms / blocks above 2^28 bytes / the comparators, a fixed-width code (D = 7 bytes for more than
+//             128 byte values, 11 for 17..32, up to 56: k_pack_keys).  One LSD radix sort of all n suffixes, 7 passes (radix.hip), fed in
+//             descending text position so that a short suffix -- a proper prefix of anything it ties with on the padded bits -- comes
+//             first: plain suffix order even when the text contains the smallest symbol.
+//   round r   unresolved suffixes only.  The active list keeps groups of equal rank contiguous and in SA order, so a group is sorted by
+//             key2 = rank[sa + h] + 1 (0 past the end) independently, h = the symbols its members are known to share (the group's depth;
+//             D, 2D, 4D, ... with the fixed-width code):
 //               * k_gather_win   key2 of every active suffix (the round's only random READ), head flags per 1024-slot window
 //               * groups of <= 1024 suffixes: k_seg_round -- one workgroup owns the groups that start in its window,
 //                 stages (sa, key2, group id) in LDS, LDS radix sort, re-ranks;
@@ -17,6 +21,8 @@
 //               * new ranks go to ISA (the round's only random WRITE); a suffix that has become a group of one is
 //                 finished: its BWT byte T[sa - 1] is emitted at its final SA position and it leaves the list;
 //               * compaction of the survivors (count / scan of tile totals / scatter).
+//   pair round  (k_pair_*, instead of a doubling round when the list stops shrinking) long repeats are resolved by induction from their
+//             successors -- what divsufsort's induced sorting does -- instead of log2(LCP) doubling rounds; see the comment at k_pair_dist.
 //   One ISA buffer: all reads of a round (k_gather_win) complete before its first write (kernel boundary), which is the
 //   condition under which parallel Larsson-Sadakane is exact.
 // No host round trip inside the loop: the number of active suffixes lives in device memory (SaState), every kernel is a
