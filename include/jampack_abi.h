@@ -54,14 +54,17 @@ typedef struct jpk_ctx jpk_ctx;
 /* per-call statistics of the last operation on a context (for bench.py / DESIGN.md accounting) */
 typedef struct jpk_stats {
     int32_t sa_rounds;            /* prefix-doubling rounds of the last forward BWT */
-    int32_t sa_key_depth;         /* bytes of every suffix that round 0's key holds (7 for alphabets above 128 byte values, up to 56) */
+    int32_t sa_key_depth;         /* symbols of a suffix that round 0's key holds: the average over the block with the variable-length code
+                                   * (about 56 / H0: 12 for English-like text, 10 over enwik8's byte alphabet), exactly floor(56 / ceil(log2 sigma))
+                                   * with the fixed-width code (flat histograms, blocks above 2^28 bytes, JPK_VARKEYS=0): 7 above 128 byte values */
     int64_t sa_sorted_elems;      /* sum over rounds of active suffixes that went through a sort */
     int64_t inv_splitters;        /* walkers used by the last inverse BWT */
     int64_t inv_overflow_slots;   /* sub-lists that exceeded one scratch slot */
     int64_t workspace_bytes;      /* HBM arena currently held by the context */
     int64_t ans_chunks;           /* 1 MiB chunks in the last entropy call */
     int64_t ans_rle_symbols;      /* RLE0 symbols in the last entropy call */
-    /* per doubling round r (r = 0: the radix round on sa_key_depth bytes, r >= 1: h = sa_key_depth * 2^(r-1)) of the last forward BWT:
+    /* per round r (r = 0: the radix round on the key; r >= 1: every group of tied suffixes compared at its own depth -- sa_key_depth * 2^(r-1)
+     * with the fixed-width code -- or a pair round, see sa_pair_rounds) of the last forward BWT:
      * suffixes still unresolved when the round starts / of those, members of groups too large for the LDS path */
     int32_t sa_round_active[JPK_SA_MAX_ROUNDS];
     int32_t sa_round_large[JPK_SA_MAX_ROUNDS];
