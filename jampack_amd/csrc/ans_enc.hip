@@ -969,57 +969,82 @@ __device__ __forceinline__ uint4 rans_record(uint32_t lo, uint32_t fr)
     return make_uint4(fr << 15, rcp, bias, (65536u - fr) | (shift << 24));
 }
 
+// Two symbols per thread (round 5): symbols 2g and 2g + 1 are the pairs 4g .. 4g + 3, i.e. index g of all four lane arrays -- a wave writes
+// 1 KiB runs of each -- and the loads of the two symbols (RLE0 symbol, two history entries or a table row each) are in flight together:
+// the kernel waited for its loads three quarters of the time with one symbol per thread.
 __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
                                              const uint16_t *__restrict__ exph, const uint32_t *__restrict__ mantad,
                                              const uint32_t *__restrict__ ord, const uint32_t *__restrict__ qcdf, uint4 *__restrict__ recs,
                                              uint16_t *__restrict__ fr16, uint32_t *__restrict__ pairs_plain)
 {
     const uint32_t c = chunk_of(d, blockIdx.y);
-    const uint32_t t = blockIdx.x * TB + threadIdx.x;
+    const uint32_t g = blockIdx.x * TB + threadIdx.x, t0 = 2u * g;
     const uint32_t rl = rlen[c];
     const size_t lane_stride = lane_stride_of(d, c, rle_stride), lb = lane_base(d, c, rle_stride);
     uint4 *rc = recs + lb;
     uint16_t *fq = fr16 + lb;                              // frequency sidecar: what the emit kernels need of a record (2 of its 16 bytes)
-    if (t >= rl) {
-        // the chain kernel walks whole batches of 16 steps: steps past a chain's last pair get identity records
-        // (xmax above every state, q * 0 + x + 0), so that it needs no bounds logic
-        const uint32_t u = t - rl;
-        if (u < 64u) {
-            const uint32_t np = 2u * rl, chain = u >> 4;
-            const uint32_t steps16 = np ? (((np - 1u) >> 2) / 16u + 1u) * 16u : 16u;
-            const uint32_t first = (chain < np) ? ((np - 1u - chain) >> 2) + 1u : 0u;
-            const uint32_t k = first + (u & 15u);
-            if (k < steps16) rc[(size_t)chain * lane_stride + k] = make_uint4(0x80000000u, 0u, 0u, 0u);
+    // the chain kernel walks whole batches of 16 steps: steps past a chain's last pair get identity records
+    // (xmax above every state, q * 0 + x + 0), so that it needs no bounds logic
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t t = t0 + (uint32_t)h;
+        if (t >= rl) {
+            const uint32_t u = t - rl;
+            if (u < 64u) {
+                const uint32_t np = 2u * rl, chain = u >> 4;
+                const uint32_t steps16 = np ? (((np - 1u) >> 2) / 16u + 1u) * 16u : 16u;
+                const uint32_t first = (chain < np) ? ((np - 1u - chain) >> 2) + 1u : 0u;
+                const uint32_t k = first + (u & 15u);
+                if (k < steps16) rc[(size_t)chain * lane_stride + k] = make_uint4(0x80000000u, 0u, 0u, 0u);
+            }
         }
-        return;
     }
-    const size_t cs = sym_stride(d, c, rle_stride), o = sym_base(d, c, rle_stride) + t;
-    const uint32_t s = rle[(size_t)c * rle_stride + t];              // (the RLE0 symbols themselves keep one row of `rle_stride` per chunk)
-    const int e = sym_class(s);
-    const uint32_t m = s - (uint32_t)class_base(e);
-    // cumulative frequencies of the exponent model before this symbol: entry e (low) and entry e + 1 (high end), from the history
-    // rows of the seven adaptive entries; entry 0 is 0 and entry 8 is 65536 by definition
-    const uint16_t *hrow = exph + 7 * sym_base(d, c, rle_stride) + t;
-    const uint32_t l0 = (e == 0) ? 0u : hrow[(size_t)(e - 1) * cs];
-    const uint32_t h0 = (e == 7) ? 65536u : (uint32_t)hrow[(size_t)e * cs];
-    uint32_t l1, f1;
-    if (e < 2) { const uint32_t p = mantad[o]; l1 = p & 0xffffu; f1 = p >> 16; }
-    else {
-        const int q = qinterval(ord[o]);
-        const uint32_t *cdf = qcdf + (((size_t)c * 6 + (e - 2)) * NQ + q) * QSTRIDE;
-        l1 = cdf[m];
-        f1 = cdf[m + 1] - l1;
+    if (t0 >= rl) return;
+    const bool two = t0 + 1u < rl;
+    const size_t cs = sym_stride(d, c, rle_stride), o = sym_base(d, c, rle_stride) + t0;
+    const uint16_t *hrow = exph + 7 * sym_base(d, c, rle_stride) + t0;
+    uint32_t sy[2], l0[2], h0[2], l1[2], f1[2], aux[2];
+    int ee[2];
+    // first wave of loads: the two RLE0 symbols (one aligned word when the pair is whole)
+    sy[0] = rle[(size_t)c * rle_stride + t0];
+    sy[1] = two ? rle[(size_t)c * rle_stride + t0 + 1u] : 0u;
+#pragma unroll
+    for (int h = 0; h < 2; h++) ee[h] = sym_class(sy[h]);
+    // second wave: for each symbol its two history entries (entry 0 is 0 and entry 8 is 65536 by definition) and its mantissa word or ordinal
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int e = ee[h];
+        const bool live = h == 0 || two;
+        l0[h] = (e == 0 || !live) ? 0u : hrow[(size_t)(e - 1) * cs + h];
+        h0[h] = (e == 7 || !live) ? 65536u : (uint32_t)hrow[(size_t)e * cs + h];
+        aux[h] = !live ? 0u : (e < 2 ? mantad[o + h] : ord[o + h]);
     }
-    // lane-major: pairs 2t, 2t+1 -> lanes (2t)&3, (2t+1)&3 at index t >> 1
-    const uint32_t j0 = 2 * t;
-    rc[(size_t)(j0 & 3u) * lane_stride + (j0 >> 2)] = rans_record(l0, h0 - l0);
-    rc[(size_t)((j0 + 1) & 3u) * lane_stride + (j0 >> 2)] = rans_record(l1, f1);
-    fq[(size_t)(j0 & 3u) * lane_stride + (j0 >> 2)] = (uint16_t)(h0 - l0);          // every model keeps each symbol >= 1: freq <= 65535
-    fq[(size_t)((j0 + 1) & 3u) * lane_stride + (j0 >> 2)] = (uint16_t)f1;
-    if (pairs_plain) {
-        uint32_t *out = pairs_plain + (size_t)c * 2 * rle_stride + 2 * (size_t)t;
-        out[0] = l0 | ((h0 - l0) << 16);
-        out[1] = l1 | (f1 << 16);
+    // third wave: the QuasiModel table rows of the classes >= 2
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int e = ee[h];
+        const uint32_t m = sy[h] - (uint32_t)class_base(e);
+        if (e < 2) { l1[h] = aux[h] & 0xffffu; f1[h] = aux[h] >> 16; }
+        else {
+            const int q = qinterval(aux[h]);
+            const uint32_t *cdf = qcdf + (((size_t)c * 6 + (e - 2)) * NQ + q) * QSTRIDE;
+            l1[h] = cdf[m];
+            f1[h] = cdf[m + 1] - l1[h];
+        }
+    }
+    // lane-major: symbol 2g -> lanes 0, 1 and symbol 2g + 1 -> lanes 2, 3, all at index g
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if (h == 1 && !two) break;
+        rc[(size_t)(2 * h) * lane_stride + g] = rans_record(l0[h], h0[h] - l0[h]);
+        rc[(size_t)(2 * h + 1) * lane_stride + g] = rans_record(l1[h], f1[h]);
+        fq[(size_t)(2 * h) * lane_stride + g] = (uint16_t)(h0[h] - l0[h]);          // every model keeps each symbol >= 1: freq <= 65535
+        fq[(size_t)(2 * h + 1) * lane_stride + g] = (uint16_t)f1[h];
+        if (pairs_plain) {
+            uint32_t *out = pairs_plain + (size_t)c * 2 * rle_stride + 2 * (size_t)(t0 + h);
+            out[0] = l0[h] | ((h0[h] - l0[h]) << 16);
+            out[1] = l1[h] | (f1[h] << 16);
+        }
     }
 }
 
@@ -1516,7 +1541,7 @@ int run_model(jpk_ctx *ctx, const uint16_t *d_rle, const uint32_t *d_rlen, const
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_tab, dim3((d.tpc + 1) / 2, 9, d.ncl), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_b, dim3(jpk_grid((size_t)d.ncl * 16, 64)), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_c, dim3((d.tpc + 63) / 64, 9, d.ncl), dim3(64), d, aa);
-    JPK_LAUNCH(ctx, PROF_ENC_PAIRS, 0, k_pairs, dim3(jpk_grid(stride, TB) + 1, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.exph, b.mantad, b.ord,
+    JPK_LAUNCH(ctx, PROF_ENC_PAIRS, 0, k_pairs, dim3(jpk_grid(stride, 2 * TB) + 1, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.exph, b.mantad, b.ord,
                        b.qcdf, b.recs, b.fr16, b.pairs);
     JPK_HIP(hipGetLastError());
     return JPK_OK;

@@ -617,8 +617,12 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                                                  const uint32_t *__restrict__ tCarry, const uint32_t *__restrict__ tOff,
                                                  uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
                                                  uint32_t *__restrict__ a_sa, uint32_t *__restrict__ a_grp, uint8_t *__restrict__ a_prev, SaState *__restrict__ st,
-                                                 const uint32_t *__restrict__ bend, uint32_t *__restrict__ GD)
+                                                 const uint32_t *__restrict__ bend, uint32_t *__restrict__ GD, uint64_t *lb_status, uint32_t *lb_ticket)
 {
+    // lb_status != null (round 5): ONE pass -- the tile learns the survivors in front of it and the last head in front of it by decoupled
+    // look-back over the tiles before it (ticket order; one 64-bit word per tile = flag | survivors << 31 | 1 + last head, agent-scope
+    // atomics; a wave looks at 64 predecessors at a time) instead of from k_r0_count + k_r0_scan, which read the sorted pairs once more.
+    __shared__ uint32_t s_tile, s_carry;
     __shared__ uint64_t HE[65];
     __shared__ uint64_t runkey[256];       // vmode: the key of a run of byte b, and the byte whose code starts a key's first 8 bits
     __shared__ uint64_t runsorted[256];    // ... and the run keys of the occurring bytes in byte order = ascending (codes above 8 bits: binary search)
@@ -641,14 +645,18 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
         if (st->present[threadIdx.x]) runsorted[st->lut[threadIdx.x]] = runkey[threadIdx.x];     // lut = the byte's index among the occurring ones
         if (threadIdx.x == 255) s_sigma = (uint32_t)st->lut[255] + (st->present[255] ? 1u : 0u);
     }
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t base = tile * CT;
+    constexpr uint64_t LB_AGG = 1ull << 62, LB_PFX = 2ull << 62, LB_LO = (1ull << 31) - 1ull;
+    for (uint32_t it = blockIdx.x; it < ntiles; it += gridDim.x) {
+        __syncthreads();                                                // (s_tile / s_carry / s_off of the previous tile have been read)
+        if (lb_status && threadIdx.x == 0) s_tile = atomicAdd(lb_ticket, 1u);
         __syncthreads();
+        const uint32_t tile = lb_status ? s_tile : it;                  // look-back: tiles in the order their workgroups START
+        const uint32_t base = tile * CT;
         uint64_t kj[CT_ITEMS];
         uint32_t sj[CT_ITEMS];
         r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend, D, vmode);
         __syncthreads();
-        const uint32_t carry = tCarry[tile];
+        uint32_t carry = lb_status ? 0u : tCarry[tile];
         if (threadIdx.x < 64) {
             const uint64_t he = HE[l], vm = valid_word(base + l * 64, n);
             const uint64_t hv = he & vm;
@@ -657,12 +665,61 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
             SV[l] = surv;
             const uint32_t cnt = (uint32_t)__popcll(surv);
             const uint32_t inc = wave_incl_sum(cnt);
-            SW[l] = tOff[tile] + inc - cnt;
             uint32_t last = hv ? base + l * 64 + top_bit(hv) + 1u : 0u;
             last = wave_incl_max(last);
+            uint32_t off;
+            if (lb_status) {
+                const uint32_t cnt_tile = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), last_tile = (uint32_t)__builtin_amdgcn_readlane((int)last, 63);
+                const uint64_t mine = ((uint64_t)cnt_tile << 31) | last_tile;
+                uint32_t o_acc = 0, c_acc = 0;
+                if (tile == 0) {
+                    if (l == 0) __hip_atomic_store(lb_status, LB_PFX | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    if (l == 0) __hip_atomic_store(lb_status + tile, LB_AGG | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int64_t pos = (int64_t)tile - 1;                    // lane l looks at tile pos - l
+                    for (;;) {
+                        const int64_t t = pos - l;
+                        uint64_t wv;
+                        uint64_t need;                                  // lanes up to the first prefix
+                        bool found;
+                        for (;;) {
+                            wv = t >= 0 ? __hip_atomic_load(lb_status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_PFX;
+                            const uint64_t pf = __ballot((wv >> 62) == 2ull), np = __ballot((wv >> 62) == 0ull);
+                            found = pf != 0ull;
+                            need = found ? mask_upto((int)__builtin_ctzll(pf)) : ~0ull;
+                            if ((np & need) == 0ull) break;            // everybody between me and the first prefix has published
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        const bool in = (need >> l) & 1ull;
+                        uint32_t so = in ? (uint32_t)((wv >> 31) & LB_LO) : 0u, sc = in ? (uint32_t)(wv & LB_LO) : 0u;
+                        so = wave_sum(so);
+                        sc = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_max(sc), 63);
+                        o_acc += so;
+                        c_acc = c_acc > sc ? c_acc : sc;
+                        if (found) break;                              // a prefix was among them (tiles before tile 0 count as one; lane 63's too)
+                        pos -= 64;
+                    }
+                    const uint32_t lt = c_acc > last_tile ? c_acc : last_tile;
+                    if (l == 0) __hip_atomic_store(lb_status + tile, LB_PFX | ((uint64_t)(o_acc + cnt_tile) << 31) | lt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                carry = c_acc;
+                off = o_acc;
+                if (l == 0) {
+                    s_carry = c_acc;
+                    if (tile + 1 == ntiles) {                           // the last tile knows the total: what k_r0_scan leaves in the state
+                        st->m[1] = o_acc + cnt_tile;
+                        st->round_m[0] = n;
+                        st->round_m[1] = o_acc + cnt_tile;
+                        st->npieces = 0;
+                        st->lc = 0;
+                    }
+                }
+            } else off = tOff[tile];
+            SW[l] = off + inc - cnt;
             LHW[l] = last > carry ? last : carry;
         }
         __syncthreads();
+        if (lb_status) carry = s_carry;
         uint32_t nrun = 0;
 #pragma unroll
         for (int k = 0; k < CT_ITEMS; k++) {
@@ -2099,6 +2156,12 @@ int key_force_bits()
     return v;
 }
 
+// JPK_R0_LOOKBACK=0: round 0's head / survivor bookkeeping in two passes (k_r0_count + k_r0_scan in front of k_r0_finish: the comparator)
+bool r0_lookback()
+{
+    static const bool v = [] { const char *e = getenv("JPK_R0_LOOKBACK"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
 // JPK_VARKEYS=0: fixed-width keys whatever the block (the comparator of the variable-length keys)
 bool var_keys_on()
 {
@@ -2246,9 +2309,20 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     b.sa_alt = reinterpret_cast<uint32_t *>(ks) + n;
 
     const unsigned g_ct = cap_grid(n, CT, CAP);
-    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_count, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.bend, b.state);
-    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_r0_scan, dim3(1), dim3(WG1), b.tA, b.tB, n, b.state);
-    JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev, b.state, b.bend, b.GD[0]);
+    if (r0_lookback()) {
+        // one pass over the sorted pairs: the radix sort's scratch (free from here on) holds one status word per tile and the ticket
+        uint64_t *lb_status = reinterpret_cast<uint64_t *>(b.scratch);
+        const size_t ntiles0 = ((size_t)n + CT - 1) / CT;
+        uint32_t *lb_ticket = reinterpret_cast<uint32_t *>(lb_status + ntiles0 + 1);
+        JPK_HIP(hipMemsetAsync(lb_status, 0, sizeof(uint64_t) * (ntiles0 + 2), st));
+        JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev, b.state, b.bend, b.GD[0],
+                   lb_status, lb_ticket);
+    } else {
+        JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_count, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.bend, b.state);
+        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_r0_scan, dim3(1), dim3(WG1), b.tA, b.tB, n, b.state);
+        JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev, b.state, b.bend, b.GD[0],
+                   (uint64_t *)nullptr, (uint32_t *)nullptr);
+    }
     ctx->stats.sa_rounds = 1;
     // remaining run lengths, only if round 0 left members of runs of >= depth equal bytes behind (the kernels return at once otherwise)
     JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_first, dim3(cap_grid(n, CT, 4096)), dim3(TB), T, n, b.state, b.tA, b.blk);
