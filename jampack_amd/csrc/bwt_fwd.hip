@@ -83,6 +83,13 @@ struct SaState {
     uint8_t vrun_d[256];                   // symbols of a run of byte b that one key holds: 56 / vlen[b]
     uint16_t vtop[256];                    // the byte whose code (of at most 8 bits) starts these 8 bits, 0xFFFF: none
     uint64_t vrunkey[256];                 // the 56-bit key of a run of byte b
+    // vmode 2 (order-1 code): every symbol but a key's first is coded in the context of the byte in front of it (256 alphabetic codes, one
+    // per context, from sampled pair counts -- k_pair_counts / k_ctx_plan); what k_key_final decides on:
+    uint32_t v0_ok, sigma, v0_wl, v0_wtot; // the order-0 code is usable (no code above 27 bits); its weighted length and weight
+    uint32_t o1_w, o1_wl, o1_maxlen;       // sampled pairs, their weighted length under the context codes, the longest context code
+    // vmode 3 (order-2 code): a key's symbols from the third on are coded in the context of the TWO bytes in front of them when that pair
+    // is one of the `nclass` <= 1024 most frequent ones (k_ctx_select; its own row of the code table), behind the one byte otherwise
+    uint32_t nclass, o2_w, o2_wl, o2_maxlen;
 };
 static_assert(offsetof(SaState, depth) == offsetof(SaState, round_m) + sizeof(uint32_t) * (2 * JPK_SA_MAX_ROUNDS + 1), "the statistics copy takes round_m, round_lc, bits, depth in one piece");
 
@@ -176,18 +183,134 @@ __global__ __launch_bounds__(TB) void k_sym_present(const uint8_t *__restrict__ 
     if (c[threadIdx.x]) atomicAdd(&st->cnt[threadIdx.x], c[threadIdx.x]);
 }
 
+// the weight-balanced splitting of the occurring bytes (cpre = exclusive prefix of their weights, in byte order, cpre[sigma] = total):
+// symbol idx walks from the root to its own leaf -- at every node the range [l, r) is cut where the weight is halved, left = 0, right = 1.
+// An alphabetic (order-preserving) prefix code with an average length below H + 2.
+__device__ __forceinline__ void wb_walk(const uint32_t *cpre, uint32_t idx, uint32_t sigma, uint32_t &code, uint32_t &len)
+{
+    uint32_t l = 0, r = sigma;
+    code = 0; len = 0;
+    while (r - l > 1u) {
+        const uint64_t tgt2 = (uint64_t)cpre[l] + cpre[r];            // twice the weight at which [l, r) is halved
+        uint32_t lo = l + 1u, hi = r - 1u;                            // the cut m lies in [l + 1, r - 1]: first index with 2 cpre[m] >= tgt2
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (2ull * cpre[mid] >= tgt2) hi = mid; else lo = mid + 1u;
+        }
+        uint32_t m = lo;
+        if (m - 1u > l) {
+            const uint64_t a = 2ull * cpre[m], b = 2ull * cpre[m - 1u];
+            const uint64_t da = a > tgt2 ? a - tgt2 : tgt2 - a, db = b > tgt2 ? b - tgt2 : tgt2 - b;
+            if (db < da) m--;
+        }
+        if (idx < m) { r = m; code <<= 1; } else { l = m; code = (code << 1) | 1u; }
+        len++;
+        if (len > 30u) break;
+    }
+    if (len == 0u) len = 1u;                                          // one byte value: the code is "0"
+}
+
+// Sampled pair counts for the order-1 code (vmode 2): ctab[c * 256 + s] += occurrences of byte s behind byte c inside the sampled 16-byte
+// vectors (every `stride`th: about a million pairs whatever the block).  Workgroup (x, y) counts the pairs whose context byte has low
+// nibble y -- 16 KB of LDS counters; text's letters spread over all sixteen -- and adds what it found to the table.
+__global__ __launch_bounds__(256) void k_pair_counts(const uint8_t *__restrict__ T, uint32_t n, uint32_t stride, uint32_t *__restrict__ ctab)
+{
+    __shared__ uint32_t c[16 * 256];
+    for (int i = threadIdx.x; i < 16 * 256; i += 256) c[i] = 0u;
+    __syncthreads();
+    const uint32_t mis0 = (uint32_t)((16u - ((uintptr_t)T & 15u)) & 15u), mis = mis0 < n ? mis0 : n;
+    const uint4 *V = reinterpret_cast<const uint4 *>(T + mis);
+    const uint32_t nv = (n - mis) / 16u, ns = (nv + stride - 1u) / stride, y = blockIdx.y;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < ns; k += gridDim.x * 256u) {
+        const uint4 x = V[(size_t)k * stride];
+        const uint32_t ws[4] = {x.x, x.y, x.z, x.w};
+        uint32_t prev = ws[0] & 255u;
+#pragma unroll
+        for (int j = 1; j < 16; j++) {
+            const uint32_t b = (ws[j >> 2] >> (8 * (j & 3))) & 255u;
+            if ((prev & 15u) == y) atomicAdd(&c[(prev >> 4) * 256u + b], 1u);
+            prev = b;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * 256; i += 256)
+        if (c[i]) atomicAdd(&ctab[((((uint32_t)i >> 8) << 4) | y) * 256u + ((uint32_t)i & 255u)], c[i]);
+}
+
+// Order-2 contexts: the (at most) JPK_O2_CLASSES most frequent byte pairs of the sample get a row of their own in the code table -- the
+// largest count threshold that admits no more than that many pairs, found by bisection over the 65 536 pair counts (one workgroup of
+// 1024, 64 counts per thread in registers).  ctxmap[c2 << 8 | c1] = the row that codes a symbol behind the bytes c2 c1: 256 + the pair's
+// rank among the chosen ones, or c1 -- the order-1 row -- for every other pair.
+constexpr uint32_t JPK_O2_CLASSES = 1024;
+__global__ __launch_bounds__(1024) void k_ctx_select(const uint32_t *__restrict__ ctab, uint16_t *__restrict__ ctxmap, SaState *__restrict__ st)
+{
+    __shared__ uint32_t sm[1024 / 64 + 1];
+    uint32_t c[32];                                                       // two counts per register, saturated at 65 535 (the order at the threshold is what matters)
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const uint2 v = reinterpret_cast<const uint2 *>(ctab)[threadIdx.x * 32u + k];
+        c[k] = (v.x < 65535u ? v.x : 65535u) | ((v.y < 65535u ? v.y : 65535u) << 16);
+    }
+    uint32_t lo = 1u, hi = 65536u;
+    while (lo < hi) {                                                     // smallest threshold with at most JPK_O2_CLASSES pairs at or above it
+        const uint32_t mid = (lo + hi) >> 1;
+        uint32_t mine = 0, tot;
+#pragma unroll
+        for (int k = 0; k < 32; k++) mine += ((c[k] & 0xFFFFu) >= mid ? 1u : 0u) + ((c[k] >> 16) >= mid ? 1u : 0u);
+        block_incl_scan<OpSum>(mine, sm, &tot);
+        if (tot <= JPK_O2_CLASSES) hi = mid; else lo = mid + 1u;
+    }
+    uint32_t mine = 0, tot;
+#pragma unroll
+    for (int k = 0; k < 32; k++) mine += ((c[k] & 0xFFFFu) >= lo ? 1u : 0u) + ((c[k] >> 16) >= lo ? 1u : 0u);
+    uint32_t rank = block_incl_scan<OpSum>(mine, sm, &tot) - mine;
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+        const uint32_t i = threadIdx.x * 64u + 2u * k;
+        const uint32_t r0 = (c[k] & 0xFFFFu) >= lo ? 256u + rank++ : (i & 255u);
+        const uint32_t r1 = (c[k] >> 16) >= lo ? 256u + rank++ : ((i + 1u) & 255u);
+        reinterpret_cast<uint32_t *>(ctxmap)[i >> 1] = r0 | (r1 << 16);
+    }
+    if (threadIdx.x == 0) st->nclass = tot;
+}
+// ... and the sampled counts of the bytes behind the chosen pairs, into their rows: workgroup (x, y) counts for the rows 256 + r with
+// r mod 16 = y (at most 64 of them: 64 KB of LDS counters, one workgroup per CU -- the kernel is short and reads 1 MiB)
+__global__ __launch_bounds__(256) void k_triple_counts(const uint8_t *__restrict__ T, uint32_t n, uint32_t stride, const uint16_t *__restrict__ ctxmap,
+                                                      uint32_t *__restrict__ ctab)
+{
+    __shared__ uint32_t c[64 * 256];
+    for (int i = threadIdx.x; i < 64 * 256; i += 256) c[i] = 0u;
+    __syncthreads();
+    const uint32_t mis0 = (uint32_t)((16u - ((uintptr_t)T & 15u)) & 15u), mis = mis0 < n ? mis0 : n;
+    const uint4 *V = reinterpret_cast<const uint4 *>(T + mis);
+    const uint32_t nv = (n - mis) / 16u, ns = (nv + stride - 1u) / stride, y = blockIdx.y;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < ns; k += gridDim.x * 256u) {
+        const uint4 x = V[(size_t)k * stride];
+        const uint32_t ws[4] = {x.x, x.y, x.z, x.w};
+        uint32_t p2 = ws[0] & 255u, p1 = (ws[0] >> 8) & 255u;
+#pragma unroll
+        for (int j = 2; j < 16; j++) {
+            const uint32_t b = (ws[j >> 2] >> (8 * (j & 3))) & 255u;
+            const uint32_t row = ctxmap[(p2 << 8) | p1];
+            if (row >= 256u && ((row - 256u) & 15u) == y) atomicAdd(&c[((row - 256u) >> 4) * 256u + b], 1u);
+            p2 = p1;
+            p1 = b;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 256; i += 256)
+        if (c[i]) atomicAdd(&ctab[(256u + ((((uint32_t)i >> 8) << 4) | y)) * 256u + ((uint32_t)i & 255u)], c[i]);
+}
+
 // one workgroup of 256: code of every byte value, bits per code, bytes per key.  force_bits: 0 = from the alphabet, 8 = plain bytes.
-// want_var: build the variable-length code as well (vmode): thread b walks the weight-balanced splitting of the occurring bytes from
-// the root to its own leaf -- at every node the byte range [l, r) is cut where the sampled weight is halved, left = 0, right = 1 -- which
-// is an alphabetic (order-preserving) prefix code with an average length below H0 + 2 (5.3 bits on an enwik8-like alphabet whose
-// H0 is 5.05; Hu-Tucker's optimum is 5.2).  A code longer than 27 bits (it cannot happen with sampled weights + 1) drops to the
-// fixed-width code.
-__global__ __launch_bounds__(256) void k_key_plan(SaState *__restrict__ st, int force_bits, int want_var, int tag_shift)
+// want_var: build the variable-length order-0 code as well -- the weight-balanced splitting of the occurring bytes on the sampled
+// histogram (wb_walk): an average length below H0 + 2 (5.3 bits on an enwik8-like alphabet whose H0 is 5.05; Hu-Tucker's optimum is
+// 5.2).  A code longer than 27 bits (it cannot happen with sampled weights + 1) leaves v0_ok = 0: the fixed-width code.  Which code the
+// keys use is k_key_final's decision.
+__global__ __launch_bounds__(256) void k_key_plan(SaState *__restrict__ st, int force_bits, int want_var)
 {
     __shared__ uint32_t sm[256 / 64 + 1];
     __shared__ uint32_t cpre[257];             // exclusive prefix of the weights of the occurring bytes, in byte order
-    __shared__ uint32_t lcode[256];
-    __shared__ uint8_t llen[256];
     const uint32_t here = st->present[threadIdx.x] ? 1u : 0u;
     uint32_t sigma;
     const uint32_t inc = block_incl_scan<OpSum>(here, sm, &sigma);
@@ -203,6 +326,7 @@ __global__ __launch_bounds__(256) void k_key_plan(SaState *__restrict__ st, int 
         st->bits = bits;
         st->depth = depth;
         st->rep = rep;
+        st->sigma = sigma;
     }
     if (!want_var || force_bits > 0) return;          // (uniform)
     const uint32_t w = here ? st->cnt[threadIdx.x] + 1u : 0u;
@@ -212,67 +336,126 @@ __global__ __launch_bounds__(256) void k_key_plan(SaState *__restrict__ st, int 
     if (threadIdx.x == 0) cpre[sigma] = wtot;
     __syncthreads();
     uint32_t code = 0, len = 0;
-    if (here) {
-        uint32_t l = 0, r = sigma;
-        while (r - l > 1u) {
-            const uint64_t tgt2 = (uint64_t)cpre[l] + cpre[r];            // twice the weight at which [l, r) is halved
-            uint32_t lo = l + 1u, hi = r - 1u;                            // the cut m lies in [l + 1, r - 1]: first index with 2 cpre[m] >= tgt2
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (2ull * cpre[mid] >= tgt2) hi = mid; else lo = mid + 1u;
-            }
-            uint32_t m = lo;
-            if (m - 1u > l) {
-                const uint64_t a = 2ull * cpre[m], b = 2ull * cpre[m - 1u];
-                const uint64_t da = a > tgt2 ? a - tgt2 : tgt2 - a, db = b > tgt2 ? b - tgt2 : tgt2 - b;
-                if (db < da) m--;
-            }
-            if (idx < m) { r = m; code <<= 1; } else { l = m; code = (code << 1) | 1u; }
-            len++;
-            if (len > 30u) break;
-        }
-        if (len == 0u) len = 1u;                                          // one byte value: the code is "0"
-    }
-    lcode[threadIdx.x] = code;
-    llen[threadIdx.x] = (uint8_t)len;
+    if (here) wb_walk(cpre, idx, sigma, code, len);
     uint32_t maxlen;
     block_incl_scan<OpMax>(len, sm, &maxlen);
     uint32_t wl;                                                          // sum of weight x length: the average code length
     // (32-bit: weights are sampled, at most n / 16 + 256 in all, lengths <= 30 -- below 2^32 for blocks of 2^26 bytes)
     block_incl_scan<OpSum>(w * len, sm, &wl);
-    __syncthreads();
-    if (maxlen > 27u) return;                                             // vmode stays 0: the fixed-width code (k_pack_keys_var keeps code | length << 27 in one word)
-    {   // ... and when the code does not buy at least 3/4 of a symbol per key over the fixed width (near-uniform alphabets: random bytes,
-        // DNA, 16-bit samples -- a balanced code of a flat histogram IS the fixed code, a slightly skewed one can even be longer)
-        uint32_t fb = 1;
-        while ((1u << fb) < sigma) fb++;
-        const uint32_t fixed_d = 56u / fb;
-        if (224ull * wtot < (uint64_t)wl * (4u * fixed_d + 3u)) return;
-    }
     st->vcode[threadIdx.x] = code;
     st->vlen[threadIdx.x] = (uint8_t)len;
+    if (threadIdx.x == 0) {
+        st->v0_ok = maxlen <= 27u ? 1u : 0u;                              // (the pack kernel keeps code | length << 27 in one word)
+        st->v0_wl = wl;
+        st->v0_wtot = wtot;
+    }
+}
+
+// Context codes: workgroup c turns row c of the sampled counts into the code of every byte BEHIND byte c (rows 0..255) or behind the
+// c - 256-th chosen pair of bytes (k_ctx_select) -- the same weight-balanced
+// splitting over all occurring bytes, weight = 8 x sampled count + a floor (a pair the sample missed still needs a code; the floor
+// grows with the context's count so that no code exceeds ~22 bits) -- in place: ctab[c * 256 + s] = code | length << 27.
+__global__ __launch_bounds__(256) void k_ctx_plan(SaState *__restrict__ st, uint32_t *__restrict__ ctab)
+{
+    __shared__ uint32_t sm[256 / 64 + 1];
+    __shared__ uint32_t cpre[257];
+    const uint32_t c = blockIdx.x;                                        // the row: a byte (order 1) or 256 + a chosen pair (order 2)
+    if (c < 256u ? !st->present[c] : c - 256u >= st->nclass) return;      // (uniform) never a context
+    const uint32_t here = st->present[threadIdx.x] ? 1u : 0u;
+    const uint32_t raw = here ? ctab[c * 256u + threadIdx.x] : 0u;
+    uint32_t sigma, nc;
+    const uint32_t inc = block_incl_scan<OpSum>(here, sm, &sigma);
+    const uint32_t idx = inc - here;
+    block_incl_scan<OpSum>(raw, sm, &nc);
+    const uint32_t w = here ? raw * 8u + 1u + ((8u * nc) >> 20) : 0u;
+    uint32_t wtot;
+    const uint32_t winc = block_incl_scan<OpSum>(w, sm, &wtot);
+    if (here) cpre[idx] = winc - w;
+    if (threadIdx.x == 0) cpre[sigma] = wtot;
+    __syncthreads();
+    uint32_t code = 0, len = 0;
+    if (here) wb_walk(cpre, idx, sigma, code, len);
+    uint32_t maxlen, wl;
+    block_incl_scan<OpMax>(len, sm, &maxlen);
+    block_incl_scan<OpSum>(raw * len, sm, &wl);
+    ctab[c * 256u + threadIdx.x] = here ? (code | (len << 27)) : 0u;      // (every thread has read its count: the scans' barriers lie in between)
+    if (threadIdx.x == 0) {
+        atomicAdd(c < 256u ? &st->o1_w : &st->o2_w, nc);
+        atomicAdd(c < 256u ? &st->o1_wl : &st->o2_wl, wl);
+        atomicMax(c < 256u ? &st->o1_maxlen : &st->o2_maxlen, maxlen);
+    }
+}
+
+// one workgroup of 256 decides which code round 0's keys use and leaves the tables of the choice in the state:
+//   vmode 0  the fixed-width code (k_pack_keys), when no variable-length code buys at least 3/4 of a symbol per key over it (near-uniform
+//            alphabets: random bytes, DNA, -- a balanced code of a flat histogram IS the fixed code, a slightly skewed one can even be longer)
+//   vmode 1  the order-0 code
+//   vmode 2  the order-1 code, when an average key holds at least half a symbol more with it: 1 + (56 - len0) / len1 against 56 / len0
+//   vmode 3  the order-2 code, when it holds half a symbol more again: 2 + (56 - 2 len0) / len2
+// and, for vmode 1 / 2: the 56-bit key of a run of byte b (b, then b behind b, ...), the whole symbols in it, the table that finds the
+// first byte of a key from its first 8 bits, the depth tag's place in the sorted value.
+__global__ __launch_bounds__(256) void k_key_final(SaState *__restrict__ st, const uint32_t *__restrict__ ctab, const uint16_t *__restrict__ ctxmap, int tag_shift,
+                                                   int want_order)
+{
+    __shared__ uint32_t lcode[256];
+    __shared__ uint8_t llen[256];
+    if (!st->v0_ok) return;                                               // (uniform) vmode stays 0
+    const uint32_t sigma = st->sigma;
+    uint32_t fb = 1;
+    while ((1u << fb) < sigma) fb++;
+    const float fixed_d = (float)(56u / fb);
+    const float a0 = (float)st->v0_wl / (float)st->v0_wtot, d0 = 56.f / a0;
+    float d1 = 0.f, d2 = 0.f, a1 = 0.f;
+    const bool o1ok = want_order >= 1 && ctab && st->o1_w > 0u && st->o1_maxlen <= 27u && st->o1_wl > 0u;
+    if (o1ok) { a1 = (float)st->o1_wl / (float)st->o1_w; d1 = 1.f + (56.f - a0) / a1; }
+    // order 2: the sampled triples behind a chosen pair are coded in its row, the others in the order-1 rows (14 triples to 15 pairs per sampled vector)
+    const bool o2ok = o1ok && want_order >= 2 && ctxmap && st->nclass > 0u && st->o2_w > 0u && st->o2_wl > 0u && st->o2_maxlen <= 27u;
+    if (o2ok) {
+        float cov = (float)st->o2_w / ((float)st->o1_w * (14.f / 15.f));
+        cov = cov > 1.f ? 1.f : cov;
+        const float a2 = cov * ((float)st->o2_wl / (float)st->o2_w) + (1.f - cov) * a1;
+        d2 = 2.f + (56.f - 2.f * a0) / a2;
+    }
+    uint32_t mode;
+    if (o2ok && d2 >= fixed_d + 0.75f && d2 >= d1 + 0.5f && d2 >= d0 + 0.5f) mode = 3u;
+    else if (o1ok && d1 >= fixed_d + 0.75f && d1 >= d0 + 0.5f) mode = 2u;
+    else if (d0 >= fixed_d + 0.75f) mode = 1u;
+    else return;
+    const uint32_t code = st->vcode[threadIdx.x], len = st->vlen[threadIdx.x];
+    const bool here = st->present[threadIdx.x] != 0u;
+    lcode[threadIdx.x] = code;
+    llen[threadIdx.x] = here ? (uint8_t)len : (uint8_t)0;
+    __syncthreads();
     if (here) {
-        const uint32_t d = 56u / len;
-        uint64_t k = 0;
-        for (uint32_t i = 0; i < d; i++) k = (k << len) | code;
-        const uint32_t left = 56u - d * len;                              // bits behind the last whole symbol: the start of one more
-        k = (k << left) | (left ? (uint64_t)(code >> (len - left)) : 0ull);
+        uint32_t c1 = code, l1 = len, c2 = code, l2 = len;                // the code of b behind b, and of b behind b b
+        if (mode >= 2u) { const uint32_t e = ctab[threadIdx.x * 256u + threadIdx.x]; c1 = c2 = e & 0x7FFFFFFu; l1 = l2 = e >> 27; }
+        if (mode == 3u) {                                                 // (order 2: a key's second symbol is in the order-0 code, see k_pack_keys_o2)
+            const uint32_t e = ctab[(uint32_t)ctxmap[threadIdx.x * 257u] * 256u + threadIdx.x];
+            c2 = e & 0x7FFFFFFu; l2 = e >> 27; c1 = code; l1 = len;
+        }
+        uint64_t k = code;
+        uint32_t used = len, d = 1;
+        for (;;) {                                                        // whole symbols while they fit, then the start of one more
+            const uint32_t cn = d == 1u ? c1 : c2, ln = d == 1u ? l1 : l2;
+            if (used + ln <= 56u) { k = (k << ln) | cn; used += ln; d++; if (used == 56u) break; }
+            else { const uint32_t left = 56u - used; k = (k << left) | (uint64_t)(cn >> (ln - left)); break; }
+        }
         st->vrun_d[threadIdx.x] = (uint8_t)d;
         st->vrunkey[threadIdx.x] = k;
     }
-    {   // the byte whose code, of at most 8 bits, starts the 8 bits `threadIdx.x`
+    {   // the byte whose (order-0) code, of at most 8 bits, starts the 8 bits `threadIdx.x`
         uint32_t hit = 0xFFFFu;
         for (uint32_t b = 0; b < 256u; b++) {
             const uint32_t lb = llen[b];
-            if (lb && lb <= 8u && st->present[b] && (threadIdx.x >> (8u - lb)) == lcode[b]) hit = b;
+            if (lb && lb <= 8u && (threadIdx.x >> (8u - lb)) == lcode[b]) hit = b;
         }
         st->vtop[threadIdx.x] = (uint16_t)hit;
     }
     if (threadIdx.x == 0) {
-        st->vmode = 1u;
+        st->vmode = mode;
         st->tag_shift = (uint32_t)tag_shift;
         st->tag_max = (tag_shift <= 26) ? 63u : ((1u << (32 - tag_shift)) - 1u);
-        const uint32_t avg_d = wl ? (uint32_t)((56ull * wtot) / wl) : 56u;   // symbols an average key holds (the statistics' key depth)
+        const uint32_t avg_d = (uint32_t)(mode == 3u ? d2 : mode == 2u ? d1 : d0);   // symbols an average key holds (the statistics' key depth)
         st->depth = avg_d ? avg_d : 1u;
     }
 }
@@ -330,29 +513,34 @@ __device__ __forceinline__ void pack_tile(const uint8_t *cc, const uint8_t *cr, 
     }
 #undef JPK_BYTE
 }
-// Variable-length keys (vmode): the same tile, every byte as its prefix code.  A thread builds the key of its LAST position from
-// scratch -- whole symbols while they fit the 56 bits, then the leading bits of one more -- and rolls backwards over its other
-// fifteen: key(i) = code(T[i]) in front of key(i + 1) shifted right by its length, and the count of WHOLE symbols in the key (its
-// depth) follows with an end pointer that only moves backwards.  Symbols past the end of the text are zero bits and do not count: a
-// suffix whose depth reaches the end is shorter than anything it ties with and becomes a group of its own (k_r0_*).  dk[x] = depth of
-// slot x (< 64: rides in bits 26..31 of the slot's value through the radix sort).
-// A kernel of its own (second half of round 5).  The first version rolled every thread over SIXTEEN consecutive positions inside
-// k_pack_keys -- a serial chain of sixteen steps with two dependent LDS lookups each, and the keys had to be turned into slot order
-// through 35 KB of LDS (three workgroups per CU: 0.44 ms alone, five times that among the blocks in flight, which compete for the CUs'
-// LDS); every position from scratch (sixteen independent byte loads and table lookups, the accumulation in registers, keys straight out
-// in slot order, 10 KB of LDS) turned out bound by its ~260 vector instructions per position instead: 0.46-0.53 ms.  This form sits between:
-// a thread builds the key of the LAST of FOUR consecutive positions from scratch and rolls backwards over the other three,
-// key(i) = code(T[i]) in front of key(i + 1) shifted right by its length; its four keys are four consecutive slots and leave as two
-// 16-byte stores, its four depths as one word.  Depth = the WHOLE symbols in the key: an end pointer that only moves backwards.
+// Variable-length keys (vmode 1 / 2): the same tile, every byte as its prefix code -- the FIRST symbol of a key in the order-0 code, every
+// other one in the order-0 code as well (vmode 1) or in the code of its context, the byte in front of it (vmode 2, O1; k_ctx_plan's table,
+// 256 KB, read through the caches).  Two suffixes that share k symbols read symbol k + 1 in the same context, so the concatenated codes
+// compare like the suffixes.  Symbols past the end of the text (group sort: of the suffix's own block) are zero bits and do not count: a
+// suffix whose depth reaches its end is shorter than anything it ties with and becomes a group of its own (k_r0_*).  D0[x] = depth of slot
+// x = the WHOLE symbols in its key (< 64: rides in bits 26..31 of the slot's value through the radix sort).
+// History of the kernel (round 5): (1) every thread rolled over SIXTEEN consecutive positions inside k_pack_keys -- a serial chain with two
+// dependent LDS lookups per step, keys turned into slot order through 35 KB of LDS: 0.44 ms; (2) every position from scratch: ~260 vector
+// instructions per position, 0.46-0.53 ms; (3) the key of the last of four consecutive positions from scratch, the other three by rolling
+// backwards: 0.29 ms; (4, this form, which the order-1 code needs: a key from scratch would be ~19 table reads from memory) no key is
+// built from scratch: a thread looks up the codes of ITS four symbols once and leaves their concatenation -- bits, codeword-end marks,
+// length -- as one chunk in LDS; the code string behind its last position is the concatenation of the following chunks (four or five
+// 8-byte reads until 64 bits are full), and it rolls backwards over its own four positions in registers:
+//     R(i) = code(T[i+1] | T[i]) in front of R(i+1) >> its length,   key(i) = code0(T[i]) in front of R(i),
+//     depth(i) = 1 + the codeword ends among the first 56 - len0 bits of R(i)     (a population count of the marks).
+// The four keys are four consecutive slots and leave as two 16-byte stores, the four depths as one word.
+constexpr int PV_NCH = (CT + 64) / 4;       // chunks of four staged positions q = 16 + 4 j + k: the tile's 1024 and 16 behind it
+template <bool O1>
 __global__ __launch_bounds__(TB) void k_pack_keys_var(const uint8_t *__restrict__ T, uint32_t n, const SaState *__restrict__ st, uint64_t *__restrict__ P,
-                                                     const uint8_t *__restrict__ blk, const uint32_t *__restrict__ bend, uint8_t *__restrict__ D0)
+                                                     const uint8_t *__restrict__ blk, const uint32_t *__restrict__ bend, uint8_t *__restrict__ D0,
+                                                     const uint32_t *__restrict__ ctab)
 {
-    if (!st->vmode) return;                                           // (the plan kept the fixed-width code: k_pack_keys does the tiles)
+    if (st->vmode != (O1 ? 2u : 1u)) return;                          // (the plan chose another code: its kernel does the tiles)
     __shared__ __align__(16) uint8_t cr[CT + PK_HALO];                // bytes: index q = position i_lo - 16 + q
     __shared__ __align__(16) uint8_t cb[CT + PK_HALO];                // block numbers (group sort)
-    __shared__ uint32_t lcl[256];                                      // code | length << 27: one lookup per symbol (k_key_plan keeps codes below 28 bits)
-    constexpr uint64_t M56 = (1ull << 56) - 1ull;
-    constexpr int R = 4;                                               // consecutive positions per thread and step
+    __shared__ uint32_t lcl[256];                                      // order-0: code | length << 27 (k_key_plan keeps codes below 28 bits)
+    __shared__ uint64_t CB[PV_NCH], CM[PV_NCH];                        // a chunk's code bits, left-aligned, and the marks of its codeword ends
+    __shared__ uint8_t CL[PV_NCH];                                     // its bits (<= 64) | 0x80: nothing follows it (the text or the block ends inside)
     lcl[threadIdx.x] = st->vcode[threadIdx.x] | ((uint32_t)st->vlen[threadIdx.x] << 27);
     const uint32_t tag_max = st->tag_max;
     const uint32_t ntiles = (n + CT - 1) / CT;
@@ -360,7 +548,7 @@ __global__ __launch_bounds__(TB) void k_pack_keys_var(const uint8_t *__restrict_
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint32_t base = tile * CT, cnt = (n - base < (uint32_t)CT) ? n - base : (uint32_t)CT;
         const int64_t i_lo = (int64_t)n - 1 - base - (CT - 1);        // position of the tile's LAST slot (negative in the last tile: no such slot)
-        __syncthreads();                                                // the table; the previous tile's bytes have been read
+        __syncthreads();                                                // the table; the previous tile's bytes and chunks have been read
         for (int q = threadIdx.x; q < CT + PK_HALO; q += TB) {
             const int64_t p = i_lo - 16 + q;
             const bool in = p >= 0 && p < (int64_t)n;
@@ -368,54 +556,217 @@ __global__ __launch_bounds__(TB) void k_pack_keys_var(const uint8_t *__restrict_
             if (blk) cb[q] = in ? blk[p] : (uint8_t)0;
         }
         __syncthreads();
-#pragma unroll 1
-        for (int it = 0; it < CT / (TB * R); it++) {
-            const uint32_t x0 = (uint32_t)((it * TB + t) * R);         // my four slots x0 .. x0 + 3 = positions i_hi, i_hi - 1, ..
-            if (x0 >= cnt) continue;
-            const int q_hi = 16 + (CT - 1) - (int)x0;                  // staging index of slot x0's position
-            uint64_t acc = 0, key[R];
-            uint32_t used = 0, dep = 0;
-            int e = q_hi;
-            // the key of a position from scratch: whole symbols while they fit the 56 bits and the suffix lasts (group sort: its own
-            // block), then the leading bits of one more
-            auto scratch = [&](int q) {
-                const int64_t lim = bend ? (int64_t)bend[cb[q]] : (int64_t)n;
-                acc = 0; used = 0; e = q;
-                for (;;) {
-                    if (i_lo - 16 + e >= lim) break;                    // zero bits from here on
-                    const uint32_t en = lcl[cr[e]], l = en >> 27, c = en & 0x7FFFFFFu;
-                    if (used + l <= 56u) { acc |= (uint64_t)c << (56u - used - l); used += l; e++; if (used == 56u) break; }
-                    else { acc |= (uint64_t)c >> (l - (56u - used)); break; }
-                }
-            };
-            scratch(q_hi);
+        // chunk j: the codes of the symbols at q = 16 + 4 j .. + 3, each behind its predecessor.  e[k] = the symbol's table entry, 0 where
+        // it cannot follow its predecessor (past the end, the first position of another block, position 0); the chunk as others see it stops there.
+        auto chunk = [&](int j, uint32_t (&e)[4]) {
+            uint64_t bits = 0, marks = 0;
+            uint32_t used = 0;
+            bool stop = false;
 #pragma unroll
-            for (int j = 0; j < R; j++) {
-                const int q = q_hi - j;
+            for (int k = 0; k < 4; k++) {
+                const int q = 16 + 4 * j + k;
+                const int64_t p = i_lo - 16 + q;
+                const bool ok = p >= 1 && p < (int64_t)n && !(blk && cb[q] != cb[q - 1]);
+                e[k] = ok ? (O1 ? ctab[(uint32_t)cr[q - 1] * 256u + cr[q]] : lcl[cr[q]]) : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (e[k] == 0u) stop = true;
+                if (!stop && used < 64u) {
+                    const uint32_t l = e[k] >> 27, c = e[k] & 0x7FFFFFFu;
+                    if (used + l <= 64u) { used += l; bits |= (uint64_t)c << (64u - used); marks |= 1ull << (64u - used); }
+                    else { bits |= (uint64_t)c >> (used + l - 64u); used = 64u; }
+                }
+            }
+            CB[j] = bits;
+            CM[j] = marks;
+            CL[j] = (uint8_t)(used | (stop ? 0x80u : 0u));
+        };
+        if (t < PV_NCH - CT / 4) { uint32_t e[4]; chunk(CT / 4 + t, e); }      // the sixteen chunks behind the tile
+#pragma unroll 1
+        for (int it = 0; it < CT / (TB * 4); it++) {
+            // chunks in descending order: what a position needs behind it has been built in the steps before
+            const int j = CT / 4 - 1 - (it * TB + t);
+            const uint32_t x0 = (uint32_t)((it * TB + t) * 4);         // my four slots x0 .. x0 + 3 = positions i_hi, i_hi - 1, ..: chunk j, backwards
+            uint32_t e[4];
+            chunk(j, e);
+            __syncthreads();
+            if (x0 >= cnt) continue;
+            const int q_hi = 16 + (CT - 1) - (int)x0;                  // = 16 + 4 j + 3
+            uint64_t R = 0, M = 0, key[4];
+            uint32_t used = 0, dep = 0;
+            for (int jj = j + 1; jj < PV_NCH; jj++) {
+                const uint32_t L = CL[jj];
+                R |= CB[jj] >> used;
+                M |= CM[jj] >> used;
+                used += L & 0x7Fu;
+                if ((L & 0x80u) || used >= 64u) break;
+            }
+#pragma unroll
+            for (int jx = 0; jx < 4; jx++) {
+                const int q = q_hi - jx;
                 const int64_t i = i_lo - 16 + q;
-                if (j && i >= 0) {
-                    if (bend && cb[q + 1] != cb[q]) scratch(q);        // the last position of its block: nothing of the next block is in its key
+                if (jx) {                                              // one position back: the code of the symbol behind it goes in front
+                    const uint32_t en = e[4 - jx];
+                    if (en == 0u) { R = 0; M = 0; }                    // nothing follows (the last position of its block)
                     else {
-                        const uint32_t en = lcl[cr[q]], l = en >> 27, c = en & 0x7FFFFFFu;
-                        acc = (((uint64_t)c << (56u - l)) | (acc >> l)) & M56;
-                        used += l;
-                        while (used > 56u) { e--; used -= lcl[cr[e]] >> 27; }
+                        const uint32_t l = en >> 27;
+                        R = ((uint64_t)(en & 0x7FFFFFFu) << (64u - l)) | (R >> l);
+                        M = (1ull << (64u - l)) | (M >> l);
                     }
                 }
+                const uint32_t e0 = lcl[cr[q]], l0 = e0 >> 27;
+                const uint64_t k56 = ((uint64_t)(e0 & 0x7FFFFFFu) << (56u - l0)) | (R >> (8u + l0));
                 const uint32_t low = bend ? cb[q] : (i > 0 ? cr[q - 1] : 0u);   // T[i - 1] rides in the low byte -- the block number in a group sort (the sort's last digit)
-                key[j] = (acc << 8) | low;
-                const uint32_t d = (uint32_t)(e - q);
-                dep |= (d < tag_max ? d : tag_max) << (8 * j);         // (a clamped depth is still a number of symbols the key's group shares)
+                key[jx] = (k56 << 8) | low;
+                const uint32_t d = 1u + (uint32_t)__popcll(M >> (8u + l0));
+                dep |= (d < tag_max ? d : tag_max) << (8 * jx);        // (a clamped depth is still a number of symbols the key's group shares)
             }
-            if (x0 + R <= cnt) {
+            if (x0 + 4 <= cnt) {
                 uint4 *o = reinterpret_cast<uint4 *>(P + base + x0);
                 o[0] = make_uint4((uint32_t)key[0], (uint32_t)(key[0] >> 32), (uint32_t)key[1], (uint32_t)(key[1] >> 32));
                 o[1] = make_uint4((uint32_t)key[2], (uint32_t)(key[2] >> 32), (uint32_t)key[3], (uint32_t)(key[3] >> 32));
                 *reinterpret_cast<uint32_t *>(D0 + base + x0) = dep;
             } else {
 #pragma unroll
-                for (int j = 0; j < R; j++)
-                    if (x0 + j < cnt) { P[base + x0 + j] = key[j]; D0[base + x0 + j] = (uint8_t)(dep >> (8 * j)); }
+                for (int jx = 0; jx < 4; jx++)
+                    if (x0 + jx < cnt) { P[base + x0 + jx] = key[jx]; D0[base + x0 + jx] = (uint8_t)(dep >> (8 * jx)); }
+            }
+        }
+    }
+}
+
+// vmode 3: the order-2 code.  key(i) = code0(T[i]), code0(T[i+1]), then U(i + 2) with U(q) = the codes of the symbols q, q + 1, ..
+// each behind the two bytes in front of it (its row from ctxmap: a chosen pair's own, or the order-1 row of the one byte) -- a string that
+// does not depend on where the key starts, so it rolls: U(q) = entry(q) in front of U(q + 1) >> its length.  A thread owns four positions
+// q0 .. q0 + 3 and looks up the four symbols q0 + 2 .. q0 + 5 -- those whose contexts START at its positions: their concatenation is its
+// chunk, what lies behind is the concatenation of the following chunks, and position q0 + k needs exactly U(q0 + k + 2): four steps
+// backwards over the thread's own entries, nothing from its neighbours.  A key's SECOND symbol is coded without context as well (an LDS
+// read instead of another scattered table read; the order-1 code would save that one symbol 0.3 bits).
+constexpr int PO2_NCH = CT / 4 + 15;        // the tile's 1024 chunks and 15 behind it (symbols up to q = 18 + 4 * 1038 + 3 < CT + PK_HALO)
+__global__ __launch_bounds__(TB) void k_pack_keys_o2(const uint8_t *__restrict__ T, uint32_t n, const SaState *__restrict__ st, uint64_t *__restrict__ P,
+                                                    const uint8_t *__restrict__ blk, const uint32_t *__restrict__ bend, uint8_t *__restrict__ D0,
+                                                    const uint32_t *__restrict__ ctab, const uint16_t *__restrict__ ctxmap)
+{
+    if (st->vmode != 3u) return;
+    __shared__ __align__(16) uint8_t cr[CT + PK_HALO];                // bytes: index q = position i_lo - 16 + q
+    __shared__ __align__(16) uint8_t cb[CT + PK_HALO];                // block numbers (group sort)
+    __shared__ uint32_t lcl[256];
+    __shared__ uint64_t CB[PO2_NCH], CM[PO2_NCH];
+    __shared__ uint8_t CL[PO2_NCH];
+    static_assert(18 + 4 * (PO2_NCH - 1) + 3 < CT + PK_HALO, "the last chunk's symbols are staged");
+    lcl[threadIdx.x] = st->vcode[threadIdx.x] | ((uint32_t)st->vlen[threadIdx.x] << 27);
+    const uint32_t tag_max = st->tag_max;
+    const uint32_t ntiles = (n + CT - 1) / CT;
+    const int t = threadIdx.x;
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t base = tile * CT, cnt = (n - base < (uint32_t)CT) ? n - base : (uint32_t)CT;
+        const int64_t i_lo = (int64_t)n - 1 - base - (CT - 1);
+        __syncthreads();
+        for (int q = threadIdx.x; q < CT + PK_HALO; q += TB) {
+            const int64_t p = i_lo - 16 + q;
+            const bool in = p >= 0 && p < (int64_t)n;
+            cr[q] = in ? T[p] : (uint8_t)0;
+            if (blk) cb[q] = in ? blk[p] : (uint8_t)0;
+        }
+        __syncthreads();
+        auto follows = [&](int q) {                                    // the symbol at q exists and belongs to the suffix that holds q - 1
+            const int64_t p = i_lo - 16 + q;
+            return p >= 1 && p < (int64_t)n && !(blk && cb[q] != cb[q - 1]);
+        };
+        // chunk j: the symbols q = 18 + 4 j .. + 3, each behind its two bytes; 0 = it cannot follow.  All table reads of a thread's chunks
+        // are issued before anything is built from them.
+        constexpr int NIT = CT / (TB * 4);
+        uint32_t g[NIT + 1][4];
+        auto lookup = [&](int j, uint32_t (&a)[4]) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int q = 18 + 4 * j + k;
+                const bool ok = follows(q) && i_lo - 16 + q >= 2;
+                const uint32_t row = ok ? ctxmap[((uint32_t)cr[q - 2] << 8) | cr[q - 1]] : 0u;
+                a[k] = ok ? ctab[row * 256u + cr[q]] : 0u;
+            }
+        };
+        auto chunk = [&](int j, const uint32_t (&a)[4]) {
+            uint64_t bits = 0, marks = 0;
+            uint32_t used = 0;
+            bool stop = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (a[k] == 0u) stop = true;
+                if (!stop && used < 64u) {
+                    const uint32_t l = a[k] >> 27, c = a[k] & 0x7FFFFFFu;
+                    if (used + l <= 64u) { used += l; bits |= (uint64_t)c << (64u - used); marks |= 1ull << (64u - used); }
+                    else { bits |= (uint64_t)c >> (used + l - 64u); used = 64u; }
+                }
+            }
+            CB[j] = bits;
+            CM[j] = marks;
+            CL[j] = (uint8_t)(used | (stop ? 0x80u : 0u));
+        };
+        {
+            const bool halo = t < PO2_NCH - CT / 4;
+            if (halo) lookup(CT / 4 + t, g[NIT]);
+#pragma unroll
+            for (int it = 0; it < NIT; it++) lookup(CT / 4 - 1 - (it * TB + t), g[it]);
+            if (halo) chunk(CT / 4 + t, g[NIT]);
+#pragma unroll
+            for (int it = 0; it < NIT; it++) chunk(CT / 4 - 1 - (it * TB + t), g[it]);
+        }
+        __syncthreads();
+        static_assert(NIT == 4, "the selection of a step's own entries below");
+#pragma unroll 1
+        for (int it = 0; it < NIT; it++) {
+            const int j = CT / 4 - 1 - (it * TB + t);
+            const uint32_t x0 = (uint32_t)((it * TB + t) * 4);         // my four slots x0 .. x0 + 3 = positions q0 + 3, q0 + 2, ..
+            if (x0 >= cnt) continue;
+            uint32_t own[4];                                           // this step's entries (the loop stays rolled: registers)
+#pragma unroll
+            for (int k = 0; k < 4; k++) own[k] = it == 0 ? g[0][k] : it == 1 ? g[1][k] : it == 2 ? g[2][k] : g[3][k];
+            const int q0 = 16 + 4 * j;
+            uint64_t U = 0, M = 0, key[4];
+            uint32_t used = 0, dep = 0;
+            for (int jj = j + 1; jj < PO2_NCH; jj++) {                 // U(q0 + 6): what lies behind my chunk
+                const uint32_t L = CL[jj];
+                U |= CB[jj] >> used;
+                M |= CM[jj] >> used;
+                used += L & 0x7Fu;
+                if ((L & 0x80u) || used >= 64u) break;
+            }
+#pragma unroll
+            for (int jx = 0; jx < 4; jx++) {
+                const int q = q0 + 3 - jx;
+                const int64_t i = i_lo - 16 + q;
+                {                                                      // the symbol q + 2 in front: U(q + 2)
+                    const uint32_t en = own[3 - jx];
+                    if (en == 0u) { U = 0; M = 0; }                    // it cannot follow: nothing behind q + 1
+                    else {
+                        const uint32_t l = en >> 27;
+                        U = ((uint64_t)(en & 0x7FFFFFFu) << (64u - l)) | (U >> l);
+                        M = (1ull << (64u - l)) | (M >> l);
+                    }
+                }
+                const uint32_t e0 = lcl[cr[q]], l0 = e0 >> 27;
+                uint64_t k56 = (uint64_t)(e0 & 0x7FFFFFFu) << (56u - l0);
+                uint32_t d = 1u;
+                if (follows(q + 1)) {
+                    const uint32_t en1 = lcl[cr[q + 1]], l1 = en1 >> 27;
+                    k56 |= ((uint64_t)(en1 & 0x7FFFFFFu) << (56u - l0 - l1)) | (U >> (8u + l0 + l1));
+                    d = 2u + (uint32_t)__popcll(M >> (8u + l0 + l1));
+                }
+                const uint32_t low = bend ? cb[q] : (i > 0 ? cr[q - 1] : 0u);
+                key[jx] = (k56 << 8) | low;
+                dep |= (d < tag_max ? d : tag_max) << (8 * jx);
+            }
+            if (x0 + 4 <= cnt) {
+                uint4 *o = reinterpret_cast<uint4 *>(P + base + x0);
+                o[0] = make_uint4((uint32_t)key[0], (uint32_t)(key[0] >> 32), (uint32_t)key[1], (uint32_t)(key[1] >> 32));
+                o[1] = make_uint4((uint32_t)key[2], (uint32_t)(key[2] >> 32), (uint32_t)key[3], (uint32_t)(key[3] >> 32));
+                *reinterpret_cast<uint32_t *>(D0 + base + x0) = dep;
+            } else {
+#pragma unroll
+                for (int jx = 0; jx < 4; jx++)
+                    if (x0 + jx < cnt) { P[base + x0 + jx] = key[jx]; D0[base + x0 + jx] = (uint8_t)(dep >> (8 * jx)); }
             }
         }
     }
@@ -2132,6 +2483,8 @@ struct SaBufs {
     uint32_t *RL;                          // remaining run length per text position (written only when round 0 leaves run members behind)
     uint32_t *GD[2] = {nullptr, nullptr};  // variable-length keys: depth of every unresolved group by its rank, read side / write side of a round
     uint8_t *D0 = nullptr;                 // ... and the depth of every slot's key (rides through the radix sort in the value's upper bits)
+    uint32_t *ctab = nullptr;              // ... and the table of the context codes (256 bytes + 1024 pairs of bytes, 256 codes each)
+    uint16_t *ctxmap = nullptr;
     const uint8_t *blk = nullptr;          // group sort: block number of every text position, and where every block ends (device)
     const uint32_t *bend = nullptr;
     Piece *pieces;
@@ -2160,6 +2513,12 @@ int key_force_bits()
 bool r0_lookback()
 {
     static const bool v = [] { const char *e = getenv("JPK_R0_LOOKBACK"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
+// JPK_KEY_ORDER=0 / 1: the variable-length keys use nothing above the order-0 / order-1 code (comparators; default 2)
+int key_order()
+{
+    static const int v = [] { const char *e = getenv("JPK_KEY_ORDER"); const int x = e ? atoi(e) : 2; return x < 0 ? 0 : x > 2 ? 2 : x; }();
     return v;
 }
 // JPK_VARKEYS=0: fixed-width keys whatever the block (the comparator of the variable-length keys)
@@ -2193,6 +2552,9 @@ void sa_layout(Arena &a, size_t n, SaBufs &b, bool var)
         b.GD[0] = a.get<uint32_t>(n);
         b.GD[1] = a.get<uint32_t>(n);
         b.D0 = b.bwt;                         // (the slots' depths are read by the radix sort's first pass; the BWT bytes arrive from k_r0_finish on)
+        // the context codes: sampled counts, then code | length << 27 of byte s behind byte c (rows 0..255) or behind a chosen pair of bytes
+        b.ctab = a.get<uint32_t>(256 * (256 + JPK_O2_CLASSES));
+        b.ctxmap = a.get<uint16_t>(65536);    // the row that codes a symbol behind the bytes c2 c1
     }
     const size_t nbmax = 256;
     b.table = a.get<uint32_t>(nbmax * 2 * nwin);
@@ -2291,11 +2653,30 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     uint32_t *vs = b.valsA;
     JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_sym_present, dim3(cap_grid(n, 16 * TB * 4, 4096)), dim3(TB), T, n, b.state);
     const bool var = b.GD[0] != nullptr;            // (sa_layout: var_keys_eligible)
-    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_key_plan, dim3(1), dim3(256), b.state, key_force_bits(), var ? 1 : 0, var_tag_shift(n));
-    if (var) JPK_HIP(hipMemsetAsync(b.D0, 0, n, st));      // (a plan that falls back to the fixed code leaves no depths: tag 0 everywhere)
+    const int order = var ? key_order() : 0;
+    const bool o1 = order >= 1, o2 = order >= 2;
+    if (o1) {       // sampled counts for the context codes: about a million pairs / triples (65 536 vectors of 16 bytes) whatever the block
+        JPK_HIP(hipMemsetAsync(b.ctab, 0, sizeof(uint32_t) * 256 * (o2 ? 256 + JPK_O2_CLASSES : 256), st));
+        const uint32_t nv = n / 16u, stride = (nv >> 16) ? (nv >> 16) : 1u;
+        JPK_LAUNCH(ctx, PROF_SA_PACK, 0, k_pair_counts, dim3(16, 16), dim3(256), T, n, stride, b.ctab);
+        if (o2) {
+            JPK_LAUNCH(ctx, PROF_SCAN, 0, k_ctx_select, dim3(1), dim3(1024), b.ctab, b.ctxmap, b.state);
+            JPK_LAUNCH(ctx, PROF_SA_PACK, 0, k_triple_counts, dim3(16, 16), dim3(256), T, n, stride, b.ctxmap, b.ctab);
+        }
+    }
+    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_key_plan, dim3(1), dim3(256), b.state, key_force_bits(), var ? 1 : 0);
+    if (var) {
+        if (o1) JPK_LAUNCH(ctx, PROF_SCAN, 0, k_ctx_plan, dim3(o2 ? 256 + JPK_O2_CLASSES : 256), dim3(256), b.state, b.ctab);
+        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_key_final, dim3(1), dim3(256), b.state, o1 ? b.ctab : (uint32_t *)nullptr, o2 ? b.ctxmap : (uint16_t *)nullptr,
+                   var_tag_shift(n), order);
+        JPK_HIP(hipMemsetAsync(b.D0, 0, n, st));           // (a plan that falls back to the fixed code leaves no depths: tag 0 everywhere)
+    }
     JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_pack_keys, dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend,
                jpk_radix_onesweep() ? (uint32_t *)nullptr : b.scratch, b.D0);
-    if (var) JPK_LAUNCH(ctx, PROF_SA_PACK, 0, k_pack_keys_var, dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.D0);
+    if (var) JPK_LAUNCH(ctx, PROF_SA_PACK, 0, (k_pack_keys_var<false>), dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.D0, (const uint32_t *)nullptr);
+    if (o1) JPK_LAUNCH(ctx, PROF_SA_PACK, 0, (k_pack_keys_var<true>), dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.D0, (const uint32_t *)b.ctab);
+    if (o2) JPK_LAUNCH(ctx, PROF_SA_PACK, 0, k_pack_keys_o2, dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.D0, (const uint32_t *)b.ctab,
+                       (const uint16_t *)b.ctxmap);
     JPK_TRY(jpk_radix_sort_slot_keys(ctx, n, b.keysA, b.valsA, b.keysB, b.valsB, b.scratch, &ks, &vs, b.blk != nullptr, b.D0, var_tag_shift(n)));
     ctx->stats.sa_sorted_elems += n;
     // The sorted pairs sit in (ks, vs).  The other pair of radix buffers is free from here on, the pair that holds the result

@@ -1,4 +1,4 @@
-"""Variable-length keys of the suffix sort's round 0 (bwt_fwd.hip k_key_plan / pack_tile_var; divsufsort.cpp:1427-1520 does not care how
+"""Variable-length keys of the suffix sort's round 0 (bwt_fwd.hip k_key_plan / k_ctx_plan / k_key_final / k_pack_keys_var; divsufsort.cpp:1427-1520 does not care how
 many byte values a block uses -- a fixed-width code does: 7 bytes per key above 128 values).  An order-preserving prefix code built
 from the block's (sampled) histogram packs about 56 / H0 symbols into a key and every group of tied suffixes carries its own depth.
 The forward BWT must stay the reference's (bwt.cpp:22-65): skewed alphabets of 129..256 values, codes that straddle the 56-bit boundary
@@ -104,6 +104,88 @@ def test_text_kinds_and_the_round_structure(gpu, ref):
         assert s.sa_key_depth > fixed_depth, (kind, s.sa_key_depth)
 
 
+def _markov(n, seed, sigma=60, fan=3, keep=0.93, lo=33):
+    """a text with strong order-1 structure: every symbol has `fan` likely successors (the order-1 code's lengths then run from 1-2 bits
+    for those to 10+ for the pairs the sample never saw)"""
+    rng = np.random.default_rng(seed)
+    succ = rng.integers(0, sigma, (sigma, fan))
+    r, pick, rnd = rng.random(n), rng.integers(0, fan, n), rng.integers(0, sigma, n)
+    out = np.empty(n, dtype=np.uint8)
+    s = 0
+    for i in range(n):
+        s = succ[s, pick[i]] if r[i] < keep else rnd[i]
+        out[i] = lo + s
+    return out
+
+
+def test_order1_code_texts_with_context_structure(gpu, oracle):
+    """vmode 2 (k_ctx_plan / k_pack_keys_var<true>): every symbol behind a key's first is coded in the context of the byte in front of
+    it.  Markov texts (likely successors in 1-2 bits: keys of 25+ symbols, depth tags near the clamp), pairs that occur once in the whole
+    text (never in the sample: the floor weight's long codes), runs of a byte that is rare behind itself, a text that ends inside a
+    likely chain, 16-bit samples (flat order-0 histogram, all the structure in the pairs)"""
+    torch, jam, ctx = gpu
+    for n, seed, sigma, fan in ((200, 1, 12, 2), (5000, 2, 60, 3), (70_001, 3, 60, 3), (300_000, 4, 200, 2), (300_000, 5, 8, 1)):
+        t = _markov(n, seed, sigma, fan)
+        if n > 3000:
+            t[1000:1003] = (250, 251, 250)                               # bytes and pairs that occur exactly once
+            t[2000:2300] = t[1500]                                       # a run of a byte that is rare behind itself
+            t[n - 120:] = t[100: 220]                                    # the text ends inside a copy
+        got, s = _fwd(torch, jam, ctx, np.ascontiguousarray(t))
+        assert np.array_equal(got, oracle.bwt_forward(np.ascontiguousarray(t), prefill=0x11)), (n, sigma, fan)
+        if n >= 70_001:
+            assert s.sa_key_depth >= 12, (n, sigma, fan, s.sa_key_depth)
+    rng = np.random.default_rng(9)
+    smp = (np.cumsum(rng.integers(-300, 301, 150_000)) & 0xFFFF).astype("<u2").view(np.uint8)     # a random walk in 16-bit samples
+    got, s = _fwd(torch, jam, ctx, np.ascontiguousarray(smp))
+    assert np.array_equal(got, oracle.bwt_forward(np.ascontiguousarray(smp), prefill=0x11))
+
+
+def _markov2(n, seed, sigma, fan=2, keep=0.95, lo=1):
+    """order-2 structure: the likely successors depend on the two bytes in front; with sigma = 200 there are far more than 1024 pair
+    contexts, so most symbols fall back to the order-1 rows and the chosen pairs change from key to key"""
+    rng = np.random.default_rng(seed)
+    succ = rng.integers(0, sigma, (sigma * sigma, fan))
+    r, pick, rnd = rng.random(n), rng.integers(0, fan, n), rng.integers(0, sigma, n)
+    out = np.empty(n, dtype=np.uint8)
+    a = b = 0
+    for i in range(n):
+        s = succ[a * sigma + b, pick[i]] if r[i] < keep else rnd[i]
+        out[i] = lo + s
+        a, b = b, s
+    return out
+
+
+def test_order2_code_pairs_of_bytes_as_contexts(gpu, oracle):
+    """vmode 3 (k_ctx_select / k_triple_counts / k_pack_keys_o2): symbols from a key's third on are coded behind the TWO bytes in front of
+    them when that pair is among the 1024 most frequent of the sample, behind the one byte otherwise.  Few contexts (all chosen), many
+    (most symbols in order-1 rows, chosen and other pairs mixed inside a key), near-deterministic chains (1-bit codes: 50+ symbols per key,
+    the depth tag at its clamp), runs, unique bytes, texts that end inside a chain, tiny texts without a usable sample"""
+    torch, jam, ctx = gpu
+    for n, seed, sigma, fan, keep in ((150, 1, 6, 2, 0.9), (3000, 2, 20, 2, 0.95), (70_001, 3, 30, 2, 0.95), (300_000, 4, 200, 2, 0.9),
+                                     (200_000, 5, 12, 1, 0.97), (120_000, 6, 90, 3, 0.8)):
+        t = _markov2(n, seed, sigma, fan, keep)
+        if n > 3000:
+            t[1000:1003] = (250, 251, 250)
+            t[2000:2400] = t[1500]
+            t[5000:5600] = np.tile(t[4000:4003], 200)                    # a period-3 stretch: the same three pair contexts over and over
+            t[n - 150:] = t[300: 450]
+        t = np.ascontiguousarray(t)
+        got, s = _fwd(torch, jam, ctx, t)
+        assert np.array_equal(got, oracle.bwt_forward(t, prefill=0x11)), (n, sigma, fan)
+        if n >= 70_001 and sigma <= 30:                                  # (90 or 200 byte values: 8 100 or 40 000 pair contexts for 1024 rows)
+            assert s.sa_key_depth >= 12, (n, sigma, fan, s.sa_key_depth)
+
+
+def test_context_codes_buy_depth_on_the_bench_texts(gpu, ref):
+    """the two bench texts at 8 MiB: deeper keys than the order-0 code's (12 and 10 symbols; the order-1 code: 13 and 12), the reference's bytes"""
+    torch, jam, ctx = gpu
+    for kind, order0_depth in (("text_survey", 13), ("text_wide", 12)):
+        t = jam.corpus.make(kind, 8 << 20, 9)
+        got, s = _fwd(torch, jam, ctx, t)
+        assert np.array_equal(got, ref.bwt_forward(t, prefill=0x11))
+        assert s.sa_key_depth > order0_depth, (kind, s.sa_key_depth)
+
+
 def test_blocks_above_64_mib_clamp_the_depth_tag(gpu, ref):
     """above 2^26 sorted bytes the depth rides in five (four) spare bits of the suffix number: depths are clamped at 31 (15), which is
     still a number of symbols the group shares -- DNA (2-bit codes, 28 symbols per key) makes the clamp bite"""
@@ -124,11 +206,13 @@ sys.path.insert(0, %(root)r)
 sys.path.insert(0, %(root)r + "/tests")
 import jampack_amd as jam
 from oracle.pyoracle import Oracle
-from test_gpu_var_keys import _skewed
+from test_gpu_var_keys import _skewed, _markov, _markov2
 o = Oracle()
 ok = True
 for sigma, n in ((129, 70_001), (205, 200_000), (256, 4097), (28, 120_000), (6, 5000)):
     t = _skewed(sigma, n, 3 * sigma)
+    ok = ok and np.array_equal(jam.Bwt().ForwardBwt(t), o.bwt_forward(t))
+for t in (_markov(120_000, 5), _markov2(120_000, 6, 40)):
     ok = ok and np.array_equal(jam.Bwt().ForwardBwt(t), o.bwt_forward(t))
 for kind, n in (("text_wide", 300_000), ("silesia", 400_000), ("runs", 200_000), ("repeat4k", 100_000)):
     t = jam.corpus.make(kind, n, 3)
@@ -137,9 +221,9 @@ print("CMP_OK" if ok else "CMP_BAD")
 """
 
 
-@pytest.mark.parametrize("env", [{"JPK_VARKEYS": "0"}, {"JPK_KEY_BITS": "8"}, {"JPK_ONESWEEP": "0"}])
+@pytest.mark.parametrize("env", [{"JPK_VARKEYS": "0"}, {"JPK_KEY_BITS": "8"}, {"JPK_ONESWEEP": "0"}, {"JPK_KEY_ORDER": "0"}, {"JPK_KEY_ORDER": "1"}])
 def test_fixed_width_forms_remain_working_comparators(env):
     """JPK_VARKEYS=0: the alphabet-packed fixed-width keys of round 4; JPK_KEY_BITS=8: plain bytes; JPK_ONESWEEP=0: the two-pass radix
-    (which has no room for the depth tag: fixed-width keys)"""
+    (which has no room for the depth tag: fixed-width keys); JPK_KEY_ORDER=0 / 1: nothing above the order-0 / order-1 variable-length code"""
     r = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert "CMP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
