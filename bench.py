@@ -954,8 +954,9 @@ def main():
                                       "in_large_groups": [int(x) for x in st.sa_round_large[:nr]],
                                       "pair_rounds": [r for r in range(min(nr, 64)) if (int(st.sa_pair_rounds) >> r) & 1],
                                       "note": "round 0 = radix sort on the first key_depth_bytes symbols of every suffix on average (an order-preserving "
-                                              "prefix code of the block's byte values, as many symbols as fit 56 bits: about 56 / H0 -- the fixed-width "
-                                              "code of round 4 held 11 bytes of this text, 7 of any block above 128 byte values); round r >= 1 sorts the "
+                                              "prefix code of the block's byte values, every symbol coded behind the one or two bytes in front of it where a "
+                                              "sample of the block says that pays; as many symbols as fit 56 bits -- the fixed-width code of round 4 held 11 "
+                                              "bytes of this text, 7 of any block above 128 byte values); round r >= 1 sorts the "
                                               "still unresolved suffixes, every group at its own depth, by the rank of the suffix that many symbols "
                                               "further; pair_rounds = rounds that resolved long repeats by induction from their successors instead"}
             del d_bwt, d_enc, d_dec, d_back

@@ -54,9 +54,10 @@ typedef struct jpk_ctx jpk_ctx;
 /* per-call statistics of the last operation on a context (for bench.py / DESIGN.md accounting) */
 typedef struct jpk_stats {
     int32_t sa_rounds;            /* prefix-doubling rounds of the last forward BWT */
-    int32_t sa_key_depth;         /* symbols of a suffix that round 0's key holds: the average over the block with the variable-length code
-                                   * (about 56 / H0: 12 for English-like text, 10 over enwik8's byte alphabet), exactly floor(56 / ceil(log2 sigma))
-                                   * with the fixed-width code (flat histograms, blocks above 2^28 bytes, JPK_VARKEYS=0): 7 above 128 byte values */
+    int32_t sa_key_depth;         /* symbols of a suffix that round 0's key holds: the average over the block with the variable-length codes
+                                   * (order 0: about 56 / H0 -- 12 for English-like text, 10 over enwik8's byte alphabet; with the order-1 /
+                                   * order-2 context codes 13-15), exactly floor(56 / ceil(log2 sigma)) with the fixed-width code (flat
+                                   * histograms, blocks above 2^28 bytes, JPK_VARKEYS=0): 7 above 128 byte values */
     int64_t sa_sorted_elems;      /* sum over rounds of active suffixes that went through a sort */
     int64_t inv_splitters;        /* walkers used by the last inverse BWT */
     int64_t inv_overflow_slots;   /* sub-lists that exceeded one scratch slot */

@@ -44,9 +44,11 @@ ls -la "$OUT"
 python3 tools/block_sizes.py 1,8,64,128 2>/dev/null > "$OUT/block_sizes.txt"
 python3 tools/batch_compress.py 2>/dev/null | grep "in flight" > "$OUT/blocks_compress_call.txt"
 # 5. round 3: the floor of the suffix sort, the drop-in block loop with 16 threads, the N > 1 code path on one GPU, SQ counters
-( echo "# headline block (text_survey, variable-length keys: round counts of tools/fwd_once.py)"; tools/_bin/sa_floor 67108800 41245987 5028889 321
+( echo "# headline block (text_survey, order-2 context codes: round counts of tools/fwd_once.py)"; tools/_bin/sa_floor 67108800 27281026 48909
+  echo "# the same block with the order-0 variable-length keys (JPK_KEY_ORDER=0)"; tools/_bin/sa_floor 67108800 41245987 5028889 321
   echo "# the same block with round 4's fixed-width keys (11 bytes)"; tools/_bin/sa_floor 67108800 47350511 8839248 3530
-  echo "# wide-alphabet block (text_wide, variable-length keys)"; tools/_bin/sa_floor 67108800 38943552 4138392 3586
+  echo "# wide-alphabet block (text_wide, order-2 context codes)"; tools/_bin/sa_floor 67108800 20205395 45204
+  echo "# the same block with the order-0 variable-length keys"; tools/_bin/sa_floor 67108800 38943552 4138392 3586
   echo "# the same block with fixed-width keys (7 bytes)"; tools/_bin/sa_floor 67108800 56766712 23323321 420103 ) > "$OUT/sa_floor.txt" 2>&1
 python3 - <<'PY'
 import sys
@@ -74,7 +76,9 @@ python3 tools/small_blocks.py 1,8,64 4,8,16 2>/dev/null | grep blocks > "$OUT/sm
     echo -n "wide (207 byte values)    JPK_VARKEYS=$v  "; JPK_VARKEYS=$v python3 bench.py --workload enwik8-wide --steps 12 --warmup 3 --no-extras --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*' | head -1
   done; done
   echo "# forward BWT of ONE 64 MiB block at a time (tools/fwd_once.py), wall clock per block"
-  for k in text_survey text_wide; do for v in 1 0; do echo -n "$k JPK_VARKEYS=$v  "; JPK_VARKEYS=$v python3 tools/fwd_once.py $k 3 2>/dev/null | tail -1; done; done ) > "$OUT/var_keys.txt"
+  for k in text_survey text_wide; do for v in 1 0; do echo -n "$k JPK_VARKEYS=$v  "; JPK_VARKEYS=$v python3 tools/fwd_once.py $k 3 2>/dev/null | tail -1; done; done
+  echo "# ... and by the order of the code (JPK_KEY_ORDER: 0 = the round's first form, 1, 2 = default)"
+  for k in text_survey text_wide; do for v in 0 1 2; do echo -n "$k JPK_KEY_ORDER=$v  "; JPK_KEY_ORDER=$v python3 tools/fwd_once.py $k 10 2>/dev/null | tail -1; done; done ) > "$OUT/var_keys.txt"
 ( echo "# the pair rule (k_pair_*) against plain prefix doubling (JPK_PAIR_SHIFT=-1) and without the repair walk (JPK_PAIR_REPAIR=0): forward BWT of one 64 MiB block"
   for k in repeat silesia runs text; do
     echo -n "$k default            "; python3 tools/fwd_once.py $k 3 2>/dev/null | tail -1
