@@ -114,6 +114,11 @@ JPK_API int jpk_thread_device(void);
 /* destroys every pooled context (arenas, streams, staging).  No host-buffer call may be in flight.  Threads that call
  * again afterwards get fresh contexts. */
 JPK_API void jpk_shutdown(void);
+/* gives back what the batch entries keep between calls and nobody is using right now: the idle worker contexts of
+ * jpk_dev_blocks_compress / jpk_dev_blocks_decompress (one arena each: ~54 bytes per block byte of the largest block they have seen) and
+ * the multi-device entries' slabs.  May run beside other calls; they create what they need again.  Returns the contexts destroyed.
+ * (The reference frees its device buffers after every block: bwt.cpp:98-114.) */
+JPK_API int jpk_release_idle(void);
 
 /* ---- host-buffer entry points (drop-in boundary) ------------------------------------------------------- */
 /* BlockSort::Bwt::ForwardBwt(Buffer,Buffer)            bwt.hpp:15, bwt.cpp:22-65.   *out_len = in_len + 480. */

@@ -56,6 +56,7 @@ _SIGS = {
     "jpk_init_devices": (C.c_int, [_i32p, C.c_int32]),
     "jpk_thread_device": (C.c_int, []),
     "jpk_shutdown": (None, []),
+    "jpk_release_idle": (C.c_int, []),
     "jpk_strerror": (C.c_char_p, [C.c_int]),
     "jpk_version": (C.c_char_p, []),
     "jpk_bwt_forward": (C.c_int, [_vp, C.c_int32, _vp, C.c_int32, _i32p]),

@@ -46,6 +46,11 @@ def shutdown() -> None:
     lib().jpk_shutdown()
 
 
+def release_idle() -> int:
+    """destroys the batch entries' idle worker contexts and the multi-device slabs; returns the contexts destroyed"""
+    return int(lib().jpk_release_idle())
+
+
 def thread_device() -> int:
     """device the calling thread's pooled context lives on"""
     d = lib().jpk_thread_device()

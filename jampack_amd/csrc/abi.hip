@@ -3,6 +3,7 @@
 // every entry point returns JPK_E_NODEVICE.
 #include <chrono>
 #include <atomic>
+#include <algorithm>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -1386,6 +1387,31 @@ extern "C" void jpk_shutdown(void)
     p.devices.clear();
     p.generation++;
     p.next_thread = 0;
+}
+
+// Gives back what the batch entries keep between calls and nobody is using: the idle worker contexts of jpk_dev_blocks_compress /
+// jpk_dev_blocks_decompress (an arena of ~54 bytes per block byte each) and the multi-device entries' slabs.  The host-buffer pool's
+// contexts stay (threads hold them).  Safe beside running calls: a context that is in use is not in the idle lists.  Returns the
+// number of contexts destroyed.
+extern "C" int jpk_release_idle(void)
+{
+    int freed = 0;
+    {
+        std::unique_lock<std::mutex> multi_lock(multi_call_mu(), std::try_to_lock);    // a multi-device call in flight keeps its slabs
+        if (multi_lock.owns_lock()) multi_slabs_free();
+    }
+    CtxPool &p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    for (auto &idle : batch_idle()) {
+        for (jpk_ctx *c : idle) {
+            auto &all = batch_all();
+            all.erase(std::remove(all.begin(), all.end(), c), all.end());
+            jpk_ctx_destroy(c);
+            freed++;
+        }
+        idle.clear();
+    }
+    return freed;
 }
 
 namespace {

@@ -111,6 +111,7 @@ def test_device_mask_api_without_gpu():
     assert jampack_amd.lib().jpk_init(0) == -6           # JPK_E_NODEVICE, never a silent CPU path
     assert jampack_amd.lib().jpk_thread_device() == -6
     jampack_amd.lib().jpk_shutdown()                     # harmless with nothing to destroy
+    assert jampack_amd.lib().jpk_release_idle() == 0     # nothing idle either
 
 
 def test_bench_refuses_a_gpus_flag_that_disagrees_with_the_launcher():

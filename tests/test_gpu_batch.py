@@ -210,6 +210,29 @@ def test_blocks_compress_equals_single_calls(gpu, oracle):
     assert ctx.blocks_compress([], [], [], [], 4) == ([], [])
 
 
+def test_release_idle_gives_the_worker_arenas_back(gpu, oracle):
+    """jpk_release_idle: the worker contexts jpk_dev_blocks_compress keeps between calls are destroyed (device memory comes back), the
+    next call creates them again and gives the same bytes"""
+    torch, jam, ctx = gpu
+    dev = torch.device("cuda", 0)
+    blocks = [jam.corpus.make("text_survey", 20_000_000 + 1000 * i, 80 + i) for i in range(4)]
+    d_in = [torch.from_numpy(t).to(dev) for t in blocks]
+    caps = [jam.ans_capacity(len(t) + jam.TRAILER) for t in blocks]
+    d_out = [torch.empty(c, dtype=torch.uint8, device=dev) for c in caps]
+    n0, st = ctx.blocks_compress(d_in, [len(t) for t in blocks], d_out, caps, 4)
+    assert st == [0] * 4
+    first = [d_out[i][: n0[i]].clone() for i in range(4)]
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    freed = jam.release_idle()
+    assert freed >= 3                                        # in_flight 4 = the caller's context + three workers
+    assert torch.cuda.mem_get_info()[0] - free_before > 3 * 40 * 20_000_000      # three arenas of > 40 bytes per block byte
+    assert jam.release_idle() == 0
+    n1, st = ctx.blocks_compress(d_in, [len(t) for t in blocks], d_out, caps, 4)
+    assert st == [0] * 4 and list(n1) == list(n0)
+    assert all(torch.equal(d_out[i][: n1[i]], first[i]) for i in range(4))
+
+
 def _leb(v):
     for nb, c in ((1, 0), (2, 127), (3, 16510), (4, 2113661)):
         if v < (127, 16510, 2113661, 270549116)[nb - 1]:
