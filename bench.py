@@ -949,7 +949,7 @@ def main():
                 st = ctx.stats()
                 nr = int(st.sa_rounds)
                 dep = int(st.sa_key_depth)
-                extra["sa_rounds"] = {"block_bytes": n, "rounds": nr, "key_depth_bytes": dep, "alphabet": int(len(np.unique(blocks[i]))),
+                extra["sa_rounds"] = {"block_bytes": n, "rounds": nr, "key_depth_bytes": dep, "key_order": int(st.sa_key_order), "alphabet": int(len(np.unique(blocks[i]))),
                                       "active_suffixes": [int(x) for x in st.sa_round_active[:nr]],
                                       "in_large_groups": [int(x) for x in st.sa_round_large[:nr]],
                                       "pair_rounds": [r for r in range(min(nr, 64)) if (int(st.sa_pair_rounds) >> r) & 1],

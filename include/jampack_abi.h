@@ -78,6 +78,10 @@ typedef struct jpk_stats {
      * resolves whole groups from the order of their successors and leaves the doubling distance alone) instead of a doubling round;
      * r >= 1 then stands for the r-th round after round 0, h = sa_key_depth * 2^(doubling rounds before it) */
     int64_t sa_pair_rounds;
+    /* the code of round 0's keys in the last forward BWT: -1 = fixed width, 0 = the variable-length code of the bytes alone, 1 / 2 = every
+     * symbol behind the one / the two bytes in front of it (chosen per block from a sample) */
+    int32_t sa_key_order;
+    int32_t reserved0;
 } jpk_stats;
 
 /* ---- contexts ------------------------------------------------------------------------------------------ */

@@ -33,7 +33,8 @@ class Stats(C.Structure):
                 ("inv_splitters", C.c_int64), ("inv_overflow_slots", C.c_int64), ("workspace_bytes", C.c_int64),
                 ("ans_chunks", C.c_int64), ("ans_rle_symbols", C.c_int64),
                 ("sa_round_active", C.c_int32 * 40), ("sa_round_large", C.c_int32 * 40),
-                ("enc_chain_cycles", C.c_int64), ("enc_chain_ns", C.c_int64), ("enc_chain_steps", C.c_int64), ("sa_pair_rounds", C.c_int64)]
+                ("enc_chain_cycles", C.c_int64), ("enc_chain_ns", C.c_int64), ("enc_chain_steps", C.c_int64), ("sa_pair_rounds", C.c_int64),
+                ("sa_key_order", C.c_int32), ("reserved0", C.c_int32)]
 
 
 _lib = None

@@ -69,13 +69,13 @@ struct SaState {
     uint32_t round_lc[JPK_SA_MAX_ROUNDS];  // per round: of those, members of groups > SEG_TILE
     // round 0's key (k_key_plan): the text's bytes renumbered 0..sigma-1 in byte order, `bits` bits each, `depth` of them in 56 bits
     uint32_t bits, depth;
+    uint32_t vmode;                        // 0: that fixed-width code; 1 / 2 / 3: the variable-length code of order 0 / 1 / 2 (below; k_key_final)
     uint64_t rep;                          // the key field of "code 1 repeated depth times": code * rep = a run of that code
     uint32_t present[256];                 // byte value occurs in the text
     uint8_t lut[256];                      // byte -> code
     // variable-length keys (vmode, round 5): an order-preserving PREFIX code of the block's bytes -- weight-balanced on a sampled
     // histogram -- instead of the fixed-width one: a key holds as many symbols as fit its 56 bits (about 56 / H0: ten for enwik8's 205
     // byte values where the fixed code holds seven) and every group of tied suffixes carries its own depth (GD, see build_sa)
-    uint32_t vmode;
     uint32_t tag_shift, tag_max;           // a key's depth rides in the sorted value's bits from tag_shift up: at most tag_max (26 and 63 up to 2^26 bytes)
     uint32_t cnt[256];                     // sampled byte counts (k_sym_present: every sixteenth 16-byte vector)
     uint32_t vcode[256];                   // code of byte b, right-justified in vlen[b] bits
@@ -91,7 +91,7 @@ struct SaState {
     // is one of the `nclass` <= 1024 most frequent ones (k_ctx_select; its own row of the code table), behind the one byte otherwise
     uint32_t nclass, o2_w, o2_wl, o2_maxlen;
 };
-static_assert(offsetof(SaState, depth) == offsetof(SaState, round_m) + sizeof(uint32_t) * (2 * JPK_SA_MAX_ROUNDS + 1), "the statistics copy takes round_m, round_lc, bits, depth in one piece");
+static_assert(offsetof(SaState, vmode) == offsetof(SaState, round_m) + sizeof(uint32_t) * (2 * JPK_SA_MAX_ROUNDS + 2), "the statistics copy takes round_m, round_lc, bits, depth, vmode in one piece");
 
 // one piece of a large group: the part of the group that lies inside one 1024-slot window of the active list
 struct Piece {
@@ -2830,7 +2830,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     }
     ctx->stats.sa_pair_rounds = (int64_t)pair_mask;
     // statistics: one small copy, read by sa_collect_stats() after the caller has synchronised the stream
-    JPK_HIP(hipMemcpyAsync(ctx->h_mail + 32, b.state->round_m, sizeof(uint32_t) * (2 * JPK_SA_MAX_ROUNDS + 2), hipMemcpyDeviceToHost, st));   // + bits, depth
+    JPK_HIP(hipMemcpyAsync(ctx->h_mail + 32, b.state->round_m, sizeof(uint32_t) * (2 * JPK_SA_MAX_ROUNDS + 3), hipMemcpyDeviceToHost, st));   // + bits, depth, vmode
     ctx->sa_stats_pending = true;
     return JPK_OK;
 }
@@ -2843,6 +2843,7 @@ void jpk_sa_stats_sync(jpk_ctx *ctx)
     ctx->sa_stats_pending = false;
     const uint32_t *rm = ctx->h_mail + 32, *rl = ctx->h_mail + 32 + JPK_SA_MAX_ROUNDS;
     ctx->stats.sa_key_depth = (int32_t)ctx->h_mail[32 + 2 * JPK_SA_MAX_ROUNDS + 1];
+    ctx->stats.sa_key_order = (int32_t)ctx->h_mail[32 + 2 * JPK_SA_MAX_ROUNDS + 2] - 1;      // vmode - 1: -1 = the fixed-width code
     for (int r = 0; r < JPK_SA_MAX_ROUNDS; r++) {
         const bool live = r < ctx->stats.sa_rounds;
         ctx->stats.sa_round_active[r] = live ? (int32_t)rm[r] : 0;

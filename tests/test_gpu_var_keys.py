@@ -91,7 +91,7 @@ def test_flat_alphabets_keep_the_fixed_width_code(gpu, oracle):
         t = rng.integers(0, sigma, 200_000).astype(np.uint8)
         got, s = _fwd(torch, jam, ctx, t)
         assert np.array_equal(got, oracle.bwt_forward(t, prefill=0x11))
-        assert s.sa_key_depth == depth, (sigma, s.sa_key_depth)
+        assert s.sa_key_depth == depth and s.sa_key_order == -1, (sigma, s.sa_key_depth, s.sa_key_order)
 
 
 def test_text_kinds_and_the_round_structure(gpu, ref):
@@ -173,7 +173,7 @@ def test_order2_code_pairs_of_bytes_as_contexts(gpu, oracle):
         got, s = _fwd(torch, jam, ctx, t)
         assert np.array_equal(got, oracle.bwt_forward(t, prefill=0x11)), (n, sigma, fan)
         if n >= 70_001 and sigma <= 30:                                  # (90 or 200 byte values: 8 100 or 40 000 pair contexts for 1024 rows)
-            assert s.sa_key_depth >= 12, (n, sigma, fan, s.sa_key_depth)
+            assert s.sa_key_depth >= 12 and s.sa_key_order == 2, (n, sigma, fan, s.sa_key_depth, s.sa_key_order)
 
 
 def test_context_codes_buy_depth_on_the_bench_texts(gpu, ref):
@@ -183,7 +183,7 @@ def test_context_codes_buy_depth_on_the_bench_texts(gpu, ref):
         t = jam.corpus.make(kind, 8 << 20, 9)
         got, s = _fwd(torch, jam, ctx, t)
         assert np.array_equal(got, ref.bwt_forward(t, prefill=0x11))
-        assert s.sa_key_depth > order0_depth, (kind, s.sa_key_depth)
+        assert s.sa_key_depth > order0_depth and s.sa_key_order == 2, (kind, s.sa_key_depth, s.sa_key_order)
 
 
 def test_blocks_above_64_mib_clamp_the_depth_tag(gpu, ref):
