@@ -2671,7 +2671,10 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
                    var_tag_shift(n), order);
         JPK_HIP(hipMemsetAsync(b.D0, 0, n, st));           // (a plan that falls back to the fixed code leaves no depths: tag 0 everywhere)
     }
-    JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_pack_keys, dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend,
+    // (with the variable-length codes in play this kernel usually finds vmode set and leaves at once -- but every workgroup of a full grid
+    // first has to get its 44 KB of LDS on a CU that the other blocks in flight are using: 1.2 ms of the block's stream in the timed loop.
+    // A grid of 1024 walks the tiles instead when it does have work: flat data, whose pack is 0.3 ms of a 6 ms sort.)
+    JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_pack_keys, dim3(cap_grid(n, CT, var ? 1024u : CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend,
                jpk_radix_onesweep() ? (uint32_t *)nullptr : b.scratch, b.D0);
     if (var) JPK_LAUNCH(ctx, PROF_SA_PACK, 0, (k_pack_keys_var<false>), dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.D0, (const uint32_t *)nullptr);
     if (o1) JPK_LAUNCH(ctx, PROF_SA_PACK, 0, (k_pack_keys_var<true>), dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.D0, (const uint32_t *)b.ctab);
