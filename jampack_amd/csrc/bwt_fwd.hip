@@ -793,6 +793,10 @@ __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T,
         const uint32_t base = tile * CT, cnt = (n - base < (uint32_t)CT) ? n - base : (uint32_t)CT;
         const int64_t i_lo = (int64_t)n - 1 - base - (CT - 1);        // position of the tile's LAST slot (negative in the last tile: no such slot)
         __syncthreads();                                                // lut; the previous tile's ko has been read
+        if (D0) {                                                       // fixed-width keys carry no depth: tag 0 in every slot (the radix sort's first pass reads the bytes)
+            if (cnt == (uint32_t)CT) reinterpret_cast<uint4 *>(D0 + base)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+            else for (uint32_t x = threadIdx.x; x < cnt; x += TB) D0[base + x] = 0;
+        }
         for (int q = threadIdx.x; q < CT + PK_HALO; q += TB) {
             const int64_t p = i_lo - 16 + q;
             const bool in = p >= 0 && p < (int64_t)n;
@@ -2669,7 +2673,6 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         if (o1) JPK_LAUNCH(ctx, PROF_SCAN, 0, k_ctx_plan, dim3(o2 ? 256 + JPK_O2_CLASSES : 256), dim3(256), b.state, b.ctab);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_key_final, dim3(1), dim3(256), b.state, o1 ? b.ctab : (uint32_t *)nullptr, o2 ? b.ctxmap : (uint16_t *)nullptr,
                    var_tag_shift(n), order);
-        JPK_HIP(hipMemsetAsync(b.D0, 0, n, st));           // (a plan that falls back to the fixed code leaves no depths: tag 0 everywhere)
     }
     // (with the variable-length codes in play this kernel usually finds vmode set and leaves at once -- but every workgroup of a full grid
     // first has to get its 44 KB of LDS on a CU that the other blocks in flight are using: 1.2 ms of the block's stream in the timed loop.
