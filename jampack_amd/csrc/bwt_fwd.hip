@@ -2726,8 +2726,9 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     // the previous round's counts first -- a few microseconds while other blocks keep the GPU busy -- and then enqueues exactly what is
     // needed: nothing when no suffix is unresolved (round 4: the trailing empty round is gone), no large-group passes (23 launches) once
     // a round has had no group above 1024 (groups only split: the count of their members never grows).
-    uint32_t *h_m = ctx->h_mail + 16;              // pinned: h_m[4 * (r & 1) ..] receives {m[0], m[1], npieces, lc} as round r leaves them
-    JPK_HIP(hipMemcpyAsync(&h_m[0], &b.state->m[0], 16, hipMemcpyDeviceToHost, st));
+    uint32_t *h_m = ctx->h_mail + 16;              // pinned: h_m[8 * (r & 1) ..] receives {m[0], m[1], npieces, lc, nrun} as round r leaves them
+    static_assert(offsetof(SaState, nrun) == 16, "the rounds' copy takes m[2], npieces, lc, nrun in one piece");
+    JPK_HIP(hipMemcpyAsync(&h_m[0], &b.state->m[0], 20, hipMemcpyDeviceToHost, st));
     JPK_HIP(hipEventRecord(ctx->ev_sa[0], st));
     uint32_t bound = n;                            // upper bound of the active count of the round being enqueued
     bool large_possible = true;                    // a group above 1024 members may still exist
@@ -2738,19 +2739,26 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     int gd = 0;                                    // variable-length keys: GD[gd] holds the groups' depths, the next doubling round writes GD[gd ^ 1]
     int last_pair = -8;
     bool prev_pair = false;
+    bool lg_heavy = false;
+    // JPK_SA_WAIT_ROUND: the first round that is enqueued on exact counts (default 1 since the context codes: round 1 of text starts with
+    // 27 M of 67 M suffixes, round 2 with 49 K -- 48 windows, no large group; enqueued blind they were 65 K / 26 K workgroups per kernel and, in
+    // round 2, 23 launches for nothing.  The wait is a few microseconds in front of a round; 3 = round 4's rule)
+    static const int wait_round = [] { const char *e = getenv("JPK_SA_WAIT_ROUND"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
     uint32_t m_prev = n;                           // the list the previous round started with
     uint64_t pair_mask = 0;
     for (int round = 1;; round++) {
         const int par = round & 1;
         bool pair = false;
-        if (round >= 3) {
+        if (round >= wait_round) {
             JPK_HIP(hipEventSynchronize(ctx->ev_sa[par ^ 1]));
-            const uint32_t m_now = h_m[4 * (par ^ 1) + par];        // round r-1 wrote m[(r-1 & 1) ^ 1] = m[par]
+            const uint32_t m_now = h_m[8 * (par ^ 1) + par];        // round r-1 wrote m[(r-1 & 1) ^ 1] = m[par]
             if (m_now == 0) break;                                    // nothing left: no empty round
             bound = m_now;
-            if (!prev_pair && h_m[4 * (par ^ 1) + 3] == 0) large_possible = false; // lc of round r-1 (a pair round does not count large groups)
+            if (round >= 2 && !prev_pair && h_m[8 * (par ^ 1) + 3] == 0) large_possible = false; // lc of round r-1 (a pair round does not count large groups)
+            // many members of large groups ahead (round 1: run members, which round 0 counts; later: what the round before had): the full grid
+            lg_heavy = round == 1 ? h_m[8 * (par ^ 1) + 4] > n / 64u : h_m[8 * (par ^ 1) + 3] > (1u << 22);
             ctx->stats.sa_rounds = round + 1;
-            pair = pair_rule_shift() >= 0 && round - last_pair >= pair_rule_gap() && m_now >= pair_rule_min() && m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift()) &&
+            pair = round >= 3 && pair_rule_shift() >= 0 && round - last_pair >= pair_rule_gap() && m_now >= pair_rule_min() && m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift()) &&
                    (uint64_t)m_now * 100u >= (uint64_t)m_prev * pair_rule_ratio();
             m_prev = m_now;
         }
@@ -2758,7 +2766,12 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         const unsigned g_seg = cap_grid(bound, SEG_TILE, CAP_SEG);
         const unsigned g_cmp = cap_grid(bound, CT, CAP);
         const size_t pc_bound = 2 * ((size_t)bound / SEG_TILE + 1);
-        const unsigned g_pc = cap_grid(pc_bound, 1, CAP);
+        // (the large-group kernels walk the pieces with a grid stride.  The bound is two pieces per window of the list -- 131 K workgroups
+        // in round 1, of which text uses a few hundred: 21 us per launch to start and retire the rest, 0.3 ms per block.  The grid is capped
+        // at JPK_LG_GRID (default 8192; 0 = the bound) unless the block is known to be mostly large groups -- runs, all-zero: there a
+        // workgroup per piece is worth 4-7 %)
+        static const unsigned lg_cap = [] { const char *e = getenv("JPK_LG_GRID"); const long v = e ? atol(e) : 8192; return (unsigned)(v <= 0 ? CAP : v); }();
+        const unsigned g_pc = cap_grid(pc_bound, 1, lg_heavy ? CAP : lg_cap);
         const unsigned g_tab = cap_grid(pc_bound << lg_db, SC_TILE, CAP);
         prev_pair = pair;
         if (pair) {
@@ -2821,12 +2834,12 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_cmp_scan, dim3(1), dim3(WG1), b.tA, b.state, par, round);
         JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_cmp_scatter, dim3(g_cmp), dim3(TB), b.b_sa, b.b_grp, b.b_prev, b.state, par, b.tA, b.a_sa, b.a_grp, b.a_prev);
         JPK_HIP(hipGetLastError());
-        JPK_HIP(hipMemcpyAsync(&h_m[4 * par], &b.state->m[0], 16, hipMemcpyDeviceToHost, st));
+        JPK_HIP(hipMemcpyAsync(&h_m[8 * par], &b.state->m[0], 20, hipMemcpyDeviceToHost, st));
         JPK_HIP(hipEventRecord(ctx->ev_sa[par], st));
-        if (round < 3) {
+        if (round < wait_round) {
             // what the PREVIOUS round (or round 0) left behind: known without draining the queue
             JPK_HIP(hipEventSynchronize(ctx->ev_sa[par ^ 1]));
-            const uint32_t m_start = h_m[4 * (par ^ 1) + par];      // = the active count this round started with (round r-1 wrote m[par])
+            const uint32_t m_start = h_m[8 * (par ^ 1) + par];      // = the active count this round started with (round r-1 wrote m[par])
             if (m_start == 0) break;                // this round was empty: done
             ctx->stats.sa_rounds = round + 1;
             bound = m_start;
