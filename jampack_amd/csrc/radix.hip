@@ -481,7 +481,10 @@ int jpk_radix_sort_slot_keys(jpk_ctx *ctx, uint32_t n32, uint64_t *keysA, uint32
         uint32_t *H = statusB + table, *gdig = H + OS_PASSES * 256, *tickets = gdig + OS_PASSES * 256;
         JPK_HIP(hipMemsetAsync(statusA, 0, table * 4, ctx->stream));
         JPK_HIP(hipMemsetAsync(statusB, 0, (table + OS_PASSES * 256 + OS_PASSES * 256 + 64) * 4, ctx->stream));
-        JPK_LAUNCH(ctx, PROF_RS_HIST, n, k_os_digits, dim3(ntiles < 2048 ? (ntiles ? ntiles : 1) : 2048), dim3(RS_THREADS), keysA, n32, H, npass);
+        {   // (every workgroup ends with up to 8 x 256 atomics on the same counters: against LDS atomics per key -- JPK_DIGITS_GRID, default 2048: 256 / 512 / 768 / 2048 / 4096 / 8192 / 16384 workgroups take 519 / 299 / 227 / 167 / 174 / 206 / 336 us)
+            static const uint32_t dg = [] { const char *e = getenv("JPK_DIGITS_GRID"); const long v = e ? atol(e) : 2048; return (uint32_t)(v < 1 ? 1 : v); }();
+            JPK_LAUNCH(ctx, PROF_RS_HIST, n, k_os_digits, dim3(ntiles < dg ? (ntiles ? ntiles : 1) : dg), dim3(RS_THREADS), keysA, n32, H, npass);
+        }
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_os_prefix, dim3(1), dim3(256), H, gdig, npass);
         for (int p = 0; p < npass; p++) {
             const int shift = p < 7 ? 8 * (p + 1) : 0;
