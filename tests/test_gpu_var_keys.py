@@ -221,9 +221,12 @@ print("CMP_OK" if ok else "CMP_BAD")
 """
 
 
-@pytest.mark.parametrize("env", [{"JPK_VARKEYS": "0"}, {"JPK_KEY_BITS": "8"}, {"JPK_ONESWEEP": "0"}, {"JPK_KEY_ORDER": "0"}, {"JPK_KEY_ORDER": "1"}])
+@pytest.mark.parametrize("env", [{"JPK_VARKEYS": "0"}, {"JPK_KEY_BITS": "8"}, {"JPK_ONESWEEP": "0"}, {"JPK_KEY_ORDER": "0"}, {"JPK_KEY_ORDER": "1"},
+                                 {"JPK_R0_LOOKBACK": "0"}, {"JPK_SA_WAIT_ROUND": "3", "JPK_LG_GRID": "0"}, {"JPK_SA_WAIT_ROUND": "2", "JPK_LG_GRID": "64"}])
 def test_fixed_width_forms_remain_working_comparators(env):
     """JPK_VARKEYS=0: the alphabet-packed fixed-width keys of round 4; JPK_KEY_BITS=8: plain bytes; JPK_ONESWEEP=0: the two-pass radix
-    (which has no room for the depth tag: fixed-width keys); JPK_KEY_ORDER=0 / 1: nothing above the order-0 / order-1 variable-length code"""
+    (which has no room for the depth tag: fixed-width keys); JPK_KEY_ORDER=0 / 1: nothing above the order-0 / order-1 variable-length code; JPK_R0_LOOKBACK=0: round 0's bookkeeping in two passes
+    (k_r0_count + k_r0_scan); JPK_SA_WAIT_ROUND / JPK_LG_GRID: round 4's round control (rounds 1 and 2 enqueued blind, grids on the bound), and a
+    tiny large-group grid (every workgroup walks many pieces)"""
     r = subprocess.run([sys.executable, "-c", _CHILD % {"root": ROOT}], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert "CMP_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
