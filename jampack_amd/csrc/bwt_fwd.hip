@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256) void k_pair_counts(const uint8_t *__restrict__
 // 1024, 64 counts per thread in registers).  ctxmap[c2 << 8 | c1] = the row that codes a symbol behind the bytes c2 c1: 256 + the pair's
 // rank among the chosen ones, or c1 -- the order-1 row -- for every other pair.
 constexpr uint32_t JPK_O2_CLASSES = 1024;
+static_assert(JPK_O2_CLASSES <= 1024 && 256 + JPK_O2_CLASSES <= 65535, "k_triple_counts keeps 64 rows of counters per group of sixteen; ctxmap holds rows in 16 bits");
 __global__ __launch_bounds__(1024) void k_ctx_select(const uint32_t *__restrict__ ctab, uint16_t *__restrict__ ctxmap, SaState *__restrict__ st)
 {
     __shared__ uint32_t sm[1024 / 64 + 1];
