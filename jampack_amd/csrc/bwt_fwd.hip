@@ -2626,6 +2626,15 @@ int pair_rule_shift()
     static const int v = [] { const char *e = getenv("JPK_PAIR_SHIFT"); const int x = e ? atoi(e) : 6; return x > 31 ? 31 : x; }();
     return v;
 }
+// JPK_PAIR_FROM: the first round that may be a pair round (default 3; 2 is possible since every round is enqueued on exact counts, and
+// measured worse: a 4 KiB period 17.2 -> 13.5 ms, but the silesia-like block 11.9 -> 16.6, long runs 18.9 -> 40.5 ms -- after one doubling
+// round the groups of a repeat still mix everything that shares 30 symbols, and the rule's passes over the text are not free.  Round 1
+// has to be a doubling round in any case: it is the one that spreads the run members)
+int pair_rule_from()
+{
+    static const int v = [] { const char *e = getenv("JPK_PAIR_FROM"); const int x = e ? atoi(e) : 3; return x < 2 ? 2 : x; }();
+    return v;
+}
 // JPK_PAIR_MIN: ... and at least this many (default 4096; the tests lower it so that tiny inputs take the path);
 // JPK_PAIR_GAP: rounds from one pair round to the next (default 3 = two doubling rounds in between, at least 2)
 uint32_t pair_rule_min()
@@ -2782,7 +2791,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             // many members of large groups ahead (round 1: run members, which round 0 counts; later: what the round before had): the full grid
             lg_heavy = round == 1 ? h_m[8 * (par ^ 1) + 4] > n / 64u : h_m[8 * (par ^ 1) + 3] > (1u << 22);
             ctx->stats.sa_rounds = round + 1;
-            pair = round >= 3 && pair_rule_shift() >= 0 && round - last_pair >= pair_rule_gap() && m_now >= pair_rule_min() && m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift()) &&
+            pair = round >= pair_rule_from() && pair_rule_shift() >= 0 && round - last_pair >= pair_rule_gap() && m_now >= pair_rule_min() && m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift()) &&
                    (uint64_t)m_now * 100u >= (uint64_t)m_prev * pair_rule_ratio();
             m_prev = m_now;
         }
