@@ -2635,6 +2635,12 @@ int pair_rule_from()
     static const int v = [] { const char *e = getenv("JPK_PAIR_FROM"); const int x = e ? atoi(e) : 3; return x < 2 ? 2 : x; }();
     return v;
 }
+// JPK_PAIR_EARLY=0: no pair round at round 2 for lists that round 1 left as they were (comparator)
+bool pair_rule_early()
+{
+    static const bool v = [] { const char *e = getenv("JPK_PAIR_EARLY"); return e ? atoi(e) != 0 : true; }();
+    return v;
+}
 // JPK_PAIR_MIN: ... and at least this many (default 4096; the tests lower it so that tiny inputs take the path);
 // JPK_PAIR_GAP: rounds from one pair round to the next (default 3 = two doubling rounds in between, at least 2)
 uint32_t pair_rule_min()
@@ -2772,7 +2778,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     int gd = 0;                                    // variable-length keys: GD[gd] holds the groups' depths, the next doubling round writes GD[gd ^ 1]
     int last_pair = -8;
     bool prev_pair = false;
-    bool lg_heavy = false;
+    bool lg_heavy = false, runs_heavy = false;
     // JPK_SA_WAIT_ROUND: the first round that is enqueued on exact counts (default 1 since the context codes: round 1 of text starts with
     // 27 M of 67 M suffixes, round 2 with 49 K -- 48 windows, no large group; enqueued blind they were 65 K / 26 K workgroups per kernel and, in
     // round 2, 23 launches for nothing.  The wait is a few microseconds in front of a round; 3 = round 4's rule)
@@ -2790,9 +2796,15 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             if (round >= 2 && !prev_pair && h_m[8 * (par ^ 1) + 3] == 0) large_possible = false; // lc of round r-1 (a pair round does not count large groups)
             // many members of large groups ahead (round 1: run members, which round 0 counts; later: what the round before had): the full grid
             lg_heavy = round == 1 ? h_m[8 * (par ^ 1) + 4] > n / 64u : h_m[8 * (par ^ 1) + 3] > (1u << 22);
+            if (round == 1) runs_heavy = lg_heavy;
             ctx->stats.sa_rounds = round + 1;
             pair = round >= pair_rule_from() && pair_rule_shift() >= 0 && round - last_pair >= pair_rule_gap() && m_now >= pair_rule_min() && m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift()) &&
                    (uint64_t)m_now * 100u >= (uint64_t)m_prev * pair_rule_ratio();
+            // ... and round 2 already when round 1 resolved next to nothing (99 % of its list is still there: periodic data, a block
+            // that holds everything twice -- doubling is futile) unless the block is mostly runs, whose groups the run rule is splitting
+            if (!pair && round == 2 && wait_round <= 1 && pair_rule_early() && pair_rule_shift() >= 0 && !runs_heavy && m_now >= pair_rule_min() &&
+                m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift()) && (uint64_t)m_now * 100u >= (uint64_t)m_prev * 99u)
+                pair = true;
             m_prev = m_now;
         }
         const unsigned g_win = cap_grid(bound, SEG_TILE, CAP);
