@@ -64,9 +64,9 @@ ALG_BYTES_PER_UNIT = {
     "k_rle_*": (2, "block byte", "hbm"),
     "k_cls_*/k_quasi_build": (9, "RLE0 symbol", "hbm"),
     "k_adaptive": (22, "RLE0 symbol", "issue"),
-    "k_pairs": (46, "RLE0 symbol", "hbm"),
-    "k_rans_lanes": (20, "rANS pair", "issue"),
-    "k_emit_*/k_put_*": (13, "rANS pair", "hbm"),
+    "k_pairs": (42, "RLE0 symbol", "hbm"),                 # round 6: no frequency sidecar (2 x 2 B per symbol less)
+    "k_rans_lanes": (18.25, "rANS pair", "issue"),         # 16-byte record read; the state's low half (2 B) + 1/16 emit-mask word written (4 B of state before)
+    "k_emit_*/k_put_*": (3, "rANS pair", "hbm"),           # masks 2 x 0.25 B + low halves 2 B + ~0.2 B of payload (12 B of states and frequencies read before)
 }
 # algorithmic bytes per block byte of the four stages (c = compressed size / block size)
 STAGE_ALG = {"forward_bwt": lambda c: 10.0, "ans_encode": lambda c: 4.0 + c, "ans_decode": lambda c: 4.0 + c, "inverse_bwt": lambda c: 12.0}
@@ -530,6 +530,38 @@ def decompress_leg(jam, torch, dev, local_rank, blocks, d_in, d_cmp, sizes, nctx
     return out, bool(ok)
 
 
+def blocks_decompress_call(jam, torch, dev, d_block, d_cmp0, clen: int):
+    """the decode rate a BATCH caller gets -- 64 and 128 copies of the workload's first block through ONE
+    jpk_dev_blocks_decompress call each (one pass over the chunks of all blocks, the inverse BWTs on three lanes behind it), every output
+    compared with the block.  The symmetric extra of `blocks_compress_call`."""
+    n = int(d_block.numel())
+    out = {"block_bytes": n, "how": "N copies of the workload's first block through one jpk_dev_blocks_decompress call (C ABI); the better of two calls"}
+    ctx = jam.Context(0, None)
+    try:
+        for N in (64, 128):
+            try:
+                outs = [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(N)]
+                encs = [d_cmp0 for _ in range(N)]
+                best = None
+                for _rep in range(3):                  # (the first call sizes the arena and the lanes)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    ln, st = ctx.blocks_decompress(encs, [clen] * N, outs, [n] * N)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                    if _rep:
+                        best = dt if best is None else min(best, dt)
+                same = st == [0] * N and all(x == n for x in ln) and all(bool(torch.equal(o, d_block)) for o in outs)
+                out[str(N)] = {"value": round(N * n / 1e6 / best, 1), "unit": "MB/s", "ms_per_call": round(best * 1e3, 2), "same_bytes": bool(same)}
+                del outs
+                torch.cuda.empty_cache()
+            except Exception as ex:       # noqa: BLE001
+                out[str(N)] = {"error": repr(ex)}
+    finally:
+        ctx.close()
+    return out
+
+
 def child_extras(args):
     """`per_block_size` and `host_buffers` in a process of their own.  HIP deals streams onto the hardware queues round robin as they
     are created and never rebalances: after the timed loop, the decompress legs and the batch calls of this bench (~60 streams created
@@ -558,6 +590,11 @@ def child_extras(args):
         c0.close()
         out["decompress"], out["decompress_ok"] = decompress_leg(jam, torch, dev, 0, blocks, d_in, d_cmp, sizes, max(1, args.contexts), 10)
         out["decompress"]["process"] = "fresh child process of bench.py"
+        try:
+            out["blocks_decompress_call"] = blocks_decompress_call(jam, torch, dev, d_in[0], d_cmp[0], sizes[0])
+            out["blocks_decompress_call"]["process"] = "fresh child process of bench.py"
+        except Exception as ex:       # noqa: BLE001
+            out["blocks_decompress_call"] = {"error": repr(ex)}
         del d_in, d_cmp
         torch.cuda.empty_cache()
         jam.shutdown()
@@ -865,6 +902,24 @@ def main():
         rows = prof_rows([c_.profile_table() for c_ in ctxs])
         for c_ in ctxs:
             c_.profile_enable(0)
+        # the chain against the yardstick of what bounds it: a chain is ONE wave on a serial recurrence -- its HBM
+        # fraction says nothing; what it can reach is the issue rate of a lone wave.  Cycles per step of the slowest chunk of each context's
+        # last block in the loop (s_memtime stamps inside k_rans_lanes, jpk_stats.enc_chain_*), against the step's dependent path: 11 of
+        # its 12 vector instructions wait for the one before them, a lone wave issues a dependent instruction every 5.2 cycles
+        # (tools/issuetest.hip, profiles/r05_issuetest.txt), + 1/16 of the ~25 instructions between two batches of sixteen steps.
+        cps = []
+        for c_ in ctxs:
+            st_ = c_.stats()
+            if st_.enc_chain_steps > 0 and st_.enc_chain_cycles > 0:
+                cps.append(st_.enc_chain_cycles / st_.enc_chain_steps)
+        floor_cps = 11 * 5.2
+        issue = None
+        if cps:
+            mean_cps = sum(cps) / len(cps)
+            issue = {"cycles_per_step": round(mean_cps, 1), "lone_wave_floor_cycles_per_step": round(floor_cps, 1), "frac": round(floor_cps / mean_cps, 3),
+                     "dependent_instructions_per_step": 11, "lone_wave_cycles_per_dependent_instruction": 5.2,
+                     "note": "issue-rate fraction of the chain in the timed loop: floor / measured cycles per step (1.0 = a lone wave's issue limit; below: the "
+                             "chain shares its SIMD with the other blocks' kernels)"}
         ctx.profile_enable(2)
         for i, b in enumerate(blocks):
             ctx.block_compress(d_in[i], len(b), d_out[i], caps[i])
@@ -878,7 +933,8 @@ def main():
             d0 = next((r for r in rows if r["kernel"] == "k_rans_lanes"), rows[0])
             traffic, pmc_file = pmc_traffic(d0["kernel"], 4, d0["launches"])
             extra_["roofline"] = {"bound": "hbm" if d0["limited_by"].startswith("hbm") else d0["limited_by"], "achieved": d0["achieved"], "peak": 8000.0, "unit": "GB/s",
-                                 "frac": d0["frac"], "traffic": traffic,
+                                 "frac": d0["frac"], "traffic": traffic, "traffic_source": f"committed profile profiles/{pmc_file} (rocprofv3 --pmc passes of this command; not measured in this run)" if pmc_file else None,
+                                 "issue": issue,
                                  "kernel": d0["kernel"], "limited_by": d0["limited_by"], "avg_launch_us": d0["avg_launch_us"], "launches": d0["launches"],
                                  "alg_bytes_per_launch": round(d0["alg_bytes_per_unit"] * d0["units"] / d0["launches"]),
                                  "largest_total_time_class": rows[0]["kernel"],
@@ -894,6 +950,7 @@ def main():
                 wt, wf = pmc_traffic(wide["kernel"], 4, wide["launches"])
                 extra_["roofline_wide"] = {"kernel": wide["kernel"], "bound": "hbm" if wide["limited_by"].startswith("hbm") else wide["limited_by"],
                                           "achieved": wide["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": wide["frac"], "traffic": wt,
+                                          "traffic_source": f"committed profile profiles/{wf} (not measured in this run)" if wf else None,
                                           "avg_launch_us": wide["avg_launch_us"], "launches": wide["launches"],
                                           "alg_bytes_per_launch": round(wide["alg_bytes_per_unit"] * wide["units"] / wide["launches"]),
                                           "note": "the radix scatter class (fixed key): the widest machine-filling class, same 4 passes of the timed loop, same accounting"}
@@ -1055,7 +1112,7 @@ def main():
         torch.cuda.empty_cache()
         if not args.no_block_sizes and not args.limit_bytes:
             if ce is not None:                   # (the fresh child process has measured them: see child_extras())
-                extra.update({k: v for k, v in ce.items() if k in ("per_block_size", "host_buffers")})
+                extra.update({k: v for k, v in ce.items() if k in ("per_block_size", "host_buffers", "blocks_decompress_call")})
             else:
                 try:
                     extra["per_block_size"] = per_block_size(jam, corpus, torch, dev, local_rank, nctx)

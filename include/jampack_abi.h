@@ -268,11 +268,18 @@ JPK_API int jpk_debug_enc_groups(int device, int32_t nch);
  * BlockSize or what jpk_ans_decoded_size reports minus the trailer); the gather moves raw_len[b] bytes per block.
  * The gather is one ncclSend / ncclRecv pair of exactly the block's bytes per block of a non-root device, grouped, over a
  * single-process RCCL communicator (ncclCommInitAll) that the library loads at first use and keeps until jpk_shutdown; the root's
- * own blocks are device-to-device copies (JPK_MULTI_FORCE_RCCL=1: through RCCL as well).  status[b] (nullable) receives every
- * block's status; a block that was never reached (its device failed early) reports an error, never JPK_OK.
- * ONE CALL AT A TIME: the communicators and the slabs are the process's; concurrent callers (and jpk_shutdown) queue on one mutex.
- * The caller's current HIP device is restored on return.
- * jpk_debug_multi_plan: the ownership rule alone, for `ndev_visible` devices (no device call). */
+ * own blocks are device-to-device copies (JPK_MULTI_FORCE_RCCL=1: through RCCL as well).  Compress: a device's inputs travel on a
+ * stream of their own, block by block, while the blocks before them are being compressed (jampack.cpp:205-224 overlaps its reads the
+ * same way).
+ * STATUS AND RESULTS: status[b] (nullable) receives every block's own status; a block that was never reached (its device failed
+ * early) reports an error, never JPK_OK.  Every block whose status is JPK_OK IS GATHERED, also when other blocks failed (a corrupt
+ * frame among healthy ones): its bytes are at [out_off[b], out_off[b + 1]), a failed block's range is empty, and the call returns the
+ * first failed block's status.  When the gather itself cannot run (JPK_E_CAPACITY: d_out too small for the blocks that are done;
+ * RCCL missing) nothing is in d_out, EVERY status is an error and every range is empty.
+ * ONE CALL AT A TIME PER DEVICE: a call holds the mutexes of the devices of its mask; calls on disjoint device sets run side by side,
+ * calls that share a device (and jpk_shutdown) queue.  The caller's current HIP device is restored on return.
+ * jpk_debug_multi_plan: the ownership rule alone, for `ndev_visible` devices (no device call).  jpk_debug_multi_lock_probe: takes the
+ * device mutexes of `device_mask` for hold_ms milliseconds (no device call; returns the number of mutexes). */
 JPK_API int jpk_blocks_compress_multi(uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, uint8_t *d_out, int64_t out_cap,
                                       int64_t *out_off, int32_t *status);
 JPK_API int jpk_blocks_compress_multi_ex(uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, uint8_t *d_out, int64_t out_cap,
@@ -280,6 +287,7 @@ JPK_API int jpk_blocks_compress_multi_ex(uint64_t device_mask, int32_t nblocks, 
 JPK_API int jpk_blocks_decompress_multi(uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, const int32_t *raw_len, uint8_t *d_out,
                                         int64_t out_cap, int64_t *out_off, int32_t *status);
 JPK_API int jpk_debug_multi_plan(uint64_t device_mask, int32_t ndev_visible, int32_t nblocks, int32_t *owner);
+JPK_API int jpk_debug_multi_lock_probe(uint64_t device_mask, int32_t hold_ms);
 /* host-logic probe: the work list jpk_dev_blocks_compress forms for these block lengths (groups of small blocks, large blocks alone):
  * task t covers blocks [first[t], first[t] + count[t]); returns the number of tasks.  No device call. */
 JPK_API int jpk_debug_group_plan(int32_t nblocks, const int32_t *in_len, int32_t *first, int32_t *count);

@@ -416,10 +416,11 @@ def multi_plan(device_mask: int, ndev_visible: int, nblocks: int):
     return g, list(own)[:nblocks]
 
 
-def blocks_compress_multi(blocks, d_out, out_cap: int, device_mask: int = 0, in_flight: int = 0):
+def blocks_compress_multi(blocks, d_out, out_cap: int, device_mask: int = 0, in_flight: int = 0, check: bool = True):
     """jpk_blocks_compress_multi(_ex): host blocks -> compressed blocks gathered in block order into `d_out` (a device buffer on the first
     device of the mask; anything with data_ptr() or an int address), `in_flight` blocks in flight per device (0: the library's default).
-    Returns (offsets [nblocks + 1], status [nblocks])."""
+    Returns (offsets [nblocks + 1], status [nblocks]); check=False: no exception for a failed block, returns (offsets, status, rc) --
+    the blocks whose status is 0 are in d_out whatever happened to the others."""
     arrs = [_np_u8(b) for b in blocks]
     n = len(arrs)
     P, I = C.c_void_p * max(n, 1), C.c_int32 * max(n, 1)
@@ -427,13 +428,17 @@ def blocks_compress_multi(blocks, d_out, out_cap: int, device_mask: int = 0, in_
     lens = I(*[len(a) for a in arrs])
     off = (C.c_int64 * (n + 1))()
     st = I()
-    _chk(lib().jpk_blocks_compress_multi_ex(device_mask, n, ins, lens, _dptr(d_out), out_cap, off, st, in_flight), "jpk_blocks_compress_multi")
+    rc = lib().jpk_blocks_compress_multi_ex(device_mask, n, ins, lens, _dptr(d_out), out_cap, off, st, in_flight)
+    if not check:
+        return list(off), list(st)[:n], int(rc)
+    _chk(rc, "jpk_blocks_compress_multi")
     return list(off), list(st)[:n]
 
 
-def blocks_decompress_multi(comp_blocks, raw_lens, d_out, out_cap: int, device_mask: int = 0):
+def blocks_decompress_multi(comp_blocks, raw_lens, d_out, out_cap: int, device_mask: int = 0, check: bool = True):
     """jpk_blocks_decompress_multi: host compressed blocks (+ the decompressed size of each) -> the blocks' bytes gathered in block order
-    into `d_out` on the first device of the mask.  Returns (offsets [nblocks + 1], status [nblocks])."""
+    into `d_out` on the first device of the mask.  Returns (offsets [nblocks + 1], status [nblocks]); check=False: (offsets, status, rc),
+    no exception -- the blocks whose status is 0 are in d_out whatever happened to the others."""
     arrs = [_np_u8(b) for b in comp_blocks]
     n = len(arrs)
     P, I = C.c_void_p * max(n, 1), C.c_int32 * max(n, 1)
@@ -442,5 +447,8 @@ def blocks_decompress_multi(comp_blocks, raw_lens, d_out, out_cap: int, device_m
     raw = I(*[int(x) for x in raw_lens])
     off = (C.c_int64 * (n + 1))()
     st = I()
-    _chk(lib().jpk_blocks_decompress_multi(device_mask, n, ins, lens, raw, _dptr(d_out), out_cap, off, st), "jpk_blocks_decompress_multi")
+    rc = lib().jpk_blocks_decompress_multi(device_mask, n, ins, lens, raw, _dptr(d_out), out_cap, off, st)
+    if not check:
+        return list(off), list(st)[:n], int(rc)
+    _chk(rc, "jpk_blocks_decompress_multi")
     return list(off), list(st)[:n]

@@ -4,6 +4,8 @@
 #include <chrono>
 #include <atomic>
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -982,8 +984,41 @@ int group_compress(jpk_ctx *c, int nb, const uint8_t *const *d_in, const int32_t
 }
 }  // namespace
 
+namespace {
+// "block k's input has arrived on the device": set by the copier thread of the multi-device entry (multi_run), waited for -- on the host,
+// task by task -- by the workers below, so that block k + 1 is still on its way in while block k is being compressed
+struct BlocksReady {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> ok;
+    bool failed = false;
+    explicit BlocksReady(size_t n) : ok(n, 0) {}
+    void set(size_t k) { { std::lock_guard<std::mutex> g(mu); ok[k] = 1; } cv.notify_all(); }
+    void fail() { { std::lock_guard<std::mutex> g(mu); failed = true; } cv.notify_all(); }
+    bool wait(int first, int count)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] {
+            if (failed) return true;
+            for (int k = first; k < first + count; k++) if (!ok[(size_t)k]) return false;
+            return true;
+        });
+        return !failed;
+    }
+};
+int blocks_compress_body(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out,
+                         const int32_t *out_cap, int32_t *out_len, int32_t *status, int32_t in_flight, BlocksReady *ready);
+}  // namespace
+
 extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out,
                                        const int32_t *out_cap, int32_t *out_len, int32_t *status, int32_t in_flight)
+{
+    return blocks_compress_body(ctx, nblocks, d_in, in_len, d_out, out_cap, out_len, status, in_flight, nullptr);
+}
+
+namespace {
+int blocks_compress_body(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_in, const int32_t *in_len, uint8_t *const *d_out,
+                         const int32_t *out_cap, int32_t *out_len, int32_t *status, int32_t in_flight, BlocksReady *ready)
 {
     JPK_ENTER(ctx);
     if (nblocks < 0 || (nblocks > 0 && (!d_in || !in_len || !d_out || !out_cap || !out_len))) return JPK_E_ARG;
@@ -1028,6 +1063,10 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
             const int k = next.fetch_add(1, std::memory_order_relaxed);
             if (k >= ntasks) return;
             const int b = tasks[(size_t)k].first, nb = tasks[(size_t)k].count;
+            if (ready && !ready->wait(b, nb)) {                 // the copy of an input failed: the blocks nobody has taken yet say so
+                for (int j = b; j < b + nb; j++) { out_len[j] = 0; stp[j] = JPK_E_DEVICE; }
+                continue;
+            }
             if (nb == 1) {
                 out_len[b] = 0;
                 stp[b] = jpk_dev_block_compress(c, d_in[b], in_len[b], d_out[b], out_cap[b], &out_len[b]);
@@ -1058,6 +1097,7 @@ extern "C" int jpk_dev_blocks_compress(jpk_ctx *ctx, int32_t nblocks, const uint
         for (int b = 0; b < nblocks; b++) if (stp[b] != JPK_OK) return stp[b];
     return JPK_OK;
 }
+}  // namespace
 
 extern "C" int jpk_debug_group_fail_next(int n)
 {
@@ -1120,7 +1160,7 @@ Rccl &rccl()
 }
 // one communicator set per device list, kept until jpk_shutdown
 struct MultiComm { std::vector<int> devices; std::vector<jpk_nccl_comm_t> comms; };
-std::vector<MultiComm> &multi_comms() { static std::vector<MultiComm> v; return v; }
+std::deque<MultiComm> &multi_comms() { static std::deque<MultiComm> v; return v; }      // (a deque: a call holds a pointer into it while another call, on other devices, adds a set)
 std::mutex &multi_mu() { static std::mutex m; return m; }
 
 // devices of the mask that exist among `ndev` visible devices, ascending (mask 0 = all)
@@ -1144,13 +1184,24 @@ extern "C" int jpk_debug_multi_plan(uint64_t device_mask, int32_t ndev_visible, 
     return (int)dv.size();
 }
 
-// Shared body of the two multi-device entries.  ONE call at a time per process: RCCL communicators are not safe for concurrent use
-// from several threads, the per-device slabs below are shared, and jpk_shutdown must not destroy either under a running call -- the
-// whole call (and jpk_shutdown) holds multi_call_mu(); concurrent callers queue.
+// Shared body of the two multi-device entries.  One call at a time PER DEVICE: a call holds the mutexes of the devices of its mask
+// (taken in ascending order) from its first device call to its last, so two calls on disjoint device sets -- two files on two halves
+// of a node -- run side by side, and calls that share a device queue (round 5: one process-wide mutex).  What the locks protect: the
+// per-device slabs and copy streams below, and the RCCL communicators, which are cached per device LIST and are not safe for
+// concurrent use -- two calls with the same list share all its devices and therefore exclude each other.  jpk_shutdown takes every
+// device's mutex before it destroys slabs and communicators.
 namespace {
-std::mutex &multi_call_mu() { static std::mutex m; return m; }
-// per device: one input slab and one output slab, kept between calls (grown when a larger call arrives), freed by jpk_shutdown
-struct MultiSlab { uint8_t *in = nullptr, *out = nullptr; size_t in_cap = 0, out_cap = 0; };
+std::mutex *multi_dev_mu() { static std::mutex m[64]; return m; }
+struct MultiLocks {                                          // the devices of a call, ascending; released in reverse
+    std::vector<int> held;
+    explicit MultiLocks(const std::vector<int> &devs) { for (int d : devs) if (d >= 0 && d < 64) { multi_dev_mu()[d].lock(); held.push_back(d); } }
+    ~MultiLocks() { for (size_t k = held.size(); k-- > 0;) multi_dev_mu()[held[k]].unlock(); }
+    MultiLocks(const MultiLocks &) = delete;
+    MultiLocks &operator=(const MultiLocks &) = delete;
+};
+// per device: one input slab and one output slab, kept between calls (grown when a larger call arrives), and the stream the inputs
+// travel on while the context's stream computes; freed by jpk_shutdown / jpk_release_idle
+struct MultiSlab { uint8_t *in = nullptr, *out = nullptr; size_t in_cap = 0, out_cap = 0; hipStream_t copy = nullptr; };
 MultiSlab *multi_slabs() { static MultiSlab v[64]; return v; }
 int slab_ensure(uint8_t **p, size_t *cap, size_t bytes)
 {
@@ -1161,17 +1212,17 @@ int slab_ensure(uint8_t **p, size_t *cap, size_t bytes)
     *cap = want;
     return JPK_OK;
 }
-void multi_slabs_free()
+// (the caller holds device d's mutex and restores the current device)
+void multi_slab_free(int d)
 {
-    int cur = 0;
-    const bool have = hipGetDevice(&cur) == hipSuccess;
-    for (int d = 0; d < 64; d++) {
-        MultiSlab &m = multi_slabs()[d];
-        if (!m.in && !m.out) continue;
-        if (hipSetDevice(d) == hipSuccess) { if (m.in) (void)hipFree(m.in); if (m.out) (void)hipFree(m.out); }
-        m = MultiSlab();
+    MultiSlab &m = multi_slabs()[d];
+    if (!m.in && !m.out && !m.copy) return;
+    if (hipSetDevice(d) == hipSuccess) {
+        if (m.copy) { (void)hipStreamSynchronize(m.copy); (void)hipStreamDestroy(m.copy); }
+        if (m.in) (void)hipFree(m.in);
+        if (m.out) (void)hipFree(m.out);
     }
-    if (have) (void)hipSetDevice(cur);
+    m = MultiSlab();
 }
 struct DeviceRestore {
     int dev = -1;
@@ -1192,12 +1243,16 @@ int multi_run(bool compress, uint64_t device_mask, int32_t nblocks, const uint8_
     if (nblocks == 0) return JPK_OK;
     for (int b = 0; b < nblocks; b++)
         if (in_len[b] < 0 || (in_len[b] > 0 && !in[b]) || (!compress && raw_len[b] < 0)) return JPK_E_ARG;
-    std::lock_guard<std::mutex> call_lock(multi_call_mu());
-    DeviceRestore restore;                                   // the caller's current device comes back on every exit path
+    std::vector<int32_t> st_local((size_t)nblocks), olen((size_t)nblocks, 0);
+    int32_t *stp = status ? status : st_local.data();
+    for (int b = 0; b < nblocks; b++) { stp[b] = JPK_E_DEVICE; out_off[b + 1] = 0; }   // a block nobody got to says so (a device whose worker bails out early)
     const int ndev = jpk_device_count();
     if (ndev <= 0) return JPK_E_NODEVICE;
+    const std::vector<int> cand = multi_devices(device_mask, ndev);
+    const MultiLocks locks(cand);                            // (ascending; before the first device call of this call)
+    DeviceRestore restore;                                   // the caller's current device comes back on every exit path
     std::vector<int> devs;
-    for (int d : multi_devices(device_mask, ndev)) {
+    for (int d : cand) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, d) != hipSuccess) continue;
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("JPK_ALLOW_ANY_ARCH")) continue;
@@ -1205,9 +1260,6 @@ int multi_run(bool compress, uint64_t device_mask, int32_t nblocks, const uint8_
     }
     if (devs.empty()) return JPK_E_NODEVICE;
     const int G = (int)devs.size(), root = devs[0];
-    std::vector<int32_t> st_local((size_t)nblocks), olen((size_t)nblocks, 0);
-    int32_t *stp = status ? status : st_local.data();
-    for (int b = 0; b < nblocks; b++) stp[b] = JPK_E_DEVICE;       // a block nobody got to says so (a device whose worker bails out early)
     uint64_t generation;
     { CtxPool &p = pool(); std::lock_guard<std::mutex> g(p.mu); generation = p.generation; }
 
@@ -1229,6 +1281,7 @@ int multi_run(bool compress, uint64_t device_mask, int32_t nblocks, const uint8_
         }
         if ((D.rc = slab_ensure(&D.slab->in, &D.slab->in_cap, itotal + 256)) != JPK_OK) return;
         if ((D.rc = slab_ensure(&D.slab->out, &D.slab->out_cap, ototal + 256)) != JPK_OK) return;
+        if (!D.slab->copy && hipStreamCreateWithFlags(&D.slab->copy, hipStreamNonBlocking) != hipSuccess) { D.slab->copy = nullptr; D.rc = JPK_E_DEVICE; return; }
         const size_t nb = D.blocks.size();
         std::vector<const uint8_t *> din(nb);
         std::vector<uint8_t *> dout(nb);
@@ -1240,11 +1293,36 @@ int multi_run(bool compress, uint64_t device_mask, int32_t nblocks, const uint8_
             ilen[k] = in_len[b];
             const size_t cap = cap_of(b);
             ocap[k] = (int32_t)(cap > 0x7fffffff ? 0x7fffffff : cap);
-            if (in_len[b] && hipMemcpyAsync(D.slab->in + D.ioff[k], in[b], (size_t)in_len[b], hipMemcpyHostToDevice, D.c->stream) != hipSuccess) { D.rc = JPK_E_DEVICE; return; }
         }
-        // (the batch entries order their work behind what is queued on the context's stream: the copies above)
-        const int rc = compress ? jpk_dev_blocks_compress(D.c, (int32_t)nb, din.data(), ilen.data(), dout.data(), ocap.data(), ol.data(), stl.data(), in_flight)
-                                : jpk_dev_blocks_decompress(D.c, (int32_t)nb, din.data(), ilen.data(), dout.data(), ocap.data(), ol.data(), stl.data());
+        int rc;
+        if (compress) {
+            // Round 6: the inputs travel on the slab's own stream, block by block in the order the batch entry takes them, from a
+            // copier thread; a worker of the batch entry waits (on the host) only for the blocks of ITS next task, so block k + 1 is on
+            // its way in while block k is being compressed -- the reference's loop overlaps its reads the same way, thread k compresses
+            // while thread k + 1 still reads (jampack.cpp:205-224).  Rounds 4-5 copied ALL of a device's blocks in before its first kernel.
+            // (Pageable host memory: the runtime stages it through pinned buffers of its own; the copies run at PCIe speed on this box,
+            // tools/pcietest.hip.)
+            BlocksReady ready(nb);
+            std::thread copier([&] {
+                if (hipSetDevice(dev) != hipSuccess) { ready.fail(); return; }
+                for (size_t k = 0; k < nb; k++) {
+                    const int b = D.blocks[k];
+                    if (in_len[b] && (hipMemcpyAsync(D.slab->in + D.ioff[k], in[b], (size_t)in_len[b], hipMemcpyHostToDevice, D.slab->copy) != hipSuccess ||
+                                      hipStreamSynchronize(D.slab->copy) != hipSuccess)) { ready.fail(); return; }
+                    ready.set(k);
+                }
+            });
+            rc = blocks_compress_body(D.c, (int32_t)nb, din.data(), ilen.data(), dout.data(), ocap.data(), ol.data(), stl.data(), in_flight, &ready);
+            copier.join();
+        } else {
+            // the decode is ONE pass over the chunks of all the device's blocks and needs every stream in place; compressed inputs are a
+            // fifth of the data and the pass is long: the copies stay in front of it, on the context's stream
+            for (size_t k = 0; k < nb; k++) {
+                const int b = D.blocks[k];
+                if (in_len[b] && hipMemcpyAsync(D.slab->in + D.ioff[k], in[b], (size_t)in_len[b], hipMemcpyHostToDevice, D.c->stream) != hipSuccess) { D.rc = JPK_E_DEVICE; return; }
+            }
+            rc = jpk_dev_blocks_decompress(D.c, (int32_t)nb, din.data(), ilen.data(), dout.data(), ocap.data(), ol.data(), stl.data());
+        }
         for (size_t k = 0; k < nb; k++) {
             const int b = D.blocks[k];
             stp[b] = rc != JPK_OK && stl[k] == JPK_OK ? rc : stl[k];
@@ -1258,22 +1336,27 @@ int multi_run(bool compress, uint64_t device_mask, int32_t nblocks, const uint8_
         work(0);
         for (auto &t : th) t.join();
     }
-    int rc = JPK_OK;
+    // What is reported and what is gathered: a block's status is its own; a device that failed as a whole fails all its
+    // blocks; EVERY block whose status is JPK_OK is gathered -- a corrupt frame among healthy ones costs its own bytes only, the others
+    // are in d_out at [out_off[b], out_off[b + 1]) as the header promises -- and when the gather itself cannot run (the output buffer
+    // is too small, RCCL is not there) NO block is reported as done: every status is an error and every range is empty.
+    int rc_blocks = JPK_OK;
     for (int g = 0; g < G; g++)
         if (dv[(size_t)g].rc != JPK_OK) {
-            rc = dv[(size_t)g].rc;
-            for (int b : dv[(size_t)g].blocks) if (stp[b] == JPK_OK) { stp[b] = rc; olen[(size_t)b] = 0; }     // a failed device: none of its blocks is reported as done
+            if (rc_blocks == JPK_OK) rc_blocks = dv[(size_t)g].rc;
+            for (int b : dv[(size_t)g].blocks) if (stp[b] == JPK_OK) { stp[b] = dv[(size_t)g].rc; olen[(size_t)b] = 0; }     // a failed device: none of its blocks is reported as done
         }
-    for (int b = 0; b < nblocks && rc == JPK_OK; b++) if (stp[b] != JPK_OK) rc = stp[b];
+    for (int b = 0; b < nblocks && rc_blocks == JPK_OK; b++) if (stp[b] != JPK_OK) rc_blocks = stp[b];
     int64_t total = 0;
     for (int b = 0; b < nblocks; b++) { out_off[b] = total; total += olen[(size_t)b]; }
     out_off[nblocks] = total;
-    if (rc == JPK_OK && total > out_cap) rc = JPK_E_CAPACITY;
+    int rc = JPK_OK;                                         // of the gather
+    if (total > out_cap) rc = JPK_E_CAPACITY;
 
     // the gather: root's own blocks are device-to-device copies; the others travel over RCCL, one send / receive pair per block.
-    // The communicators are used under multi_call_mu() only (this call, and jpk_shutdown destroys them under it).
+    // A communicator set belongs to a device LIST and is used under the mutexes of all its devices (this call holds them).
     static const bool force_rccl = [] { const char *e = getenv("JPK_MULTI_FORCE_RCCL"); return e && atoi(e) != 0; }();
-    const bool use_rccl = rc == JPK_OK && (G > 1 || force_rccl);
+    const bool use_rccl = rc == JPK_OK && total > 0 && (G > 1 || force_rccl);
     const std::vector<jpk_nccl_comm_t> *comms = nullptr;
     if (use_rccl) {
         std::lock_guard<std::mutex> lk(multi_mu());
@@ -1289,7 +1372,7 @@ int multi_run(bool compress, uint64_t device_mask, int32_t nblocks, const uint8_
             }
         }
     }
-    if (rc == JPK_OK) {
+    if (rc == JPK_OK && total > 0) {
         if (hipSetDevice(root) != hipSuccess) rc = JPK_E_DEVICE;
         Dev &R = dv[0];
         hipStream_t rs = R.c ? R.c->stream : nullptr;
@@ -1297,7 +1380,7 @@ int multi_run(bool compress, uint64_t device_mask, int32_t nblocks, const uint8_
             bool grouped = rccl().GroupStart() == 0;
             for (int g = 0; g < G && grouped; g++) {
                 Dev &D = dv[(size_t)g];
-                if (g == 0 && !force_rccl) continue;
+                if ((g == 0 && !force_rccl) || !D.c || !D.slab) continue;
                 for (size_t k = 0; k < D.blocks.size(); k++) {
                     const int b = D.blocks[k];
                     if (olen[(size_t)b] == 0) continue;
@@ -1307,7 +1390,7 @@ int multi_run(bool compress, uint64_t device_mask, int32_t nblocks, const uint8_
             }
             if (!grouped || rccl().GroupEnd() != 0) rc = JPK_E_DEVICE;
         }
-        if (rc == JPK_OK && !(use_rccl && force_rccl))
+        if (rc == JPK_OK && !(use_rccl && force_rccl) && R.c && R.slab)
             for (size_t k = 0; k < R.blocks.size(); k++) {
                 const int b = R.blocks[k];
                 if (olen[(size_t)b] && hipMemcpyAsync(d_out + out_off[b], R.slab->out + R.ooff[k], (size_t)olen[(size_t)b], hipMemcpyDeviceToDevice, rs) != hipSuccess) rc = JPK_E_DEVICE;
@@ -1320,9 +1403,27 @@ int multi_run(bool compress, uint64_t device_mask, int32_t nblocks, const uint8_
         if (hipSetDevice(devs[(size_t)g]) != hipSuccess || hipStreamSynchronize(D.c->stream) != hipSuccess) rc = rc == JPK_OK ? JPK_E_DEVICE : rc;
         batch_ctx_release(devs[(size_t)g], D.c, generation);
     }
-    return rc;
+    if (rc != JPK_OK) {                                      // no gather: nothing is in d_out, and nobody is told otherwise
+        for (int b = 0; b < nblocks; b++) { if (stp[b] == JPK_OK) stp[b] = rc; out_off[b] = 0; }
+        out_off[nblocks] = 0;
+        return rc;
+    }
+    return rc_blocks;
 }
 }  // namespace
+
+// host-logic probe (no device call): takes the device mutexes a multi-device call with this mask would take (bit d = device d; every
+// bit counts, whether such a device exists or not), holds them for hold_ms milliseconds and lets go.  Two probes with disjoint masks
+// overlap, two that share a bit queue: tests/test_abi_and_host.py.
+extern "C" int jpk_debug_multi_lock_probe(uint64_t device_mask, int32_t hold_ms)
+{
+    if (hold_ms < 0 || hold_ms > 10000) return JPK_E_ARG;
+    std::vector<int> devs;
+    for (int d = 0; d < 64; d++) if ((device_mask >> d) & 1u) devs.push_back(d);
+    const MultiLocks locks(devs);
+    std::this_thread::sleep_for(std::chrono::milliseconds(hold_ms));
+    return (int)devs.size();
+}
 
 extern "C" int jpk_blocks_compress_multi(uint64_t device_mask, int32_t nblocks, const uint8_t *const *in, const int32_t *in_len, uint8_t *d_out, int64_t out_cap,
                                          int64_t *out_off, int32_t *status)
@@ -1368,7 +1469,10 @@ extern "C" int jpk_thread_device(void)
 
 extern "C" void jpk_shutdown(void)
 {
-    std::lock_guard<std::mutex> multi_lock(multi_call_mu());    // no multi-device call is using the communicators / slabs destroyed below
+    std::vector<int> every;
+    for (int d = 0; d < 64; d++) every.push_back(d);
+    const MultiLocks multi_lock(every);                         // no multi-device call is using the communicators / slabs destroyed below
+    DeviceRestore restore;                                      // (destroying contexts and slabs moves the current device around: ADVICE r5)
     CtxPool &p = pool();
     std::lock_guard<std::mutex> g(p.mu);
     for (jpk_ctx *c : p.all) jpk_ctx_destroy(c);    // synchronises each context's streams first
@@ -1383,7 +1487,7 @@ extern "C" void jpk_shutdown(void)
             for (jpk_nccl_comm_t cm : m.comms) if (cm && rccl().ok) (void)rccl().CommDestroy(cm);
         multi_comms().clear();
     }
-    multi_slabs_free();
+    for (int d = 0; d < 64; d++) multi_slab_free(d);
     p.devices.clear();
     p.generation++;
     p.next_thread = 0;
@@ -1396,9 +1500,10 @@ extern "C" void jpk_shutdown(void)
 extern "C" int jpk_release_idle(void)
 {
     int freed = 0;
-    {
-        std::unique_lock<std::mutex> multi_lock(multi_call_mu(), std::try_to_lock);    // a multi-device call in flight keeps its slabs
-        if (multi_lock.owns_lock()) multi_slabs_free();
+    DeviceRestore restore;                                      // jpk_ctx_destroy and the slabs' hipFree set the device: the caller's comes back
+    for (int d = 0; d < 64; d++) {
+        std::unique_lock<std::mutex> dev_lock(multi_dev_mu()[d], std::try_to_lock);    // a multi-device call in flight on the device keeps its slabs
+        if (dev_lock.owns_lock()) multi_slab_free(d);
     }
     CtxPool &p = pool();
     std::lock_guard<std::mutex> g(p.mu);

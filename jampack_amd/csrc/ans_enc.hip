@@ -942,7 +942,8 @@ __global__ __launch_bounds__(64) void k_adapt_c(EncDims d, AdArgs a)
 // records are stored lane-major (rec[lane][j >> 2]) so that every lane streams its own array.  A record is
 // {low | freq << 16, Alverson reciprocal of freq}: x / freq == mulhi(x, rcp) >> (ceil(log2 freq) - 1) for x < 2^31.
 // records per state lane, a multiple of the 128-record staging tile
-__host__ __device__ __forceinline__ size_t rans_lane_stride(size_t rle_stride) { return (rle_stride / 2 + 128) & ~(size_t)127; }
+// (a chain is padded with identity steps to whole rounds of the sixteen-batch ring, RANS_PAD = 256 steps: k_rans_lanes)
+__host__ __device__ __forceinline__ size_t rans_lane_stride(size_t rle_stride) { return (rle_stride / 2 + 384) & ~(size_t)127; }
 // records per lane of chunk c and the first record of its four lanes (see EncDims::sbase)
 __device__ __forceinline__ size_t lane_stride_of(const EncDims &d, uint32_t c, size_t rle_stride) { return rans_lane_stride(sym_stride(d, c, rle_stride)); }
 __device__ __forceinline__ size_t lane_base(const EncDims &d, uint32_t c, size_t rle_stride) { return d.lbase ? (size_t)d.lbase[c] : (size_t)c * 4 * rans_lane_stride(rle_stride); }
@@ -951,6 +952,9 @@ __device__ __forceinline__ size_t lane_base(const EncDims &d, uint32_t c, size_t
 // is computed here, in parallel (ryg's RansEncSymbolInit, rans_byte.hpp:188-246, restated for 16-bit frequencies):
 //   x / freq == mulhi(x, rcp) >> shift  with rcp = ceil(2^(31+s) / freq), s = ceil(log2 freq), shift = s - 1 (x < 2^31);
 //   freq == 1: rcp = 2^32 - 1, shift = 0 gives q = x - 1, compensated by bias += 65535.
+// (Round 6 tried the reciprocal from a 256 KB table of the 65 536 frequencies instead of the two 32-bit divisions per record -- ~70 vector
+// instructions, eight per thread of k_pairs: 133 -> 169 us per launch, profiles/r06_entropy_ab.txt.  The kernel waits for its three
+// dependent waves of loads, not for its vector work; the table read is a fourth.  Not kept.)
 __device__ __forceinline__ uint4 rans_record(uint32_t lo, uint32_t fr)
 {
     uint32_t rcp, shift, bias = lo;
@@ -975,27 +979,27 @@ __device__ __forceinline__ uint4 rans_record(uint32_t lo, uint32_t fr)
 __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
                                              const uint16_t *__restrict__ exph, const uint32_t *__restrict__ mantad,
                                              const uint32_t *__restrict__ ord, const uint32_t *__restrict__ qcdf, uint4 *__restrict__ recs,
-                                             uint16_t *__restrict__ fr16, uint32_t *__restrict__ pairs_plain)
+                                             uint32_t *__restrict__ pairs_plain)
 {
     const uint32_t c = chunk_of(d, blockIdx.y);
     const uint32_t g = blockIdx.x * TB + threadIdx.x, t0 = 2u * g;
     const uint32_t rl = rlen[c];
     const size_t lane_stride = lane_stride_of(d, c, rle_stride), lb = lane_base(d, c, rle_stride);
     uint4 *rc = recs + lb;
-    uint16_t *fq = fr16 + lb;                              // frequency sidecar: what the emit kernels need of a record (2 of its 16 bytes)
-    // the chain kernel walks whole batches of 16 steps: steps past a chain's last pair get identity records
-    // (xmax above every state, q * 0 + x + 0), so that it needs no bounds logic
+    // the chain kernel walks whole rounds of its sixteen-batch ring (256 steps): steps past a chain's last pair get identity records
+    // (xmax above every state, q * 0 + x + 0), so that it needs no bounds logic -- at most 271 per chain, written by the threads
+    // behind the chunk's last symbol
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const uint32_t t = t0 + (uint32_t)h;
         if (t >= rl) {
             const uint32_t u = t - rl;
-            if (u < 64u) {
-                const uint32_t np = 2u * rl, chain = u >> 4;
-                const uint32_t steps16 = np ? (((np - 1u) >> 2) / 16u + 1u) * 16u : 16u;
+            if (u < 4u * 288u) {
+                const uint32_t np = 2u * rl, chain = u / 288u;
+                const uint32_t steps_pad = np ? (((np - 1u) >> 2) / 256u + 1u) * 256u : 256u;
                 const uint32_t first = (chain < np) ? ((np - 1u - chain) >> 2) + 1u : 0u;
-                const uint32_t k = first + (u & 15u);
-                if (k < steps16) rc[(size_t)chain * lane_stride + k] = make_uint4(0x80000000u, 0u, 0u, 0u);
+                const uint32_t k = first + u % 288u;
+                if (k < steps_pad) rc[(size_t)chain * lane_stride + k] = make_uint4(0x80000000u, 0u, 0u, 0u);
             }
         }
     }
@@ -1038,8 +1042,6 @@ __global__ __launch_bounds__(TB) void k_pairs(const uint16_t *__restrict__ rle, 
         if (h == 1 && !two) break;
         rc[(size_t)(2 * h) * lane_stride + g] = rans_record(l0[h], h0[h] - l0[h]);
         rc[(size_t)(2 * h + 1) * lane_stride + g] = rans_record(l1[h], f1[h]);
-        fq[(size_t)(2 * h) * lane_stride + g] = (uint16_t)(h0[h] - l0[h]);          // every model keeps each symbol >= 1: freq <= 65535
-        fq[(size_t)(2 * h + 1) * lane_stride + g] = (uint16_t)f1[h];
         if (pairs_plain) {
             uint32_t *out = pairs_plain + (size_t)c * 2 * rle_stride + 2 * (size_t)(t0 + h);
             out[0] = l0[h] | ((h0[h] - l0[h]) << 16);
@@ -1111,25 +1113,28 @@ __device__ __forceinline__ uint32_t rans_step_turn2(uint32_t xprev, const uint4 
 // lane l -> ring[slot][l]) and NO register holds data in flight: a record becomes a register value through an ordinary ds_read
 // that the compiler tracks itself (lgkmcnt), placed behind an asm s_waitcnt with a memory clobber that it cannot be moved across.
 // What remains hand-counted is vmcnt, and the count is exact by program text: every vector-memory instruction of the loop (one
-// LDS-DMA load, one state store per batch) is issued from asm volatile, loads and stores share vmcnt and retire in order, and
+// LDS-DMA load and two stores per batch: the states' low halves and, round 6, the emit masks) is issued from asm volatile, loads and stores share vmcnt and retire in order, and
 // anything the compiler might add (a spill) is YOUNGER than the load being waited for or older than all of them, which can only make
 // the wait stricter.  tests/test_chain_codegen.py checks the generated loop for exactly that instruction census.
 constexpr int RANS_RING = 16;                   // batches of records in flight
 constexpr int RANS_SLACK = 16 * RANS_RING;      // records in front of the record array: the prefetches of batches that do not exist read there
-// One statement per batch for the three instructions that touch vector memory or M0: the LDS-DMA load takes its LDS address from
-// M0 and needs one instruction between the SALU write of M0 and itself (the state store is that instruction), and M0 is
+// One statement per batch for the four instructions that touch vector memory or M0: the LDS-DMA load takes its LDS address from
+// M0 and needs one instruction between the SALU write of M0 and itself (the stores are), and M0 is
 // compiler-reserved: the kernel uses it nowhere else (tests/test_chain_codegen.py checks), so it is not saved.  Addresses: a
 // wave-uniform base in SGPRs + a 32-bit lane offset + an immediate -- inside the sixteen-fold unrolled loop body nothing is computed.
 // (The LDS-DMA load carries no immediate: its instruction offset moves the LDS address as well as the global one -- measured the
 // hard way -- so the lane offset of the records is stepped by one v_add per batch; the store's offset is an immediate.)
-#define JPK_RING_STORE_LOAD(SLOT, SOFF)                                                                                \
+#define JPK_RING_STORE_LOAD(SLOT, SOFF, MOFF)                                                                          \
     asm volatile("s_mov_b32 m0, %[slot]\n\t"                                                                           \
-                 "global_store_dword %[xoff], %[keep], %[xbase] offset:" #SOFF "\n\t"                                  \
+                 "global_store_short %[xoff], %[keep], %[xbase] offset:" #SOFF "\n\t"                                  \
+                 "global_store_dword %[moff], %[mw], %[mbase] offset:" #MOFF "\n\t"                                    \
                  "global_load_lds_dwordx4 %[roff], %[rbase]"                                                           \
-                 : : [slot] "s"(ring0 + (uint32_t)(SLOT) * 1024u), [xoff] "v"(xoff), [keep] "v"(keep), [xbase] "s"(xbase), [roff] "v"(roff), [rbase] "s"(rbase)   \
+                 : : [slot] "s"(ring0 + (uint32_t)(SLOT) * 1024u), [xoff] "v"(xoff), [keep] "v"(keep), [xbase] "s"(xbase), [moff] "v"(moff), [mw] "v"(mw),   \
+                     [mbase] "s"(mbase), [roff] "v"(roff), [rbase] "s"(rbase)                                          \
                  : "memory")
 __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ recs, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
-                                                  uint32_t *__restrict__ xs, uint32_t *__restrict__ fstate, uint64_t *__restrict__ stamp)
+                                                  uint16_t *__restrict__ x16, uint32_t *__restrict__ emask, uint32_t *__restrict__ fstate,
+                                                  uint64_t *__restrict__ stamp)
 {
     __shared__ uint4 ring[RANS_RING][64];
     const uint64_t t0c = __builtin_amdgcn_s_memtime(), t0r = __builtin_amdgcn_s_memrealtime();
@@ -1146,7 +1151,10 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
     }
     const int chain = t >> 4, s = t & 15;
     const size_t lane_stride = lane_stride_of(d, c, rle_stride), lb = lane_base(d, c, rle_stride);
-    const int32_t nbatch = (int32_t)((np - 1) / 4) / 16 + 1;
+    // batches of sixteen steps, rounded up to whole rounds of the ring (round 6: the padding -- identity records, k_pairs -- is walked
+    // first, from the start state, and costs at most fifteen batches per chunk; the exit test behind every batch of the unrolled loop,
+    // three scalar instructions of 231, is gone)
+    const int32_t nbatch = (((int32_t)((np - 1) / 4) / 16 + 1) + RANS_RING - 1) & ~(RANS_RING - 1);
     const int32_t K0 = 16 * nbatch - 1 - s;                        // this lane's step index in the first batch
     uint32_t x = RANS_L;                                           // lane 15 of a row hands the start state to lane 0
     const uint32_t ring0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)&ring[0][0];     // LDS byte address
@@ -1154,9 +1162,12 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
     // chunk's first record, so that the offset of a prefetch past the last batch (step index down to -256) stays non-negative: those
     // loads read the slack enc_layout leaves in front of the array (or the chains of the chunk before) and nobody uses them.
     const uint4 *rbase = recs + lb - RANS_SLACK;
-    uint32_t *xbase = xs + lb;
+    uint16_t *xbase = x16 + lb;
+    uint32_t *mbase = emask + (lb >> 4);                           // (lane bases and strides are multiples of 128 records)
     uint32_t roff = (uint32_t)(((size_t)chain * lane_stride + (size_t)(K0 + RANS_SLACK)) * 16u);
-    uint32_t xoff = (uint32_t)(((size_t)chain * lane_stride + (size_t)K0) * 4u);
+    uint32_t xoff = (uint32_t)(((size_t)chain * lane_stride + (size_t)K0) * 2u);
+    uint32_t moff = (uint32_t)((((size_t)chain * lane_stride) >> 4) + (size_t)(nbatch - 1)) * 4u;    // the row's mask word of the first batch
+    const uint32_t rowsh = 16u * (uint32_t)chain;
     // prologue: the first sixteen batches' records, all landed before the loop starts -- one memory latency per chunk -- so that
     // from here on the steady-state count below holds for every wait
 #define JPK_RING_PROLOGUE(SLOT)                                                                                         \
@@ -1171,38 +1182,43 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");            // (roff now points at the lane's record sixteen batches ahead)
     uint4 cur = ring[0][t];
     // One batch: the record of the NEXT batch (slot k + 1) was requested sixteen batches ago minus one; issued after it, in program
-    // order: the stores of 14 batches and the loads of 14 batches -- vmcnt(28) -- (the first fifteen batches read slots the
+    // order: the two stores and the load of each of 14 batches -- vmcnt(42) -- (the first fifteen batches read slots the
     // prologue has drained).  It becomes a register value through an ordinary LDS read behind the wait, used one batch later.
     // Then 16 steps of every chain on `cur`, the store of the kept states, and the request for batch + 16 into the slot `cur` came from.
-#define JPK_BATCH(KSLOT, SOFF)                                                                                          \
+#define JPK_BATCH(KSLOT, SOFF, MOFF)                                                                                    \
     {                                                                                                                   \
-        asm volatile("s_waitcnt vmcnt(28)" : : : "memory");                                                             \
+        asm volatile("s_waitcnt vmcnt(42)" : : : "memory");                                                             \
         const uint4 nxt = ring[((KSLOT) + 1) & (RANS_RING - 1)][t];                                                     \
         _Pragma("unroll") for (int st = 0; st < 16; st += 2)                                                            \
             x = rans_step_turn2(x, cur, keep, 0x0001000100010001ull << st, 0x0001000100010001ull << (st + 1));          \
-        JPK_RING_STORE_LOAD(KSLOT, SOFF);                                                                               \
+        /* what the step of every lane emitted (round 6): one byte when its start state reached xmax, two when state >> 8 did -- as a     \
+           bit per lane, the sixteen lanes of a row = the sixteen steps of the row's chain in this batch (bit s <-> step K - s) */       \
+        const uint64_t e1 = __ballot(keep >= cur.x), e2 = __ballot((keep >> 8) >= cur.x);                               \
+        const uint32_t mw = ((uint32_t)(e1 >> rowsh) & 0xffffu) | ((uint32_t)(e2 >> rowsh) << 16);                      \
+        JPK_RING_STORE_LOAD(KSLOT, SOFF, MOFF);                                                                         \
         roff -= 256u;                                                                                                   \
         cur = nxt;                                                                                                      \
     }
     uint32_t keep = 0;                                             // (every lane's turn comes once per batch and overwrites it)
-    for (int32_t left = nbatch; left > 0; left -= RANS_RING) {    // batches left when the body starts
-        JPK_BATCH(0, 0)        if (left <= 1) break;
-        JPK_BATCH(1, -64)      if (left <= 2) break;
-        JPK_BATCH(2, -128)     if (left <= 3) break;
-        JPK_BATCH(3, -192)     if (left <= 4) break;
-        JPK_BATCH(4, -256)     if (left <= 5) break;
-        JPK_BATCH(5, -320)     if (left <= 6) break;
-        JPK_BATCH(6, -384)     if (left <= 7) break;
-        JPK_BATCH(7, -448)     if (left <= 8) break;
-        JPK_BATCH(8, -512)     if (left <= 9) break;
-        JPK_BATCH(9, -576)     if (left <= 10) break;
-        JPK_BATCH(10, -640)    if (left <= 11) break;
-        JPK_BATCH(11, -704)    if (left <= 12) break;
-        JPK_BATCH(12, -768)    if (left <= 13) break;
-        JPK_BATCH(13, -832)    if (left <= 14) break;
-        JPK_BATCH(14, -896)    if (left <= 15) break;
-        JPK_BATCH(15, -960)
-        xoff -= 16u * 64u;
+    for (int32_t left = nbatch; left > 0; left -= RANS_RING) {    // whole rounds: no exit inside
+        JPK_BATCH(0, 0, 0)
+        JPK_BATCH(1, -32, -4)
+        JPK_BATCH(2, -64, -8)
+        JPK_BATCH(3, -96, -12)
+        JPK_BATCH(4, -128, -16)
+        JPK_BATCH(5, -160, -20)
+        JPK_BATCH(6, -192, -24)
+        JPK_BATCH(7, -224, -28)
+        JPK_BATCH(8, -256, -32)
+        JPK_BATCH(9, -288, -36)
+        JPK_BATCH(10, -320, -40)
+        JPK_BATCH(11, -352, -44)
+        JPK_BATCH(12, -384, -48)
+        JPK_BATCH(13, -416, -52)
+        JPK_BATCH(14, -448, -56)
+        JPK_BATCH(15, -480, -60)
+        xoff -= 16u * 32u;
+        moff -= 16u * 4u;
     }
 #undef JPK_BATCH
 #undef JPK_RING_STORE_LOAD
@@ -1219,33 +1235,24 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
 // Pair j of a chunk (chain j & 3, step j >> 2) emitted 0..2 bytes; the encoder walks the pairs last to first and the stream grows
 // downwards, so the bytes of pair j start  sum_{j' >= j} count(j')  bytes before the end of the chunk's payload.
 constexpr int ETILE = 4096;                    // pairs per tile
-// (state before the step, frequency): 6 bytes per pair -- the 16-byte step records are read once, by the chain
-__device__ __forceinline__ uint32_t pair_emit(const uint32_t *__restrict__ xs, const uint16_t *__restrict__ fr16, size_t chunk_base, size_t lane_stride, uint32_t j)
-{
-    const size_t o = chunk_base + (size_t)(j & 3u) * lane_stride + (j >> 2);
-    const uint32_t f = fr16[o];
-    return emit_word(xs[o], f ? f << 15 : 0x80000000u);       // a frequency of 65536 wraps to 0 in the sidecar (cannot occur: every symbol keeps >= 1)
-}
+// Round 6: what the emit kernels read is what the chain left behind for them -- per step the low 16 bits of the state it started
+// from (the only bits a step can emit) and, per chain and batch of sixteen steps, one word of emit masks (low half: "one byte at
+// least", high half: "two"; bit s <-> step 16 m + 15 - s of the chain: lane s of the chain's row, k_rans_lanes) -- 2.25 bytes per
+// pair.  Rounds 2-5 kept the whole 32-bit state and a 2-byte frequency sidecar written by k_pairs and recomputed the comparison
+// against x_max twice: 12 bytes read per pair to place 0.17 (profiles/r05_pmc_traffic.json: k_put_payload fetched 418 MB per launch).
+// mask words of one chain that are written: one per batch of the chunk
+__device__ __forceinline__ uint32_t rans_batches(uint32_t np) { return np ? ((np - 1u) >> 2) / 16u + 1u : 0u; }
 
-__global__ __launch_bounds__(TB) void k_emit_count(const uint32_t *__restrict__ xs, const uint16_t *__restrict__ recs, size_t rle_stride, EncDims d,
+__global__ __launch_bounds__(TB) void k_emit_count(const uint32_t *__restrict__ emask, size_t rle_stride, EncDims d,
                                                   const uint32_t *__restrict__ rlen, uint32_t *__restrict__ tsum, uint32_t etpc)
 {
     const uint32_t c = chunk_of(d, blockIdx.y), tile = blockIdx.x;
     const uint32_t np = 2 * rlen[c];
     if (tile * ETILE >= np) return;
     const size_t lane_stride = lane_stride_of(d, c, rle_stride), cb = lane_base(d, c, rle_stride);
-    uint32_t n = 0;
-    uint32_t ew[ETILE / TB];
-#pragma unroll
-    for (int it = 0; it < ETILE / TB; it++) {          // loads first (clamped), all in flight
-        const uint32_t j = tile * ETILE + it * TB + threadIdx.x;
-        ew[it] = pair_emit(xs, recs, cb, lane_stride, j < np ? j : np - 1);
-    }
-#pragma unroll
-    for (int it = 0; it < ETILE / TB; it++) {
-        const uint32_t j = tile * ETILE + it * TB + threadIdx.x;
-        if (j < np) n += ew[it] >> 16;
-    }
+    // the tile's pairs are the steps [1024 tile, 1024 tile + 1024) of the four chains: 64 mask words each, one per thread
+    const uint32_t chain = threadIdx.x >> 6, w = tile * (ETILE / 64) + (threadIdx.x & 63u);
+    const uint32_t n = w < rans_batches(np) ? (uint32_t)__popc(emask[((cb + (size_t)chain * lane_stride) >> 4) + w]) : 0u;   // (padding steps carry identity records: no bits)
     __shared__ uint32_t sm[TB / 64 + 1];
     uint32_t tot;
     block_incl_scan<OpSum>(n, sm, &tot);
@@ -1337,7 +1344,7 @@ __global__ __launch_bounds__(TB) void k_put_headers(EncDims d, const uint8_t *__
 }
 
 // payload bytes: every pair places its 0..2 bytes (offset = bytes of all later pairs, from the end of the chunk's payload)
-__global__ __launch_bounds__(TB) void k_put_payload(const uint32_t *__restrict__ xs, const uint16_t *__restrict__ recs, size_t rle_stride, EncDims d,
+__global__ __launch_bounds__(TB) void k_put_payload(const uint16_t *__restrict__ x16, const uint32_t *__restrict__ emask, size_t rle_stride, EncDims d,
                                                    const uint32_t *__restrict__ rlen, const uint32_t *__restrict__ tsuf, uint32_t etpc,
                                                    const uint32_t *__restrict__ csize, const uint32_t *__restrict__ hsize, const uint64_t *__restrict__ outoff,
                                                    uint8_t *__restrict__ out)
@@ -1348,16 +1355,28 @@ __global__ __launch_bounds__(TB) void k_put_payload(const uint32_t *__restrict__
     uint8_t *const ob = d.cblk ? d.bout[d.cblk[c]] : out;
     if (!ob) return;                        // (uniform over the workgroup; see k_put_headers)
     const size_t lane_stride = lane_stride_of(d, c, rle_stride), cb = lane_base(d, c, rle_stride);
-    // thread t owns the 16 consecutive pairs [j0, j0 + 16) of the tile; suffix sums run from the tile's last pair backwards
-    const uint32_t j0 = tile * ETILE + threadIdx.x * 16;
+    // thread t owns the 16 consecutive pairs [j0, j0 + 16) of the tile = the four steps [s0, s0 + 4) of the four chains (pair j: chain
+    // j & 3, step j >> 2): per chain one mask word (the four steps share it) and one 8-byte load of their four 16-bit states
+    const uint32_t s0 = tile * (ETILE / 4) + threadIdx.x * 4u;
+    const bool live = (s0 >> 4) < rans_batches(np);
+    uint32_t mw[4];
+    uint2 xv[4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ch++) {        // loads first (a live thread's four steps lie inside the chain's batches: 16 | 4)
+        const size_t o = cb + (size_t)ch * lane_stride + (live ? s0 : 0u);
+        mw[ch] = live ? emask[o >> 4] : 0u;
+        xv[ch] = *reinterpret_cast<const uint2 *>(x16 + o);
+    }
     uint32_t e[16];
     uint32_t n = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) e[k] = pair_emit(xs, recs, cb, lane_stride, j0 + k < np ? j0 + k : np - 1);     // loads first (clamped)
-#pragma unroll
     for (int k = 0; k < 16; k++) {
-        if (j0 + k >= np) e[k] = 0u;
-        n += e[k] >> 16;
+        const int ch = k & 3, q = k >> 2;                           // pair j0 + k
+        const uint32_t bit = 15u - ((s0 + (uint32_t)q) & 15u);
+        const uint32_t cnt = ((mw[ch] >> bit) & 1u) + ((mw[ch] >> (16u + bit)) & 1u);
+        const uint32_t xw = q < 2 ? xv[ch].x : xv[ch].y;
+        e[k] = ((q & 1) ? xw >> 16 : xw & 0xffffu) | (cnt << 16);
+        n += cnt;
     }
     // bytes emitted by the threads after me = block total - inclusive prefix
     __shared__ uint32_t sm[TB / 64 + 1];
@@ -1383,8 +1402,8 @@ struct EncBufs {
     uint32_t *clscnt, *clstotal, *ord, *qhist, *qcdf, *dens, *cmap;
     uint8_t *cls8; uint32_t *clist;
     uint32_t *seg_flag; int32_t *seg_lo, *seg_end, *seg_start; uint16_t *seg_tab;
-    uint16_t *exph; uint32_t *mantad, *pairs; uint4 *recs; uint16_t *fr16;
-    uint32_t *xs, *etsum, *fstate, *csize;
+    uint16_t *exph; uint32_t *mantad, *pairs; uint4 *recs;
+    uint16_t *x16; uint32_t *emask, *etsum, *fstate, *csize;
     uint64_t *stamp;
     uint8_t *hdr; uint32_t *hsize; uint64_t *outoff;
 };
@@ -1435,11 +1454,11 @@ void enc_layout(Arena &a, const EncDims &d, EncBufs &b, int what, size_t sym_tot
         b.seg_start = a.get<int32_t>(segs);
         b.seg_tab = a.get<uint16_t>(segs * 32);
         b.recs = a.get<uint4>(nlane + RANS_SLACK) + (a.planning ? 0 : RANS_SLACK);   // slack in front: k_rans_lanes' prefetches past the last batch
-        b.fr16 = a.get<uint16_t>(nlane);
         b.pairs = (what & LAY_PLAIN) ? a.get<uint32_t>((size_t)d.nch * stride * 2) : nullptr;
     }
     if (what & LAY_RANS) {
-        b.xs = a.get<uint32_t>(nlane);             // state before every step, lane-major like recs
+        b.x16 = a.get<uint16_t>(nlane + 64);       // low half of the state before every step, lane-major like recs
+        b.emask = a.get<uint32_t>(nlane / 16 + 64); // emit masks: one word per chain and batch of sixteen steps
         b.etsum = a.get<uint32_t>((size_t)d.nch * emit_tiles_per_chunk(stride));
         b.fstate = a.get<uint32_t>((size_t)d.nch * 4);
         b.csize = a.get<uint32_t>(d.nch);
@@ -1541,8 +1560,8 @@ int run_model(jpk_ctx *ctx, const uint16_t *d_rle, const uint32_t *d_rlen, const
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_tab, dim3((d.tpc + 1) / 2, 9, d.ncl), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_b, dim3(jpk_grid((size_t)d.ncl * 16, 64)), dim3(64), d, aa);
     JPK_LAUNCH(ctx, PROF_ENC_ADAPTIVE, 0, k_adapt_c, dim3((d.tpc + 63) / 64, 9, d.ncl), dim3(64), d, aa);
-    JPK_LAUNCH(ctx, PROF_ENC_PAIRS, 0, k_pairs, dim3(jpk_grid(stride, 2 * TB) + 1, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.exph, b.mantad, b.ord,
-                       b.qcdf, b.recs, b.fr16, b.pairs);
+    JPK_LAUNCH(ctx, PROF_ENC_PAIRS, 0, k_pairs, dim3(jpk_grid(stride, 2 * TB) + 3, d.ncl), dim3(TB), d_rle, stride, d, d_rlen, b.exph, b.mantad, b.ord,
+                       b.qcdf, b.recs, b.pairs);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
 }
@@ -1606,7 +1625,7 @@ size_t enc_plan_bytes(const EncDims &d, int nblk, uint32_t sym_per_byte_256)
     const size_t worst = (size_t)d.nch * d.chunk;
     size_t sym = worst / 256 * sym_per_byte_256 + 256 * (size_t)d.nch;
     if (sym > worst) sym = worst;
-    enc_layout(plan, d, b, LAY_MODEL | LAY_RANS, sym, 2 * sym + 4 * 128 * (size_t)d.nch);
+    enc_layout(plan, d, b, LAY_MODEL | LAY_RANS, sym, 2 * sym + 4 * 384 * (size_t)d.nch);
     return plan.need;
 }
 int encode_core(jpk_ctx *ctx, const uint8_t *d_in, EncDims &d, EncBufs &b, int inflight_n, const GroupTabs *gt = nullptr)
@@ -1652,6 +1671,7 @@ int encode_core(jpk_ctx *ctx, const uint8_t *d_in, EncDims &d, EncBufs &b, int i
         d.sbase = sbase; d.lbase = lbase;
         break;
     }
+    // (clearing the histograms inside k_cls_count instead of a memset of its own: k_cls_ord 64 -> 85 us per launch, round 6 -- not kept)
     JPK_HIP(hipMemsetAsync(b.qhist, 0, (size_t)d.nch * 6 * NQ * QSTRIDE * 4, st));
     // The stage is bounded by the longest rANS chain (the densest chunk), a single wave, and several of the parallel
     // kernels in front of it are latency-bound per chunk as well.  The chunks are ordered by a density estimate and cut
@@ -1662,9 +1682,9 @@ int encode_core(jpk_ctx *ctx, const uint8_t *d_in, EncDims &d, EncBufs &b, int i
         return JPK_OK;
     };
     auto chain = [&](const EncDims &g) -> int {
-        JPK_LAUNCH(ctx, PROF_ENC_RANS, 0, k_rans_lanes, dim3(g.ncl), dim3(64), b.recs, stride, g, b.rlen, b.xs, b.fstate, b.stamp);
+        JPK_LAUNCH(ctx, PROF_ENC_RANS, 0, k_rans_lanes, dim3(g.ncl), dim3(64), b.recs, stride, g, b.rlen, b.x16, b.emask, b.fstate, b.stamp);
         const uint32_t etpc = emit_tiles_per_chunk(stride);
-        JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_emit_count, dim3(etpc, g.ncl), dim3(TB), b.xs, b.fr16, stride, g, b.rlen, b.etsum, etpc);
+        JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_emit_count, dim3(etpc, g.ncl), dim3(TB), b.emask, stride, g, b.rlen, b.etsum, etpc);
         JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_emit_prefix, dim3(g.ncl), dim3(64), g, b.rlen, b.etsum, etpc, b.csize);
         return JPK_OK;
     };
@@ -1769,7 +1789,7 @@ int jpk_ans_encode_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_
     }
     if (total > (uint64_t)out_cap) return JPK_E_CAPACITY;
     JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_headers, dim3(d.nch), dim3(TB), d, b.hdr, b.hsize, b.outoff, b.fstate, d_out);
-    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_payload, dim3(emit_tiles_per_chunk(stride), d.nch), dim3(TB), b.xs, b.fr16, stride, d, b.rlen, b.etsum,
+    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_payload, dim3(emit_tiles_per_chunk(stride), d.nch), dim3(TB), b.x16, b.emask, stride, d, b.rlen, b.etsum,
                emit_tiles_per_chunk(stride), b.csize, b.hsize, b.outoff, d_out);
     JPK_HIP(hipGetLastError());
     JPK_HIP(hipStreamSynchronize(st));
@@ -1833,7 +1853,7 @@ int jpk_ans_encode_group_device(jpk_ctx *ctx, int nblk, const uint8_t *d_stage, 
     }
     const size_t stride = d.chunk;
     JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_headers, dim3(d.nch), dim3(TB), d, b.hdr, b.hsize, b.outoff, b.fstate, (uint8_t *)nullptr);
-    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_payload, dim3(emit_tiles_per_chunk(stride), d.nch), dim3(TB), b.xs, b.fr16, stride, d, b.rlen, b.etsum,
+    JPK_LAUNCH(ctx, PROF_ENC_EMIT, 0, k_put_payload, dim3(emit_tiles_per_chunk(stride), d.nch), dim3(TB), b.x16, b.emask, stride, d, b.rlen, b.etsum,
                emit_tiles_per_chunk(stride), b.csize, b.hsize, b.outoff, (uint8_t *)nullptr);
     JPK_HIP(hipGetLastError());
     JPK_HIP(hipStreamSynchronize(st));

@@ -25,9 +25,11 @@
 //             successors -- what divsufsort's induced sorting does -- instead of log2(LCP) doubling rounds; see the comment at k_pair_dist.
 //   One ISA buffer: all reads of a round (k_gather_win) complete before its first write (kernel boundary), which is the
 //   condition under which parallel Larsson-Sadakane is exact.
-// No host round trip inside the loop: the number of active suffixes lives in device memory (SaState), every kernel is a
-// grid-stride loop that reads it, and the host only learns -- one round late, through an asynchronous copy -- when to stop
-// enqueueing rounds.
+// Host synchronisations (since round 5, JPK_SA_WAIT_ROUND = 1): the number of active suffixes lives in device memory (SaState) and every
+// kernel reads it there, but the host waits for the 20-byte copy of the previous round's counts in front of EVERY round (hipEventSynchronize:
+// a few microseconds while the other blocks in flight keep the GPU busy) and enqueues exactly the grids, the large-group passes and the
+// pair rounds that round needs; round 6 adds one 4-byte read back in front of round 0's pack kernel (which code k_key_final chose).
+// JPK_SA_WAIT_ROUND=3 keeps rounds 1 and 2 enqueued blind, one round behind the host's knowledge (rounds 2-4).
 // Every array stays in HBM: T n, ISA 4n, BWT-in-SA-order n, radix ping-pong 24n (re-used by the rounds), active list 8n.
 #include "common.hpp"
 #include "prims.hpp"
@@ -105,8 +107,11 @@ __device__ __forceinline__ uint64_t mask_upto(int l) { return (l >= 63) ? ~0ull 
 __device__ __forceinline__ uint32_t top_bit(uint64_t v) { return 63u - (uint32_t)__clzll((long long)v); }   // v != 0
 
 // ---- single-workgroup scans over small per-tile / per-window arrays (1024 threads) -----------------------------------
-constexpr int WG1 = 1024;
-constexpr int WG1_ITEMS = 8;
+// (256 threads x 32 items since round 6 -- rounds 1-5: 1024 x 8.  A workgroup of 1024 needs sixteen free wave slots on ONE CU at the same
+// moment; among the blocks in flight of the timed loop these kernels waited 100-500 us for that -- k_win_scan1 211 us on average for 3.5 us
+// of work, profiles/r05_kernel_stats_bench_loop.txt -- and every kernel behind them on the block's stream with them.)
+constexpr int WG1 = 256;
+constexpr int WG1_ITEMS = 32;
 // out[i] = scan of in[0..i] (inclusive) or in[0..i-1] (exclusive) starting from `init`; REV walks the array backwards
 // (suffix scan).  Returns the reduction of everything (all threads).  in == out is allowed.
 template <class Op, bool EXCL, bool REV>
@@ -266,35 +271,39 @@ __global__ __launch_bounds__(256) void k_pair_counts(const uint8_t *__restrict__
 
 // Order-2 contexts: the (at most) JPK_O2_CLASSES most frequent byte pairs of the sample get a row of their own in the code table -- the
 // largest count threshold that admits no more than that many pairs, found by bisection over the 65 536 pair counts (one workgroup of
-// 1024, 64 counts per thread in registers).  ctxmap[c2 << 8 | c1] = the row that codes a symbol behind the bytes c2 c1: 256 + the pair's
+// 256, 256 counts per thread in registers).  ctxmap[c2 << 8 | c1] = the row that codes a symbol behind the bytes c2 c1: 256 + the pair's
 // rank among the chosen ones, or c1 -- the order-1 row -- for every other pair.
 constexpr uint32_t JPK_O2_CLASSES = 1024;
 static_assert(JPK_O2_CLASSES <= 1024 && 256 + JPK_O2_CLASSES <= 65535, "k_triple_counts keeps 64 rows of counters per group of sixteen; ctxmap holds rows in 16 bits");
-__global__ __launch_bounds__(1024) void k_ctx_select(const uint32_t *__restrict__ ctab, uint16_t *__restrict__ ctxmap, SaState *__restrict__ st)
+__global__ __launch_bounds__(256) void k_ctx_select(const uint32_t *__restrict__ ctab, uint16_t *__restrict__ ctxmap, SaState *__restrict__ st)
 {
-    __shared__ uint32_t sm[1024 / 64 + 1];
-    uint32_t c[32];                                                       // two counts per register, saturated at 65 535 (the order at the threshold is what matters)
+    // (one workgroup of 256 threads, 256 counts each, since round 6: the 1024-thread form waited 490 us on average in the timed loop for
+    // sixteen free wave slots on one CU -- 38 us alone)
+    constexpr int NT = 256, NR = 65536 / NT / 2;                          // 128 registers of two counts
+    __shared__ uint32_t sm[NT / 64 + 1];
+    uint32_t c[NR];                                                       // two counts per register, saturated at 65 535 (the order at the threshold is what matters)
 #pragma unroll
-    for (int k = 0; k < 32; k++) {
-        const uint2 v = reinterpret_cast<const uint2 *>(ctab)[threadIdx.x * 32u + k];
-        c[k] = (v.x < 65535u ? v.x : 65535u) | ((v.y < 65535u ? v.y : 65535u) << 16);
+    for (int k = 0; k < NR / 2; k++) {
+        const uint4 v = reinterpret_cast<const uint4 *>(ctab)[threadIdx.x * (NR / 2) + k];
+        c[2 * k] = (v.x < 65535u ? v.x : 65535u) | ((v.y < 65535u ? v.y : 65535u) << 16);
+        c[2 * k + 1] = (v.z < 65535u ? v.z : 65535u) | ((v.w < 65535u ? v.w : 65535u) << 16);
     }
     uint32_t lo = 1u, hi = 65536u;
     while (lo < hi) {                                                     // smallest threshold with at most JPK_O2_CLASSES pairs at or above it
         const uint32_t mid = (lo + hi) >> 1;
         uint32_t mine = 0, tot;
 #pragma unroll
-        for (int k = 0; k < 32; k++) mine += ((c[k] & 0xFFFFu) >= mid ? 1u : 0u) + ((c[k] >> 16) >= mid ? 1u : 0u);
+        for (int k = 0; k < NR; k++) mine += ((c[k] & 0xFFFFu) >= mid ? 1u : 0u) + ((c[k] >> 16) >= mid ? 1u : 0u);
         block_incl_scan<OpSum>(mine, sm, &tot);
         if (tot <= JPK_O2_CLASSES) hi = mid; else lo = mid + 1u;
     }
     uint32_t mine = 0, tot;
 #pragma unroll
-    for (int k = 0; k < 32; k++) mine += ((c[k] & 0xFFFFu) >= lo ? 1u : 0u) + ((c[k] >> 16) >= lo ? 1u : 0u);
+    for (int k = 0; k < NR; k++) mine += ((c[k] & 0xFFFFu) >= lo ? 1u : 0u) + ((c[k] >> 16) >= lo ? 1u : 0u);
     uint32_t rank = block_incl_scan<OpSum>(mine, sm, &tot) - mine;
 #pragma unroll
-    for (int k = 0; k < 32; k++) {
-        const uint32_t i = threadIdx.x * 64u + 2u * k;
+    for (int k = 0; k < NR; k++) {
+        const uint32_t i = threadIdx.x * (2u * NR) + 2u * k;
         const uint32_t r0 = (c[k] & 0xFFFFu) >= lo ? 256u + rank++ : (i & 255u);
         const uint32_t r1 = (c[k] >> 16) >= lo ? 256u + rank++ : ((i + 1u) & 255u);
         reinterpret_cast<uint32_t *>(ctxmap)[i >> 1] = r0 | (r1 << 16);
@@ -478,7 +487,7 @@ __global__ __launch_bounds__(256) void k_key_final(SaState *__restrict__ st, con
     if (threadIdx.x == 0) {
         st->vmode = mode;
         st->tag_shift = (uint32_t)tag_shift;
-        st->tag_max = (tag_shift <= 26) ? 63u : ((1u << (32 - tag_shift)) - 1u);
+        st->tag_max = (tag_shift <= 26 || tag_shift >= 32) ? 63u : ((1u << (32 - tag_shift)) - 1u);      // (32: the depths stay in their own array, see r0_short)
         const uint32_t avg_d = (uint32_t)(mode == 3u ? d2 : mode == 2u ? d1 : d0);   // symbols an average key holds (the statistics' key depth)
         st->depth = avg_d ? avg_d : 1u;
     }
@@ -657,6 +666,9 @@ __global__ __launch_bounds__(TB) void k_pack_keys_var(const uint8_t *__restrict_
                     if (x0 + jx < cnt) { P[base + x0 + jx] = key[jx]; D0[base + x0 + jx] = (uint8_t)(dep >> (8 * jx)); }
             }
         }
+        // the slots between the text's end and the end of the last tile: the largest key, so that the radix sort (stable, fed whole
+        // tiles since round 6) leaves them behind every suffix; nothing reads them afterwards
+        for (uint32_t x = cnt + threadIdx.x; x < (uint32_t)CT; x += TB) { P[base + x] = ~0ull; D0[base + x] = 0; }
     }
 }
 
@@ -793,6 +805,9 @@ __global__ __launch_bounds__(TB) void k_pack_keys_o2(const uint8_t *__restrict__
                     if (x0 + jx < cnt) { P[base + x0 + jx] = key[jx]; D0[base + x0 + jx] = (uint8_t)(dep >> (8 * jx)); }
             }
         }
+        // the slots between the text's end and the end of the last tile: the largest key, so that the radix sort (stable, fed whole
+        // tiles since round 6) leaves them behind every suffix; nothing reads them afterwards
+        for (uint32_t x = cnt + threadIdx.x; x < (uint32_t)CT; x += TB) { P[base + x] = ~0ull; D0[base + x] = 0; }
     }
 }
 
@@ -858,6 +873,7 @@ __global__ __launch_bounds__(TB) void k_pack_keys(const uint8_t *__restrict__ T,
                 }
             }
         }
+        for (uint32_t x = cnt + threadIdx.x; x < (uint32_t)CT; x += TB) { P[base + x] = ~0ull; if (D0) D0[base + x] = 0; }   // pad slots of the last tile: see k_pack_keys_var
         __syncthreads();
         if (tilehist) {
             uint32_t sum = 0;
@@ -881,16 +897,25 @@ __device__ __forceinline__ uint32_t r0_end(uint64_t key, uint32_t n, const uint3
 // vmode (variable-length keys): the sorted value carries the key's depth in its upper bits (from SaState::tag_shift up) and a
 // suffix is "short" (a group of its own) when its depth reaches the end of the text: every symbol it has is in the key
 // (in vmode the parameter D of the helpers below is the tag shift, not a depth)
-__device__ __forceinline__ bool r0_short(uint32_t v, uint64_t key, uint32_t n, const uint32_t *__restrict__ bend, uint32_t D, bool vmode)
+// Blocks above 2^28 bytes (round 6; format.hpp:22 allows 1000 MiB): a 29- or 30-bit suffix number leaves no room for a depth, so the tag
+// shift is 32 -- nothing rides in the value -- and the depth of suffix s is read from the slots' own array, Dx[n - 1 - s] (slot j holds
+// suffix n - 1 - j; sa_layout gives the array a buffer of its own there).  Only a suffix within 63 symbols of its end can be short, so
+// the heads cost no extra read; what does is the depth of every unresolved group (one random byte per group head, k_r0_finish).
+__device__ __forceinline__ bool r0_short(uint32_t v, uint64_t key, uint32_t n, const uint32_t *__restrict__ bend, uint32_t D, bool vmode,
+                                         const uint8_t *__restrict__ Dx = nullptr)
 {
+    if (vmode && Dx) {
+        const uint32_t e = r0_end(key, n, bend);
+        return (uint64_t)v + 63u >= e && v + Dx[n - 1u - v] >= e;
+    }
     return vmode ? (v & ((1u << D) - 1u)) + (v >> D) >= r0_end(key, n, bend) : v + D > r0_end(key, n, bend);
 }
 __device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t j, uint32_t n, const uint32_t *__restrict__ bend,
-                                        uint32_t D, bool vmode)
+                                        uint32_t D, bool vmode, const uint8_t *__restrict__ Dx)
 {
     if (j == 0) return true;
     const uint64_t a = keys[j], b = keys[j - 1];
-    return ((a ^ b) >> (bend ? 0 : 8)) != 0ull || r0_short(sa[j], a, n, bend, D, vmode) || r0_short(sa[j - 1], b, n, bend, D, vmode);   // bits 7..0 carry T[sa-1], not key
+    return ((a ^ b) >> (bend ? 0 : 8)) != 0ull || r0_short(sa[j], a, n, bend, D, vmode, Dx) || r0_short(sa[j - 1], b, n, bend, D, vmode, Dx);   // bits 7..0 carry T[sa-1], not key
 }
 
 // head words of one 4096-slot tile: HE[word] = heads | slots past the end (so that "the next slot is a head" is one shift),
@@ -900,7 +925,8 @@ __device__ __forceinline__ bool r0_head(const uint64_t *__restrict__ keys, const
 // and "the suffix in front is shorter than D bytes" is the shifted ballot of the row's own "short" bits.
 // (vmode: sj[] comes back WITH the depth tag in its upper bits)
 __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n, uint32_t base, uint64_t *HE,
-                                              uint64_t (&kj)[CT_ITEMS], uint32_t (&sj)[CT_ITEMS], const uint32_t *__restrict__ bend, uint32_t D, bool vmode)
+                                              uint64_t (&kj)[CT_ITEMS], uint32_t (&sj)[CT_ITEMS], const uint32_t *__restrict__ bend, uint32_t D, bool vmode,
+                                              const uint8_t *__restrict__ Dx)
 {
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const uint32_t j0 = base + w * (64 * CT_ITEMS);
@@ -915,7 +941,7 @@ __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys,
     const uint64_t kb = keys[jb];
     const uint32_t sb = sa[jb];
     uint32_t plo = (uint32_t)kb, phi = (uint32_t)(kb >> 32);
-    uint64_t carry_short = (j0 && r0_short(sb, kb, n, bend, D, vmode)) ? 1ull : 0ull;
+    uint64_t carry_short = (j0 && r0_short(sb, kb, n, bend, D, vmode, Dx)) ? 1ull : 0ull;
     const int low_shift = bend ? 0 : 8;                                              // bits 7..0 carry T[sa-1], not key -- or the block number, which is key
 #pragma unroll
     for (int k = 0; k < CT_ITEMS; k++) {
@@ -924,7 +950,7 @@ __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys,
         const uint32_t qlo = (uint32_t)__builtin_amdgcn_update_dpp((int)plo, (int)lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
         const uint32_t qhi = (uint32_t)__builtin_amdgcn_update_dpp((int)phi, (int)hi, 0x138, 0xf, 0xf, false);
         const bool differs = (((lo ^ qlo) >> low_shift) | (hi ^ qhi)) != 0u;
-        const uint64_t S = __ballot(r0_short(sj[k], kj[k], n, bend, D, vmode));      // a suffix with fewer than `depth` bytes is a group of its own
+        const uint64_t S = __ballot(r0_short(sj[k], kj[k], n, bend, D, vmode, Dx));      // a suffix with fewer than `depth` bytes is a group of its own
         const uint64_t b = __ballot(differs || j >= n || j == 0) | S | (S << 1) | carry_short;
         if (l == 0) HE[w * CT_ITEMS + k] = b;
         carry_short = S >> 63;
@@ -933,7 +959,7 @@ __device__ __forceinline__ void r0_tile_heads(const uint64_t *__restrict__ keys,
     }
     if (threadIdx.x == 0) {
         const uint32_t jn = base + CT;
-        HE[64] = (jn >= n || r0_head(keys, sa, jn, n, bend, D, vmode)) ? 1ull : 0ull;
+        HE[64] = (jn >= n || r0_head(keys, sa, jn, n, bend, D, vmode, Dx)) ? 1ull : 0ull;
     }
 }
 __device__ __forceinline__ uint64_t valid_word(uint32_t word_base, uint32_t n)
@@ -946,7 +972,7 @@ __device__ __forceinline__ uint64_t valid_word(uint32_t word_base, uint32_t n)
 // per tile: 1 + position of its last head (0: none), number of suffixes that stay unresolved
 __global__ __launch_bounds__(TB) void k_r0_count(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ sa, uint32_t n,
                                                 uint32_t *__restrict__ tLast, uint32_t *__restrict__ tSurv, const uint32_t *__restrict__ bend,
-                                                const SaState *__restrict__ st)
+                                                const SaState *__restrict__ st, const uint8_t *__restrict__ Dx)
 {
     __shared__ uint64_t HE[65];
     const uint32_t ntiles = (n + CT - 1) / CT;
@@ -957,7 +983,7 @@ __global__ __launch_bounds__(TB) void k_r0_count(const uint64_t *__restrict__ ke
         __syncthreads();
         uint64_t kj[CT_ITEMS];
         uint32_t sj[CT_ITEMS];
-        r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend, D, vmode);
+        r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend, D, vmode, Dx);
         __syncthreads();
         if (threadIdx.x < 64) {
             const int l = threadIdx.x;
@@ -996,7 +1022,8 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                                                  const uint32_t *__restrict__ tCarry, const uint32_t *__restrict__ tOff,
                                                  uint32_t *__restrict__ ISA, uint8_t *__restrict__ bwt, uint32_t *__restrict__ SA,
                                                  uint32_t *__restrict__ a_sa, uint32_t *__restrict__ a_grp, uint8_t *__restrict__ a_prev, SaState *__restrict__ st,
-                                                 const uint32_t *__restrict__ bend, uint32_t *__restrict__ GD, uint64_t *lb_status, uint32_t *lb_ticket)
+                                                 const uint32_t *__restrict__ bend, uint32_t *__restrict__ GD, uint64_t *lb_status, uint32_t *lb_ticket,
+                                                 const uint8_t *__restrict__ Dx)
 {
     // lb_status != null (round 5): ONE pass -- the tile learns the survivors in front of it and the last head in front of it by decoupled
     // look-back over the tiles before it (ticket order; one 64-bit word per tile = flag | survivors << 31 | 1 + last head, agent-scope
@@ -1015,7 +1042,7 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
     const bool vmode = st->vmode != 0u;
     const uint32_t D = vmode ? st->tag_shift : st->depth, code_shift = 56u - st->bits;
     const uint64_t rep = st->rep;
-    const uint32_t TAGM = vmode ? (1u << D) - 1u : 0xFFFFFFFFu;
+    const uint32_t TAGM = (vmode && !Dx) ? (1u << D) - 1u : 0xFFFFFFFFu;       // (Dx: blocks above 2^28 bytes, no tag in the value -- r0_short)
     if (vmode) {
         runkey[threadIdx.x] = st->vrunkey[threadIdx.x];
         vtop[threadIdx.x] = st->vtop[threadIdx.x];
@@ -1033,7 +1060,7 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
         const uint32_t base = tile * CT;
         uint64_t kj[CT_ITEMS];
         uint32_t sj[CT_ITEMS];
-        r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend, D, vmode);
+        r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend, D, vmode, Dx);
         __syncthreads();
         uint32_t carry = lb_status ? 0u : tCarry[tile];
         if (threadIdx.x < 64) {
@@ -1130,7 +1157,7 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (runsorted[mid] < k7) lo = mid + 1u; else hi = mid; }
                             inrun = lo < s_sigma && runsorted[lo] == k7;
                         }
-                        if ((HE[word] >> l) & 1ull) GD[grp] = sj[k] >> D;      // the group's depth, written by its first member
+                        if ((HE[word] >> l) & 1ull) GD[grp] = Dx ? (uint32_t)Dx[n - 1u - s] : sj[k] >> D;      // the group's depth, written by its first member
                     } else inrun = k7 == (k7 >> code_shift) * rep;
                     nrun += inrun ? 1u : 0u;
                     a_sa[pos] = s;
@@ -2510,7 +2537,7 @@ struct SaBufs {
     uint8_t *a_prev, *b_prev, *p_alt;      // T[sa - 1] of every active suffix: travels with (sa, rank) through the rounds
     uint32_t *RL;                          // remaining run length per text position (written only when round 0 leaves run members behind)
     uint32_t *GD[2] = {nullptr, nullptr};  // variable-length keys: depth of every unresolved group by its rank, read side / write side of a round
-    uint8_t *D0 = nullptr;                 // ... and the depth of every slot's key (rides through the radix sort in the value's upper bits)
+    uint8_t *D0 = nullptr;                 // ... and the depth of every slot's key (rides through the radix sort in the value's upper bits up to 2^28 bytes)
     uint32_t *ctab = nullptr;              // ... and the table of the context codes (256 bytes + 1024 pairs of bytes, 256 codes each)
     uint16_t *ctxmap = nullptr;
     const uint8_t *blk = nullptr;          // group sort: block number of every text position, and where every block ends (device)
@@ -2557,21 +2584,23 @@ bool var_keys_on()
 }
 // variable-length keys: sorts (one block, or a group of small ones) of at most 2^28 bytes (the key's depth rides in the spare bits of the 32-bit suffix number:
 // six up to 2^26 bytes, five up to 2^27, four -- depths clamped at 15 -- up to 2^28), the one-pass radix form, no forced code width
-bool var_keys_eligible(size_t n, bool group) { (void)group; return n <= ((size_t)1 << 28) && var_keys_on() && jpk_radix_onesweep() && key_force_bits() == 0; }
-int var_tag_shift(size_t n) { int s = 26; while (((size_t)1 << s) < n) s++; return s; }
+// (round 6: above 2^28 bytes -- JPK_MAX_BLOCKSIZE is 1000 MiB, format.hpp:22 -- the depths stay in the slots' own array: tag shift 32, r0_short)
+bool var_keys_eligible(size_t n, bool group) { (void)group; return n < ((size_t)1 << 30) && var_keys_on() && jpk_radix_onesweep() && key_force_bits() == 0; }
+int var_tag_shift(size_t n) { if (n > ((size_t)1 << 28)) return 32; int s = 26; while (((size_t)1 << s) < n) s++; return s; }
 
 void sa_layout(Arena &a, size_t n, SaBufs &b, bool var)
 {
     const size_t nwin = n / SEG_TILE + 2, ntile = n / CT + 2;
     memset(&b, 0, sizeof b);
-    b.keysA = a.get<uint64_t>(n);
-    b.keysB = a.get<uint64_t>(n);
-    b.valsA = a.get<uint32_t>(n);
-    b.valsB = a.get<uint32_t>(n);
+    // (+ CT: round 0 sorts whole tiles -- the pack kernels fill the slots behind the text's end with the largest key)
+    b.keysA = a.get<uint64_t>(n + CT);
+    b.keysB = a.get<uint64_t>(n + CT);
+    b.valsA = a.get<uint32_t>(n + CT);
+    b.valsB = a.get<uint32_t>(n + CT);
     b.ISA = a.get<uint32_t>(n);
     b.a_sa = a.get<uint32_t>(n);
     b.a_grp = a.get<uint32_t>(n);
-    b.bwt = a.get<uint8_t>(n);
+    b.bwt = a.get<uint8_t>(n + CT);
     b.a_prev = a.get<uint8_t>(n);
     b.b_prev = a.get<uint8_t>(n);
     b.p_alt = a.get<uint8_t>(n);
@@ -2579,7 +2608,8 @@ void sa_layout(Arena &a, size_t n, SaBufs &b, bool var)
     if (var) {
         b.GD[0] = a.get<uint32_t>(n);
         b.GD[1] = a.get<uint32_t>(n);
-        b.D0 = b.bwt;                         // (the slots' depths are read by the radix sort's first pass; the BWT bytes arrive from k_r0_finish on)
+        // (the slots' depths are read by the radix sort's first pass; the BWT bytes arrive from k_r0_finish on -- which, above 2^28 bytes, still reads the depths)
+        b.D0 = var_tag_shift(n) < 32 ? b.bwt : a.get<uint8_t>(n + CT);
         // the context codes: sampled counts, then code | length << 27 of byte s behind byte c (rows 0..255) or behind a chosen pair of bytes
         b.ctab = a.get<uint32_t>(256 * (256 + JPK_O2_CLASSES));
         b.ctxmap = a.get<uint16_t>(65536);    // the row that codes a symbol behind the bytes c2 c1
@@ -2597,7 +2627,7 @@ void sa_layout(Arena &a, size_t n, SaBufs &b, bool var)
     b.pLast = a.get<uint32_t>(2 * nwin);
     b.pieces = a.get<Piece>(2 * nwin);
     b.state = a.get<SaState>(1);
-    b.scratch = a.get<uint32_t>(jpk_radix_scratch_words(n));
+    b.scratch = a.get<uint32_t>(jpk_radix_scratch_words(n + CT));
 }
 
 inline unsigned cap_grid(size_t work, unsigned per_block, unsigned cap)
@@ -2703,7 +2733,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         const uint32_t nv = n / 16u, stride = (nv >> 16) ? (nv >> 16) : 1u;
         JPK_LAUNCH(ctx, PROF_SA_PACK, 0, k_pair_counts, dim3(16, 16), dim3(256), T, n, stride, b.ctab);
         if (o2) {
-            JPK_LAUNCH(ctx, PROF_SCAN, 0, k_ctx_select, dim3(1), dim3(1024), b.ctab, b.ctxmap, b.state);
+            JPK_LAUNCH(ctx, PROF_SCAN, 0, k_ctx_select, dim3(1), dim3(256), b.ctab, b.ctxmap, b.state);
             JPK_LAUNCH(ctx, PROF_SA_PACK, 0, k_triple_counts, dim3(16, 16), dim3(256), T, n, stride, b.ctxmap, b.ctab);
         }
     }
@@ -2713,16 +2743,39 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_key_final, dim3(1), dim3(256), b.state, o1 ? b.ctab : (uint32_t *)nullptr, o2 ? b.ctxmap : (uint16_t *)nullptr,
                    var_tag_shift(n), order);
     }
-    // (with the variable-length codes in play this kernel usually finds vmode set and leaves at once -- but every workgroup of a full grid
-    // first has to get its 44 KB of LDS on a CU that the other blocks in flight are using: 1.2 ms of the block's stream in the timed loop.
-    // A grid of 1024 walks the tiles instead when it does have work: flat data, whose pack is 0.3 ms of a 6 ms sort.)
-    JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_pack_keys, dim3(cap_grid(n, CT, var ? 1024u : CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend,
-               jpk_radix_onesweep() ? (uint32_t *)nullptr : b.scratch, b.D0);
-    if (var) JPK_LAUNCH(ctx, PROF_SA_PACK, 0, (k_pack_keys_var<false>), dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.D0, (const uint32_t *)nullptr);
-    if (o1) JPK_LAUNCH(ctx, PROF_SA_PACK, 0, (k_pack_keys_var<true>), dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.D0, (const uint32_t *)b.ctab);
-    if (o2) JPK_LAUNCH(ctx, PROF_SA_PACK, 0, k_pack_keys_o2, dim3(cap_grid(n, CT, CAP)), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.D0, (const uint32_t *)b.ctab,
-                       (const uint16_t *)b.ctxmap);
-    JPK_TRY(jpk_radix_sort_slot_keys(ctx, n, b.keysA, b.valsA, b.keysB, b.valsB, b.scratch, &ks, &vs, b.blk != nullptr, b.D0, var_tag_shift(n)));
+    // Which code did k_key_final choose?  One 4-byte read back (round 6; the host waits in front of every round anyway): exactly one pack
+    // kernel is launched.  Rounds 4-5 enqueued all four and let the device pick: the three that "leave at once" averaged 524 + 210 + 189 us
+    // in the timed loop -- every workgroup of a full grid first has to get its LDS on a CU that the other blocks in flight are using --
+    // and held the block's stream meanwhile (profiles/r05_kernel_stats_bench_loop.txt).
+    uint32_t vmode_h = 0;
+    if (var) {
+        JPK_HIP(hipMemcpyAsync(&ctx->h_mail[120], &b.state->vmode, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        JPK_HIP(hipEventRecord(ctx->ev_sa[1], st));
+        JPK_HIP(hipEventSynchronize(ctx->ev_sa[1]));
+        vmode_h = ctx->h_mail[120];
+        if (vmode_h > 3u) return JPK_E_DEVICE;
+    }
+    const unsigned g_pack = cap_grid(n, CT, CAP);
+    switch (vmode_h) {
+    case 0:
+        JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_pack_keys, dim3(g_pack), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, jpk_radix_onesweep() ? (uint32_t *)nullptr : b.scratch, b.D0);
+        break;
+    case 1:
+        JPK_LAUNCH(ctx, PROF_SA_PACK, n, (k_pack_keys_var<false>), dim3(g_pack), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.D0, (const uint32_t *)nullptr);
+        break;
+    case 2:
+        JPK_LAUNCH(ctx, PROF_SA_PACK, n, (k_pack_keys_var<true>), dim3(g_pack), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.D0, (const uint32_t *)b.ctab);
+        break;
+    default:
+        JPK_LAUNCH(ctx, PROF_SA_PACK, n, k_pack_keys_o2, dim3(g_pack), dim3(TB), T, n, b.state, b.keysA, b.blk, b.bend, b.D0, (const uint32_t *)b.ctab, (const uint16_t *)b.ctxmap);
+        break;
+    }
+    // whole tiles for the one-pass radix sort (the pack kernels have filled the pad slots): no pass needs a second, one-workgroup launch
+    // for a partial last tile (seven per block, 200-360 us each in the timed loop)
+    const uint32_t n_sort = jpk_radix_onesweep() ? (uint32_t)(((size_t)n + CT - 1) / CT * CT) : n;
+    const bool tagless = var && var_tag_shift(n) >= 32;        // blocks above 2^28 bytes: nothing rides in the value (r0_short)
+    JPK_TRY(jpk_radix_sort_slot_keys(ctx, n_sort, b.keysA, b.valsA, b.keysB, b.valsB, b.scratch, &ks, &vs, b.blk != nullptr, tagless ? (const uint8_t *)nullptr : b.D0, tagless ? 26 : var_tag_shift(n), n));
+    const uint8_t *Dx = tagless ? b.D0 : (const uint8_t *)nullptr;
     ctx->stats.sa_sorted_elems += n;
     // The sorted pairs sit in (ks, vs).  The other pair of radix buffers is free from here on, the pair that holds the result
     // once k_r0_finish has read it: the doubling rounds live in them.
@@ -2742,18 +2795,35 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
         uint32_t *lb_ticket = reinterpret_cast<uint32_t *>(lb_status + ntiles0 + 1);
         JPK_HIP(hipMemsetAsync(lb_status, 0, sizeof(uint64_t) * (ntiles0 + 2), st));
         JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev, b.state, b.bend, b.GD[0],
-                   lb_status, lb_ticket);
+                   lb_status, lb_ticket, Dx);
     } else {
-        JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_count, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.bend, b.state);
+        JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_count, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.bend, b.state, Dx);
         JPK_LAUNCH(ctx, PROF_SCAN, 0, k_r0_scan, dim3(1), dim3(WG1), b.tA, b.tB, n, b.state);
         JPK_LAUNCH(ctx, PROF_SA_RERANK, n, k_r0_finish, dim3(g_ct), dim3(TB), ks, vs, n, b.tA, b.tB, b.ISA, b.bwt, b.SA, b.a_sa, b.a_grp, b.a_prev, b.state, b.bend, b.GD[0],
-                   (uint64_t *)nullptr, (uint32_t *)nullptr);
+                   (uint64_t *)nullptr, (uint32_t *)nullptr, Dx);
     }
     ctx->stats.sa_rounds = 1;
-    // remaining run lengths, only if round 0 left members of runs of >= depth equal bytes behind (the kernels return at once otherwise)
-    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_first, dim3(cap_grid(n, CT, 4096)), dim3(TB), T, n, b.state, b.tA, b.blk);
-    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_scan, dim3(1), dim3(WG1), b.tA, n, b.state);
-    JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_fill, dim3(cap_grid(n, CT, 4096)), dim3(TB), T, n, b.state, b.tA, b.RL, b.blk);
+    uint32_t *h_m = ctx->h_mail + 16;              // pinned: h_m[8 * (r & 1) ..] receives {m[0], m[1], npieces, lc, nrun} as round r leaves them
+    static_assert(offsetof(SaState, nrun) == 16, "the rounds' copy takes m[2], npieces, lc, nrun in one piece");
+    JPK_HIP(hipMemcpyAsync(&h_m[0], &b.state->m[0], 20, hipMemcpyDeviceToHost, st));
+    JPK_HIP(hipEventRecord(ctx->ev_sa[0], st));
+    // JPK_SA_WAIT_ROUND: the first round that is enqueued on exact counts (default 1 since the context codes: round 1 of text starts with
+    // 27 M of 67 M suffixes, round 2 with 49 K -- 48 windows, no large group; enqueued blind they were 65 K / 26 K workgroups per kernel and, in
+    // round 2, 23 launches for nothing.  The wait is a few microseconds in front of a round; 3 = round 4's rule)
+    static const int wait_round = [] { const char *e = getenv("JPK_SA_WAIT_ROUND"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+    // remaining run lengths, only if round 0 left members of runs of >= depth equal bytes behind.  The host knows (round 6: it waits for
+    // round 0's counts here, where round 1 would wait a moment later): the three kernels -- 130-160 us each in the timed loop to find
+    // nothing to do -- are launched only when there is (enqueued blind they return at once otherwise)
+    bool runs_possible = true;
+    if (wait_round <= 1) {
+        JPK_HIP(hipEventSynchronize(ctx->ev_sa[0]));
+        runs_possible = h_m[4] != 0u;
+    }
+    if (runs_possible) {
+        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_first, dim3(cap_grid(n, CT, 4096)), dim3(TB), T, n, b.state, b.tA, b.blk);
+        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_scan, dim3(1), dim3(WG1), b.tA, n, b.state);
+        JPK_LAUNCH(ctx, PROF_SCAN, 0, k_run_fill, dim3(cap_grid(n, CT, 4096)), dim3(TB), T, n, b.state, b.tA, b.RL, b.blk);
+    }
 
     const int kbits = jpk_bits_for(3u * n);        // key2 <= n (a rank + 1); round 1 spreads the keys of groups of run members up to 3n; group rank < n
     int lg_pass = 0;
@@ -2765,10 +2835,6 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     // the previous round's counts first -- a few microseconds while other blocks keep the GPU busy -- and then enqueues exactly what is
     // needed: nothing when no suffix is unresolved (round 4: the trailing empty round is gone), no large-group passes (23 launches) once
     // a round has had no group above 1024 (groups only split: the count of their members never grows).
-    uint32_t *h_m = ctx->h_mail + 16;              // pinned: h_m[8 * (r & 1) ..] receives {m[0], m[1], npieces, lc, nrun} as round r leaves them
-    static_assert(offsetof(SaState, nrun) == 16, "the rounds' copy takes m[2], npieces, lc, nrun in one piece");
-    JPK_HIP(hipMemcpyAsync(&h_m[0], &b.state->m[0], 20, hipMemcpyDeviceToHost, st));
-    JPK_HIP(hipEventRecord(ctx->ev_sa[0], st));
     uint32_t bound = n;                            // upper bound of the active count of the round being enqueued
     bool large_possible = true;                    // a group above 1024 members may still exist
     // The pair rule (k_pair_*): from round 3 on -- the host knows the exact count there -- a round whose list is still a sizeable share
@@ -2779,10 +2845,6 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     int last_pair = -8;
     bool prev_pair = false;
     bool lg_heavy = false, runs_heavy = false;
-    // JPK_SA_WAIT_ROUND: the first round that is enqueued on exact counts (default 1 since the context codes: round 1 of text starts with
-    // 27 M of 67 M suffixes, round 2 with 49 K -- 48 windows, no large group; enqueued blind they were 65 K / 26 K workgroups per kernel and, in
-    // round 2, 23 launches for nothing.  The wait is a few microseconds in front of a round; 3 = round 4's rule)
-    static const int wait_round = [] { const char *e = getenv("JPK_SA_WAIT_ROUND"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
     uint32_t m_prev = n;                           // the list the previous round started with
     uint64_t pair_mask = 0;
     for (int round = 1;; round++) {
@@ -2840,8 +2902,10 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             JPK_LAUNCH(ctx, PROF_SA_RERANK, 0, k_pair_finish, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.a_prev, b.state, par, b.PH, b.NH, VL, BAD, b.ISA, b.bwt, b.SA,
                        b.b_sa, b.b_grp, b.b_prev);
         } else {
-        const uint32_t *gdr = var ? b.GD[gd] : nullptr;
-        uint32_t *gdw = var ? b.GD[gd ^ 1] : nullptr;
+        // (the groups' depths exist only when k_key_final chose a variable-length code: with the fixed-width code nothing wrote GD[0], and
+        // every new group would cost two random reads of uninitialised memory and a random write nobody uses -- ADVICE r5)
+        const uint32_t *gdr = vmode_h ? b.GD[gd] : nullptr;
+        uint32_t *gdw = vmode_h ? b.GD[gd ^ 1] : nullptr;
         JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_gather_win, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, n, hshift, b.ISA, b.k2, b.FH, b.LH, T, b.RL, round == 1 ? 1 : 0,
                    b.a_prev, b.bend, gdr);
         hshift++;

@@ -147,7 +147,8 @@ int jpk_radix_sort_pairs_u64_nocopy(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals
                                     const int *shifts, int nshifts, uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out);
 bool jpk_radix_onesweep();   // round 0's radix passes in the one-pass form (default; JPK_ONESWEEP=0: histogram + scan + scatter per pass)
 int jpk_radix_sort_slot_keys(jpk_ctx *ctx, uint32_t n, uint64_t *keysA, uint32_t *valsA, uint64_t *keysB, uint32_t *valsB,
-                             uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out, bool group, const uint8_t *slot_tag = nullptr, int tag_shift = 26);
+                             uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out, bool group, const uint8_t *slot_tag = nullptr, int tag_shift = 26,
+                             uint32_t slot_n = 0);
 // Heavy-phase gate (experiment, off by default -- see gate_on() in abi.hip for the numbers): the GPU-saturating phases of the
 // blocks in flight on one device -- the suffix sort and the wide kernels of the entropy stage in front of the rANS chains --
 // run one block after the other on the GPU, in the order the blocks arrive here, while the chains (a few waves that run for

@@ -168,6 +168,8 @@ struct OsArgs {
     const uint32_t *gdig;      // [256] exclusive global offsets of this pass's digit
     uint32_t *ticket;          // tile numbers of this pass
     int tag_shift;             // pass 0 with slot tags: the tag goes into the value's bits from here up
+    uint32_t slot_n;           // pass 0 (SLOTS): slot j holds suffix slot_n - 1 - j (the sort itself may cover pad slots behind slot_n - 1, whose
+                               // keys are the largest: the stable sort leaves them at the end)
 };
 constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_PFX = 2u << 30, OS_MASK = (1u << 30) - 1u;
 
@@ -185,10 +187,15 @@ __device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restric
     uint32_t val[RS_ITEMS];
     uint32_t rnk[RS_ITEMS];
     const uint64_t lt = lanemask_lt();
+    // (one-pass form) the digit's global offset is requested with the tile's pairs, in front of everything: loaded behind the look-back
+    // it made the wave wait for vmcnt(0) there -- i.e. for the acknowledgement of the two status stores in front of it, a memory round
+    // trip on the tile's critical path (round 6)
+    uint32_t gdig_d = 0;
+    if (LOOKBACK) gdig_d = os->gdig[threadIdx.x];
     if (FULL) {
         const uint64_t *kw = kin + tbase + (size_t)w * (64 * RS_ITEMS);      // wave-uniform
         const uint32_t *vw = vin + tbase + (size_t)w * (64 * RS_ITEMS);
-        const uint32_t v0 = (uint32_t)(n - 1 - (tbase + (size_t)w * (64 * RS_ITEMS)));   // SLOTS: slot j holds suffix n-1-j
+        const uint32_t v0 = (uint32_t)((os ? (size_t)os->slot_n : n) - 1 - (tbase + (size_t)w * (64 * RS_ITEMS)));   // SLOTS: slot j holds suffix n-1-j (pad slots wrap: never read)
 #pragma unroll
         for (int it = 0; it < RS_ITEMS; it++) {
             key[it] = kw[(uint32_t)(it * 64 + l)];
@@ -203,6 +210,18 @@ __device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restric
             for (int it = 0; it < RS_ITEMS; it++) val[it] |= tg[it] << (os ? os->tag_shift : 26);
         }
     } else rs_load_tile<SLOTS>(kin, vin, n, base, key, val, os ? os->tag_shift : 26);
+#ifdef JPK_OS_EARLY_AGG
+    // experiment (round 6): the tile's digit counts by LDS atomics as soon as its keys are there, published as the aggregate BEFORE the
+    // match phase, so that the tiles behind this one find it a match phase earlier (gbase holds the counts until the scan below)
+    if (LOOKBACK) {
+#pragma unroll
+        for (int it = 0; it < RS_ITEMS; it++)
+            if (FULL || base + (size_t)it * 64 < n) atomicAdd(&gbase[(uint32_t)(key[it] >> shift) & 255u], 1u);
+        __syncthreads();
+        const uint32_t s0 = gbase[threadIdx.x];
+        __hip_atomic_store(os->status + (size_t)tile * 256u + threadIdx.x, (tile == 0 ? OS_FLAG_PFX : OS_FLAG_AGG) | s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++) {
         const bool valid = FULL || base + (size_t)it * 64 < n;
@@ -228,9 +247,13 @@ __device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restric
         if (LOOKBACK) {
             uint32_t *row = os->status + (size_t)tile * 256u;
             uint32_t excl = 0;
+#ifdef JPK_OS_EARLY_AGG
+            if (tile != 0) {
+#else
             if (tile == 0) __hip_atomic_store(row + d, OS_FLAG_PFX | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else {
                 __hip_atomic_store(row + d, OS_FLAG_AGG | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
                 // The walk is latency: every word comes from the memory side (~1.5 us), and with ~1000 tiles resident a tile finds
                 // aggregates, not prefixes, for a long way back.  Four rows are requested at once and consumed in order; the walk
                 // stops at the first prefix, an unpublished word is polled alone.  (Forward BWT of a 64 MiB block with 1 / 2 / 3 / 4 / 8 / 16 /
@@ -261,7 +284,7 @@ __device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restric
                 __hip_atomic_store(row + d, OS_FLAG_PFX | (excl + s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             os->status_next[(size_t)tile * 256u + d] = 0u;
-            goff = os->gdig[d] + excl;
+            goff = gdig_d + excl;
         } else goff = tileoff[(size_t)d * ntiles + tile];
         gbase[d] = goff - ts;
     }
@@ -327,6 +350,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_scatter(const uint64_t *__res
     __shared__ uint32_t s_tile;
     if (threadIdx.x == 0) s_tile = atomicAdd(os.ticket, 1u);
     for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
+#ifdef JPK_OS_EARLY_AGG
+    gbase[threadIdx.x] = 0;
+#endif
     __syncthreads();
     const uint32_t tile = s_tile;
     rs_scatter_staged_tile<SLOTS, FULL, true>(kin, vin, kout, vout, n, shift, nullptr, ntiles, tile, cnt, gbase, stage, sm, &os);
@@ -460,10 +486,14 @@ int jpk_radix_sort_pairs_u64(jpk_ctx *ctx, uint64_t *keys, uint32_t *vals, uint6
 // `scratch`; its tiles are RS_TILE slots like ours) and lands in B; keysA is overwritten by the second.  Result: (*keys_out, *vals_out).
 // `slot_tag` (one-pass form only; may be null): a byte per slot that rides in the bits of the slot's value from `tag_shift` up through the
 // sort (the suffix sort's variable-length keys carry the number of symbols a key holds there); n <= 2^tag_shift, tag < 2^(32 - tag_shift).
+// `slot_n` (one-pass form only; 0 = n32): the sort covers n32 >= slot_n slots, the last n32 - slot_n of them pads with the largest key (the
+// caller rounds n32 up to whole tiles so that no pass needs a second launch for a partial tile); slot j < slot_n holds suffix slot_n - 1 - j.
 int jpk_radix_sort_slot_keys(jpk_ctx *ctx, uint32_t n32, uint64_t *keysA, uint32_t *valsA, uint64_t *keysB, uint32_t *valsB,
-                             uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out, bool group, const uint8_t *slot_tag, int tag_shift)
+                             uint32_t *scratch, uint64_t **keys_out, uint32_t **vals_out, bool group, const uint8_t *slot_tag, int tag_shift, uint32_t slot_n)
 {
-    if (slot_tag && (!rs_onesweep() || tag_shift < 1 || tag_shift > 31 || (uint64_t)n32 > (1ull << tag_shift))) return JPK_E_ARG;
+    if (slot_n == 0) slot_n = n32;
+    if (slot_n > n32 || (slot_n != n32 && (!rs_onesweep() || n32 % RS_TILE))) return JPK_E_ARG;
+    if (slot_tag && (!rs_onesweep() || tag_shift < 1 || tag_shift > 31 || (uint64_t)slot_n > (1ull << tag_shift))) return JPK_E_ARG;
     const size_t n = n32;
     *keys_out = keysB;
     *vals_out = valsB;
@@ -494,6 +524,7 @@ int jpk_radix_sort_slot_keys(jpk_ctx *ctx, uint32_t n32, uint64_t *keysA, uint32
             os.gdig = gdig + p * 256;
             os.ticket = tickets + p;
             os.tag_shift = tag_shift;
+            os.slot_n = slot_n;
             if (p == 0) {
                 launch_os_scatter<true>(ctx, keysA, reinterpret_cast<const uint32_t *>(slot_tag), keysB, valsB, n, shift, ntiles, os);
                 continue;

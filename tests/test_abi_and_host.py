@@ -175,11 +175,11 @@ def test_reserve_follows_the_stage_layouts():
     n = 64 << 20
     per_byte = [lib().jpk_debug_arena_bytes(n, st) / n for st in range(5)]
     assert 53 < per_byte[0] < 56          # forward BWT: radix ping-pong 24 n + ISA 4 n + active list 8 n + BWT bytes n + carried BWT bytes 3 n + run lengths 4 n + tables
-                                          # + the groups' depths 2 x 4 n (variable-length keys, blocks up to 2^28 bytes; 46.3 n with fixed-width keys)
+                                          # + the groups' depths 2 x 4 n (variable-length keys; + n above 2^28 bytes, where the slots' depths keep a buffer of their own; 46.3 n with fixed-width keys)
     assert 40 < per_byte[1] < 47          # rANS encode sized for text (0.55 RLE0 symbols per byte at ~75 bytes per symbol + ranks n + RLE0 symbols 2 n)
     assert 9 < per_byte[2] < 11           # inverse BWT
     assert 3 <= per_byte[3] < 3.2         # rANS decode bound
-    assert 75 < per_byte[4] < 85          # rANS encode, densest data (every byte a symbol): records 32 n, states 8 n, exponent histories 14 n, ...
+    assert 68 < per_byte[4] < 78          # rANS encode, densest data (every byte a symbol): records 32 n, states' low halves 4 n + emit masks 0.5 n (round 6; 8 n + a 4 n frequency sidecar before), exponent histories 14 n, ...
     assert lib().jpk_debug_arena_bytes(n, 5) == -1 and lib().jpk_debug_arena_bytes(-1, 0) == -1
 
 
@@ -208,6 +208,30 @@ def test_decoded_size_rejects_more_rle_symbols_than_bytes():
     with pytest.raises(jampack_amd.JampackError) as e:
         ans_decoded_size(bad)
     assert e.value.status == -3
+
+
+def test_multi_device_calls_on_disjoint_device_sets_run_side_by_side():
+    """the multi-device entries hold the mutexes of the devices of THEIR mask (ascending), not one process-wide mutex:
+    two files on two halves of a node compress concurrently, calls that share a device queue.  Host logic through the probe that takes
+    exactly those mutexes and holds them (no device call)."""
+    import threading
+    import time
+    from jampack_amd import lib
+
+    def span(masks, hold_ms=300):
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=lib().jpk_debug_multi_lock_probe, args=(m, hold_ms)) for m in masks]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        return time.perf_counter() - t0
+
+    assert lib().jpk_debug_multi_lock_probe(0b10110, 0) == 3
+    assert span([0b00001111, 0b11110000]) < 0.5               # disjoint halves of an 8-GPU node: side by side
+    assert span([0b0011, 0b1100, 0b110000]) < 0.5
+    assert span([0b00001111, 0b00011000]) >= 0.58             # they share device 3: one after the other
+    assert span([0b1, 0b1, 0b1]) >= 0.88
+    assert span([0b0101, 0b1010, 0b0110]) >= 0.58             # the third needs a device of each of the first two (no deadlock: ascending order)
+    assert lib().jpk_debug_multi_lock_probe(1, -1) == -1
 
 
 def test_multi_device_ownership_and_order():

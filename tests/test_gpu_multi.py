@@ -58,6 +58,19 @@ try:
     raise SystemExit("expected an error for the corrupt block")
 except jam.JampackError as e:
     assert e.status in (-3, -2), e.status
+# ... and the healthy blocks are THERE (ADVICE r5: the gather used to be skipped as a whole, their ranges pointed at garbage): every block
+# whose status is 0 is gathered at its range, the failed block's range is empty, the call returns the failed block's status
+d_back.zero_()
+boff, bst, brc = jam.blocks_decompress_multi(bad, raw, d_back, sum(raw) + 64, 0b1, check=False)
+assert brc in (-3, -2) and bst[0] == brc and bst[1:] == [0] * (len(blocks) - 1), (brc, bst)
+assert boff[1] - boff[0] == 0
+back = d_back.cpu().numpy()
+for i, t in enumerate(blocks):
+    if i:
+        assert boff[i + 1] - boff[i] == len(t) and np.array_equal(back[boff[i]: boff[i + 1]], t), i
+# when the gather cannot run nothing is reported as done: every status is an error, every range empty
+soff, sst, src = jam.blocks_compress_multi(blocks, small, 1000, 0b1, check=False)
+assert src == -2 and all(x != 0 for x in sst) and soff == [0] * (len(blocks) + 1), (src, sst, soff)
 # the caller's device is what it was, and a second call re-uses the slabs
 assert torch.cuda.current_device() == 0
 off2, st2 = jam.blocks_compress_multi(blocks, d_out, cap, 0b1, 4)
@@ -87,10 +100,12 @@ t_batch(); t_multi()
 tb = min(t_batch()[0] for _ in range(3)); n = t_batch()[1]
 tm = min(t_multi()[0] for _ in range(3)); off = t_multi()[1]
 tot = sum(len(b) for b in blocks)
-pcie = tot / 45e9                       # the multi entry also moves the blocks in from (pageable) host memory
-print("batch %%.1f ms = %%.0f MB/s, multi %%.1f ms = %%.0f MB/s (host copies ~%%.1f ms inside)" %% (tb * 1e3, tot / tb / 1e6, tm * 1e3, tot / tm / 1e6, pcie * 1e3))
+pcie = tot / 45e9                       # the multi entry also moves the blocks in from (pageable) host memory ...
+print("batch %%.1f ms = %%.0f MB/s, multi %%.1f ms = %%.0f MB/s (host copies ~%%.1f ms, under the blocks before them)" %% (tb * 1e3, tot / tb / 1e6, tm * 1e3, tot / tm / 1e6, pcie * 1e3))
 assert [off[i + 1] - off[i] for i in range(len(blocks))] == list(n)
-assert tm - pcie <= 1.10 * tb + 0.005, (tm, tb)
+# ... block k + 1 while block k is being compressed (round 6): the WALL time of the multi entry, copies included, within 10 %% of the batch
+# entry on resident inputs (round 5 subtracted an assumed PCIe time here: every copy sat in front of the first kernel)
+assert tm <= 1.10 * tb + 0.005, (tm, tb)
 jam.shutdown()
 print("speed ok")
 '''
@@ -106,8 +121,8 @@ def test_blocks_compress_multi_world1(force_rccl):
 
 
 def test_multi_entry_runs_at_the_batch_entry_speed():
-    """every device drives its blocks through jpk_dev_blocks_compress (8 in flight), not one block at a time: within 10 %
-    of that entry on the same blocks once the host-to-device copies the multi entry has to make are taken out"""
+    """every device drives its blocks through jpk_dev_blocks_compress (8 in flight), not one block at a time, and
+    moves block k + 1 in from host memory while block k is compressed: wall time within 10 % of that entry on resident inputs"""
     env = dict(os.environ)
     r = subprocess.run([sys.executable, "-c", SPEED % ROOT], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "speed ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -49,6 +49,56 @@ def _gen(rng):
     return bytes(s)
 
 
+def _fib(n):
+    x, y = bytes([0]), bytes([1])
+    while len(y) < n:
+        x, y = y, y + x
+    return y[:n]
+
+
+def _thue_morse(n):
+    return bytes(bin(i).count("1") & 1 for i in range(n))
+
+
+def _period_doubling(n):
+    s = bytes([0])
+    while len(s) < n:
+        s = b"".join(bytes([0, 1]) if c == 0 else bytes([0, 0]) for c in s)
+    return s[:n]
+
+
+def test_self_similar_words_any_schedule_of_pair_rounds():
+    """the Fibonacci, Thue-Morse and period-doubling words -- the classic worst cases of prefix doubling -- under every
+    schedule of pair rounds, also pair rounds that FOLLOW each other (the host's rule keeps doubling rounds between them; the rule itself
+    is sound whatever the schedule: it only finishes groups whose order is decided)"""
+    for word in (_fib, _thue_morse, _period_doubling):
+        for n in (1, 2, 3, 55, 89, 233, 610, 1000):
+            t = word(n)
+            want = _brute(t)
+            for d0 in (1, 3, 7):
+                for pr in ((), (2,), (2, 3, 4), (3, 4, 5, 6, 7, 8), (3, 6, 9, 12), tuple(range(2, 60))):
+                    sa, _ = suffix_array(t, d0, pr)
+                    assert sa == want, (word.__name__, n, d0, pr)
+
+
+def test_pair_rounds_do_not_replace_the_doubling_rounds_of_a_self_similar_word():
+    """Why the host keeps two doubling rounds between two pair rounds (bwt_fwd.hip build_sa) and the Fibonacci word stays the sort's
+    worst case (profiles/r06_structured_inputs.txt): on these words a pair round finishes part of the list, but what it leaves still needs
+    every doubling round -- log2(n / depth) of them, each over most of the block -- so denser schedules only ADD rounds.  (A period, two
+    copies, a run: one pair round finishes them, test_pair_rule_removes_the_rounds_of_a_long_repeat.)"""
+    for word in (_fib, _thue_morse, _period_doubling):
+        t = word(4000)
+        want = _brute(t)
+        rounds = {}
+        for name, pr in (("none", ()), ("every third", tuple(range(3, 60, 3))), ("every second", tuple(range(3, 60, 2))), ("from 3 on", tuple(range(3, 60)))):
+            sa, rounds[name] = suffix_array(t, 7, pr)
+            assert sa == want, (word.__name__, name)
+        doubling = rounds["none"] - 1
+        assert doubling >= 8                                   # ~ log2(4000 / 7)
+        assert rounds["every second"] >= rounds["every third"] >= rounds["none"], rounds
+        assert rounds["from 3 on"] >= 60 or rounds["from 3 on"] >= rounds["every third"], rounds     # back-to-back pair rounds: never fewer rounds
+
+
 def test_pair_rule_keeps_the_suffix_order_on_repeat_heavy_texts():
     rng = random.Random(5)
     for it in range(900):
