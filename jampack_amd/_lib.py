@@ -123,7 +123,14 @@ def lib():
                 "or make -C jampack_amd/csrc). jampack_amd has no CPU fallback.")
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
-            fn = getattr(l, name)          # AttributeError if the ABI is incomplete
+            try:
+                fn = getattr(l, name)      # AttributeError if the ABI is incomplete
+            except AttributeError:
+                # an OLDER build chosen through JPK_LIB (the A/B scripts compare a previous round's library on the same box) may lack the
+                # newest host-logic probes; the product library must export everything
+                if os.environ.get("JPK_LIB") and name.startswith("jpk_debug_"):
+                    continue
+                raise
             fn.restype = res
             fn.argtypes = args
         _lib = l

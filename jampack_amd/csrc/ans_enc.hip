@@ -1129,7 +1129,7 @@ constexpr int RANS_SLACK = 16 * RANS_RING;      // records in front of the recor
                  "global_store_short %[xoff], %[keep], %[xbase] offset:" #SOFF "\n\t"                                  \
                  "global_store_dword %[moff], %[mw], %[mbase] offset:" #MOFF "\n\t"                                    \
                  "global_load_lds_dwordx4 %[roff], %[rbase]"                                                           \
-                 : : [slot] "s"(ring0 + (uint32_t)(SLOT) * 1024u), [xoff] "v"(xoff), [keep] "v"(keep), [xbase] "s"(xbase), [moff] "v"(moff), [mw] "v"(mw),   \
+                 : : [slot] "s"(ring0 + (uint32_t)((SLOT) & (RANS_RING - 1)) * 1024u), [xoff] "v"(xoff), [keep] "v"(keep), [xbase] "s"(xbase), [moff] "v"(moff), [mw] "v"(mw),   \
                      [mbase] "s"(mbase), [roff] "v"(roff), [rbase] "s"(rbase)                                          \
                  : "memory")
 __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ recs, size_t rle_stride, EncDims d, const uint32_t *__restrict__ rlen,
@@ -1187,7 +1187,7 @@ __global__ __launch_bounds__(64) void k_rans_lanes(const uint4 *__restrict__ rec
     // Then 16 steps of every chain on `cur`, the store of the kept states, and the request for batch + 16 into the slot `cur` came from.
 #define JPK_BATCH(KSLOT, SOFF, MOFF)                                                                                    \
     {                                                                                                                   \
-        asm volatile("s_waitcnt vmcnt(42)" : : : "memory");                                                             \
+        asm volatile("s_waitcnt vmcnt(%0)" : : "n"(3 * (RANS_RING - 2)) : "memory");                                    \
         const uint4 nxt = ring[((KSLOT) + 1) & (RANS_RING - 1)][t];                                                     \
         _Pragma("unroll") for (int st = 0; st < 16; st += 2)                                                            \
             x = rans_step_turn2(x, cur, keep, 0x0001000100010001ull << st, 0x0001000100010001ull << (st + 1));          \

@@ -210,9 +210,11 @@ __device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restric
             for (int it = 0; it < RS_ITEMS; it++) val[it] |= tg[it] << (os ? os->tag_shift : 26);
         }
     } else rs_load_tile<SLOTS>(kin, vin, n, base, key, val, os ? os->tag_shift : 26);
-#ifdef JPK_OS_EARLY_AGG
-    // experiment (round 6): the tile's digit counts by LDS atomics as soon as its keys are there, published as the aggregate BEFORE the
-    // match phase, so that the tiles behind this one find it a match phase earlier (gbase holds the counts until the scan below)
+    // (one-pass form, round 6) THE AGGREGATE LEAVES EARLY: the tile's digit counts by LDS atomics as soon as its keys are there, published
+    // as the tile's aggregate BEFORE the match phase (rounds 4-5: after it and the scan), so that the tiles behind this one find a published
+    // word a match phase earlier instead of polling an empty one -- 483 -> 446 us per pass, forward BWT 7.86 -> 7.64 ms (wide text 7.50 ->
+    // 7.17), profiles/r06_scatter_ab.txt.  gbase holds the counts until the scan below; the packed keys' digits are spread over all 256
+    // bins: few same-address conflicts.
     if (LOOKBACK) {
 #pragma unroll
         for (int it = 0; it < RS_ITEMS; it++)
@@ -221,7 +223,6 @@ __device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restric
         const uint32_t s0 = gbase[threadIdx.x];
         __hip_atomic_store(os->status + (size_t)tile * 256u + threadIdx.x, (tile == 0 ? OS_FLAG_PFX : OS_FLAG_AGG) | s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-#endif
 #pragma unroll
     for (int it = 0; it < RS_ITEMS; it++) {
         const bool valid = FULL || base + (size_t)it * 64 < n;
@@ -247,13 +248,7 @@ __device__ __forceinline__ void rs_scatter_staged_tile(const uint64_t *__restric
         if (LOOKBACK) {
             uint32_t *row = os->status + (size_t)tile * 256u;
             uint32_t excl = 0;
-#ifdef JPK_OS_EARLY_AGG
-            if (tile != 0) {
-#else
-            if (tile == 0) __hip_atomic_store(row + d, OS_FLAG_PFX | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else {
-                __hip_atomic_store(row + d, OS_FLAG_AGG | s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+            if (tile != 0) {                                                // (tile 0's word is a prefix already; every aggregate left before the match phase)
                 // The walk is latency: every word comes from the memory side (~1.5 us), and with ~1000 tiles resident a tile finds
                 // aggregates, not prefixes, for a long way back.  Four rows are requested at once and consumed in order; the walk
                 // stops at the first prefix, an unpublished word is polled alone.  (Forward BWT of a 64 MiB block with 1 / 2 / 3 / 4 / 8 / 16 /
@@ -338,7 +333,20 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter_staged(const uint64_t
 }
 
 // (two launches per pass, like the two-pass form: the full tiles -- no bounds logic, a third of the registers -- and then the last,
-// partial tile alone; it takes the next ticket and finds every prefix published)
+// partial tile alone; it takes the next ticket and finds every prefix published.  The suffix sort pads its slots to whole tiles since
+// round 6: only the first launch exists there.)
+// Round 6, what else was built around the look-back and NOT kept (profiles/r06_scatter_ab.txt):
+//   * twice the occupancy -- the same tile on 512 threads x 8 pairs, 64 registers, eight waves per SIMD, the per-wave counters inside the
+//     staging buffer (34 KB of LDS): 496 us per pass against 483, bench line 5 767-5 891 against 5 831-6 040 MB/s.  The waves do not wait
+//     for each other's latencies;
+//   * a two-level look-back -- groups of sixteen tiles, tile rows that only ever hold the tile's own counts, the group's last tile
+//     publishing the group's aggregate and then its prefix, every tile reading <= 15 rows of its own group and the group rows in front of it
+//     (one or two round trips, 14 KB of status words per tile instead of a walk of four rows per round trip): 474 us per pass with the
+//     early aggregate against 446 without the second level, forward BWT 7.77 against 7.64 ms.  The walk is short once the aggregates are
+//     out early; what a tile waits for is that its predecessors HAVE counted their keys.
+// (With the early aggregate the kernel takes 130 registers: three waves per SIMD, three tiles per CU.  Forced back to 128 and four --
+// amdgpu_waves_per_eu(4, 4) -- it measured 7.65 against 7.55 ms per forward BWT and 6 223 against 6 349 MB/s on the bench line; with
+// two tiles per CU (JPK_OS_LDS=16384) 7.72 ms: profiles/r06_scatter_ab.txt.  Three it is.)
 template <bool SLOTS, bool FULL>
 __global__ __launch_bounds__(RS_THREADS) void k_os_scatter(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                           uint64_t *__restrict__ kout, uint32_t *__restrict__ vout, size_t n, int shift, uint32_t ntiles, OsArgs os)
@@ -350,9 +358,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_scatter(const uint64_t *__res
     __shared__ uint32_t s_tile;
     if (threadIdx.x == 0) s_tile = atomicAdd(os.ticket, 1u);
     for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&cnt[0][0])[i] = 0;
-#ifdef JPK_OS_EARLY_AGG
-    gbase[threadIdx.x] = 0;
-#endif
+    gbase[threadIdx.x] = 0;                       // (the early aggregate's counters)
     __syncthreads();
     const uint32_t tile = s_tile;
     rs_scatter_staged_tile<SLOTS, FULL, true>(kin, vin, kout, vout, n, shift, nullptr, ntiles, tile, cnt, gbase, stage, sm, &os);
@@ -362,7 +368,9 @@ void launch_os_scatter(jpk_ctx *ctx, const uint64_t *kin, const uint32_t *vin, u
                        const OsArgs &os)
 {
     const uint32_t nfull = (uint32_t)(n / RS_TILE);
-    if (nfull) JPK_LAUNCH(ctx, PROF_RS_SCATTER, (size_t)nfull * RS_TILE, (k_os_scatter<SLOTS, true>), dim3(nfull), dim3(RS_THREADS), kin, vin, kout, vout, n, shift, ntiles, os);
+    // JPK_OS_LDS: extra dynamic LDS per workgroup (bytes), i.e. fewer tiles resident per CU (experiments: 16384 = two per CU)
+    static const size_t extra_lds = [] { const char *e = getenv("JPK_OS_LDS"); const long v = e ? atol(e) : 0; return (size_t)(v < 0 ? 0 : (v > 120000 ? 120000 : v)); }();
+    if (nfull) JPK_LAUNCH_LDS(ctx, PROF_RS_SCATTER, (size_t)nfull * RS_TILE, extra_lds, (k_os_scatter<SLOTS, true>), dim3(nfull), dim3(RS_THREADS), kin, vin, kout, vout, n, shift, ntiles, os);
     if (nfull < ntiles) JPK_LAUNCH(ctx, PROF_RS_SCATTER, n - (size_t)nfull * RS_TILE, (k_os_scatter<SLOTS, false>), dim3(1), dim3(RS_THREADS), kin, vin, kout, vout, n, shift,
                                    ntiles, os);
 }
