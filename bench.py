@@ -44,7 +44,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
 
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 # algorithmic HBM bytes per processed unit of every timed kernel class, and what the class is
 # actually limited by ("hbm": streaming traffic; "hbm-random": 4-byte gathers/scatters, ~55 G accesses/s whatever the bytes;
@@ -78,7 +78,7 @@ def pmc_traffic(kernel_class: str, passes: float, launches: int):
     half-count of wide coalesced loads, MI355X_MICROARCH.md section HBM).  The encoder's launch shape follows the blocks in
     flight, so the file's bytes per PASS over the workload are scaled to the `launches` that `passes` passes took here.
     None if no PMC summary is committed."""
-    for rnd in (PROFILE_ROUND, "r04", "r03", "r02", "r01"):
+    for rnd in (PROFILE_ROUND, "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic.json")
         if os.path.exists(path):
             break
@@ -116,7 +116,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (multi-GPU children print this anyway)")
     # 8 since round 4: a context's arena is 3.1 GB now (6 GB before), and 8 blocks in flight measured +4.8 % over 4 (+3.2 % with 6) in
     # twelve alternating runs on one box (profiles/r04_blocks_in_flight.txt)
-    ap.add_argument("--contexts", type=int, default=8, help="blocks in flight per GPU (one context + HIP stream each)")
+    ap.add_argument("--contexts", type=int, default=10,
+                    help="blocks in flight per GPU (one context + HIP stream each; 10 since round 6: 6 / 8 / 10 / 12 in flight measured 5 966 / 6 230 / 6 375 / 6 198 MB/s, "
+                         "profiles/r06_blocks_in_flight.txt; 8 in rounds 4-5)")
     ap.add_argument("--cpu-sample-mib", type=int, default=64, help="bytes of block 0 the CPU reference is timed on")
     ap.add_argument("--no-block-sizes", action="store_true", help="skip the per_block_size extra (1 / 64 / 256 MiB blocks)")
     ap.add_argument("--master-port", type=int, default=29511)

@@ -208,7 +208,7 @@ JPK_API int jpk_dev_blocks_decompress(jpk_ctx *ctx, int32_t nblocks, const uint8
 /* The compress direction of the same loop (jampack.cpp:205-224: Threads blocks read, Comp() in an OpenMP loop, written in order)
  * for blocks that sit in HBM: ForwardBwt + Ans::Encode of nblocks independent blocks in ONE call.  Compression wants several
  * blocks IN FLIGHT rather than one wide grid (the suffix sort fills the GPU by itself; the entropy stage of the other blocks
- * hides in its latency), so the library runs `in_flight` worker threads (<= 0: 8; at most 16), each with a context of its own on
+ * hides in its latency), so the library runs `in_flight` worker threads (<= 0: 10; at most 16), each with a context of its own on
  * ctx's device (kept by the library between calls, released by jpk_shutdown), that take the work in array order.  Blocks of up to
  * 16 MiB -- the reference's default block is 8 MiB, its smallest 1 MiB (format.hpp:20-22) -- are compressed in GROUPS of
  * consecutive blocks (a quarter of their total bytes, 8 .. 64 MiB, at most 256 blocks; JPK_GROUP_MIB fixes the size, JPK_GROUP=0
@@ -261,7 +261,7 @@ JPK_API int jpk_debug_enc_groups(int device, int32_t nch);
 /* The block loops of Jampack::Compress / Jampack::Decompress (jampack.cpp:205-224, 286-317) over the GPUs of one node, natively:
  * block b runs on the (b mod G)-th device of `device_mask` (bit d = device d, 0 = every visible gfx950 device; one worker thread per
  * device; `in[b]` are HOST buffers, copied into a per-device slab the library keeps between calls), THROUGH THE LIBRARY'S BATCH ENTRY
- * on that device -- jpk_dev_blocks_compress with `in_flight` blocks in flight (<= 0: its default, 8) and small blocks in groups, or
+ * on that device -- jpk_dev_blocks_compress with `in_flight` blocks in flight (<= 0: its default, 10) and small blocks in groups, or
  * jpk_dev_blocks_decompress (one pass over the chunks of all the device's blocks) -- and the results are gathered in block order into
  * `d_out`, a buffer of out_cap bytes on the FIRST device of the mask: block b occupies [out_off[b], out_off[b + 1]) (out_off has
  * nblocks + 1 entries).  Decompress: in_len[b] = compressed bytes, raw_len[b] = the block's decompressed size (the frame header's

@@ -1042,7 +1042,7 @@ int blocks_compress_body(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_
             if (sb > max_stage) max_stage = sb;
             if (ab > max_arena) max_arena = ab;
         }
-    int nw = in_flight > 0 ? in_flight : 8;        // (8 since round 4: +9 % over 4 in flight, profiles/r04_blocks_compress_call.txt; an arena is 3 GB now)
+    int nw = in_flight > 0 ? in_flight : 10;       // (10 since round 6, like the bench line: profiles/r06_blocks_in_flight.txt; 8 in rounds 4-5; an arena is 3.7 GB)
     if (nw > ntasks) nw = ntasks;
     if (nw > 16) nw = 16;
     uint64_t generation;

@@ -1035,7 +1035,8 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
     __shared__ uint16_t vtop[256];
     __shared__ uint32_t s_sigma;
     __shared__ uint64_t SV[64];            // survivor bits per word
-    __shared__ uint32_t LHW[64];           // 1 + last head position at or before the end of word l (carry included)
+    __shared__ uint32_t LHW[64];           // 1 + last head position at or before the end of word l (carry included; the two-pass form)
+    __shared__ uint32_t LHL[64];           // ... inside the tile only (0: none yet)
     __shared__ uint32_t SW[64];            // output position of the first survivor of word l
     const uint32_t ntiles = (n + CT - 1) / CT;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -1063,25 +1064,88 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
         r0_tile_heads(keys, sa, n, base, HE, kj, sj, bend, D, vmode, Dx);
         __syncthreads();
         uint32_t carry = lb_status ? 0u : tCarry[tile];
+        uint32_t nrun = 0;
+        // one slot of the tile.  PHASE 0: everything at once (the two-pass comparator: carry and offsets are known up front).  Look-back form,
+        // round 6: PHASE 1 = what needs nothing from the tiles in front -- the rank store (the block's one 64 Mi-element random write), the
+        // BWT byte and the depth of every slot whose group's head lies INSIDE the tile -- issued while wave 0 is still looking back; PHASE 2 =
+        // the rest: the survivors' list entries (their positions start at the survivors in front of the tile) and the slots in front of the
+        // tile's first head (their group's head is the last head in front of the tile).
+        auto slot = [&](int k, int phase) {
+            const int word = w * CT_ITEMS + k;
+            const uint32_t j = base + word * 64 + l;
+            if (j >= n) return;
+            const uint64_t hv = HE[word] & valid_word(base + word * 64, n);
+            const uint64_t le = hv & mask_upto(l);
+            // 1 + the head of my group if it lies inside the tile (0: in front of it)
+            const uint32_t local = le ? base + word * 64 + top_bit(le) + 1u : (word ? (phase == 0 ? LHW[word - 1] : LHL[word - 1]) : 0u);
+            const bool inside = phase == 0 || local != 0u;
+            if (phase == 1 && !inside) return;
+            const uint32_t grp = (local ? local : carry) - 1u;
+            const uint32_t s = sj[k] & TAGM;                        // (loaded once, by r0_tile_heads)
+            const uint8_t pv = (uint8_t)kj[k];                      // T[s - 1], carried in the key's low byte since pass 0 (group sort: the block number)
+            const uint64_t sv = SV[word];
+            const bool survivor = (sv >> l) & 1ull;
+            if (phase != 2 || !inside) {                            // (phase 2 repeats nothing phase 1 has stored)
+                ISA[s] = grp;
+                if (!survivor) {
+                    bwt[j] = pv;
+                    if (SA) SA[j] = s;
+                } else if (vmode && ((HE[word] >> l) & 1ull)) GD[grp] = Dx ? (uint32_t)Dx[n - 1u - s] : sj[k] >> D;      // the group's depth, written by its first member
+            }
+            if (phase == 1 || !survivor) return;
+            const uint32_t pos = SW[word] + (uint32_t)__popcll(sv & mask_below(l));
+            // `depth` equal bytes (a survivor has all of them: short suffixes are groups of their own): a run member
+            const uint64_t k7 = kj[k] >> 8;
+            bool inrun;
+            if (vmode) {
+                // the key of a run is a function of its byte; the byte is the one whose code starts the key: a table on the
+                // key's first 8 bits for codes up to 8 bits, a binary search over the (ascending) run keys for the rare longer ones
+                const uint32_t c = vtop[(uint32_t)(k7 >> 48)];
+                if (c != 0xFFFFu) inrun = k7 == runkey[c];
+                else {
+                    uint32_t lo = 0, hi = s_sigma;
+                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (runsorted[mid] < k7) lo = mid + 1u; else hi = mid; }
+                    inrun = lo < s_sigma && runsorted[lo] == k7;
+                }
+            } else inrun = k7 == (k7 >> code_shift) * rep;
+            nrun += inrun ? 1u : 0u;
+            a_sa[pos] = s;
+            a_grp[pos] = grp | (inrun ? RUNF : 0u);
+            a_prev[pos] = pv;
+        };
+        uint32_t cnt = 0, inc = 0, last = 0;                            // (wave 0: survivors of my word, their running sum, 1 + last head so far in the tile)
         if (threadIdx.x < 64) {
             const uint64_t he = HE[l], vm = valid_word(base + l * 64, n);
             const uint64_t hv = he & vm;
             const uint64_t nexth = (he >> 1) | (HE[l + 1] << 63);
             const uint64_t surv = vm & ~(hv & nexth);
             SV[l] = surv;
-            const uint32_t cnt = (uint32_t)__popcll(surv);
-            const uint32_t inc = wave_incl_sum(cnt);
-            uint32_t last = hv ? base + l * 64 + top_bit(hv) + 1u : 0u;
+            cnt = (uint32_t)__popcll(surv);
+            inc = wave_incl_sum(cnt);
+            last = hv ? base + l * 64 + top_bit(hv) + 1u : 0u;
             last = wave_incl_max(last);
-            uint32_t off;
-            if (lb_status) {
-                const uint32_t cnt_tile = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), last_tile = (uint32_t)__builtin_amdgcn_readlane((int)last, 63);
+            LHL[l] = last;
+        }
+        if (!lb_status) {
+            if (threadIdx.x < 64) {
+                SW[l] = tOff[tile] + inc - cnt;
+                LHW[l] = last > carry ? last : carry;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < CT_ITEMS; k++) slot(k, 0);
+        } else {
+            uint32_t cnt_tile = 0, last_tile = 0;
+            if (threadIdx.x < 64) {                                     // the aggregate leaves before anything else
+                cnt_tile = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                last_tile = (uint32_t)__builtin_amdgcn_readlane((int)last, 63);
                 const uint64_t mine = ((uint64_t)cnt_tile << 31) | last_tile;
+                if (l == 0) __hip_atomic_store(lb_status + tile, (tile == 0 ? LB_PFX : LB_AGG) | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();                                            // SV, LHL
+            if (threadIdx.x < 64) {
                 uint32_t o_acc = 0, c_acc = 0;
-                if (tile == 0) {
-                    if (l == 0) __hip_atomic_store(lb_status, LB_PFX | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else {
-                    if (l == 0) __hip_atomic_store(lb_status + tile, LB_AGG | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tile != 0) {
                     int64_t pos = (int64_t)tile - 1;                    // lane l looks at tile pos - l
                     for (;;) {
                         const int64_t t = pos - l;
@@ -1108,8 +1172,7 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                     const uint32_t lt = c_acc > last_tile ? c_acc : last_tile;
                     if (l == 0) __hip_atomic_store(lb_status + tile, LB_PFX | ((uint64_t)(o_acc + cnt_tile) << 31) | lt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                carry = c_acc;
-                off = o_acc;
+                SW[l] = o_acc + inc - cnt;
                 if (l == 0) {
                     s_carry = c_acc;
                     if (tile + 1 == ntiles) {                           // the last tile knows the total: what k_r0_scan leaves in the state
@@ -1120,51 +1183,14 @@ __global__ __launch_bounds__(TB) void k_r0_finish(const uint64_t *__restrict__ k
                         st->lc = 0;
                     }
                 }
-            } else off = tOff[tile];
-            SW[l] = off + inc - cnt;
-            LHW[l] = last > carry ? last : carry;
-        }
-        __syncthreads();
-        if (lb_status) carry = s_carry;
-        uint32_t nrun = 0;
-#pragma unroll
-        for (int k = 0; k < CT_ITEMS; k++) {
-            const int word = w * CT_ITEMS + k;
-            const uint32_t j = base + word * 64 + l;
-            if (j < n) {
-                const uint64_t hv = HE[word] & valid_word(base + word * 64, n);
-                const uint64_t le = hv & mask_upto(l);
-                const uint32_t grp = le ? base + word * 64 + top_bit(le) : (word ? LHW[word - 1] : carry) - 1u;
-                const uint32_t s = sj[k] & TAGM;                    // (loaded once, by r0_tile_heads)
-                const uint8_t pv = (uint8_t)kj[k];                  // T[s - 1], carried in the key's low byte since pass 0 (group sort: the block number)
-                ISA[s] = grp;
-                const uint64_t sv = SV[word];
-                if (!((sv >> l) & 1ull)) {
-                    bwt[j] = pv;
-                    if (SA) SA[j] = s;
-                } else {
-                    const uint32_t pos = SW[word] + (uint32_t)__popcll(sv & mask_below(l));
-                    // `depth` equal bytes (a survivor has all of them: short suffixes are groups of their own): a run member
-                    const uint64_t k7 = kj[k] >> 8;
-                    bool inrun;
-                    if (vmode) {
-                        // the key of a run is a function of its byte; the byte is the one whose code starts the key: a table on the
-                        // key's first 8 bits for codes up to 8 bits, a binary search over the (ascending) run keys for the rare longer ones
-                        const uint32_t c = vtop[(uint32_t)(k7 >> 48)];
-                        if (c != 0xFFFFu) inrun = k7 == runkey[c];
-                        else {
-                            uint32_t lo = 0, hi = s_sigma;
-                            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (runsorted[mid] < k7) lo = mid + 1u; else hi = mid; }
-                            inrun = lo < s_sigma && runsorted[lo] == k7;
-                        }
-                        if ((HE[word] >> l) & 1ull) GD[grp] = Dx ? (uint32_t)Dx[n - 1u - s] : sj[k] >> D;      // the group's depth, written by its first member
-                    } else inrun = k7 == (k7 >> code_shift) * rep;
-                    nrun += inrun ? 1u : 0u;
-                    a_sa[pos] = s;
-                    a_grp[pos] = grp | (inrun ? RUNF : 0u);
-                    a_prev[pos] = pv;
-                }
             }
+            // phase 1: waves 1..3 at once, wave 0 behind its look-back (its prefix is out before its own stores)
+#pragma unroll
+            for (int k = 0; k < CT_ITEMS; k++) slot(k, 1);
+            __syncthreads();                                            // SW, s_carry
+            carry = s_carry;
+#pragma unroll
+            for (int k = 0; k < CT_ITEMS; k++) slot(k, 2);
         }
         if (__ballot(nrun != 0)) {                                   // (rare: text has few runs that long)
             nrun = wave_sum(nrun);

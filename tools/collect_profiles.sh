@@ -3,7 +3,7 @@
 # Produces gpurun_out/<tag>/: PMC passes + summary, rocprofv3 kernel stats of the bench command, bench lines, worst cases.
 # (counters and traces in separate runs; the program itself after `--`)
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -70,6 +70,7 @@ tools/_bin/issuetest > "$OUT/issuetest.txt" 2>&1
 # 6. round 4: small blocks through one call (a fresh process)
 python3 tools/small_blocks.py 1,8,64 4,8,16 2>/dev/null | grep blocks > "$OUT/small_blocks.txt"
 # 7. round 5: variable-length keys against the fixed-width ones, the pair rule against plain doubling (same box, alternating)
+if [ "${JPK_COLLECT_AB:-0}" = 1 ]; then      # (round 5's A/B sections: unchanged code in round 6, ~10 GPU-minutes; JPK_COLLECT_AB=1 repeats them)
 ( echo "# bench.py --steps 12 --warmup 3 --no-extras, same box, alternating: variable-length keys (default) against JPK_VARKEYS=0 (round 4's alphabet-packed fixed-width keys)"
   for i in 1 2 3; do for v in 1 0; do
     echo -n "headline (28 byte values) JPK_VARKEYS=$v  "; JPK_VARKEYS=$v python3 bench.py --steps 12 --warmup 3 --no-extras --no-cpu-baseline 2>/dev/null | grep -o '"value": [0-9.]*' | head -1
@@ -87,6 +88,15 @@ python3 tools/small_blocks.py 1,8,64 4,8,16 2>/dev/null | grep blocks > "$OUT/sm
   done
   echo "# config 5: bench.py --workload silesia --block-mib 256 --steps 4 --warmup 1 --no-extras"
   for e in "" "JPK_PAIR_SHIFT=-1" "JPK_VARKEYS=0" "JPK_PAIR_SHIFT=-1 JPK_VARKEYS=0"; do echo -n "silesia-like 212 MB [$e]  "; env $e python3 bench.py --workload silesia --block-mib 256 --steps 4 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | grep -o '"value": [0-9.]*' | head -1; done ) > "$OUT/pair_rule.txt"
+fi
 rm -rf /tmp/kfw
 ( cd /tmp; rocprofv3 --kernel-trace -d /tmp/kfw -o f -- python3 $REPO/tools/fwd_once.py text_wide 3 > /dev/null 2>&1; python3 $REPO/tools/rocpd_stats.py /tmp/kfw/f_results.db 4 > "$OUT/kernel_stats_forward_bwt_64mib_wide.txt" 2>&1 )
+ls -la "$OUT"
+# 8. round 6: structured inputs (cliffs), blocks above 2^28 bytes, contexts in flight on the bench line, the ticket micro-benchmark
+python3 tools/structured_inputs.py > "$OUT/structured_inputs.txt" 2>/dev/null
+( for c in 8 10 8 10 8 10; do echo -n "contexts $c "; python3 bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --contexts $c 2>/dev/null | grep -o '"value": [0-9.]*' | head -1; done ) > "$OUT/blocks_in_flight.txt"
+( echo "# one 300 MiB block (above 2^28 bytes: the slots' depths in their own array), variable-length keys (default) against JPK_VARKEYS=0 (round 4's fixed-width keys, what such blocks got before round 6)"
+  python3 tools/big_block.py $((300 << 20)) 2>/dev/null | tail -3
+  echo "# JPK_VARKEYS=0"; JPK_VARKEYS=0 python3 tools/big_block.py $((300 << 20)) 2>/dev/null | tail -3 ) > "$OUT/big_block_300mib.txt"
+tools/_bin/tickettest > "$OUT/tickettest.txt" 2>&1
 ls -la "$OUT"
