@@ -795,6 +795,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Every context compresses every block of the batch once before anything is counted (round 6).  The W warm-up steps go through the
+    # same work queue as the timed ones: with ten contexts and two blocks per step, W = 5 steps are ten tasks, and a context that happens
+    # to take none of them would make its first call -- stream and event creation, the encoder's second arena layout, pinned mailboxes --
+    # inside the timed region.  Inputs stay resident; the timed region is exactly K steps, behind exactly W warm-up steps.
+    def prime(k):
+        for i in order:
+            ctxs[k].block_compress(d_in[i], len(blocks[i]), out_bufs[k][0][i], caps[i])
+    if nblk:
+        pth = [threading.Thread(target=prime, args=(k,)) for k in range(nctx)]
+        for t_ in pth:
+            t_.start()
+        for t_ in pth:
+            t_.join()
+        torch.cuda.synchronize()
     run_steps(args.warmup)
     sync_all()
     gather_s[0], gather_s[1] = 0.0, 0
