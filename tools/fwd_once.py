@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""N forward BWTs of a 64 MiB block (for rocprofv3 --kernel-trace --stats):  python tools/fwd_once.py [kind] [reps]"""
+"""N forward BWTs of a 64 MiB block (for rocprofv3 --kernel-trace --stats):  python tools/fwd_once.py [kind] [reps] [MiB]"""
 import os
 import sys
 
@@ -11,7 +11,7 @@ import jampack_amd as jam
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "text_survey"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-n = 64 << 20
+n = (int(sys.argv[3]) if len(sys.argv) > 3 else 64) << 20
 t = jam.corpus.make(kind, n, 8)
 dev = torch.device("cuda", 0)
 ctx = jam.Context(0, None)
