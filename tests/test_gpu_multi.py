@@ -71,7 +71,9 @@ for i, t in enumerate(blocks):
 # when the gather cannot run nothing is reported as done: every status is an error, every range empty
 soff, sst, src = jam.blocks_compress_multi(blocks, small, 1000, 0b1, check=False)
 assert src == -2 and all(x != 0 for x in sst) and soff == [0] * (len(blocks) + 1), (src, sst, soff)
-# the caller's device is what it was, and a second call re-uses the slabs
+# the caller's device is what it was (also behind jpk_release_idle, which destroys contexts and slabs: ADVICE r5), and a second call re-uses / re-creates the slabs
+assert torch.cuda.current_device() == 0
+jam.release_idle()
 assert torch.cuda.current_device() == 0
 off2, st2 = jam.blocks_compress_multi(blocks, d_out, cap, 0b1, 4)
 assert off2 == off and st2 == st and np.array_equal(d_out.cpu().numpy()[: off[-1]], out[: off[-1]])
