@@ -36,6 +36,9 @@ extern "C" {
 #define JPK_ANS_CHUNK (1 << 20)           /* ans.hpp:21     StackSize */
 #define JPK_MIN_BLOCKSIZE (1 << 20)       /* format.hpp:21  MIN_BLOCKSIZE */
 #define JPK_MAX_BLOCKSIZE (1000 << 20)    /* format.hpp:22  MAX_BLOCKSIZE */
+/* the forward BWT (jpk_bwt_forward, jpk_block_compress and their jpk_dev_ / batch forms) takes in_len < JPK_FWD_BWT_LIMIT and returns
+ * JPK_E_ARG above (the sort keeps the two upper bits of a 32-bit rank for flags): the format's largest block is below it */
+#define JPK_FWD_BWT_LIMIT (1u << 30)
 #define JPK_SA_MAX_ROUNDS 40               /* rounds reported in jpk_stats (h doubles: 7 * 2^31 > any block) */
 #define JPK_JAM_HEADER_BYTES 15           /* jampack.cpp:128-131: "JAM" + crc + payload size + BlockSize */
 
@@ -125,7 +128,7 @@ JPK_API void jpk_shutdown(void);
 JPK_API int jpk_release_idle(void);
 
 /* ---- host-buffer entry points (drop-in boundary) ------------------------------------------------------- */
-/* BlockSort::Bwt::ForwardBwt(Buffer,Buffer)            bwt.hpp:15, bwt.cpp:22-65.   *out_len = in_len + 480. */
+/* BlockSort::Bwt::ForwardBwt(Buffer,Buffer)            bwt.hpp:15, bwt.cpp:22-65.   *out_len = in_len + 480.  in_len < JPK_FWD_BWT_LIMIT. */
 JPK_API int jpk_bwt_forward(const uint8_t *in, int32_t in_len, uint8_t *out, int32_t out_cap, int32_t *out_len);
 /* BlockSort::Bwt::InverseBwt(Buffer,Buffer,Options)    bwt.hpp:16, bwt.cpp:72-282.  threads/use_gpu mirror
  * Options.Threads / Options.Gpu (format.hpp:46-54); they do not change the bytes and are accepted for ABI fidelity. */

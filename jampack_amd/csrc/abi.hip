@@ -454,7 +454,7 @@ extern "C" int jpk_dev_block_compress(jpk_ctx *ctx, const uint8_t *d_in, int32_t
 {
     JPK_ENTER(ctx);
     if (!d_out || !out_len || in_len < 0 || out_cap < 0 || (in_len > 0 && !d_in)) return JPK_E_ARG;
-    if ((int64_t)in_len + JPK_TRAILER_BYTES > 0x7fffffffLL) return JPK_E_ARG;
+    if ((uint32_t)in_len >= JPK_FWD_BWT_LIMIT) return JPK_E_ARG;      // before anything is allocated for it (jpk_fwd_bwt_device)
     const size_t mid = (size_t)in_len + JPK_TRAILER_BYTES;
     JPK_TRY(buf_ensure(ctx, &ctx->stage_out, &ctx->stage_out_cap, mid));
     if (in_len < JPK_BWT_UNITS) JPK_HIP(hipMemsetAsync(ctx->stage_out, 0, mid, ctx->stream));   // untouched trailer: defined bytes

@@ -49,6 +49,7 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 // compare at the END of their run (distance = remaining run length, uniform inside the group by then) instead of at distance h.
 constexpr uint32_t RUNF = 0x40000000u;
 static_assert((uint64_t)JPK_MAX_BLOCKSIZE < (1ull << 30), "bit 30 of a rank is free");
+static_assert(JPK_FWD_BWT_LIMIT == (1u << 30) && (uint64_t)JPK_MAX_BLOCKSIZE < JPK_FWD_BWT_LIMIT, "jpk_fwd_bwt_device refuses what would need bit 30");
 
 constexpr int CT = 4096;                   // slots per tile of the streaming kernels (count / scatter), 16 per thread
 constexpr int CT_ITEMS = CT / TB;          // 16: slot(w, k, l) = tile * CT + w * 1024 + k * 64 + l  -> ballot = one 64-bit word
@@ -3149,6 +3150,9 @@ int jpk_fwd_bwt_group_device(jpk_ctx *ctx, int nblk, const uint8_t *const *d_in,
 
 int jpk_fwd_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *d_out)
 {
+    // ranks keep bit 30 and bit 31 for flags (above): a block of 2^30 bytes or more is refused, not sorted wrongly.  The format's largest
+    // block (JPK_MAX_BLOCKSIZE = 1000 MiB, format.hpp:22) is below that
+    if (len < 0 || (uint32_t)len >= JPK_FWD_BWT_LIMIT) return JPK_E_ARG;
     const JpkCompressInflight inflight(ctx->device);      // counted while this block is in its suffix sort
     const int32_t rem = len % JPK_BWT_UNITS, nlen = len - rem;
     if (nlen <= 0) {
