@@ -19,6 +19,7 @@
 constexpr int TILE = 4096, TB = 256, ITEMS = TILE / TB;
 
 // dig[i] = the run slot i of a tile belongs to, start[d] = first slot of run d, gbase[d] = where digit d's output begins, len[d] = its length per tile
+template <int NT>      // 1: non-temporal stores, 2: non-temporal loads as well, 3: non-temporal loads only
 __global__ __launch_bounds__(TB) void k_part(const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout, uint32_t *__restrict__ vout,
                                              const uint8_t *__restrict__ dig, const uint32_t *__restrict__ start, const uint64_t *__restrict__ gbase,
                                              const uint32_t *__restrict__ len, uint32_t kgrp)
@@ -38,16 +39,16 @@ __global__ __launch_bounds__(TB) void k_part(const uint64_t *__restrict__ kin, c
     uint32_t v[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {                                   // slot = j * 256 + thread: a wave's instruction covers 64 consecutive slots
-        k[j] = kin[base + j * TB + threadIdx.x];
-        v[j] = vin[base + j * TB + threadIdx.x];
+        if (NT >= 2) { k[j] = __builtin_nontemporal_load(kin + base + j * TB + threadIdx.x); v[j] = __builtin_nontemporal_load(vin + base + j * TB + threadIdx.x); }
+        else { k[j] = kin[base + j * TB + threadIdx.x]; v[j] = vin[base + j * TB + threadIdx.x]; }
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {
         const uint32_t slot = j * TB + threadIdx.x;
         const uint32_t d = dig[slot];
         const size_t o = s_base[d] + (size_t)tile * s_len[d] + (slot - s_start[d]);
-        kout[o] = k[j];
-        vout[o] = v[j];
+        if (NT == 1 || NT == 2) { __builtin_nontemporal_store(k[j], kout + o); __builtin_nontemporal_store(v[j], vout + o); }
+        else { kout[o] = k[j]; vout[o] = v[j]; }
     }
 }
 
@@ -154,8 +155,18 @@ int main(int argc, char **argv)
             if (kgrp != 1 && ntiles % (8 * kgrp)) continue;
             char line[200]; snprintf(line, sizeof line, "%s%s%u", what, kgrp == 1 ? "" : "  | tiles per XCD and window: ", kgrp);
             if (kgrp == 1) snprintf(line, sizeof line, "%s", what);
-            if (time_it(line, [&] { hipLaunchKernelGGL(k_part, dim3(ntiles), dim3(TB), 0, 0, kin, vin, kout, vout, d_dig, d_start, d_gbase, d_len, kgrp); })) return 1;
+            if (time_it(line, [&] { hipLaunchKernelGGL(k_part<0>, dim3(ntiles), dim3(TB), 0, 0, kin, vin, kout, vout, d_dig, d_start, d_gbase, d_len, kgrp); })) return 1;
             if (only_first) break;
+        }
+        {
+            char line[200]; snprintf(line, sizeof line, "%s  | non-temporal stores", what);
+            if (time_it(line, [&] { hipLaunchKernelGGL(k_part<1>, dim3(ntiles), dim3(TB), 0, 0, kin, vin, kout, vout, d_dig, d_start, d_gbase, d_len, 1u); })) return 1;
+            snprintf(line, sizeof line, "%s  | non-temporal LOADS only", what);
+            if (time_it(line, [&] { hipLaunchKernelGGL(k_part<3>, dim3(ntiles), dim3(TB), 0, 0, kin, vin, kout, vout, d_dig, d_start, d_gbase, d_len, 1u); })) return 1;
+            snprintf(line, sizeof line, "%s  | non-temporal LOADS only, tiles per XCD and window: 8", what);
+            if (time_it(line, [&] { hipLaunchKernelGGL(k_part<3>, dim3(ntiles), dim3(TB), 0, 0, kin, vin, kout, vout, d_dig, d_start, d_gbase, d_len, 8u); })) return 1;
+            snprintf(line, sizeof line, "%s  | non-temporal stores and loads", what);
+            if (time_it(line, [&] { hipLaunchKernelGGL(k_part<2>, dim3(ntiles), dim3(TB), 0, 0, kin, vin, kout, vout, d_dig, d_start, d_gbase, d_len, 1u); })) return 1;
         }
         for (uint32_t kgrp : {1u, 8u}) {
             char line[200]; snprintf(line, sizeof line, "%s  | 12-byte records%s", what, kgrp == 1 ? "" : ", tiles per XCD and window: 8");
