@@ -189,6 +189,13 @@ int main(int argc, char **argv)
         for (int d = 0; d < 256; d++) len[d] = (d & 1) ? 17 : 15;
         if (pattern("256 runs of 15 / 17 pairs (unaligned)", len)) return 1;
     }
+    for (int runs : {128, 64}) {   // fewer, longer unaligned runs: what a tile of 8192 / 16384 pairs would write per 4096 of them
+        std::vector<uint32_t> len(256, 0);
+        const uint32_t m = TILE / runs;
+        for (int d = 0; d < runs; d++) len[d] = (d & 1) ? m + 1 : m - 1;
+        char what[128]; snprintf(what, sizeof what, "%d runs of %u / %u pairs (unaligned)", runs, m - 1, m + 1);
+        if (pattern(what, len)) return 1;
+    }
     {   // text-like: geometric weights (digit d ~ 0.985^d), at least one pair per run
         std::vector<uint32_t> len(256, 1);
         double w[256], tot = 0;
