@@ -26,7 +26,8 @@ if sys.argv[2] == "batch":          # device buffers come from torch: let its HI
 import jampack_amd as jam
 from jampack_amd import JampackError
 which, rounds = sys.argv[2], int(sys.argv[3])
-rng = np.random.default_rng(20261003)
+import os
+rng = np.random.default_rng(int(os.environ.get("JPK_FUZZ_SEED", "20261003")))     # (tools/fuzz_long.py runs other seeds)
 OKSET = (-1, -2, -3)       # ARG, CAPACITY, CORRUPT are legitimate answers; DEVICE/ALLOC/NODEVICE are not
 
 def mutate(a):
