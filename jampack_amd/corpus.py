@@ -388,6 +388,35 @@ def load_or_make(name: str, limit: int | None = None, seed_offset: int = 0, star
     return out, "synthetic"
 
 
+SOURCE_ROOTS = ("/usr/lib/python3.10", "/usr/lib/python3/dist-packages", "/opt/rocm/include", "/usr/local/lib/python3.10/dist-packages")
+SOURCE_SUFFIXES = (".py", ".pyi", ".h", ".hpp", ".c", ".inc", ".txt", ".md", ".rst", ".json", ".yaml", ".cmake")
+
+
+def system_sources(nbytes: int):
+    """REAL data for the checks that want some: the first `nbytes` of the source and text files of this image's Python and ROCm trees,
+    in sorted path order (the GPU box runs the same image).  None if the trees hold less.  Not a benchmark corpus -- the numbers BASELINE.json
+    names are quoted on the synthetic workloads above -- but real files have what generators lack: licence headers repeated thousands of
+    times, generated tables, long runs of blanks, near-duplicate files."""
+    parts, left = [], nbytes
+    for root in SOURCE_ROOTS:
+        for d, dirs, files in os.walk(root):
+            dirs.sort()
+            for f in sorted(files):
+                if not f.endswith(SOURCE_SUFFIXES):
+                    continue
+                try:
+                    a = np.fromfile(os.path.join(d, f), dtype=np.uint8)
+                except OSError:
+                    continue
+                if len(a) == 0:
+                    continue
+                parts.append(a[:left])
+                left -= len(parts[-1])
+                if left == 0:
+                    return np.concatenate(parts)
+    return None
+
+
 def block_ranges(total: int, block_size: int):
     """(start, length) of every block of a `total`-byte stream (jampack.cpp:205-213 reads BlockSize bytes per block)"""
     return [(o, min(block_size, total - o)) for o in range(0, total, block_size)]
