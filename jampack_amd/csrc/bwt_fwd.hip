@@ -2705,11 +2705,21 @@ uint32_t pair_rule_min()
     static const uint32_t v = [] { const char *e = getenv("JPK_PAIR_MIN"); const long x = e ? atol(e) : 4096L; return (uint32_t)(x < 2 ? 2 : x); }();
     return v;
 }
-// JPK_PAIR_RATIO: ... and the previous round left at least this percentage of ITS list unresolved (default 60: text halves its list
-// every round and never takes the path; a block of repeats keeps its list) -- 0 = whatever the previous round did
+// JPK_PAIR_RATIO: ... and the previous round left at least this percentage of ITS list unresolved -- 0 = whatever the previous round did.
+// Default 90 since the end of round 6 (60 before): what the rule is for -- exact repeats, periodic data, a block that holds a file twice --
+// keeps 99-100 % of its list through a doubling round (tools/pair_yield.py) and a pair round then resolves 84-100 % of it; REAL trees of
+// near-duplicate files (64 MiB of this image's Python and ROCm sources: 16 rounds, each leaving 60-85 %) crossed the old threshold three
+// times, every pair round there left 74-90 % of its list and cost 4 ms (k_pair_repair's walks): 35.0 against 22.9 ms per block without them.
 uint32_t pair_rule_ratio()
 {
-    static const uint32_t v = [] { const char *e = getenv("JPK_PAIR_RATIO"); const int x = e ? atoi(e) : 60; return (uint32_t)(x < 0 ? 0 : (x > 100 ? 100 : x)); }();
+    static const uint32_t v = [] { const char *e = getenv("JPK_PAIR_RATIO"); const int x = e ? atoi(e) : 90; return (uint32_t)(x < 0 ? 0 : (x > 100 ? 100 : x)); }();
+    return v;
+}
+// JPK_PAIR_KEEP: a pair round that leaves more than this percentage of its list is the block's last one (default 50; 100 = never give up).
+// The Fibonacci word took nine pair rounds that resolved NOTHING (every one a round in which the doubling distance stands still).
+uint32_t pair_rule_keep()
+{
+    static const uint32_t v = [] { const char *e = getenv("JPK_PAIR_KEEP"); const int x = e ? atoi(e) : 50; return (uint32_t)(x < 0 ? 0 : (x > 100 ? 100 : x)); }();
     return v;
 }
 // JPK_PAIR_ITERS: passes of k_pair_fill per pair round (default 1; 2..4: later passes decide an end pair inside one group by the chain
@@ -2871,6 +2881,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     int gd = 0;                                    // variable-length keys: GD[gd] holds the groups' depths, the next doubling round writes GD[gd ^ 1]
     int last_pair = -8;
     bool prev_pair = false;
+    bool pair_pays = true;                         // no pair round so far has left most of its list (pair_rule_keep)
     bool lg_heavy = false, runs_heavy = false;
     uint32_t m_prev = n;                           // the list the previous round started with
     uint64_t pair_mask = 0;
@@ -2887,11 +2898,12 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             lg_heavy = round == 1 ? h_m[8 * (par ^ 1) + 4] > n / 64u : h_m[8 * (par ^ 1) + 3] > (1u << 22);
             if (round == 1) runs_heavy = lg_heavy;
             ctx->stats.sa_rounds = round + 1;
-            pair = round >= pair_rule_from() && pair_rule_shift() >= 0 && round - last_pair >= pair_rule_gap() && m_now >= pair_rule_min() && m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift()) &&
-                   (uint64_t)m_now * 100u >= (uint64_t)m_prev * pair_rule_ratio();
+            if (prev_pair && (uint64_t)m_now * 100u > (uint64_t)m_prev * pair_rule_keep()) pair_pays = false;
+            pair = pair_pays && round >= pair_rule_from() && pair_rule_shift() >= 0 && round - last_pair >= pair_rule_gap() && m_now >= pair_rule_min() &&
+                   m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift()) && (uint64_t)m_now * 100u >= (uint64_t)m_prev * pair_rule_ratio();
             // ... and round 2 already when round 1 resolved next to nothing (99 % of its list is still there: periodic data, a block
             // that holds everything twice -- doubling is futile) unless the block is mostly runs, whose groups the run rule is splitting
-            if (!pair && round == 2 && wait_round <= 1 && pair_rule_early() && pair_rule_shift() >= 0 && !runs_heavy && m_now >= pair_rule_min() &&
+            if (!pair && pair_pays && round == 2 && wait_round <= 1 && pair_rule_early() && pair_rule_shift() >= 0 && !runs_heavy && m_now >= pair_rule_min() &&
                 m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift()) && (uint64_t)m_now * 100u >= (uint64_t)m_prev * 99u)
                 pair = true;
             m_prev = m_now;

@@ -69,13 +69,13 @@ def _run_child(env_extra, iters=250, seed=11, timeout=1500):
 
 def test_forced_pair_rounds_on_small_repeat_heavy_texts():
     """every round from the third on that may be a pair round is one (any list size, a doubling round in between)"""
-    r = _run_child({"JPK_PAIR_SHIFT": "31", "JPK_PAIR_MIN": "2", "JPK_PAIR_GAP": "2", "JPK_PAIR_RATIO": "0"})
+    r = _run_child({"JPK_PAIR_SHIFT": "31", "JPK_PAIR_MIN": "2", "JPK_PAIR_GAP": "2", "JPK_PAIR_RATIO": "0", "JPK_PAIR_KEEP": "100"})
     assert "PAIR_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 def test_forced_pair_rounds_with_plain_byte_keys():
     """7-byte keys (what any block above 128 byte values gets) leave more to the rounds"""
-    r = _run_child({"JPK_PAIR_SHIFT": "31", "JPK_PAIR_MIN": "2", "JPK_PAIR_GAP": "3", "JPK_PAIR_RATIO": "0", "JPK_KEY_BITS": "8"}, iters=120, seed=12)
+    r = _run_child({"JPK_PAIR_SHIFT": "31", "JPK_PAIR_MIN": "2", "JPK_PAIR_GAP": "3", "JPK_PAIR_RATIO": "0", "JPK_PAIR_KEEP": "100", "JPK_KEY_BITS": "8"}, iters=120, seed=12)
     assert "PAIR_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
