@@ -417,6 +417,35 @@ def system_sources(nbytes: int):
     return None
 
 
+def system_binaries(nbytes: int, skip: int = 0):
+    """`nbytes` of REAL machine code and tables: the largest shared libraries of this image's ROCm tree in sorted name order, from byte
+    `skip` of their concatenation (ELF sections, gfx code objects, symbol and string tables, zero padding).  None if there is less."""
+    root = "/opt/rocm/lib"
+    try:
+        names = sorted(f for f in os.listdir(root) if ".so" in f and not os.path.islink(os.path.join(root, f)))
+    except OSError:
+        return None
+    parts, left = [], nbytes
+    for f in names:
+        p = os.path.join(root, f)
+        try:
+            sz = os.path.getsize(p)
+        except OSError:
+            continue
+        if skip >= sz:
+            skip -= sz
+            continue
+        a = np.fromfile(p, dtype=np.uint8, count=min(left, sz - skip), offset=skip)
+        skip = 0
+        if len(a) == 0:
+            continue
+        parts.append(a)
+        left -= len(a)
+        if left == 0:
+            return np.concatenate(parts)
+    return None
+
+
 def block_ranges(total: int, block_size: int):
     """(start, length) of every block of a `total`-byte stream (jampack.cpp:205-213 reads BlockSize bytes per block)"""
     return [(o, min(block_size, total - o)) for o in range(0, total, block_size)]

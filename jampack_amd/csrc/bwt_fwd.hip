@@ -2268,9 +2268,8 @@ __global__ __launch_bounds__(TB) void k_pair_dist(const uint32_t *__restrict__ a
 // stretch is the long one.  Any winner is a true same-group distance.
 constexpr int PAIR_WALK_MAX = 2048;
 __global__ __launch_bounds__(TB) void k_pair_repair(uint32_t *P, uint32_t n, const uint32_t *__restrict__ ISA, const uint8_t *__restrict__ blk,
-                                                   const uint32_t *__restrict__ bend, SaState *__restrict__ st)
+                                                   const uint32_t *__restrict__ bend, SaState *__restrict__ st, uint32_t budget)
 {
-    const uint32_t budget = (n < 0x1E000000u) ? 8u * n : 0xF0000000u;
     for (uint32_t x = blockIdx.x * TB + threadIdx.x; x + 1u < n; x += gridDim.x * TB) {
         const uint32_t p = P[x];
         if (p == 0u || (p & PREP)) continue;
@@ -2715,8 +2714,19 @@ uint32_t pair_rule_ratio()
     static const uint32_t v = [] { const char *e = getenv("JPK_PAIR_RATIO"); const int x = e ? atoi(e) : 90; return (uint32_t)(x < 0 ? 0 : (x > 100 ? 100 : x)); }();
     return v;
 }
-// JPK_PAIR_KEEP: a pair round that leaves more than this percentage of its list is the block's last one (default 50; 100 = never give up).
-// The Fibonacci word took nine pair rounds that resolved NOTHING (every one a round in which the doubling distance stands still).
+// JPK_PAIR_BUDGET: positions all walks of k_pair_repair together may visit in one pair round, in eighths of n (default 1; 8 n until the end of
+// round 6: no block whose pair rounds pay notices the difference, a pair round that does not pay costs 7 ms less on 64 MiB of real binaries)
+uint32_t pair_rule_budget(uint32_t n)
+{
+    static const uint32_t e8 = [] { const char *e = getenv("JPK_PAIR_BUDGET"); const long x = e ? atol(e) : 1; return (uint32_t)(x < 0 ? 0 : (x > 64 ? 64 : x)); }();
+    const uint64_t b = (uint64_t)n * e8 / 8u;
+    return b > 0xF0000000ull ? 0xF0000000u : (uint32_t)b;
+}
+// JPK_PAIR_KEEP: a pair round that leaves more than this percentage of its list did not pay (default 50; 100 = every one pays): the next one
+// waits twice as long (two doubling rounds, then six, fourteen, thirty).  The Fibonacci word took nine pair rounds that resolved NOTHING, every
+// one a round in which the doubling distance stands still (105 -> 60 ms per 32 MiB); a block that holds a real tree TWICE -- near-duplicate files
+// inside an exact copy -- takes pair rounds that leave 93-100 % until doubling has dissolved the inner repeats, and then one that leaves nothing
+// (round 12-15 of 23): giving up after the first would cost such a block its best round (tools/pair_yield.py, profiles/r06_real_files_pair_rounds.txt).
 uint32_t pair_rule_keep()
 {
     static const uint32_t v = [] { const char *e = getenv("JPK_PAIR_KEEP"); const int x = e ? atoi(e) : 50; return (uint32_t)(x < 0 ? 0 : (x > 100 ? 100 : x)); }();
@@ -2881,7 +2891,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     int gd = 0;                                    // variable-length keys: GD[gd] holds the groups' depths, the next doubling round writes GD[gd ^ 1]
     int last_pair = -8;
     bool prev_pair = false;
-    bool pair_pays = true;                         // no pair round so far has left most of its list (pair_rule_keep)
+    int pair_gap = pair_rule_gap();                // rounds from the last pair round to the next: doubles (+ 1) behind one that did not pay (pair_rule_keep)
     bool lg_heavy = false, runs_heavy = false;
     uint32_t m_prev = n;                           // the list the previous round started with
     uint64_t pair_mask = 0;
@@ -2898,12 +2908,12 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             lg_heavy = round == 1 ? h_m[8 * (par ^ 1) + 4] > n / 64u : h_m[8 * (par ^ 1) + 3] > (1u << 22);
             if (round == 1) runs_heavy = lg_heavy;
             ctx->stats.sa_rounds = round + 1;
-            if (prev_pair && (uint64_t)m_now * 100u > (uint64_t)m_prev * pair_rule_keep()) pair_pays = false;
-            pair = pair_pays && round >= pair_rule_from() && pair_rule_shift() >= 0 && round - last_pair >= pair_rule_gap() && m_now >= pair_rule_min() &&
+            if (prev_pair) pair_gap = ((uint64_t)m_now * 100u > (uint64_t)m_prev * pair_rule_keep()) ? 2 * pair_gap + 1 : pair_rule_gap();
+            pair = round >= pair_rule_from() && pair_rule_shift() >= 0 && round - last_pair >= pair_gap && m_now >= pair_rule_min() &&
                    m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift()) && (uint64_t)m_now * 100u >= (uint64_t)m_prev * pair_rule_ratio();
             // ... and round 2 already when round 1 resolved next to nothing (99 % of its list is still there: periodic data, a block
             // that holds everything twice -- doubling is futile) unless the block is mostly runs, whose groups the run rule is splitting
-            if (!pair && pair_pays && round == 2 && wait_round <= 1 && pair_rule_early() && pair_rule_shift() >= 0 && !runs_heavy && m_now >= pair_rule_min() &&
+            if (!pair && round == 2 && wait_round <= 1 && pair_rule_early() && pair_rule_shift() >= 0 && !runs_heavy && m_now >= pair_rule_min() &&
                 m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift()) && (uint64_t)m_now * 100u >= (uint64_t)m_prev * 99u)
                 pair = true;
             m_prev = m_now;
@@ -2932,7 +2942,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             JPK_HIP(hipMemsetAsync(&b.state->pair_steps, 0, sizeof(uint32_t), st));
             JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_pair_dist, dim3(g_win), dim3(TB), b.a_sa, b.a_grp, b.state, par, P, b.FH, b.LH);
             JPK_LAUNCH(ctx, PROF_SCAN, 0, k_win_scan1, dim3(1), dim3(WG1), b.FH, b.LH, b.PH, b.NH, b.state, par);
-            if (pair_rule_repair()) JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_pair_repair, dim3(cap_grid(n, TB * 4, 8192)), dim3(TB), P, n, b.ISA, b.blk, b.bend, b.state);
+            if (pair_rule_repair()) JPK_LAUNCH(ctx, PROF_SA_KEYS, 0, k_pair_repair, dim3(cap_grid(n, TB * 4, 8192)), dim3(TB), P, n, b.ISA, b.blk, b.bend, b.state, pair_rule_budget(n));
             JPK_LAUNCH(ctx, PROF_SCAN, 0, k_pair_first, dim3(cap_grid(n, CT, 4096)), dim3(TB), P, n, b.tB);
             JPK_LAUNCH(ctx, PROF_SCAN, 0, k_pair_scan, dim3(1), dim3(WG1), b.tB, n);
             for (int it = 0; it < pair_rule_iters(); it++)     // later passes decide stretches that end in a group mixing two repeats (pair_verdict)

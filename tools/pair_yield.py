@@ -23,7 +23,14 @@ cases = {
     "fibonacci word 32 MiB": b[: 32 << 20].copy(),
     "phrase-book text": corpus.make("text", n, 3),
     "sawtooth 32 MiB": (np.arange(32 << 20) % 251).astype(np.uint8),
+    "twin real sources 2 x 32 MiB": (lambda h: None if h is None else np.concatenate([h, h]))(corpus.system_sources(32 << 20)),
+    "real binaries twice 2 x 32 MiB": (lambda h: None if h is None else np.concatenate([h, h]))(corpus.system_binaries(32 << 20, 1000 << 20)),
+    "real binaries (libMIOpen, first 64 MiB)": corpus.system_binaries(n),
+    "real binaries from 200 MiB": corpus.system_binaries(n, 200 << 20),
+    "real binaries from 3000 MiB": corpus.system_binaries(n, 3000 << 20),
 }
+if os.environ.get("JPK_YIELD_ONLY"):
+    cases = {k: v for k, v in cases.items() if any(w in k for w in os.environ["JPK_YIELD_ONLY"].split(","))}
 for name, t in cases.items():
     if t is None:
         continue
