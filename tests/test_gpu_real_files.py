@@ -58,6 +58,35 @@ def test_64_mib_of_real_source_files_equal_the_reference(gpu, ref, sources):
     assert s.sa_rounds <= 24, s.sa_rounds
 
 
+@pytest.mark.parametrize("skip_mib", [0, 200])
+def test_64_mib_of_real_shared_libraries_equal_the_reference(gpu, ref, skip_mib):
+    """machine code, gfx code objects, symbol and string tables, padding (corpus.system_binaries: the ROCm tree's shared libraries): the first
+    64 MiB (ratio 0.065) and the 64 MiB from byte 200 Mi on (ratio 0.003: tables repeated almost verbatim; 16 rounds, most of the block in
+    groups above 1024 members for seven of them, a pair round that resolves nothing)"""
+    from jampack_amd import corpus
+    torch, jam, ctx = gpu
+    t = corpus.system_binaries(64 << 20, skip_mib << 20)
+    if t is None:
+        pytest.skip("this image's ROCm tree holds less")
+    n = len(t)
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(t).to(dev)
+    cap = jam.ans_capacity(n + 480)
+    d_bwt = torch.empty(n + 480, dtype=torch.uint8, device=dev)
+    d_enc = torch.empty(cap, dtype=torch.uint8, device=dev)
+    assert ctx.bwt_forward(d_in, n, d_bwt, n + 480) == n + 480
+    s = ctx.stats()
+    clen = ctx.ans_encode(d_bwt, n + 480, d_enc, cap)
+    rb = ref.bwt_forward(t)
+    assert hashlib.sha256(rb.tobytes()).hexdigest() == _sha(d_bwt)
+    re_ = ref.ans_encode(rb)
+    assert len(re_) == clen and hashlib.sha256(re_.tobytes()).hexdigest() == _sha(d_enc[:clen])
+    d_back = torch.empty(n, dtype=torch.uint8, device=dev)
+    assert ctx.block_decompress(d_enc, clen, d_back, n) == n
+    assert torch.equal(d_back, d_in)
+    print(f"real shared libraries from {skip_mib} MiB: ratio {clen / n:.3f}, rounds {s.sa_rounds}, pair rounds {[r for r in range(40) if (s.sa_pair_rounds >> r) & 1]}")
+
+
 def test_group_of_real_8_mib_blocks_equals_the_reference(gpu, ref, sources):
     """four 8 MiB blocks behind the first 64 MiB (other files): one jpk_dev_blocks_compress call = one group sort"""
     torch, jam, ctx = gpu
