@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""soak: N random blocks (mixed generators, ragged sizes) through compress -> batch decompress; small ones also against the oracle.
+"""soak: N random blocks (mixed generators and slices of real files, ragged sizes) through compress -> batch decompress; small ones also against the oracle.
    python tools/soak.py [N=300] [seed=1]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,6 +16,8 @@ dev = torch.device("cuda", 0)
 ctx = jam.Context(0, None)
 kinds = ["text_survey", "text", "text_wide", "random", "runs", "geometric", "dna", "silesia", "zero", "two", "samples16", "repeat", "repeat4k"]
 kinds = [k for k in kinds if k in jam.corpus.KINDS] if hasattr(jam.corpus, "KINDS") else kinds
+# REAL bytes as well (round 6): random slices of this image's source trees and shared libraries (corpus.system_sources / system_binaries)
+real = [x for x in (jam.corpus.system_sources(96 << 20), jam.corpus.system_binaries(96 << 20), jam.corpus.system_binaries(64 << 20, 200 << 20)) if x is not None]
 t0 = time.time()
 blocks, comp = [], []
 checked = 0
@@ -23,7 +25,12 @@ for i in range(N):
     k = kinds[int(rng.integers(len(kinds)))]
     r = rng.random()
     n = int(rng.integers(1, 3000)) if r < 0.15 else (int(rng.integers(3000, 1_300_000)) if r < 0.7 else int(rng.integers(1_300_000, 9_000_000)))
-    if rng.random() < 0.35:
+    if real and rng.random() < 0.25:
+        src = real[int(rng.integers(len(real)))]
+        lo = int(rng.integers(0, len(src) - n))
+        t = np.ascontiguousarray(src[lo:lo + n])
+        k = "real"
+    elif rng.random() < 0.35:
         # a phrase text over a random alphabet of 1..256 byte values (round 0's keys pack by the alphabet: every code width, real repeats)
         sigma = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 16, 17, 28, 32, 33, 64, 65, 128, 129, 200, 256]))
         sym = np.sort(rng.choice(256, sigma, replace=False)).astype(np.uint8)
