@@ -294,6 +294,11 @@ JPK_API int jpk_debug_multi_lock_probe(uint64_t device_mask, int32_t hold_ms);
 /* host-logic probe: the work list jpk_dev_blocks_compress forms for these block lengths (groups of small blocks, large blocks alone):
  * task t covers blocks [first[t], first[t] + count[t]); returns the number of tasks.  No device call. */
 JPK_API int jpk_debug_group_plan(int32_t nblocks, const int32_t *in_len, int32_t *first, int32_t *count);
+/* host-logic probe: which rounds of a suffix sort the host makes PAIR rounds (bwt_fwd.hip PairSchedule: behind a doubling round that left >= 90 % of
+ * its list, two doubling rounds apart, twice as far behind a pair round that left most of its list; JPK_PAIR_* override), given what the host
+ * knows -- list[r] = the unresolved suffixes round r started with (list[0] = n; 0 = the sort had ended).  is_pair[r] = 1 for pair rounds; returns
+ * their number.  No device call. */
+JPK_API int jpk_debug_pair_schedule(int64_t n, int32_t nrounds, const uint32_t *list, int32_t runs_heavy, int32_t *is_pair);
 /* Hooks that CHANGE live state work only in a process with JPK_DEBUG_HOOKS=1 in its environment (JPK_E_ARG otherwise):
  * jpk_debug_compress_inflight with delta != 0, and jpk_debug_combiner_fail_next(n): the next n merged decode passes fail as a
  * whole before they run -- every merged request must then come back through its own thread's single-block path. */

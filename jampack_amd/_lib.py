@@ -109,6 +109,7 @@ _SIGS = {
     "jpk_debug_multi_plan": (C.c_int, [C.c_uint64, C.c_int32, C.c_int32, C.c_void_p]),
     "jpk_debug_multi_lock_probe": (C.c_int, [C.c_uint64, C.c_int32]),
     "jpk_debug_group_plan": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jpk_debug_pair_schedule": (C.c_int, [C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
 }
 
 ABI_SYMBOLS = tuple(_SIGS)

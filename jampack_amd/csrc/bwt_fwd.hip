@@ -2751,6 +2751,30 @@ int pair_rule_gap()
     return v;
 }
 
+// When a round is a pair round: the host's rule as a function of what it knows -- the list every round started with -- so that the CPU suite can
+// run it on recorded lists (jpk_debug_pair_schedule, tests/test_abi_and_host.py).  `step` is called once per round >= 1 whose list size is known
+// before it is enqueued, in order.
+struct PairSchedule {
+    int last_pair = -8;
+    int gap = pair_rule_gap();          // rounds from the last pair round to the next: doubles (+ 1) behind one that did not pay (pair_rule_keep)
+    bool prev_pair = false;
+    uint32_t m_prev;                    // the list the previous round started with
+    explicit PairSchedule(uint32_t n) : m_prev(n) {}
+    bool step(int round, uint32_t m_now, uint32_t n, bool runs_heavy, bool exact_from_round_1)
+    {
+        if (prev_pair) gap = ((uint64_t)m_now * 100u > (uint64_t)m_prev * pair_rule_keep()) ? 2 * gap + 1 : pair_rule_gap();
+        const bool sizeable = pair_rule_shift() >= 0 && m_now >= pair_rule_min() && m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift());
+        bool pair = sizeable && round >= pair_rule_from() && round - last_pair >= gap && (uint64_t)m_now * 100u >= (uint64_t)m_prev * pair_rule_ratio();
+        // ... and round 2 already when round 1 resolved next to nothing (99 % of its list is still there: periodic data, a block
+        // that holds everything twice -- doubling is futile) unless the block is mostly runs, whose groups the run rule is splitting
+        if (!pair && round == 2 && exact_from_round_1 && pair_rule_early() && sizeable && !runs_heavy && (uint64_t)m_now * 100u >= (uint64_t)m_prev * 99u) pair = true;
+        m_prev = m_now;
+        prev_pair = pair;
+        if (pair) last_pair = round;
+        return pair;
+    }
+};
+
 // builds the BWT-in-SA-order bytes (b.bwt), the complete inverse suffix array (b.ISA) and, if b.SA is set, the suffix array
 int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
 {
@@ -2889,11 +2913,9 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
     // between two pair rounds (a group with dissenting pairs has to split before the rule can say more about it).
     int hshift = 0;                                // the next doubling round compares at distance depth << hshift
     int gd = 0;                                    // variable-length keys: GD[gd] holds the groups' depths, the next doubling round writes GD[gd ^ 1]
-    int last_pair = -8;
+    PairSchedule sched(n);
     bool prev_pair = false;
-    int pair_gap = pair_rule_gap();                // rounds from the last pair round to the next: doubles (+ 1) behind one that did not pay (pair_rule_keep)
     bool lg_heavy = false, runs_heavy = false;
-    uint32_t m_prev = n;                           // the list the previous round started with
     uint64_t pair_mask = 0;
     for (int round = 1;; round++) {
         const int par = round & 1;
@@ -2908,15 +2930,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             lg_heavy = round == 1 ? h_m[8 * (par ^ 1) + 4] > n / 64u : h_m[8 * (par ^ 1) + 3] > (1u << 22);
             if (round == 1) runs_heavy = lg_heavy;
             ctx->stats.sa_rounds = round + 1;
-            if (prev_pair) pair_gap = ((uint64_t)m_now * 100u > (uint64_t)m_prev * pair_rule_keep()) ? 2 * pair_gap + 1 : pair_rule_gap();
-            pair = round >= pair_rule_from() && pair_rule_shift() >= 0 && round - last_pair >= pair_gap && m_now >= pair_rule_min() &&
-                   m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift()) && (uint64_t)m_now * 100u >= (uint64_t)m_prev * pair_rule_ratio();
-            // ... and round 2 already when round 1 resolved next to nothing (99 % of its list is still there: periodic data, a block
-            // that holds everything twice -- doubling is futile) unless the block is mostly runs, whose groups the run rule is splitting
-            if (!pair && round == 2 && wait_round <= 1 && pair_rule_early() && pair_rule_shift() >= 0 && !runs_heavy && m_now >= pair_rule_min() &&
-                m_now >= (uint32_t)((uint64_t)n >> pair_rule_shift()) && (uint64_t)m_now * 100u >= (uint64_t)m_prev * 99u)
-                pair = true;
-            m_prev = m_now;
+            pair = sched.step(round, m_now, n, runs_heavy, wait_round <= 1);
         }
         const unsigned g_win = cap_grid(bound, SEG_TILE, CAP);
         const unsigned g_seg = cap_grid(bound, SEG_TILE, CAP_SEG);
@@ -2935,7 +2949,6 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             // (no gather in this round)
             uint32_t *P = vs;
             uint8_t *V = reinterpret_cast<uint8_t *>(b.k2), *BAD = V + n, *VL = V + 2 * (size_t)n;
-            last_pair = round;
             if (round < 64) pair_mask |= 1ull << round;
             JPK_HIP(hipMemsetAsync(P, 0, sizeof(uint32_t) * ((size_t)n + 1), st));
             JPK_HIP(hipMemsetAsync(BAD, 0, n, st));
@@ -3001,7 +3014,7 @@ int build_sa(jpk_ctx *ctx, const uint8_t *T, uint32_t n, SaBufs &b)
             if (m_start == 0) break;                // this round was empty: done
             ctx->stats.sa_rounds = round + 1;
             bound = m_start;
-            m_prev = m_start;
+            sched.m_prev = m_start;
         }
         if (round >= 2 * JPK_SA_MAX_ROUNDS) return JPK_E_DEVICE;     // cannot happen: the distance doubles, every suffix is unique once it is >= n
     }
@@ -3200,4 +3213,18 @@ int jpk_fwd_bwt_device(jpk_ctx *ctx, const uint8_t *d_in, int32_t len, uint8_t *
     hipLaunchKernelGGL(k_bwt_trailer, dim3(1), dim3(128), 0, ctx->stream, d_in, b.ISA, (uint32_t)nlen, (uint32_t)len, d_out);
     JPK_HIP(hipGetLastError());
     return JPK_OK;
+}
+
+// host-logic probe (include/jampack_abi.h): the pair-round schedule on recorded lists
+extern "C" JPK_API int jpk_debug_pair_schedule(int64_t n, int32_t nrounds, const uint32_t *list, int32_t runs_heavy, int32_t *is_pair)
+{
+    if (n <= 0 || n >= (int64_t)JPK_FWD_BWT_LIMIT || nrounds < 1 || !list || !is_pair) return JPK_E_ARG;
+    PairSchedule sched((uint32_t)n);
+    int count = 0;
+    is_pair[0] = 0;
+    for (int r = 1; r < nrounds; r++) {
+        is_pair[r] = list[r] ? (sched.step(r, list[r], (uint32_t)n, runs_heavy != 0, true) ? 1 : 0) : 0;
+        count += is_pair[r];
+    }
+    return count;
 }

@@ -255,6 +255,43 @@ def test_multi_device_ownership_and_order():
     assert "rccl" not in out
 
 
+def test_pair_round_schedule_on_recorded_lists():
+    """which rounds of a suffix sort are PAIR rounds (bwt_fwd.hip PairSchedule, host logic): a round from the third on behind a doubling round that
+    left >= 90 % of its list, two doubling rounds apart -- and six, then fourteen, behind a pair round that left more than half of its list; round 2
+    already when round 1 left 99 %.  The lists are the ones the GPU recorded (profiles/r06_real_files_pair_rounds.txt, tools/pair_yield.py): the
+    schedule must pick the rounds it picked there, keep the rounds that resolve exact repeats, and stay away from real near-duplicate trees."""
+    from jampack_amd import lib
+
+    def pairs(n, lst, runs_heavy=0):
+        L = (ctypes.c_uint32 * len(lst))(*lst)
+        out = (ctypes.c_int32 * len(lst))()
+        k = lib().jpk_debug_pair_schedule(n, len(lst), L, runs_heavy, out)
+        got = [r for r in range(len(lst)) if out[r]]
+        assert k == len(got)
+        return got
+
+    n = 67108800
+    # real source trees: every round leaves 60-85 % of its list -- no pair round (with the round-5 threshold of 60 %: rounds 3, 6, 9, 12 ms wasted)
+    assert pairs(n, [n, 58502091, 48754810, 40065036, 32193135, 24239432, 15533282, 10290246, 6549112, 4124712, 2326215, 1313193, 777774, 390726, 249406, 20642]) == []
+    # the headline text: its list shrinks 2.5x and 500x -- never
+    assert pairs(n, [n, 27281026, 48909]) == []
+    # a block that holds a text twice: round 1 leaves everything, round 2 is the pair round that resolves it
+    assert pairs(33554400, [33554400, 33554306, 33554306, 40764, 1722, 20]) == [2]
+    # config 5 / the silesia-like mix (a list shaped like the recorded one): text and samples resolve, the repeated segment is what round 4 leaves as it was
+    assert pairs(211938480, [211938480, 110000000, 40000000, 26000000, 21400000, 21193563]) == [5]
+    # a 1 MiB period: the early pair round leaves 16 %, two doubling rounds, nothing left for another
+    assert pairs(n, [n, 67108772, 67108772, 10964920, 3100000, 400000]) == [2]
+    # real shared libraries twice: pair rounds 3 and 10 (the first leaves 93 %: the next one waits six rounds and resolves 89 %), then 13
+    # (zero padding: the block counts as runs-heavy, so no early pair round at 2)
+    assert pairs(n, [n, 67108695, 67108695, 67108695, 62202089, 62100000, 62000000, 61900000, 61850000, 61800000, 61745666, 6628360, 6500000, 6319522], runs_heavy=1) == [3, 10, 13]
+    # the Fibonacci word: pair rounds resolve nothing -- 2, then 9, then not before 24 (nine of them, every third round, until the end of round 6)
+    fib = [33554400] + [33554289] * 9 + [33547233] * 3 + [33525729] * 3 + [33095649, 31719393, 26214369, 15000000, 4000000, 100000]
+    assert pairs(33554400, fib) == [2, 9]
+    # mostly runs: the run rule is splitting those groups, no early pair round
+    assert pairs(n, [n, 67000000, 66900000], runs_heavy=1) == []
+    assert lib().jpk_debug_pair_schedule(0, 3, (ctypes.c_uint32 * 3)(), 0, (ctypes.c_int32 * 3)()) == -1
+
+
 def test_group_plan_covers_every_block_once_and_in_order():
     """jpk_dev_blocks_compress' work list (host logic): small blocks (<= 16 MiB) in groups of consecutive blocks -- at most 256 blocks, at
     most the target size beyond the first block (a quarter of the small blocks' bytes, 8..64 MiB) --, a larger block alone"""
