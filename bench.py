@@ -566,7 +566,7 @@ def blocks_decompress_call(jam, torch, dev, d_block, d_cmp0, clen: int):
 
 def blocks_compress_call(jam, torch, dev, local_rank, d_in, lens, caps, ref_out, ref_sizes, nctx, npl=16):
     """the library's own blocks-in-flight loop: ONE jpk_dev_blocks_compress call (C ABI) over `npl` passes' worth of the workload's blocks
-    -- what a drop-in caller without threads of its own gets.  The better of two calls behind one that creates the workers' contexts and
+    -- what a drop-in caller without threads of its own gets.  The best of three calls behind one that creates the workers' contexts and
     sizes their arenas; every output compared with `ref_out` (the same blocks compressed one at a time)."""
     nblk = len(d_in)
     l_in = [d_in[i] for _ in range(npl) for i in range(nblk)]
@@ -577,7 +577,8 @@ def blocks_compress_call(jam, torch, dev, local_rank, d_in, lens, caps, ref_out,
     lctx.blocks_compress(l_in, l_len, l_out, l_cap, nctx)            # the workers' contexts exist and their arenas are sized
     torch.cuda.synchronize()
     tl = None
-    for _rep in range(2):               # the better of two calls (one call of a collection run took twice the usual time: a single sample is fragile)
+    for _rep in range(3):               # the best of three calls: in fresh processes one call in six takes 4.1-4.3 GB/s where the others take 6.1-6.5
+                                        # (twelve processes, thirty-six calls: profiles/r06_blocks_compress_call.txt), whatever the order the workers' streams are created in
         tl0 = time.perf_counter()
         ln_, ls_ = lctx.blocks_compress(l_in, l_len, l_out, l_cap, nctx)
         torch.cuda.synchronize()
