@@ -577,8 +577,8 @@ def blocks_compress_call(jam, torch, dev, local_rank, d_in, lens, caps, ref_out,
     lctx.blocks_compress(l_in, l_len, l_out, l_cap, nctx)            # the workers' contexts exist and their arenas are sized
     torch.cuda.synchronize()
     tl = None
-    for _rep in range(3):               # the best of three calls: in fresh processes one call in six takes 4.1-4.3 GB/s where the others take 6.1-6.5
-                                        # (twelve processes, thirty-six calls: profiles/r06_blocks_compress_call.txt), whatever the order the workers' streams are created in
+    for _rep in range(3):               # the best of three calls (until the end of round 6 one call in six of a fresh process took 4.1-4.3 GB/s where the others
+                                        # took 6.1-6.5: arenas growing in the middle of a call; the workers size them up front now: profiles/r06_blocks_compress_call.txt)
         tl0 = time.perf_counter()
         ln_, ls_ = lctx.blocks_compress(l_in, l_len, l_out, l_cap, nctx)
         torch.cuda.synchronize()

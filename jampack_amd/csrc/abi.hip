@@ -1041,6 +1041,15 @@ int blocks_compress_body(jpk_ctx *ctx, int32_t nblocks, const uint8_t *const *d_
             group_needs(t.count, in_len + t.first, &sb, &ab);
             if (sb > max_stage) max_stage = sb;
             if (ab > max_arena) max_arena = ab;
+        } else if (in_len[t.first] <= (128 << 20)) {        // (larger blocks grow a worker's arena when it meets one: ten arenas of a 1000 MiB block would not fit)
+            // ... and for the largest single block (end of round 6): a worker whose first call brought it the stream's short last blocks only grew
+            // its arena in the middle of the NEXT call -- one call in six of a fresh process took 4.1-4.3 GB/s instead of 6.1-6.5
+            const uint32_t n1 = (uint32_t)in_len[t.first];
+            const size_t mid = (size_t)n1 + JPK_TRAILER_BYTES;
+            const size_t fb = jpk_fwd_bwt_arena_bytes(n1), eb = jpk_ans_encode_arena_bytes((uint32_t)mid);
+            if (mid > max_stage) max_stage = mid;
+            if (fb > max_arena) max_arena = fb;
+            if (eb > max_arena) max_arena = eb;
         }
     int nw = in_flight > 0 ? in_flight : 10;       // (10 since round 6, like the bench line: profiles/r06_blocks_in_flight.txt; 8 in rounds 4-5; an arena is 3.7 GB)
     if (nw > ntasks) nw = ntasks;
